@@ -1,0 +1,1268 @@
+// =============================================================================
+// TEST INFRASTRUCTURE ONLY -- NOT PART OF THE PRODUCT PATH.
+//
+// CPU restatement ("oracle") of kakao/buffalo's ALS / BPRMF / WARP training hot
+// path.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+// may load this library, and only as the checker / the timed CPU baseline.
+//
+// PARITY UNPINNED: the reference ships no golden vectors or known-answer tests
+// for the training arithmetic and its C++ cannot be
+// compiled here (Eigen / json11 / spdlog submodules are empty).  This file is
+// therefore pinned only by (a) line-by-line correspondence with the reference
+// sources cited on every function and (b) the independent numpy
+// transliterations + analytic micro-cases in tests/test_oracle_pins.py.
+//
+// All citations are relative to /root/reference/.
+// Quirk numbers (Q-n) refer to SURVEY.md section 7.4.
+//
+// Eigen is replaced by plain loops; float/double promotion follows Eigen's
+// rule for `double_scalar * float_matrix` (the scalar is cast to float first).
+// libstdc++'s std::mt19937 / uniform_int_distribution / unordered_set are used
+// directly, so sample order (Q-3, Q-4) is reproduced exactly on this toolchain.
+// =============================================================================
+#include <omp.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
+#include <cstdint>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <mutex>
+#include <numeric>
+#include <random>
+#include <string>
+#include <thread>
+#include <unordered_set>
+#include <utility>
+#include <vector>
+
+namespace {
+
+static const float FEPS = 1e-10f;  // lib/algo.cc:11, lib/algo_impl/warp/warp.cc:15
+static const int MAX_EXP = 6;      // lib/algo_impl/bpr/bpr.cc:16
+static const int EXP_TABLE_SIZE = 1000;  // include/buffalo/algo_impl/bpr/bpr.hpp:17
+
+// ----------------------------------------------------------------------------
+// Options.  The reference parses a JSON file with json11 (lib/algo.cc:19-37);
+// here the Python wrapper parses the same file and pushes typed key/values.
+// Accessors mimic json11: a missing key or a key of another type reads as
+// 0 / "" / false (Q-7, Q-22).
+// ----------------------------------------------------------------------------
+struct Opt {
+    std::map<std::string, double> num;
+    std::map<std::string, std::string> str;
+    std::map<std::string, bool> boo;
+    int i(const char* k) const {
+        auto it = num.find(k);
+        return it == num.end() ? 0 : static_cast<int>(it->second);
+    }
+    double d(const char* k) const {
+        auto it = num.find(k);
+        return it == num.end() ? 0.0 : it->second;
+    }
+    bool b(const char* k) const {
+        auto it = boo.find(k);
+        return it == boo.end() ? false : it->second;
+    }
+    std::string s(const char* k) const {
+        auto it = str.find(k);
+        return it == str.end() ? std::string() : it->second;
+    }
+};
+
+// ----------------------------------------------------------------------------
+// Counter-based sampler used ONLY when sampler==1 ("counter" mode): replaces
+// the reference's mt19937 stream with Philox4x32-10 keyed on
+// (seed, stream) and counted on (nnz position, attempt, epoch) so that the HIP
+// kernels -- which cannot consume a sequential mt19937 stream -- can be checked
+// draw-for-draw.  This is an independent implementation of the published
+// Philox4x32-10 (Salmon et al., SC'11); the product has its own copy in
+// buffalo_amd/csrc.  Known-answer vectors: tests/test_oracle_pins.py.
+// ----------------------------------------------------------------------------
+static inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                 uint32_t k0, uint32_t k1, uint32_t out[4]) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    const uint32_t W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)M0 * c0;
+        uint64_t p1 = (uint64_t)M1 * c2;
+        uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+        uint32_t n0 = hi1 ^ c1 ^ k0;
+        uint32_t n1 = lo1;
+        uint32_t n2 = hi0 ^ c3 ^ k1;
+        uint32_t n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// Draw `attempt` for nnz position `pos_idx` (global position in the rowwise key
+// array), negative slot `slot`, epoch `epoch`.  Stream 0 = BPR, 1 = WARP.
+static inline void counter_draw(uint32_t seed, uint32_t stream, uint64_t pos_idx, uint32_t slot,
+                                uint32_t epoch, uint32_t attempt, uint32_t out[4]) {
+    philox4x32_10((uint32_t)pos_idx, (uint32_t)(pos_idx >> 32), attempt, (epoch << 8) | (slot & 0xffu),
+                  seed, 0x5bf03635u ^ stream, out);
+}
+// uniform in [0, n) from 32 random bits (multiply-shift).
+static inline int64_t mulhi_u32(uint32_t r, uint32_t n) { return (int64_t)(((uint64_t)r * n) >> 32); }
+// uniform in [0, n) for 64-bit n from 64 random bits.
+static inline int64_t mulhi_u64(uint64_t r, uint64_t n) {
+    return (int64_t)(((unsigned __int128)r * n) >> 64);
+}
+
+// ----------------------------------------------------------------------------
+// include/buffalo/concurrent_queue.hpp:9-79 -- mutex + condvar MPMC queue.
+// ----------------------------------------------------------------------------
+template <typename T>
+class Queue {
+ public:
+    T pop() {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return !q_.empty(); });
+        T v = std::move(q_.front());
+        q_.pop_front();
+        return v;
+    }
+    void push(const T& v) {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            q_.push_back(v);
+        }
+        cv_.notify_one();
+    }
+    size_t get_size() {
+        std::lock_guard<std::mutex> lk(m_);
+        return q_.size();
+    }
+
+ private:
+    std::deque<T> q_;
+    std::mutex m_;
+    std::condition_variable cv_;
+};
+
+// include/buffalo/algo.hpp:28-48
+struct job_t {
+    int size = 0;
+    double alpha = 0.0;
+    std::vector<std::vector<int>> samples;
+    std::vector<int64_t> base;  // oracle-only: global nnz position of samples[i][1] (counter sampler)
+    void add(const std::vector<int>& s, int64_t b) {
+        samples.push_back(s);
+        base.push_back(b);
+        size += (int)s.size();
+    }
+};
+// include/buffalo/algo.hpp:51-69
+struct progress_t {
+    int num_sents, num_processed_samples, num_total_samples;
+    double loss;
+};
+
+static inline float dotf(const float* a, const float* b, int n) {
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += a[i] * b[i];
+    return s;
+}
+
+// ============================================================================
+// SGDAlgorithm  (include/buffalo/algo.hpp:93-148, lib/algo.cc:133-492)
+// ============================================================================
+class SGD {
+ public:
+    virtual ~SGD() {}
+    Opt opt_;
+    float *P_ = nullptr, *Q_ = nullptr, *Qb_ = nullptr;
+    int P_rows_ = 0, Q_rows_ = 0, D_ = 0;
+    int iters_ = 0;
+    double lr_ = 0.0;  // written by the progress thread, read by add_jobs (racy by design, Q-8)
+    std::string optimizer_;
+    double total_processed_ = 0.0;
+    std::vector<int> Pcnt_, Qcnt_;
+    std::vector<float> gradP_, gradQ_, gradQb_, momP_, momQ_, momQb_, velP_, velQ_, velQb_;
+    std::vector<std::thread> workers_;
+    std::thread* progress_manager_ = nullptr;
+    Queue<job_t> job_queue_;
+    Queue<progress_t> progress_queue_;
+    int64_t* cum_table_ = nullptr;
+    int cum_table_size_ = 0;
+
+    // ---- oracle-only switches (all default to reference behaviour) ----------
+    int sampler_ = 0;    // 0: std::mt19937 (reference) | 1: Philox counter draws
+    int pos_order_ = 0;  // 0: std::unordered_set order (reference, Q-3) | 1: CSR order
+    int inline_ = 0;     // 0: worker threads + queue (reference) | 1: process jobs inside add_jobs,
+                         //    lr stamped once per add_jobs call from completed progress (deterministic Q-8)
+    uint32_t epoch_ = 0;  // counts update_parameters calls (counter sampler)
+    long long inl_total_processed_ = 0;
+    std::vector<std::mt19937> inl_rng_;
+    // statistics exported to the tests / bench
+    std::atomic<long long> stat_samples_{0}, stat_scored_negs_{0}, stat_updates_{0};
+    std::vector<int32_t>* trace_ = nullptr;  // (u,pos,neg) triples in processing order when tracing
+    std::mutex trace_m_;
+
+    virtual void worker(int worker_id) = 0;
+    virtual void process_job(job_t& job, int worker_id, std::mt19937& RNG) = 0;
+
+    // lib/algo.cc:197-208 (+ bpr.cc:38-46 / warp.cc:68-85)
+    virtual bool init() {
+        int num_workers = opt_.i("num_workers");
+        omp_set_num_threads(std::max(1, num_workers));
+        optimizer_ = opt_.s("optimizer");
+        return true;
+    }
+
+    // lib/algo.cc:148-176
+    virtual void initialize_model(float* P, int P_rows, float* Q, int Q_rows, float* Qb,
+                                  int64_t num_total_samples) {
+        D_ = opt_.i("d");
+        P_ = P; P_rows_ = P_rows;
+        Q_ = Q; Q_rows_ = Q_rows;
+        Qb_ = Qb;
+        if (optimizer_ != "sgd") initialize_adam_optimizer();
+        else initialize_sgd_optimizer();
+        iters_ = 0;
+        int num_iters = opt_.i("num_iters");
+        total_processed_ = (double)num_total_samples * num_iters;
+        inl_total_processed_ = 0;
+        epoch_ = 0;
+    }
+
+    // lib/algo.cc:221-255.  gradQb_ is allocated unconditionally here because
+    // update_parameters touches it even when use_bias is false (Q-9).
+    void initialize_adam_optimizer() {
+        size_t np = (size_t)P_rows_ * D_, nq = (size_t)Q_rows_ * D_;
+        gradP_.assign(np, 0.f); gradQ_.assign(nq, 0.f);
+        momP_.assign(np, 0.f);  momQ_.assign(nq, 0.f);
+        velP_.assign(np, 0.f);  velQ_.assign(nq, 0.f);
+        gradQb_.assign(Q_rows_, 0.f); momQb_.assign(Q_rows_, 0.f); velQb_.assign(Q_rows_, 0.f);
+        if (opt_.b("per_coordinate_normalize")) {
+            Pcnt_.assign(P_rows_, 0);
+            Qcnt_.assign(Q_rows_, 0);
+        }
+    }
+    // lib/algo.cc:257-260
+    void initialize_sgd_optimizer() { lr_ = opt_.d("lr"); }
+
+    // lib/algo.cc:211-219
+    void launch_workers() {
+        int num_workers = opt_.i("num_workers");
+        if (inline_) {
+            inl_rng_.clear();
+            for (int i = 0; i < std::max(1, num_workers); ++i)
+                inl_rng_.emplace_back(opt_.i("random_seed") + i);
+            lr_ = opt_.d("lr");
+            return;
+        }
+        workers_.clear();
+        for (int i = 0; i < num_workers; ++i) workers_.emplace_back(&SGD::worker, this, i);
+        progress_manager_ = new std::thread(&SGD::progress_manager, this);
+    }
+
+    // lib/algo.cc:261-306 (logging dropped)
+    void progress_manager() {
+        double alpha = opt_.d("lr");
+        double min_alpha = opt_.d("min_lr");
+        lr_ = alpha;
+        long long total_processed_samples = 0;
+        while (true) {
+            progress_t p = progress_queue_.pop();
+            if (p.num_sents == -1 && p.num_processed_samples == -1) break;
+            total_processed_samples += p.num_total_samples;
+            double progress = total_processed_samples / total_processed_;
+            double new_alpha = alpha - (alpha - min_alpha) * progress;
+            new_alpha = std::max(new_alpha, min_alpha);
+            lr_ = new_alpha;
+        }
+    }
+
+    // lib/algo.cc:308-362.  `positives` is the chunk's key array shifted by
+    // indptr[start_x-1]; indptr holds END offsets (no leading zero).
+    void add_jobs(int start_x, int next_x, const int64_t* indptr, const int32_t* positives) {
+        if ((next_x - start_x) == 0) return;
+        int batch_size = opt_.i("batch_size");  // key absent from BPRMF/WARP options => 0 (Q-7)
+        if (batch_size < 0) batch_size = 10000;
+
+        if (inline_) {
+            // deterministic idealisation of Q-8: every job of this call carries the lr that
+            // results from all previously *completed* work.
+            double alpha = opt_.d("lr"), min_alpha = opt_.d("min_lr");
+            double progress = inl_total_processed_ / total_processed_;
+            lr_ = std::max(alpha - (alpha - min_alpha) * progress, min_alpha);
+        }
+
+        job_t job;
+        int job_size = 0;
+        int end_loop = next_x - start_x;
+        const int64_t shifted = start_x == 0 ? 0 : indptr[start_x - 1];
+        std::vector<int> S;
+        auto flush = [&](job_t& j) {
+            j.alpha = lr_;
+            if (inline_) {
+                process_job(j, 0, inl_rng_[0]);
+                inl_total_processed_ += j.size;
+            } else {
+                job_queue_.push(j);
+            }
+        };
+        for (int i = 0; i < end_loop; ++i) {
+            int x = start_x + i;
+            const int u = x;
+            int64_t beg = x == 0 ? 0 : indptr[x - 1];
+            int64_t end = indptr[x];
+            int64_t data_size = end - beg;
+            if (data_size == 0) continue;
+            S.push_back(u);
+            for (int64_t it = beg; it < end; ++it) S.push_back(positives[it - shifted]);
+            if (data_size + job_size <= batch_size) {
+                job.add(S, beg);
+                job_size += (int)S.size();
+            } else {
+                flush(job);  // with batch_size==0 the very first flush is an empty job (Q-7)
+                job = job_t();
+                job.add(S, beg);
+                job_size = (int)S.size();
+            }
+            S.clear();
+        }
+        if (job.size) flush(job);
+    }
+
+    // lib/algo.cc:365-375 (Q-5: bias-correction exponent iters_+1, FEPS outside the sqrt)
+    void update_adam(float* grad, float* mom, float* vel, int n, double beta1, double beta2) {
+        const float b1 = (float)beta1, omb1 = (float)(1.0 - beta1);
+        const float b2 = (float)beta2, omb2 = (float)(1.0 - beta2);
+        const float c1 = (float)(1.0 - std::pow(beta1, iters_ + 1));
+        const float c2 = (float)(1.0 - std::pow(beta2, iters_ + 1));
+        for (int k = 0; k < n; ++k) {
+            mom[k] = b1 * mom[k] + omb1 * grad[k];
+            vel[k] = b2 * vel[k] + omb2 * (grad[k] * grad[k]);
+            float m_hat = mom[k] / c1;
+            float v_hat = vel[k] / c2;
+            grad[k] = m_hat / (std::sqrt(v_hat) + FEPS);
+        }
+    }
+    // lib/algo.cc:377-380
+    void update_adagrad(float* grad, float* vel, int n) {
+        for (int k = 0; k < n; ++k) {
+            vel[k] = vel[k] + grad[k] * grad[k];
+            grad[k] = grad[k] / (std::sqrt(vel[k]) + FEPS);
+        }
+    }
+
+    // lib/algo.cc:382-465.  NOTE Q-5 (beta2 read from "beta1"), Q-6 (grad buffers
+    // are left holding the transformed step and are never re-zeroed), Q-9
+    // (gradQb divided by the count even when use_bias is false).
+    virtual void update_parameters() {
+        int num_workers = std::max(1, opt_.i("num_workers"));
+        omp_set_num_threads(num_workers);
+        bool use_bias = opt_.b("use_bias");
+        double reg_u = opt_.d("reg_u"), reg_i = opt_.d("reg_i"), reg_b = opt_.d("reg_b");
+        bool pcn = opt_.b("per_coordinate_normalize");
+        const int D = D_;
+        if (optimizer_ == "adam" || optimizer_ == "adagrad") {
+            const bool adam = optimizer_ == "adam";
+            double lr = opt_.d("lr");
+            double beta1 = opt_.d("beta1");
+            double beta2 = opt_.d("beta1");  // sic (lib/algo.cc:396)
+            const float lrf = (float)lr;
+            const float ru2 = (float)(2 * reg_u), ri2 = (float)(2 * reg_i), rb2 = (float)(2 * reg_b);
+#pragma omp parallel for schedule(static)
+            for (int u = 0; u < P_rows_; ++u) {
+                float* g = &gradP_[(size_t)u * D];
+                float* p = &P_[(size_t)u * D];
+                if (pcn && Pcnt_[u]) {
+                    const float c = (float)Pcnt_[u];
+                    for (int k = 0; k < D; ++k) g[k] /= c;
+                }
+                for (int k = 0; k < D; ++k) g[k] -= p[k] * ru2;
+                if (adam) update_adam(g, &momP_[(size_t)u * D], &velP_[(size_t)u * D], D, beta1, beta2);
+                else update_adagrad(g, &velP_[(size_t)u * D], D);
+                for (int k = 0; k < D; ++k) p[k] += lrf * g[k];
+            }
+#pragma omp parallel for schedule(static)
+            for (int i = 0; i < Q_rows_; ++i) {
+                float* g = &gradQ_[(size_t)i * D];
+                float* q = &Q_[(size_t)i * D];
+                if (pcn && Qcnt_[i]) {
+                    const float c = (float)Qcnt_[i];
+                    for (int k = 0; k < D; ++k) g[k] /= c;
+                    gradQb_[i] /= c;
+                }
+                for (int k = 0; k < D; ++k) g[k] -= q[k] * ri2;
+                if (adam) update_adam(g, &momQ_[(size_t)i * D], &velQ_[(size_t)i * D], D, beta1, beta2);
+                else update_adagrad(g, &velQ_[(size_t)i * D], D);
+                for (int k = 0; k < D; ++k) q[k] += lrf * g[k];
+                if (use_bias) {
+                    gradQb_[i] -= Qb_[i] * rb2;
+                    if (adam) update_adam(&gradQb_[i], &momQb_[i], &velQb_[i], 1, beta1, beta2);
+                    else update_adagrad(&gradQb_[i], &velQb_[i], 1);
+                    Qb_[i] += lrf * gradQb_[i];
+                }
+            }
+            if (pcn) {
+                Pcnt_.assign(P_rows_, 0);
+                Qcnt_.assign(Q_rows_, 0);
+            }
+        }
+        iters_ += 1;
+        epoch_ += 1;
+    }
+
+    // lib/algo.cc:467-472 -- "queue empty" is not "work finished"; the oracle
+    // additionally offers drain() for tests that need completed work.
+    void wait_until_done() {
+        if (inline_) return;
+        while (job_queue_.get_size() > 0) std::this_thread::sleep_for(std::chrono::milliseconds(100));
+    }
+
+    // lib/algo.cc:474-492
+    double join() {
+        if (inline_) return 0.0;
+        int num_workers = opt_.i("num_workers");
+        for (int i = 0; i < num_workers; ++i) {
+            job_t job;
+            job.size = -1;
+            job_queue_.push(job);
+        }
+        for (auto& t : workers_) t.join();
+        progress_queue_.push(progress_t{-1, -1, -1, 0.0});
+        progress_manager_->join();
+        delete progress_manager_;
+        progress_manager_ = nullptr;
+        workers_.clear();
+        return 0.0;
+    }
+
+    void trace_push(int u, int pos, int neg) {
+        if (!trace_) return;
+        std::lock_guard<std::mutex> lk(trace_m_);
+        trace_->push_back(u); trace_->push_back(pos); trace_->push_back(neg);
+    }
+};
+
+// ============================================================================
+// CBPRMF  (lib/algo_impl/bpr/bpr.cc)
+// ============================================================================
+class BPR : public SGD {
+ public:
+    float exp_table_[EXP_TABLE_SIZE];
+
+    // bpr.cc:47-55
+    void initialize_model(float* P, int P_rows, float* Q, int Q_rows, float* Qb,
+                          int64_t num_total_samples) override {
+        SGD::initialize_model(P, P_rows, Q, Q_rows, Qb, num_total_samples);
+        build_exp_table();
+    }
+    // bpr.cc:57-63 (Q-2)
+    void build_exp_table() {
+        for (int i = 0; i < EXP_TABLE_SIZE; ++i) {
+            exp_table_[i] = (float)std::exp((i / (float)EXP_TABLE_SIZE * 2 - 1) * MAX_EXP);
+            exp_table_[i] = 1.0 / (exp_table_[i] + 1);
+        }
+    }
+
+    // bpr.cc:72-188 outer loop
+    void worker(int worker_id) override {
+        std::mt19937 RNG(opt_.i("random_seed") + worker_id);
+        while (true) {
+            job_t job = job_queue_.pop();
+            if (job.size == -1) break;
+            process_job(job, worker_id, RNG);
+        }
+    }
+
+    // bpr.cc:92-186 (body of the while loop)
+    void process_job(job_t& job, int worker_id, std::mt19937& RNG) override {
+        (void)worker_id;
+        const bool use_bias = opt_.b("use_bias");
+        const bool update_i = opt_.b("update_i");
+        const bool update_j = opt_.b("update_j");
+        const float reg_u = (float)opt_.d("reg_u"), reg_i = (float)opt_.d("reg_i");
+        const float reg_j = (float)opt_.d("reg_j"), reg_b = (float)opt_.d("reg_b");
+        const int num_negative_samples = opt_.i("num_negative_samples");
+        const double sample_power = opt_.d("sampling_power");
+        const bool verify_neg = opt_.b("verify_neg");
+        const int uniform_sampling = sample_power == 0.0 ? 1 : 0;
+        const bool pcn = opt_.b("per_coordinate_normalize");
+        const bool sgd = optimizer_ == "sgd";
+        const int D = D_;
+        const uint32_t seed = (uint32_t)opt_.i("random_seed");
+        // Q-20: rng1 is only constructed when it can be drawn from.
+        const int64_t cum_total = (!uniform_sampling && cum_table_size_ > 0) ? cum_table_[cum_table_size_ - 1] : 1;
+        std::uniform_int_distribution<int64_t> rng1(0, std::max<int64_t>(cum_total - 1, 0));
+        std::uniform_int_distribution<int64_t> rng2(0, Q_rows_ - 1);
+
+        int processed_samples = 0, total_samples = job.size;
+        const float alpha = (float)job.alpha;
+        std::vector<float> item_deriv(D);
+        for (size_t si = 0; si < job.samples.size(); ++si) {
+            const auto& _seen = job.samples[si];
+            const int u = _seen[0];
+            std::unordered_set<int> seen(_seen.begin() + 1, _seen.end());
+            float* Pu = &P_[(size_t)u * D];
+            // iteration order over the user's positives
+            std::vector<std::pair<int, int64_t>> order;  // (pos, global nnz index)
+            order.reserve(_seen.size());
+            if (pos_order_ == 0) {
+                for (const auto pos : seen) order.emplace_back(pos, -1);
+                if (sampler_ == 1) {  // need nnz positions: look them up
+                    for (auto& pr : order)
+                        for (size_t k = 1; k < _seen.size(); ++k)
+                            if (_seen[k] == pr.first) { pr.second = job.base[si] + (int64_t)k - 1; break; }
+                }
+            } else {
+                for (size_t k = 1; k < _seen.size(); ++k) order.emplace_back(_seen[k], job.base[si] + (int64_t)k - 1);
+            }
+            for (const auto& pr : order) {
+                const int pos = pr.first;
+                for (int i = 0; i < num_negative_samples; ++i) {
+                    int neg = 0;
+                    uint32_t attempt = 0;
+                    while (true) {
+                        if (sampler_ == 0) {
+                            if (uniform_sampling) {
+                                neg = (int)rng2(RNG);
+                            } else {
+                                int64_t r = rng1(RNG);
+                                neg = (int)(std::lower_bound(cum_table_, cum_table_ + cum_table_size_, r) - cum_table_);
+                            }
+                        } else {
+                            uint32_t o[4];
+                            counter_draw(seed, 0u, (uint64_t)pr.second, (uint32_t)i, epoch_, attempt++, o);
+                            if (uniform_sampling) {
+                                neg = (int)mulhi_u32(o[0], (uint32_t)Q_rows_);
+                            } else {
+                                int64_t r = mulhi_u64(((uint64_t)o[1] << 32) | o[0], (uint64_t)cum_total);
+                                neg = (int)(std::lower_bound(cum_table_, cum_table_ + cum_table_size_, r) - cum_table_);
+                            }
+                        }
+                        if (!verify_neg || (seen.find(neg) == seen.end())) break;
+                    }
+                    trace_push(u, pos, neg);
+                    float* Qp = &Q_[(size_t)pos * D];
+                    float* Qn = &Q_[(size_t)neg * D];
+                    float x_uij = 0.f;
+                    for (int k = 0; k < D; ++k) x_uij += Pu[k] * (Qp[k] - Qn[k]);
+                    if (use_bias) x_uij += (Qb_[pos] - Qb_[neg]);
+
+                    float logit = 0.0;
+                    if (MAX_EXP < x_uij) {
+                        logit = 0.0;
+                    } else if (x_uij < -MAX_EXP) {
+                        logit = 1.0;
+                    } else {
+                        // integer arithmetic: EXP_TABLE_SIZE / MAX_EXP / 2 == 83 (Q-2)
+                        logit = exp_table_[(int)((x_uij + MAX_EXP) * (EXP_TABLE_SIZE / MAX_EXP / 2))];
+                    }
+                    if (update_i || update_j)
+                        for (int k = 0; k < D; ++k) item_deriv[k] = logit * Pu[k];
+
+                    if (!sgd) {
+                        if (pcn) {
+#pragma omp atomic
+                            Qcnt_[neg] += 1;
+                        }
+                        float* gP = &gradP_[(size_t)u * D];
+                        for (int k = 0; k < D; ++k) gP[k] += logit * (Qp[k] - Qn[k]);
+                        if (update_i) {
+                            float* g = &gradQ_[(size_t)pos * D];
+                            for (int k = 0; k < D; ++k) g[k] += item_deriv[k];
+                            if (use_bias) gradQb_[pos] += logit;
+                        }
+                        if (update_j) {
+                            float* g = &gradQ_[(size_t)neg * D];
+                            for (int k = 0; k < D; ++k) g[k] -= item_deriv[k];
+                            if (use_bias) gradQb_[neg] -= logit;
+                        }
+                    } else {
+                        // Q-1: `g` is a lazy Eigen expression in the reference: it is evaluated at
+                        // the final `P_.row(u) += alpha * g`, i.e. AFTER Q rows were updated, while
+                        // item_deriv (a concrete matrix) holds logit * OLD P_u.
+                        if (update_i) {
+                            for (int k = 0; k < D; ++k) Qp[k] += alpha * (item_deriv[k] - reg_i * Qp[k]);
+                            if (use_bias) Qb_[pos] += alpha * (logit - reg_b * Qb_[pos]);
+                        }
+                        if (update_j) {
+                            for (int k = 0; k < D; ++k) Qn[k] += alpha * (-item_deriv[k] - reg_j * Qn[k]);
+                            if (use_bias) Qb_[neg] += alpha * (-logit - reg_b * Qb_[neg]);
+                        }
+                        for (int k = 0; k < D; ++k)
+                            Pu[k] += alpha * (logit * (Qp[k] - Qn[k]) - reg_u * Pu[k]);
+                    }
+                    stat_updates_ += 1;
+                }
+                if (!sgd && pcn) {
+                    Pcnt_[u] += 1;
+#pragma omp atomic
+                    Qcnt_[pos] += 1;
+                }
+            }
+            processed_samples += (int)_seen.size() - 1;
+        }
+        stat_samples_ += processed_samples;
+        if (!inline_)
+            progress_queue_.push(progress_t{(int)job.samples.size(), processed_samples, total_samples, 0.0});
+    }
+
+    // bpr.cc:217-225
+    double distance(size_t p, size_t q) {
+        bool use_bias = opt_.b("use_bias");
+        float ret = dotf(&P_[p * D_], &Q_[q * D_], D_);
+        if (use_bias) ret += Qb_[q];
+        return ret;
+    }
+    // bpr.cc:227-244
+    double compute_loss(int32_t n, const int32_t* users, const int32_t* positives, const int32_t* negatives) {
+        int num_workers = std::max(1, opt_.i("num_workers"));
+        omp_set_num_threads(num_workers);
+        std::vector<double> loss(num_workers, 0.0);
+#pragma omp parallel for schedule(static)
+        for (int idx = 0; idx < n; ++idx) {
+            int u = users[idx], i = positives[idx], j = negatives[idx];
+            double x_uij = distance(u, i) - distance(u, j);
+            loss[omp_get_thread_num()] += std::log(1.0 + std::exp(-x_uij));
+        }
+        double l = std::accumulate(loss.begin(), loss.end(), 0.0);
+        return l / (double)n;
+    }
+};
+
+// ============================================================================
+// CWARP  (lib/algo_impl/warp/warp.cc)
+// ============================================================================
+class WARP : public SGD {
+ public:
+    bool l2_ = false;
+
+    // warp.cc:68-85: only the exact string "l2" selects the L2 score (Q-23)
+    bool init() override {
+        SGD::init();
+        l2_ = opt_.s("score_func") == "l2";
+        return true;
+    }
+    // warp.cc:21-28
+    float score(const float* u, const float* i) const {
+        if (!l2_) return dotf(u, i, D_);
+        float s = 0.f;
+        for (int k = 0; k < D_; ++k) {
+            float df = u[k] - i[k];
+            s += df * df;
+        }
+        return -s;
+    }
+
+    void worker(int worker_id) override {
+        std::mt19937 RNG(opt_.i("random_seed") + worker_id);
+        while (true) {
+            job_t job = job_queue_.pop();
+            if (job.size == -1) break;
+            process_job(job, worker_id, RNG);
+        }
+    }
+
+    // warp.cc:103-173 (body).  Q-10, Q-11.
+    void process_job(job_t& job, int worker_id, std::mt19937& RNG) override {
+        (void)worker_id;
+        const int max_trial = opt_.i("max_trials");
+        const double threshold = opt_.d("threshold");
+        const float reg_u = (float)opt_.d("reg_u"), reg_i = (float)opt_.d("reg_i"), reg_j = (float)opt_.d("reg_j");
+        const int Q_rows = Q_rows_;
+        const int D = D_;
+        const bool pcn = opt_.b("per_coordinate_normalize");
+        const uint32_t seed = (uint32_t)opt_.i("random_seed");
+        std::uniform_int_distribution<int64_t> rng(0, Q_rows - 1);
+        int processed_samples = 0, total_samples = job.size;
+        double partial_loss = 0.0;
+        std::vector<float> ud(D), id(D), jd(D);
+        for (size_t si = 0; si < job.samples.size(); ++si) {
+            const auto& _seen = job.samples[si];
+            const int u = _seen[0];
+            std::unordered_set<int> seen(_seen.begin() + 1, _seen.end());
+            const float* Pu = &P_[(size_t)u * D];
+            std::vector<std::pair<int, int64_t>> order;
+            if (pos_order_ == 0) {
+                for (const auto pos : seen) order.emplace_back(pos, -1);
+                if (sampler_ == 1)
+                    for (auto& pr : order)
+                        for (size_t k = 1; k < _seen.size(); ++k)
+                            if (_seen[k] == pr.first) { pr.second = job.base[si] + (int64_t)k - 1; break; }
+            } else {
+                for (size_t k = 1; k < _seen.size(); ++k) order.emplace_back(_seen[k], job.base[si] + (int64_t)k - 1);
+            }
+            for (const auto& pr : order) {
+                const int pos = pr.first;
+                const float* Qp = &Q_[(size_t)pos * D];
+                float ui = score(Pu, Qp);
+                float uj = 0;
+                int neg = 0;
+                int trial = 1;
+                uint32_t attempt = 0;
+                while (trial <= max_trial) {
+                    if (sampler_ == 0) {
+                        neg = (int)rng(RNG);
+                    } else {
+                        uint32_t o[4];
+                        counter_draw(seed, 1u, (uint64_t)pr.second, 0u, epoch_, attempt++, o);
+                        neg = (int)mulhi_u32(o[0], (uint32_t)Q_rows);
+                    }
+                    if (seen.find(neg) != seen.end()) continue;  // false negative: not counted
+                    trial += 1;
+                    uj = score(Pu, &Q_[(size_t)neg * D]);
+                    stat_scored_negs_ += 1;
+                    if ((ui - uj) < threshold) break;  // violating pair
+                    trial += 1;
+                }
+                if (trial >= max_trial) continue;
+                const float* Qn = &Q_[(size_t)neg * D];
+                float Phi = std::log(std::max(1, int((Q_rows - seen.size() - 1) / trial)));
+                trace_push(u, pos, neg);
+                if (!l2_) {  // warp.cc:30-40
+                    for (int k = 0; k < D; ++k) {
+                        ud[k] = Phi * (Qp[k] - Qn[k]);
+                        id[k] = Phi * Pu[k];
+                        jd[k] = -id[k];
+                    }
+                } else {  // warp.cc:42-52
+                    for (int k = 0; k < D; ++k) {
+                        ud[k] = Phi * 2 * (Qp[k] - Qn[k]);
+                        id[k] = Phi * (Pu[k] - Qp[k]);
+                        jd[k] = -Phi * (Pu[k] - Qn[k]);
+                    }
+                }
+                float* gP = &gradP_[(size_t)u * D];
+                float* gI = &gradQ_[(size_t)pos * D];
+                float* gJ = &gradQ_[(size_t)neg * D];
+                for (int k = 0; k < D; ++k) gP[k] += ud[k] - reg_u * Pu[k];
+                for (int k = 0; k < D; ++k) gI[k] += id[k] - reg_i * Qp[k];
+                for (int k = 0; k < D; ++k) gJ[k] += jd[k] - reg_j * Qn[k];
+                if (pcn) {
+#pragma omp atomic
+                    Pcnt_[u] += 1;
+                    Qcnt_[pos] += 1;  // the pragma covers only the first increment (warp.cc:161-164)
+                    Qcnt_[neg] += 1;
+                }
+                partial_loss += (uj - ui + threshold);
+                stat_updates_ += 1;
+            }
+            processed_samples += (int)_seen.size() - 1;
+        }
+        stat_samples_ += processed_samples;
+        if (!inline_)
+            progress_queue_.push(progress_t{(int)job.samples.size(), processed_samples, total_samples, partial_loss});
+    }
+
+    // warp.cc:192-201 (Q-12)
+    void update_parameters() override {
+        SGD::update_parameters();
+        const int D = D_;
+#pragma omp parallel for schedule(static)
+        for (int i = 0; i < Q_rows_; ++i) {
+            float* q = &Q_[(size_t)i * D];
+            float n = std::max(1.0f, std::sqrt(dotf(q, q, D)));
+            for (int k = 0; k < D; ++k) q[k] /= n;
+        }
+#pragma omp parallel for schedule(static)
+        for (int u = 0; u < P_rows_; ++u) {
+            float* p = &P_[(size_t)u * D];
+            float n = std::max(1.0f, std::sqrt(dotf(p, p, D)));
+            for (int k = 0; k < D; ++k) p[k] /= n;
+        }
+    }
+
+    // warp.cc:205-226
+    double compute_loss(int32_t n, const int32_t* users, const int32_t* positives, const int32_t* negatives) {
+        int num_workers = std::max(1, opt_.i("num_workers"));
+        omp_set_num_threads(num_workers);
+        double threshold = opt_.d("threshold");
+        std::vector<int> loss(num_workers, 0);
+#pragma omp parallel for schedule(static)
+        for (int idx = 0; idx < n; ++idx) {
+            int u = users[idx], i = positives[idx], j = negatives[idx];
+            double x_ui = score(&P_[(size_t)u * D_], &Q_[(size_t)i * D_]);
+            double x_uj = score(&P_[(size_t)u * D_], &Q_[(size_t)j * D_]);
+            loss[omp_get_thread_num()] += int((x_ui - x_uj) < threshold);
+        }
+        double l = double(std::accumulate(loss.begin(), loss.end(), 0));
+        return l / (double)n;
+    }
+};
+
+// ============================================================================
+// CALS  (lib/algo_impl/als/als.cc) + Algorithm::_leastsquare (lib/algo.cc:39-131)
+// ============================================================================
+class ALS {
+ public:
+    Opt opt_;
+    float *P_ = nullptr, *Q_ = nullptr;
+    int P_rows_ = 0, Q_rows_ = 0, D_ = 0;
+    std::vector<float> FF_;  // D x D; symmetric so the reference's col-major storage is immaterial
+    bool use_ialspp_ = false;
+    char optimizer_code_ = 0;
+    int num_cg_max_iters_ = 3;      // include/buffalo/algo.hpp:88
+    float cg_tolerance_ = 1e-10f;   // :89
+    float eps_ = 1e-10f;            // :90
+
+    // als.cc:30-69
+    bool init() {
+        int num_workers = std::max(1, opt_.i("num_workers"));
+        omp_set_num_threads(num_workers);
+        int d = opt_.i("d");
+        D_ = d;
+        FF_.assign((size_t)d * d, 0.f);
+        eps_ = (float)opt_.d("eps");
+        cg_tolerance_ = (float)opt_.d("cg_tolerance");
+        num_cg_max_iters_ = opt_.i("num_cg_max_iters");
+        std::string optimizer = opt_.s("optimizer");
+        if (d >= 128) optimizer = "ialspp";  // Q-13
+        use_ialspp_ = false;
+        if (optimizer == "llt") optimizer_code_ = 0;
+        else if (optimizer == "ldlt") optimizer_code_ = 1;
+        else if (optimizer == "manual_cg") optimizer_code_ = 2;
+        else if (optimizer == "ialspp") { use_ialspp_ = true; optimizer_code_ = 8; }
+        else return false;  // eigen_* Krylov solvers are out of scope
+        return true;
+    }
+    // als.cc:77-84
+    void initialize_model(float* P, int P_rows, float* Q, int Q_rows) {
+        P_ = P; P_rows_ = P_rows; Q_ = Q; Q_rows_ = Q_rows;
+    }
+    // als.cc:86-93
+    void precompute(int axis) {
+        const float* F = axis == 0 ? Q_ : P_;
+        const int rows = axis == 0 ? Q_rows_ : P_rows_;
+        const int D = D_;
+        // float products accumulated blockwise; Eigen's GEMM order is not reproducible anyway.
+        const int nth = std::max(1, opt_.i("num_workers"));
+        std::vector<std::vector<float>> part(nth, std::vector<float>((size_t)D * D, 0.f));
+#pragma omp parallel num_threads(nth)
+        {
+            std::vector<float>& a = part[omp_get_thread_num()];
+#pragma omp for schedule(static)
+            for (int r = 0; r < rows; ++r) {
+                const float* f = F + (size_t)r * D;
+                for (int i = 0; i < D; ++i) {
+                    const float fi = f[i];
+                    float* ai = &a[(size_t)i * D];
+                    for (int j = 0; j < D; ++j) ai[j] += fi * f[j];
+                }
+            }
+        }
+        for (size_t k = 0; k < (size_t)D * D; ++k) {
+            float s = 0.f;
+            for (int t = 0; t < nth; ++t) s += part[t][k];
+            FF_[k] = s;
+        }
+    }
+
+    // lib/algo.cc:39-82.  A is D x D row-major symmetric, y length D, x = row to update.
+    void leastsquare(float* x, std::vector<float>& A, const std::vector<float>& y) {
+        const int D = D_;
+        if (optimizer_code_ == 0 || optimizer_code_ == 1) {
+            // case 0: A.llt().solve(y); case 1: A.ldlt().solve(y).  Both are exact solves of an SPD
+            // system; restated as an unpivoted Cholesky (llt) / LDL^T (ldlt) in float.
+            std::vector<float> L(A);
+            std::vector<float> z(y);
+            if (optimizer_code_ == 0) {
+                for (int j = 0; j < D; ++j) {
+                    float s = L[(size_t)j * D + j];
+                    for (int k = 0; k < j; ++k) s -= L[(size_t)j * D + k] * L[(size_t)j * D + k];
+                    float ljj = std::sqrt(s);
+                    L[(size_t)j * D + j] = ljj;
+                    for (int i = j + 1; i < D; ++i) {
+                        float t = L[(size_t)i * D + j];
+                        for (int k = 0; k < j; ++k) t -= L[(size_t)i * D + k] * L[(size_t)j * D + k];
+                        L[(size_t)i * D + j] = t / ljj;
+                    }
+                }
+                for (int i = 0; i < D; ++i) {
+                    float t = z[i];
+                    for (int k = 0; k < i; ++k) t -= L[(size_t)i * D + k] * z[k];
+                    z[i] = t / L[(size_t)i * D + i];
+                }
+                for (int i = D - 1; i >= 0; --i) {
+                    float t = z[i];
+                    for (int k = i + 1; k < D; ++k) t -= L[(size_t)k * D + i] * z[k];
+                    z[i] = t / L[(size_t)i * D + i];
+                }
+            } else {
+                std::vector<float> dg(D);
+                for (int j = 0; j < D; ++j) {
+                    float s = L[(size_t)j * D + j];
+                    for (int k = 0; k < j; ++k) s -= L[(size_t)j * D + k] * L[(size_t)j * D + k] * dg[k];
+                    dg[j] = s;
+                    for (int i = j + 1; i < D; ++i) {
+                        float t = L[(size_t)i * D + j];
+                        for (int k = 0; k < j; ++k) t -= L[(size_t)i * D + k] * L[(size_t)j * D + k] * dg[k];
+                        L[(size_t)i * D + j] = t / s;
+                    }
+                }
+                for (int i = 0; i < D; ++i) {
+                    float t = z[i];
+                    for (int k = 0; k < i; ++k) t -= L[(size_t)i * D + k] * z[k];
+                    z[i] = t;
+                }
+                for (int i = 0; i < D; ++i) z[i] /= dg[i];
+                for (int i = D - 1; i >= 0; --i) {
+                    float t = z[i];
+                    for (int k = i + 1; k < D; ++k) t -= L[(size_t)k * D + i] * z[k];
+                    z[i] = t;
+                }
+            }
+            for (int i = 0; i < D; ++i) x[i] = z[i];
+            return;
+        }
+        // case 2: manual conjugate gradient (algo.cc:58-82, Q-17)
+        std::vector<float> r(D), p(D), Ap(D);
+        auto rowmat = [&](const float* v, std::vector<float>& out) {  // out = v * A
+            for (int j = 0; j < D; ++j) out[j] = 0.f;
+            for (int i = 0; i < D; ++i) {
+                const float vi = v[i];
+                const float* Ai = &A[(size_t)i * D];
+                for (int j = 0; j < D; ++j) out[j] += vi * Ai[j];
+            }
+        };
+        rowmat(x, Ap);
+        for (int i = 0; i < D; ++i) r[i] = y[i] - Ap[i];
+        if (dotf(y.data(), y.data(), D) < dotf(r.data(), r.data(), D)) {
+            for (int i = 0; i < D; ++i) x[i] = 0.f;
+            r = y;
+        }
+        p = r;
+        float rs_old = dotf(r.data(), r.data(), D);
+        for (int it = 0; it < num_cg_max_iters_; ++it) {
+            rowmat(p.data(), Ap);
+            float alpha = rs_old / (dotf(Ap.data(), p.data(), D) + eps_);
+            for (int i = 0; i < D; ++i) x[i] += alpha * p[i];
+            for (int i = 0; i < D; ++i) r[i] -= alpha * Ap[i];
+            float rs_new = dotf(r.data(), r.data(), D);
+            if (rs_new < cg_tolerance_) break;
+            float beta = rs_new / (rs_old + eps_);
+            for (int i = 0; i < D; ++i) p[i] = r[i] + beta * p[i];
+            rs_old = rs_new;
+        }
+    }
+
+    // als.cc:95-105
+    std::pair<double, double> partial_update(int start_x, int next_x, const int64_t* indptr,
+                                             const int32_t* keys, const float* vals, int axis) {
+        if (use_ialspp_) return partial_update_ialspp(start_x, next_x, indptr, keys, vals, axis);
+        return partial_update_dense(start_x, next_x, indptr, keys, vals, axis);
+    }
+
+    // als.cc:107-209
+    std::pair<double, double> partial_update_dense(int start_x, int next_x, const int64_t* indptr,
+                                                   const int32_t* keys, const float* vals, int axis) {
+        if ((next_x - start_x) == 0) return std::make_pair(0.0, 0.0);
+        float reg = axis == 0 ? (float)opt_.d("reg_u") : (float)opt_.d("reg_i");
+        float* P = axis == 0 ? P_ : Q_;
+        const float* Q = axis == 0 ? Q_ : P_;
+        const int Q_rows = axis == 0 ? Q_rows_ : P_rows_;
+        const int D = D_;
+        const int num_workers = std::max(1, opt_.i("num_workers"));
+        const bool adaptive_reg = opt_.b("adaptive_reg");
+        const bool closs = opt_.b("compute_loss_on_training");
+        const float alpha = (float)opt_.d("alpha");
+        omp_set_num_threads(num_workers);
+        std::vector<double> loss_nume(num_workers, 0.0), loss_deno(num_workers, 0.0);
+        const int end_loop = next_x - start_x;
+        const int64_t shifted = start_x == 0 ? 0 : indptr[start_x - 1];
+#pragma omp parallel num_threads(num_workers)
+        {
+            int worker_id = omp_get_thread_num();
+            std::vector<float> m((size_t)D * D), Fxy(D), tmp(D);
+#pragma omp for schedule(dynamic, 4)
+            for (int i = 0; i < end_loop; ++i) {
+                int x = start_x + i;
+                const int u = x;
+                int64_t beg = x == 0 ? 0 : indptr[x - 1];
+                int64_t end = indptr[x];
+                int64_t data_size = end - beg;
+                if (data_size == 0) continue;  // Q-16: empty rows are left unchanged
+                float* Pu = &P[(size_t)u * D];
+                std::fill(m.begin(), m.end(), 0.f);
+                std::fill(Fxy.begin(), Fxy.end(), 0.f);
+                if (closs && axis == 1) {
+                    // P.row(u).dot(P.row(u) * FF_)
+                    for (int j = 0; j < D; ++j) {
+                        float s = 0.f;
+                        for (int k = 0; k < D; ++k) s += Pu[k] * FF_[(size_t)k * D + j];
+                        tmp[j] = s;
+                    }
+                    loss_nume[worker_id] += dotf(Pu, tmp.data(), D);
+                    loss_deno[worker_id] += Q_rows;
+                }
+                for (int64_t it = beg; it < end; ++it) {
+                    const int c = keys[it - shifted];
+                    const float v = vals[it - shifted];
+                    const float* q = &Q[(size_t)c * D];
+                    const float coef = (float)(1.0 + v * alpha);
+                    for (int k = 0; k < D; ++k) Fxy[k] += q[k] * coef;
+                    // FiF += (v q)^T q   (Fs^T * Fs2, scaled by alpha below)
+                    for (int a = 0; a < D; ++a) {
+                        const float va = v * q[a];
+                        float* ma = &m[(size_t)a * D];
+                        for (int b = 0; b < D; ++b) ma[b] += va * q[b];
+                    }
+                    if (closs && axis == 1) {
+                        float dot = dotf(Pu, q, D);
+                        loss_nume[worker_id] -= dot * dot;
+                        loss_nume[worker_id] += (dot - 1) * (dot - 1) * (1.0 + v * alpha);
+                        loss_deno[worker_id] += v * alpha;
+                    }
+                }
+                for (size_t k = 0; k < (size_t)D * D; ++k) m[k] = FF_[k] + m[k] * alpha;
+                float ada_reg = adaptive_reg ? (float)data_size : 1.0f;
+                if (closs) loss_nume[worker_id] += ada_reg * reg * dotf(Pu, Pu, D);
+                for (int d = 0; d < D; ++d) m[(size_t)d * D + d] += (reg * ada_reg);
+                leastsquare(Pu, m, Fxy);
+            }
+        }
+        return std::make_pair(std::accumulate(loss_nume.begin(), loss_nume.end(), 0.0),
+                              std::accumulate(loss_deno.begin(), loss_deno.end(), 0.0));
+    }
+
+    // als.cc:211-358 (Q-14).  Rows are independent (Yui is indexed per nnz), so the reference's
+    // "for block: for row" nest is restated as "for row: for block".
+    std::pair<double, double> partial_update_ialspp(int start_x, int next_x, const int64_t* indptr,
+                                                    const int32_t* keys, const float* vals, int axis) {
+        if ((next_x - start_x) == 0) return std::make_pair(0.0, 0.0);
+        float reg = axis == 0 ? (float)opt_.d("reg_u") : (float)opt_.d("reg_i");
+        float* P = axis == 0 ? P_ : Q_;
+        const float* Q = axis == 0 ? Q_ : P_;
+        const int Q_rows = axis == 0 ? Q_rows_ : P_rows_;
+        const int D = D_;
+        const int num_workers = std::max(1, opt_.i("num_workers"));
+        const bool adaptive_reg = opt_.b("adaptive_reg");
+        const bool closs = opt_.b("compute_loss_on_training");
+        const float alpha = (float)opt_.d("alpha");
+        const int block_size_ = std::min(D, opt_.i("block_size"));
+        omp_set_num_threads(num_workers);
+        std::vector<double> loss_nume(num_workers, 0.0), loss_deno(num_workers, 0.0);
+        const int end_loop = next_x - start_x;
+        const int64_t shifted = start_x == 0 ? 0 : indptr[start_x - 1];
+        // Q-15: the reference sizes Yui as indptr[end_loop-1], which is the chunk nnz only when the
+        // chunk starts at row 0; sized correctly here (identical in single-chunk mode).
+        std::vector<float> Yui((size_t)(indptr[next_x - 1] - shifted));
+#pragma omp parallel for schedule(dynamic, 16)
+        for (int i = 0; i < end_loop; ++i) {
+            int x = start_x + i;
+            int64_t beg = x == 0 ? 0 : indptr[x - 1];
+            int64_t end = indptr[x];
+            for (int64_t it = beg; it < end; ++it)
+                Yui[it - shifted] = dotf(&P[(size_t)x * D], &Q[(size_t)keys[it - shifted] * D], D);
+        }
+#pragma omp parallel num_threads(num_workers)
+        {
+            int worker_id = omp_get_thread_num();
+            std::vector<float> pc(D), b, xs, r, pv, Ap, tmp(D);
+#pragma omp for schedule(dynamic, 4)
+            for (int i = 0; i < end_loop; ++i) {
+                int x = start_x + i;
+                const int u = x;
+                int64_t beg = x == 0 ? 0 : indptr[x - 1];
+                int64_t end = indptr[x];
+                int64_t data_size = end - beg;
+                if (data_size == 0) continue;
+                float* Pu = &P[(size_t)u * D];
+                for (int block_beg = 0; block_beg < D; block_beg += block_size_) {
+                    int bs = block_size_;
+                    if (block_beg + bs >= D) bs = D - block_beg;
+                    // p: copy of the whole row at block start (const FactorType& p = P.row(u))
+                    for (int k = 0; k < D; ++k) pc[k] = Pu[k];
+                    b.assign(bs, 0.f);
+                    // b = p * gramian + reg * block_p,  gramian = FF_.block(0, block_beg, D, bs)
+                    for (int j = 0; j < bs; ++j) {
+                        float s = 0.f;
+                        for (int k = 0; k < D; ++k) s += pc[k] * FF_[(size_t)k * D + block_beg + j];
+                        b[j] = s + reg * pc[block_beg + j];
+                    }
+                    if (block_beg == 0 && closs && axis == 1) {
+                        for (int j = 0; j < D; ++j) {
+                            float s = 0.f;
+                            for (int k = 0; k < D; ++k) s += Pu[k] * FF_[(size_t)k * D + j];
+                            tmp[j] = s;
+                        }
+                        loss_nume[worker_id] += dotf(Pu, tmp.data(), D);
+                        loss_deno[worker_id] += Q_rows;
+                    }
+                    for (int64_t it = beg; it < end; ++it) {
+                        const int col = keys[it - shifted];
+                        const float val = vals[it - shifted];
+                        float residual = Yui[it - shifted] - 1.0;
+                        const float* v = &Q[(size_t)col * D + block_beg];
+                        const float coef = residual * val * alpha;
+                        for (int j = 0; j < bs; ++j) b[j] += coef * v[j];
+                        if ((block_beg == 0) && closs && axis == 1) {
+                            float dot = dotf(Pu, &Q[(size_t)col * D], D);
+                            loss_nume[worker_id] -= dot * dot;
+                            loss_nume[worker_id] += (dot - 1) * (dot - 1) * (1.0 + val * alpha);
+                            loss_deno[worker_id] += val * alpha;
+                        }
+                    }
+                    float ada_reg = adaptive_reg ? (float)data_size : 1.0f;
+                    if ((block_beg == 0) && closs) loss_nume[worker_id] += ada_reg * reg * dotf(Pu, Pu, D);
+                    // CG (hard-coded 3 steps, plain reg, no eps; rs in double)
+                    xs.assign(bs, 0.f);
+                    r = b;
+                    pv = r;
+                    Ap.assign(bs, 0.f);
+                    double rsold = dotf(r.data(), r.data(), bs);
+                    if (rsold > cg_tolerance_) {
+                        for (int cg_step = 0; cg_step < 3; ++cg_step) {
+                            // Ap = A * p,  A = FF[blk,blk] + I*reg
+                            for (int a = 0; a < bs; ++a) {
+                                float s = 0.f;
+                                for (int c = 0; c < bs; ++c)
+                                    s += (FF_[(size_t)(block_beg + a) * D + block_beg + c] + (a == c ? reg : 0.f)) * pv[c];
+                                Ap[a] = s;
+                            }
+                            for (int64_t it = beg; it < end; ++it) {
+                                const int col = keys[it - shifted];
+                                const float val = vals[it - shifted];
+                                const float* v = &Q[(size_t)col * D + block_beg];
+                                const float coef = val * alpha * dotf(v, pv.data(), bs);
+                                for (int j = 0; j < bs; ++j) Ap[j] += coef * v[j];
+                            }
+                            float step_size = rsold / dotf(pv.data(), Ap.data(), bs);
+                            for (int j = 0; j < bs; ++j) xs[j] += step_size * pv[j];
+                            for (int j = 0; j < bs; ++j) r[j] -= step_size * Ap[j];
+                            double rsnew = dotf(r.data(), r.data(), bs);
+                            if (rsnew < cg_tolerance_) break;
+                            const float ratio = (float)(rsnew / rsold);
+                            for (int j = 0; j < bs; ++j) pv[j] = r[j] + ratio * pv[j];
+                            rsold = rsnew;
+                        }
+                    }
+                    for (int j = 0; j < bs; ++j) Pu[block_beg + j] -= xs[j];
+                    for (int64_t it = beg; it < end; ++it) {
+                        const int col = keys[it - shifted];
+                        Yui[it - shifted] -= dotf(&Q[(size_t)col * D + block_beg], xs.data(), bs);
+                    }
+                }
+            }
+        }
+        return std::make_pair(std::accumulate(loss_nume.begin(), loss_nume.end(), 0.0),
+                              std::accumulate(loss_deno.begin(), loss_deno.end(), 0.0));
+    }
+};
+
+struct Handle {
+    int kind;  // 0 bpr, 1 warp, 2 als
+    SGD* sgd = nullptr;
+    ALS* als = nullptr;
+    std::vector<int32_t> trace;
+    Opt* opt() { return kind == 2 ? &als->opt_ : &sgd->opt_; }
+};
+
+}  // namespace
+
+// ============================================================================
+// C ABI consumed by oracle/oracle.py (ctypes)
+// ============================================================================
+extern "C" {
+
+void* orc_create(int kind) {
+    Handle* h = new Handle();
+    h->kind = kind;
+    if (kind == 0) h->sgd = new BPR();
+    else if (kind == 1) h->sgd = new WARP();
+    else h->als = new ALS();
+    return h;
+}
+void orc_destroy(void* hp) {
+    Handle* h = (Handle*)hp;
+    delete h->sgd;
+    delete h->als;
+    delete h;
+}
+void orc_opt_num(void* hp, const char* k, double v) { ((Handle*)hp)->opt()->num[k] = v; }
+void orc_opt_str(void* hp, const char* k, const char* v) { ((Handle*)hp)->opt()->str[k] = v; }
+void orc_opt_bool(void* hp, const char* k, int v) { ((Handle*)hp)->opt()->boo[k] = v != 0; }
+int orc_init(void* hp) {
+    Handle* h = (Handle*)hp;
+    return h->kind == 2 ? (int)h->als->init() : (int)h->sgd->init();
+}
+void orc_set_modes(void* hp, int sampler, int pos_order, int inline_mode) {
+    Handle* h = (Handle*)hp;
+    h->sgd->sampler_ = sampler;
+    h->sgd->pos_order_ = pos_order;
+    h->sgd->inline_ = inline_mode;
+}
+void orc_trace(void* hp, int on) {
+    Handle* h = (Handle*)hp;
+    h->trace.clear();
+    h->sgd->trace_ = on ? &h->trace : nullptr;
+}
+int64_t orc_trace_size(void* hp) { return (int64_t)((Handle*)hp)->trace.size() / 3; }
+void orc_trace_copy(void* hp, int32_t* out) {
+    Handle* h = (Handle*)hp;
+    std::memcpy(out, h->trace.data(), h->trace.size() * sizeof(int32_t));
+}
+void orc_sgd_initialize_model(void* hp, float* P, int P_rows, float* Q, int Q_rows, float* Qb, int64_t n) {
+    ((Handle*)hp)->sgd->initialize_model(P, P_rows, Q, Q_rows, Qb, n);
+}
+void orc_sgd_set_cumulative_table(void* hp, int64_t* t, int size) {
+    Handle* h = (Handle*)hp;
+    h->sgd->cum_table_ = t;
+    h->sgd->cum_table_size_ = size;
+}
+void orc_sgd_launch_workers(void* hp) { ((Handle*)hp)->sgd->launch_workers(); }
+void orc_sgd_add_jobs(void* hp, int s, int n, const int64_t* indptr, const int32_t* keys) {
+    ((Handle*)hp)->sgd->add_jobs(s, n, indptr, keys);
+}
+void orc_sgd_update_parameters(void* hp) { ((Handle*)hp)->sgd->update_parameters(); }
+void orc_sgd_wait_until_done(void* hp) { ((Handle*)hp)->sgd->wait_until_done(); }
+double orc_sgd_join(void* hp) { return ((Handle*)hp)->sgd->join(); }
+double orc_sgd_compute_loss(void* hp, int n, const int32_t* u, const int32_t* p, const int32_t* q) {
+    Handle* h = (Handle*)hp;
+    if (h->kind == 0) return static_cast<BPR*>(h->sgd)->compute_loss(n, u, p, q);
+    return static_cast<WARP*>(h->sgd)->compute_loss(n, u, p, q);
+}
+void orc_sgd_stats(void* hp, long long* out3) {
+    SGD* s = ((Handle*)hp)->sgd;
+    out3[0] = s->stat_samples_;
+    out3[1] = s->stat_scored_negs_;
+    out3[2] = s->stat_updates_;
+}
+// optimizer state access for tests: which = 0 gradP,1 gradQ,2 gradQb,3 momP,4 momQ,5 momQb,6 velP,7 velQ,8 velQb
+float* orc_sgd_state(void* hp, int which, int64_t* n) {
+    SGD* s = ((Handle*)hp)->sgd;
+    std::vector<float>* v[] = {&s->gradP_, &s->gradQ_, &s->gradQb_, &s->momP_, &s->momQ_, &s->momQb_,
+                               &s->velP_, &s->velQ_, &s->velQb_};
+    *n = (int64_t)v[which]->size();
+    return v[which]->data();
+}
+void orc_bpr_exp_table(void* hp, float* out) {
+    BPR* b = static_cast<BPR*>(((Handle*)hp)->sgd);
+    b->build_exp_table();
+    std::memcpy(out, b->exp_table_, sizeof(float) * EXP_TABLE_SIZE);
+}
+void orc_als_initialize_model(void* hp, float* P, int P_rows, float* Q, int Q_rows) {
+    ((Handle*)hp)->als->initialize_model(P, P_rows, Q, Q_rows);
+}
+void orc_als_precompute(void* hp, int axis) { ((Handle*)hp)->als->precompute(axis); }
+void orc_als_get_ff(void* hp, float* out) {
+    ALS* a = ((Handle*)hp)->als;
+    std::memcpy(out, a->FF_.data(), a->FF_.size() * sizeof(float));
+}
+void orc_als_partial_update(void* hp, int s, int n, const int64_t* indptr, const int32_t* keys,
+                            const float* vals, int axis, double* out2) {
+    auto r = ((Handle*)hp)->als->partial_update(s, n, indptr, keys, vals, axis);
+    out2[0] = r.first;
+    out2[1] = r.second;
+}
+void orc_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out) {
+    philox4x32_10(c0, c1, c2, c3, k0, k1, out);
+}
+void orc_counter_draw(uint32_t seed, uint32_t stream, uint64_t pos_idx, uint32_t slot, uint32_t epoch,
+                      uint32_t attempt, uint32_t* out) {
+    counter_draw(seed, stream, pos_idx, slot, epoch, attempt, out);
+}
+
+}  // extern "C"

@@ -1,0 +1,250 @@
+"""ctypes front for the CPU oracle (TEST INFRASTRUCTURE ONLY -- see buffalo_oracle.cc header).
+
+The three classes expose the method surface of the reference's CPU Cython bindings so that
+parity tests read like the reference's own tests:
+
+* ``OracleBPRMF``  ~ ``buffalo.algo._bpr.CyBPRMF``   (/root/reference/buffalo/algo/_bpr.pyx:35-92)
+* ``OracleWARP``   ~ ``buffalo.algo._warp.CyWARP``   (/root/reference/buffalo/algo/_warp.pyx)
+* ``OracleALS``    ~ ``buffalo.algo._als.CyALS``     (/root/reference/buffalo/algo/_als.pyx:24-63)
+
+Only tests/, ``__graft_entry__.smoke()`` and ``bench.py``'s cpu_baseline leg may import this.
+"""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libbuffalo_oracle.so")
+_lib = None
+
+
+def build(force=False):
+    """Compile the oracle with the reference's CPU flags (oracle/Makefile)."""
+    src = os.path.join(_HERE, "buffalo_oracle.cc")
+    if (not force and os.path.exists(_LIB_PATH)
+            and os.path.getmtime(_LIB_PATH) >= os.path.getmtime(src)):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-C", _HERE, "-B", "libbuffalo_oracle.so"],
+                          stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        build()
+    L = C.CDLL(_LIB_PATH)
+    vp, i32, i64, f64 = C.c_void_p, C.c_int, C.c_int64, C.c_double
+    pf = C.POINTER(C.c_float)
+    pi32 = C.POINTER(C.c_int32)
+    pi64 = C.POINTER(C.c_int64)
+    pu32 = C.POINTER(C.c_uint32)
+    sig = {
+        "orc_create": (vp, [i32]),
+        "orc_destroy": (None, [vp]),
+        "orc_opt_num": (None, [vp, C.c_char_p, f64]),
+        "orc_opt_str": (None, [vp, C.c_char_p, C.c_char_p]),
+        "orc_opt_bool": (None, [vp, C.c_char_p, i32]),
+        "orc_init": (i32, [vp]),
+        "orc_set_modes": (None, [vp, i32, i32, i32]),
+        "orc_trace": (None, [vp, i32]),
+        "orc_trace_size": (i64, [vp]),
+        "orc_trace_copy": (None, [vp, pi32]),
+        "orc_sgd_initialize_model": (None, [vp, pf, i32, pf, i32, pf, i64]),
+        "orc_sgd_set_cumulative_table": (None, [vp, pi64, i32]),
+        "orc_sgd_launch_workers": (None, [vp]),
+        "orc_sgd_add_jobs": (None, [vp, i32, i32, pi64, pi32]),
+        "orc_sgd_update_parameters": (None, [vp]),
+        "orc_sgd_wait_until_done": (None, [vp]),
+        "orc_sgd_join": (f64, [vp]),
+        "orc_sgd_compute_loss": (f64, [vp, i32, pi32, pi32, pi32]),
+        "orc_sgd_stats": (None, [vp, C.POINTER(C.c_longlong)]),
+        "orc_sgd_state": (pf, [vp, i32, pi64]),
+        "orc_bpr_exp_table": (None, [vp, pf]),
+        "orc_als_initialize_model": (None, [vp, pf, i32, pf, i32]),
+        "orc_als_precompute": (None, [vp, i32]),
+        "orc_als_get_ff": (None, [vp, pf]),
+        "orc_als_partial_update": (None, [vp, i32, i32, pi64, pi32, pf, i32, C.POINTER(f64)]),
+        "orc_philox": (None, [C.c_uint32] * 6 + [pu32]),
+        "orc_counter_draw": (None, [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32,
+                                    C.c_uint32, pu32]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def _p(a, ct):
+    return a.ctypes.data_as(C.POINTER(ct))
+
+
+def _chk(a, dtype, ndim=None):
+    assert isinstance(a, np.ndarray) and a.dtype == dtype and a.flags["C_CONTIGUOUS"], \
+        "expected C-contiguous %s ndarray" % dtype
+    if ndim is not None:
+        assert a.ndim == ndim
+    return a
+
+
+class _Base:
+    KIND = -1
+
+    def __init__(self):
+        self._h = lib().orc_create(self.KIND)
+        self._keep = {}
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().orc_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def init(self, opt_path):
+        """Reads the option JSON exactly like `Algorithm::parse_option` (lib/algo.cc:19-37):
+        returns False when the file is missing or unparsable."""
+        if isinstance(opt_path, bytes):
+            opt_path = opt_path.decode("utf-8")
+        try:
+            with open(opt_path) as fin:
+                opt = json.load(fin)
+        except (OSError, ValueError):
+            return False
+        L = lib()
+        for k, v in opt.items():
+            kb = k.encode()
+            if isinstance(v, bool):
+                L.orc_opt_bool(self._h, kb, int(v))
+            elif isinstance(v, (int, float)):
+                L.orc_opt_num(self._h, kb, float(v))
+            elif isinstance(v, str):
+                L.orc_opt_str(self._h, kb, v.encode())
+        return bool(L.orc_init(self._h))
+
+
+class _SGDBase(_Base):
+    def set_modes(self, sampler="mt19937", pos_order="unordered_set", inline=False):
+        """Oracle-only switches; defaults are the reference behaviour.
+
+        sampler: "mt19937" (reference) | "counter" (Philox draws shared with the HIP kernels)
+        pos_order: "unordered_set" (reference, Q-3) | "csr"
+        inline: process jobs inside add_jobs on the caller thread (deterministic lr, Q-8)
+        """
+        lib().orc_set_modes(self._h, {"mt19937": 0, "counter": 1}[sampler],
+                            {"unordered_set": 0, "csr": 1}[pos_order], int(inline))
+
+    def initialize_model(self, P, Q, Qb, num_total_samples):
+        _chk(P, np.float32, 2), _chk(Q, np.float32, 2), _chk(Qb, np.float32, 2)
+        self._keep.update(P=P, Q=Q, Qb=Qb)
+        lib().orc_sgd_initialize_model(self._h, _p(P, C.c_float), P.shape[0], _p(Q, C.c_float),
+                                       Q.shape[0], _p(Qb, C.c_float), int(num_total_samples))
+
+    def set_cumulative_table(self, cum_table, size):
+        _chk(cum_table, np.int64, 1)
+        self._keep["cum"] = cum_table
+        lib().orc_sgd_set_cumulative_table(self._h, _p(cum_table, C.c_int64), int(size))
+
+    def launch_workers(self):
+        lib().orc_sgd_launch_workers(self._h)
+
+    def add_jobs(self, start_x, next_x, indptr, keys):
+        _chk(indptr, np.int64, 1), _chk(keys, np.int32, 1)
+        lib().orc_sgd_add_jobs(self._h, int(start_x), int(next_x), _p(indptr, C.c_int64),
+                               _p(keys, C.c_int32))
+
+    def update_parameters(self):
+        lib().orc_sgd_update_parameters(self._h)
+
+    def wait_until_done(self):
+        lib().orc_sgd_wait_until_done(self._h)
+
+    def join(self):
+        return lib().orc_sgd_join(self._h)
+
+    def compute_loss(self, users, positives, negatives):
+        _chk(users, np.int32, 1), _chk(positives, np.int32, 1), _chk(negatives, np.int32, 1)
+        return lib().orc_sgd_compute_loss(self._h, users.shape[0], _p(users, C.c_int32),
+                                          _p(positives, C.c_int32), _p(negatives, C.c_int32))
+
+    # ---- oracle-only introspection -------------------------------------------------
+    def trace(self, on=True):
+        lib().orc_trace(self._h, int(on))
+
+    def get_trace(self):
+        n = lib().orc_trace_size(self._h)
+        out = np.zeros((n, 3), dtype=np.int32)
+        if n:
+            lib().orc_trace_copy(self._h, _p(out, C.c_int32))
+        return out
+
+    def stats(self):
+        out = (C.c_longlong * 3)()
+        lib().orc_sgd_stats(self._h, out)
+        return {"samples": out[0], "scored_negatives": out[1], "updates": out[2]}
+
+    def state(self, name):
+        idx = ["gradP", "gradQ", "gradQb", "momP", "momQ", "momQb", "velP", "velQ", "velQb"].index(name)
+        n = C.c_int64(0)
+        ptr = lib().orc_sgd_state(self._h, idx, C.byref(n))
+        if n.value == 0:
+            return np.zeros(0, dtype=np.float32)
+        return np.ctypeslib.as_array(ptr, shape=(n.value,)).copy()
+
+
+class OracleBPRMF(_SGDBase):
+    KIND = 0
+
+    def exp_table(self):
+        out = np.zeros(1000, dtype=np.float32)
+        lib().orc_bpr_exp_table(self._h, _p(out, C.c_float))
+        return out
+
+
+class OracleWARP(_SGDBase):
+    KIND = 1
+
+
+class OracleALS(_Base):
+    KIND = 2
+
+    def initialize_model(self, P, Q):
+        _chk(P, np.float32, 2), _chk(Q, np.float32, 2)
+        self._keep.update(P=P, Q=Q)
+        lib().orc_als_initialize_model(self._h, _p(P, C.c_float), P.shape[0], _p(Q, C.c_float),
+                                       Q.shape[0])
+
+    def precompute(self, axis):
+        lib().orc_als_precompute(self._h, int(axis))
+
+    def get_ff(self, d):
+        out = np.zeros((d, d), dtype=np.float32)
+        lib().orc_als_get_ff(self._h, _p(out, C.c_float))
+        return out
+
+    def partial_update(self, start_x, next_x, indptr, keys, vals, axis):
+        _chk(indptr, np.int64, 1), _chk(keys, np.int32, 1), _chk(vals, np.float32, 1)
+        out = (C.c_double * 2)()
+        lib().orc_als_partial_update(self._h, int(start_x), int(next_x), _p(indptr, C.c_int64),
+                                     _p(keys, C.c_int32), _p(vals, C.c_float), int(axis), out)
+        return out[0], out[1]
+
+
+def philox4x32_10(ctr, key):
+    out = (C.c_uint32 * 4)()
+    lib().orc_philox(*[int(c) for c in ctr], *[int(k) for k in key], out)
+    return [int(x) for x in out]
+
+
+def counter_draw(seed, stream, pos_idx, slot, epoch, attempt):
+    out = (C.c_uint32 * 4)()
+    lib().orc_counter_draw(seed, stream, pos_idx, slot, epoch, attempt, out)
+    return [int(x) for x in out]

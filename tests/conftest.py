@@ -1,0 +1,109 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` through gpurun)")
+
+
+def has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if has_gpu():
+        return
+    skip = pytest.mark.skip(reason="no GPU visible")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture
+def opt_file(tmp_path):
+    """dict -> temp JSON option file, like `create_temporary_option_from_dict`
+    (/root/reference/buffalo/misc/_aux.py:82-89)."""
+    counter = [0]
+
+    def make(opt):
+        counter[0] += 1
+        p = tmp_path / ("opt_%d.json" % counter[0])
+        p.write_text(json.dumps(opt))
+        return str(p)
+    return make
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as orc
+    orc.build()
+    return orc
+
+
+def bpr_opt(**kw):
+    """BPRMFOption defaults (/root/reference/buffalo/algo/options.py:220-252)."""
+    opt = {
+        "evaluation_on_learning": True, "compute_loss_on_training": True, "early_stopping_rounds": 0,
+        "save_best": False, "evaluation_period": 100, "save_period": 10, "random_seed": 0,
+        "validation": {}, "accelerator": False, "use_bias": True, "num_workers": 1,
+        "hyper_threads": 256, "num_iters": 100, "d": 20, "update_i": True, "update_j": True,
+        "reg_u": 0.025, "reg_i": 0.025, "reg_j": 0.025, "reg_b": 0.025, "optimizer": "sgd",
+        "lr": 0.002, "min_lr": 0.0001, "beta1": 0.9, "beta2": 0.999, "eps": 1e-10,
+        "per_coordinate_normalize": False, "num_negative_samples": 1, "sampling_power": 0.0,
+        "verify_neg": True, "random_positive": False, "model_path": "", "data_opt": {},
+    }
+    opt.update(kw)
+    return opt
+
+
+def warp_opt(**kw):
+    """WARPOption defaults (options.py:286-311)."""
+    opt = {
+        "evaluation_on_learning": True, "compute_loss_on_training": True, "early_stopping_rounds": 0,
+        "save_best": False, "evaluation_period": 5, "save_period": 10, "random_seed": 0,
+        "validation": {}, "accelerator": False, "num_workers": 1, "hyper_threads": 256,
+        "num_iters": 40, "d": 64, "threshold": 1.0, "score_func": "dot", "max_trials": 500,
+        "update_i": True, "update_j": True, "reg_u": 0.0, "reg_i": 0.0, "reg_j": 0.0,
+        "optimizer": "adagrad", "lr": 0.05, "min_lr": 0.0001, "beta1": 0.9, "beta2": 0.999,
+        "eps": 1e-10, "per_coordinate_normalize": False, "model_path": "", "data_opt": {},
+    }
+    opt.update(kw)
+    return opt
+
+
+def als_opt(**kw):
+    """ALSOption defaults (options.py:66-86)."""
+    opt = {
+        "evaluation_on_learning": True, "compute_loss_on_training": True, "early_stopping_rounds": 0,
+        "save_best": False, "evaluation_period": 1, "save_period": 10, "random_seed": 0,
+        "validation": {}, "adaptive_reg": False, "save_factors": False, "accelerator": False,
+        "d": 20, "num_iters": 10, "num_workers": 1, "hyper_threads": 256, "num_cg_max_iters": 3,
+        "reg_u": 0.1, "reg_i": 0.1, "alpha": 8.0, "optimizer": "manual_cg", "cg_tolerance": 1e-10,
+        "block_size": 32, "eps": 1e-10, "model_path": "", "data_opt": {},
+    }
+    opt.update(kw)
+    return opt
+
+
+def tiny_csr(U=12, I=17, density=0.3, seed=3, counts=False):
+    from buffalo_amd.synth import CSR
+    rng = np.random.default_rng(seed)
+    M = rng.random((U, I)) < density
+    M[np.arange(U), rng.integers(0, I, size=U)] = True  # no empty rows
+    r, c = np.nonzero(M)
+    cnt = np.bincount(r, minlength=U)
+    vals = (1 + rng.poisson(1.0, size=c.shape[0])).astype(np.float32) if counts \
+        else np.ones(c.shape[0], dtype=np.float32)
+    return CSR(U, I, np.cumsum(cnt, dtype=np.int64), c.astype(np.int32), vals)

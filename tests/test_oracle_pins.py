@@ -1,0 +1,315 @@
+"""Pins for the CPU oracle: the reference has no golden vectors for its training arithmetic
+(SURVEY.md section 4), so the C++ restatement is checked against independent numpy transliterations
+(tests/ref_numpy.py), analytic micro-cases and published known-answer vectors."""
+import numpy as np
+import pytest
+
+from conftest import als_opt, bpr_opt, tiny_csr, warp_opt
+import ref_numpy as rn
+
+
+def test_philox_known_answers(oracle):
+    for ctr, key, want in rn.PHILOX_KAT:
+        assert tuple(rn.philox4x32_10(ctr, key)) == want
+        assert tuple(oracle.philox4x32_10(ctr, key)) == want
+    for args in [(7, 0, 0, 0, 0, 0), (777, 1, 20000262, 3, 9, 41), (1, 0, 2 ** 33 + 5, 0, 1, 2)]:
+        assert oracle.counter_draw(*args) == rn.counter_draw(*args)
+
+
+def test_exp_table_and_index(oracle):
+    t = oracle.OracleBPRMF().exp_table()
+    want = rn.exp_table()
+    np.testing.assert_allclose(t, want, rtol=3e-7)  # expf implementations differ by <= 1 ulp
+    # analytic: entry i is sigmoid(-x_i), x_i = (2i/1000 - 1) * 6
+    for i in (0, 500, 999):
+        x = (i / 1000.0 * 2 - 1) * 6
+        assert abs(float(t[i]) - 1.0 / (np.exp(x) + 1.0)) < 1e-6
+    assert abs(float(t[500]) - 0.5) < 1e-7
+    assert 1000 // 6 // 2 == 83 and int((6.0 + 6) * 83) == 996  # Q-2: max index reachable
+
+
+def _bpr(oracle, opt_file, csr, P, Q, Qb, **kw):
+    o = oracle.OracleBPRMF()
+    assert o.init(opt_file(bpr_opt(**kw)))
+    o.initialize_model(P, Q, Qb, csr.nnz)
+    o.set_cumulative_table(np.zeros(csr.num_items, dtype=np.int64), csr.num_items)
+    return o
+
+
+def test_bpr_single_triple_analytic(oracle, opt_file):
+    """1 user, 2 items, d=4: the negative is forced (verify_neg rejects the only positive)."""
+    from buffalo_amd.synth import CSR
+    csr = CSR(1, 2, [1], [0], [1.0])
+    P = np.array([[0.5, -0.25, 0.125, 1.0]], dtype=np.float32)
+    Q = np.array([[0.2, 0.1, -0.3, 0.4], [-0.1, 0.3, 0.2, 0.05]], dtype=np.float32)
+    Qb = np.array([[0.01], [-0.02]], dtype=np.float32)
+    kw = dict(d=4, lr=0.1, min_lr=0.1, num_iters=1, random_seed=5)
+    P0, Q0, Qb0 = P.copy(), Q.copy(), Qb.copy()
+    o = _bpr(oracle, opt_file, csr, P, Q, Qb, **kw)
+    o.set_modes(inline=True)
+    o.launch_workers()
+    o.add_jobs(0, 1, csr.indptr, csr.keys)
+    o.join()
+    opt = bpr_opt(**kw)
+    rn.bpr_sgd_step(P0, Q0, Qb0, 0, 0, 1, 0.1, opt, rn.exp_table())
+    np.testing.assert_allclose(P, P0, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(Q, Q0, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(Qb, Qb0, rtol=1e-6, atol=1e-8)
+    # hand formula for the user row makes Q-1 explicit: P uses the UPDATED item rows
+    x = float(np.dot([0.5, -0.25, 0.125, 1.0], np.array([0.2, 0.1, -0.3, 0.4]) - [-0.1, 0.3, 0.2, 0.05])
+              + 0.03)
+    logit = float(rn.exp_table()[int((x + 6) * 83)])
+    assert abs(logit - 1 / (1 + np.exp(x))) < 2e-2  # LUT (index step 1/83, table step 12/1000) is only ~1e-2 accurate
+
+
+@pytest.mark.parametrize("optimizer", ["sgd", "adagrad", "adam"])
+def test_bpr_epoch_matches_transliteration(oracle, opt_file, optimizer):
+    """Replay the oracle's own (u,pos,neg) trace through the numpy transliteration."""
+    csr = tiny_csr(U=10, I=14, seed=11)
+    d = 6
+    rng = np.random.default_rng(1)
+    P = rng.normal(scale=0.3, size=(csr.num_users, d)).astype(np.float32)
+    Q = rng.normal(scale=0.3, size=(csr.num_items, d)).astype(np.float32)
+    Qb = rng.normal(scale=0.1, size=(csr.num_items, 1)).astype(np.float32)
+    kw = dict(d=d, lr=0.05, min_lr=0.05, num_iters=2, random_seed=7, optimizer=optimizer,
+              num_negative_samples=2, per_coordinate_normalize=(optimizer == "adam"))
+    P0, Q0, Qb0 = P.copy(), Q.copy(), Qb.copy()
+    o = _bpr(oracle, opt_file, csr, P, Q, Qb, **kw)
+    o.set_modes(inline=True)
+    o.trace(True)
+    o.launch_workers()
+    opt = bpr_opt(**kw)
+    table = rn.exp_table()
+    gP, gQ, gQb = np.zeros_like(P0), np.zeros_like(Q0), np.zeros(csr.num_items, dtype=np.float32)
+    st = {k: np.zeros_like(v) for k, v in (("mP", P0), ("vP", P0), ("mQ", Q0), ("vQ", Q0))}
+    mb, vb = np.zeros((csr.num_items, 1), np.float32), np.zeros((csr.num_items, 1), np.float32)
+    seen_total = 0
+    for it in range(2):
+        o.add_jobs(0, csr.num_users, csr.indptr, csr.keys)
+        tr = o.get_trace()[seen_total:]
+        seen_total += len(tr)
+        assert len(tr) == csr.nnz * 2
+        cntP, cntQ = np.zeros(csr.num_users, int), np.zeros(csr.num_items, int)
+        for k, (u, pos, neg) in enumerate(tr):
+            if optimizer == "sgd":
+                rn.bpr_sgd_step(P0, Q0, Qb0, u, pos, neg, 0.05, opt, table)
+            else:
+                rn.bpr_accumulate_step(P0, Q0, Qb0, gP, gQ, gQb, u, pos, neg, opt, table)
+                cntQ[neg] += 1            # bpr.cc:139-143: per negative
+                if k % 2 == 1:            # bpr.cc:175-181: per positive (after its negatives)
+                    cntP[u] += 1
+                    cntQ[pos] += 1
+        o.update_parameters()
+        if optimizer != "sgd":
+            g2 = gQb.reshape(-1, 1)
+            if opt["per_coordinate_normalize"]:  # Q-9: gradQb is divided together with gradQ
+                nz = cntQ > 0
+                g2[nz, 0] = g2[nz, 0] / cntQ[nz].astype(np.float32)
+            rn.update_parameters(P0, gP, st["mP"], st["vP"], cntP, opt["reg_u"], opt, it)
+            rn.update_parameters(Q0, gQ, st["mQ"], st["vQ"], cntQ, opt["reg_i"], opt, it)
+            o2 = dict(opt, per_coordinate_normalize=False)
+            rn.update_parameters(Qb0, g2, mb, vb, None, opt["reg_b"], o2, it)
+    o.join()
+    np.testing.assert_allclose(P, P0, rtol=2e-5, atol=2e-7)
+    np.testing.assert_allclose(Q, Q0, rtol=2e-5, atol=2e-7)
+    np.testing.assert_allclose(Qb, Qb0, rtol=2e-5, atol=2e-7)
+    if optimizer != "sgd":  # Q-6: grad buffers keep the transformed step (never re-zeroed)
+        np.testing.assert_allclose(o.state("gradP").reshape(P.shape), gP, rtol=2e-5, atol=2e-7)
+        assert np.abs(o.state("gradQ")).max() > 0
+
+
+def test_bpr_sampling_quirks(oracle, opt_file):
+    """Q-3 (unordered_set order), Q-4 (lower_bound on int64 cumulative counts), verify_neg."""
+    csr = tiny_csr(U=8, I=20, seed=5)
+    d = 4
+    P, Q, Qb = [np.zeros((n, c), np.float32) for n, c in ((8, d), (20, d), (20, 1))]
+    o = _bpr(oracle, opt_file, csr, P, Q, Qb, d=d, random_seed=3, sampling_power=1.0, lr=0.0, min_lr=0.0)
+    cnt = np.bincount(csr.keys, minlength=20).astype(np.int64)
+    cum = np.cumsum(cnt)
+    o.set_cumulative_table(cum, 20)
+    o.set_modes(inline=True)
+    o.trace(True)
+    o.launch_workers()
+    for _ in range(30):
+        o.add_jobs(0, 8, csr.indptr, csr.keys)
+    tr = o.get_trace()
+    for u in range(8):
+        keys, _ = csr.row(u)
+        m = tr[:, 0] == u
+        assert set(tr[m, 1]) == set(keys)               # every positive visited
+        assert not (set(tr[m, 2]) & set(keys))          # verify_neg
+        first = tr[m, 1][:len(keys)]
+        assert sorted(first) == sorted(keys)
+    # popularity sampling: an item with zero count whose predecessor has cum==r can still be drawn
+    # (lower_bound quirk), but items are overwhelmingly drawn ~ counts
+    neg_hist = np.bincount(tr[:, 2], minlength=20)
+    assert neg_hist[np.argmax(cnt)] > neg_hist[np.argmin(cnt)]
+
+
+def test_threaded_equals_inline_with_one_worker(oracle, opt_file):
+    """Q-8: with min_lr == lr the reference path is deterministic for num_workers == 1."""
+    csr = tiny_csr(U=30, I=40, seed=9)
+    d = 8
+    outs = []
+    for inline in (False, True):
+        rng = np.random.default_rng(2)
+        P = rng.normal(scale=0.2, size=(30, d)).astype(np.float32)
+        Q = rng.normal(scale=0.2, size=(40, d)).astype(np.float32)
+        Qb = np.zeros((40, 1), np.float32)
+        o = _bpr(oracle, opt_file, csr, P, Q, Qb, d=d, lr=0.03, min_lr=0.03, num_iters=3, random_seed=7)
+        o.set_modes(inline=inline)
+        o.launch_workers()
+        for _ in range(3):
+            o.add_jobs(0, 30, csr.indptr, csr.keys)
+            o.update_parameters()
+            o.wait_until_done()
+        o.join()
+        outs.append((P, Q, Qb))
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_inline_lr_decay_per_call(oracle, opt_file):
+    """Deterministic idealisation of Q-8: lr(call) = max(min_lr, lr - (lr-min_lr)*processed/total),
+    processed counting job.size = sum(1 + n_pos)."""
+    from buffalo_amd.synth import CSR
+    csr = CSR(2, 3, [1, 2], [0, 1], [1.0, 1.0])
+    P = np.array([[1.0], [1.0]], np.float32)
+    Q = np.zeros((3, 1), np.float32)
+    Qb = np.zeros((3, 1), np.float32)
+    kw = dict(d=1, lr=0.5, min_lr=0.1, num_iters=2, reg_u=1.0, reg_i=0, reg_j=0, reg_b=0,
+              update_i=False, update_j=False, use_bias=False)
+    o = _bpr(oracle, opt_file, csr, P, Q, Qb, **kw)
+    o.set_modes(inline=True)
+    o.launch_workers()
+    o.add_jobs(0, 2, csr.indptr, csr.keys)   # lr = 0.5: P *= (1 - 0.5)
+    np.testing.assert_allclose(P, [[0.5], [0.5]], rtol=1e-6)
+    o.add_jobs(0, 2, csr.indptr, csr.keys)   # progress = 4 / (2*2) = 1 -> lr = 0.1
+    np.testing.assert_allclose(P, [[0.45], [0.45]], rtol=1e-6)
+
+
+def test_warp_epoch_matches_transliteration(oracle, opt_file):
+    csr = tiny_csr(U=9, I=25, seed=4)
+    d = 5
+    rng = np.random.default_rng(8)
+    P = rng.normal(scale=0.8, size=(9, d)).astype(np.float32)
+    Q = rng.normal(scale=0.8, size=(25, d)).astype(np.float32)
+    Qb = np.zeros((25, 1), np.float32)
+    kw = dict(d=d, random_seed=13, max_trials=12, threshold=0.6, reg_u=0.01, reg_i=0.02, reg_j=0.03,
+              num_iters=2, lr=0.05)
+    o = oracle.OracleWARP()
+    assert o.init(opt_file(warp_opt(**kw)))
+    P0, Q0 = P.copy(), Q.copy()
+    o.initialize_model(P, Q, Qb, csr.nnz)
+    o.set_modes(sampler="counter", pos_order="csr", inline=True)
+    o.launch_workers()
+    opt = warp_opt(**kw)
+    gP, gQ = np.zeros_like(P0), np.zeros_like(Q0)
+    vP, vQ = np.zeros_like(P0), np.zeros_like(Q0)
+    scored = accepted = 0
+    for epoch in range(2):
+        o.add_jobs(0, 9, csr.indptr, csr.keys)
+        for u in range(9):
+            keys, _ = csr.row(u)
+            beg = 0 if u == 0 else int(csr.indptr[u - 1])
+            seen = set(int(k) for k in keys)
+            for k, pos in enumerate(keys):
+                draw = lambda a, idx=beg + k: (rn.counter_draw(13, 1, idx, 0, epoch, a)[0] * 25) >> 32
+                ok, _, trial, ns = rn.warp_positive(P0, Q0, gP, gQ, u, int(pos), seen, draw, opt)
+                scored += ns
+                accepted += int(ok)
+        o.update_parameters()
+        rn.update_parameters(P0, gP, None, vP, None, opt["reg_u"], opt, epoch)
+        rn.update_parameters(Q0, gQ, None, vQ, None, opt["reg_i"], opt, epoch)
+        rn.unit_ball_project(Q0)
+        rn.unit_ball_project(P0)
+    st = o.stats()
+    assert st["scored_negatives"] == scored and st["updates"] == accepted
+    assert 0 < accepted < csr.nnz * 2  # both the accept and the give-up branch were exercised
+    np.testing.assert_allclose(P, P0, rtol=3e-5, atol=3e-7)
+    np.testing.assert_allclose(Q, Q0, rtol=3e-5, atol=3e-7)
+
+
+def test_warp_trial_counting_q10(oracle, opt_file):
+    """k-th counted try accepted => trial == 2k; skipped when trial >= max_trials."""
+    P = np.array([[1.0, 0.0]], np.float32)
+    Q = np.array([[5.0, 0], [0.0, 0], [0.0, 0], [0.0, 0]], np.float32)  # ui - uj = 5 > threshold: never violates
+    gP, gQ = np.zeros_like(P), np.zeros_like(Q)
+    opt = warp_opt(max_trials=7, threshold=1.0)
+    ok, _, trial, scored = rn.warp_positive(P, Q, gP, gQ, 0, 0, {0}, lambda a: 1 + a % 3, opt)
+    assert not ok and scored == 4 and trial == 9          # 1 -> 3 -> 5 -> 7 -> 9 (> max_trials)
+    Q[2, 0] = 4.5                                         # violator at the 2nd counted try
+    ok, neg, trial, scored = rn.warp_positive(P, Q, gP, gQ, 0, 0, {0}, lambda a: 1 + a % 3, opt)
+    assert ok and neg == 2 and trial == 4 and scored == 2
+    Phi = np.log(max(1, (4 - 1 - 1) // 4))
+    assert Phi == 0.0 and np.all(gQ == 0)                 # Phi = log(max(1, 0)) = 0: zero update
+
+
+@pytest.mark.parametrize("optimizer", ["llt", "ldlt", "manual_cg"])
+@pytest.mark.parametrize("axis", [0, 1])
+def test_als_dense_row_solve(oracle, opt_file, optimizer, axis):
+    csr = tiny_csr(U=11, I=13, seed=6, counts=True)
+    mat = csr if axis == 0 else csr.transpose()
+    d = 7
+    rng = np.random.default_rng(3)
+    P = np.abs(rng.normal(scale=0.3, size=(11, d))).astype(np.float32)
+    Q = np.abs(rng.normal(scale=0.3, size=(13, d))).astype(np.float32)
+    kw = dict(d=d, optimizer=optimizer, alpha=4.0, reg_u=0.2, reg_i=0.3, adaptive_reg=(axis == 1))
+    o = oracle.OracleALS()
+    assert o.init(opt_file(als_opt(**kw)))
+    P0, Q0 = P.copy(), Q.copy()
+    o.initialize_model(P, Q)
+    o.precompute(axis)
+    X0, Y0 = (P0, Q0) if axis == 0 else (Q0, P0)
+    FF = (Y0.astype(np.float64).T @ Y0.astype(np.float64)).astype(np.float32)
+    np.testing.assert_allclose(o.get_ff(d), FF, rtol=1e-5, atol=1e-6)
+    nume, deno = o.partial_update(0, mat.num_users, mat.indptr, mat.keys, mat.vals, axis)
+    reg = kw["reg_u"] if axis == 0 else kw["reg_i"]
+    X = P if axis == 0 else Q
+    wn = wd = 0.0
+    for u in range(mat.num_users):
+        keys, vals = mat.row(u)
+        A, y = rn.als_normal_equations(X0, Y0, FF, u, keys, vals, 4.0, reg, kw["adaptive_reg"])
+        n_, d_ = rn.als_loss_terms(X0, Y0, FF, u, keys, vals, 4.0, reg, kw["adaptive_reg"], axis)
+        wn, wd = wn + n_, wd + d_
+        if optimizer == "manual_cg":
+            want = rn.manual_cg(X0[u], A, y)
+            assert np.abs(X[u] - want).max() <= 1e-4 * np.abs(want).max()  # 3 fp32 CG steps
+        else:
+            want = np.linalg.solve(A, y)
+            np.testing.assert_allclose(X[u], want, rtol=5e-4, atol=5e-6)
+    assert abs(nume - wn) <= 1e-4 * max(1.0, abs(wn)) and abs(deno - wd) <= 1e-4 * max(1.0, abs(wd))
+
+
+def test_als_empty_rows_untouched_q16(oracle, opt_file):
+    from buffalo_amd.synth import CSR
+    csr = CSR(3, 4, [2, 2, 3], [0, 3, 1], [1, 2, 1])
+    P = np.full((3, 4), 0.25, np.float32)
+    Q = np.abs(np.random.default_rng(0).normal(size=(4, 4))).astype(np.float32)
+    o = oracle.OracleALS()
+    assert o.init(opt_file(als_opt(d=4, optimizer="llt")))
+    o.initialize_model(P, Q)
+    o.precompute(0)
+    o.partial_update(0, 3, csr.indptr, csr.keys, csr.vals, 0)
+    assert np.all(P[1] == 0.25) and not np.allclose(P[0], 0.25)
+
+
+@pytest.mark.parametrize("d,block", [(12, 5), (128, 32)])
+def test_ialspp_matches_transliteration(oracle, opt_file, d, block):
+    csr = tiny_csr(U=6, I=9, seed=8, counts=True)
+    rng = np.random.default_rng(5)
+    P = np.abs(rng.normal(scale=0.2, size=(6, d))).astype(np.float32)
+    Q = np.abs(rng.normal(scale=0.2, size=(9, d))).astype(np.float32)
+    o = oracle.OracleALS()
+    assert o.init(opt_file(als_opt(d=d, optimizer="ialspp" if d < 128 else "manual_cg",  # Q-13
+                                   block_size=block, alpha=3.0, reg_u=0.15)))
+    P0, Q0 = P.copy(), Q.copy()
+    o.initialize_model(P, Q)
+    o.precompute(0)
+    FF = o.get_ff(d)
+    o.partial_update(0, 6, csr.indptr, csr.keys, csr.vals, 0)
+    for u in range(6):
+        keys, vals = csr.row(u)
+        want = rn.ialspp_row(P0, Q0, FF, u, keys, vals, 3.0, 0.15, block)
+        assert np.abs(P[u] - want).max() <= 3e-4 * np.abs(want).max()  # 3 fp32 CG steps per block
+    assert not np.allclose(P, P0)
