@@ -1,0 +1,237 @@
+#!/usr/bin/env python
+"""Headline benchmark: BPRMF training throughput on ML-20M-shaped synthetic interactions, d=128.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one epoch of the hot path: one `add_jobs` pass of the fused sampler + BPR update kernel
+over every interaction of the (resident) CSR, followed by `update_parameters` (a no-op for sgd).
+N=1 runs BASELINE.json configs[1]; N>1 is launched by torch.distributed.run, one rank per GPU, users
+sharded, item factors replicated and delta-all-reduced over RCCL once per minibatch (buffalo_amd/dist.py).
+Rank 0 prints ONE JSON line (metric/value/roofline/cpu_baseline ...).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+D = 128
+
+
+def bpr_options(num_iters, seed=7, **kw):
+    opt = {  # BPRMFOption defaults (/root/reference/buffalo/algo/options.py:220-252) at d=128
+        "evaluation_on_learning": False, "compute_loss_on_training": False, "early_stopping_rounds": 0,
+        "save_best": False, "evaluation_period": 100, "save_period": 10, "random_seed": seed,
+        "validation": {}, "accelerator": True, "use_bias": True, "num_workers": 8, "hyper_threads": 256,
+        "num_iters": num_iters, "d": D, "update_i": True, "update_j": True, "reg_u": 0.025,
+        "reg_i": 0.025, "reg_j": 0.025, "reg_b": 0.025, "optimizer": "sgd", "lr": 0.002,
+        "min_lr": 0.0001, "beta1": 0.9, "beta2": 0.999, "eps": 1e-10, "per_coordinate_normalize": False,
+        "num_negative_samples": 1, "sampling_power": 0.0, "verify_neg": True, "random_positive": False,
+        "model_path": "", "data_opt": {},
+    }
+    opt.update(kw)
+    return opt
+
+
+def write_opt(opt):
+    import tempfile
+    f = tempfile.NamedTemporaryFile(mode="w", suffix=".json", delete=False)
+    json.dump(opt, f)
+    f.close()
+    return f.name
+
+
+def load_matrix(shape_name, seed):
+    """Synthetic CSR; cached under /tmp so repeated runs on one box skip the ~25 s generation."""
+    from buffalo_amd import synth
+    U, I, nnz = synth.SHAPES[shape_name]
+    cache = "/tmp/bfh_synth_%s_%d.npz" % (shape_name, seed)
+    if os.path.exists(cache):
+        z = np.load(cache)
+        return synth.CSR(U, I, z["indptr"], z["keys"], np.ones(z["keys"].shape[0], np.float32))
+    csr = synth.generate(U, I, nnz, seed=seed)
+    try:
+        np.savez(cache, indptr=csr.indptr, keys=csr.keys)
+    except OSError:
+        pass
+    return csr
+
+
+def cpu_baseline(csr, target_seconds=12.0):
+    """The oracle (restatement of the reference CPU path, reference's compile flags) timed on this
+    box's host cores over a bounded prefix of the same workload."""
+    from oracle import oracle as orc
+    from buffalo_amd import synth
+    orc.build()
+    cores = os.cpu_count() or 1
+    I = csr.num_items
+
+    def run(n_users):
+        nnz = int(csr.indptr[n_users - 1])
+        opt = bpr_options(1, accelerator=False, num_workers=cores)
+        P, Q, Qb = synth.init_factors(n_users, I, D, seed=7)
+        o = orc.OracleBPRMF()
+        path = write_opt(opt)
+        assert o.init(path)
+        os.unlink(path)
+        o.initialize_model(P, Q, Qb, nnz)
+        o.set_cumulative_table(np.zeros(I, np.int64), I)
+        o.launch_workers()
+        keys = np.ascontiguousarray(csr.keys[:nnz])
+        ip = np.ascontiguousarray(csr.indptr[:n_users])
+        t0 = time.perf_counter()
+        o.add_jobs(0, n_users, ip, keys)
+        o.join()                     # returns when every queued job has been processed
+        dt = time.perf_counter() - t0
+        return nnz, dt
+
+    probe_users = int(np.searchsorted(csr.indptr, 300000)) + 1
+    nnz0, dt0 = run(probe_users)
+    rate0 = nnz0 / dt0
+    want = int(min(csr.nnz, max(nnz0, rate0 * target_seconds)))
+    n_users = min(csr.num_users, int(np.searchsorted(csr.indptr, want)) + 1)
+    nnz1, dt1 = run(n_users)
+    return {"value": nnz1 / dt1, "unit": "updates/s", "cores": cores, "kind": "port",
+            "sample": "first %d users (%d interactions, 1 epoch) of the same matrix, %d std::thread workers, %.1f s"
+                      % (n_users, nnz1, cores, dt1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--shape", default="ml20m")
+    ap.add_argument("--seed", type=int, default=7)
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--minibatches", type=int, default=1, help="all-reduce points per epoch (N>1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", action="append", default=[], help="backend knob name=value (e.g. hogwild_atomic=0)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from buffalo_amd import synth
+    from buffalo_amd.backend import CyBPR
+    from buffalo_amd.dist import DataParallelSGD, HipEngine, shard_csr
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, "WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus)
+
+    csr = load_matrix(args.shape, args.seed)
+    U, I, nnz = csr.num_users, csr.num_items, csr.nnz
+    if world > 1 and args.scaling == "strong":
+        u0, u1, ip, keys, nnz_off = shard_csr(csr.indptr, csr.keys, rank, world)
+        total_nnz = nnz
+    else:
+        # weak scaling: every rank trains its own ML-20M-shaped user population against shared items
+        u0, u1, ip, keys, nnz_off = 0, U, csr.indptr, csr.keys, rank * nnz
+        total_nnz = nnz * world
+    n_local_users = u1 - u0
+    local_nnz = int(keys.shape[0])
+
+    steps, warmup = args.steps, args.warmup
+    opt = bpr_options(num_iters=steps + warmup, seed=args.seed)
+    P, Q, Qb = synth.init_factors(U, I, D, seed=args.seed)
+    P = np.ascontiguousarray(P[u0:u1])
+
+    obj = CyBPR()
+    obj.set_device(local_rank)
+    path = write_opt(opt)
+    assert obj.init(path)
+    os.unlink(path)
+    obj.sync_every_epoch = False           # keep the model in HBM inside the timed region
+    for kv in args.mode:
+        k, v = kv.split("=")
+        obj.set_mode(k, int(v))
+    obj.initialize_model(P, Q, Qb, total_nnz, True)
+    obj.set_cumulative_table(np.zeros(I, np.int64), I)
+    obj.set_resident_csr(ip, keys)        # inputs resident in HBM before the timed region starts
+    obj.set_shard(nnz_off, world)
+    dp = DataParallelSGD(HipEngine(obj, I, D, opt["optimizer"]), opt["optimizer"]) if world > 1 else None
+    edges = np.linspace(0, n_local_users, (args.minibatches if world > 1 else 1) + 1).astype(int)
+
+    def step():
+        for a, b in zip(edges[:-1], edges[1:]):
+            if b <= a:
+                continue
+            if dp is not None:
+                dp.minibatch(int(a), int(b), ip, None)
+            else:
+                obj.add_jobs(int(a), int(b), ip, None)
+        obj.update_parameters()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    obj.reset_stats()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    st = obj.stats()
+
+    if rank == 0:
+        updates = float(total_nnz) * opt["num_negative_samples"] * steps
+        # roofline of the dominant kernel (bpr_update_kernel), HIP events on the backend's stream
+        bytes_per_update = 24 * D + 20            # read+write P_u, Q_i, Q_j, 2 biases, key
+        kernel_ms = st["kernel_ms"] / max(st["launches"], 1)
+        alg_bytes = bytes_per_update * (st["samples"] / max(st["launches"], 1))
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "BPRMF training throughput (interactions/s), ML-20M-shaped synthetic, d=128",
+            "value": updates / elapsed, "unit": "updates/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BPRMF sgd, %s-shaped synthetic (%d x %d, %d nnz%s), d=%d, 1 negative/positive, "
+                                   "uniform sampling + verify_neg, CSR + factors resident in HBM"
+                                   % (args.shape, U, I, nnz, "" if args.scaling == "strong" or world == 1 else " per GPU", D),
+                       "parallelism": "1 GPU" if world == 1 else "dp%d: users sharded, Q replicated, %d RCCL delta all-reduce/epoch"
+                                      % (world, args.minibatches),
+                       "hogwild": "fp32 atomics" if "hogwild_atomic=0" not in args.mode else "racy stores"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "bpr_update_kernel", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes},
+            "epoch_ms": elapsed / steps * 1e3,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(csr)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

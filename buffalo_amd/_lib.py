@@ -1,0 +1,118 @@
+"""ctypes binding of libbuffalo_hip.so (the C ABI declared in include/buffalo_hip.h).
+
+There is deliberately no fallback: if the shared library is missing or a call fails, an exception
+is raised -- the product path never routes through the CPU oracle or any eager substitute.
+"""
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbuffalo_hip.so")
+HEADER_PATH = os.path.join(_HERE, "..", "include", "buffalo_hip.h")
+
+
+class BuffaloHipError(RuntimeError):
+    """Raised for every non-OK status of the C ABI (the reference raises C++ exceptions through
+    Cython's `except +`: /root/reference/buffalo/algo/cuda/_bpr.pyx:14-23)."""
+
+
+class Stats(C.Structure):
+    _fields_ = [("samples", C.c_int64), ("scored_negatives", C.c_int64), ("accepted", C.c_int64),
+                ("launches", C.c_int64), ("kernel_ms", C.c_double), ("optimizer_ms", C.c_double),
+                ("aux_ms", C.c_double), ("h2d_bytes", C.c_double), ("d2h_bytes", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_vp, _i32, _i64, _f64, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_size_t
+_pf = C.POINTER(C.c_float)
+_pi32 = C.POINTER(C.c_int32)
+_pi64 = C.POINTER(C.c_int64)
+_pf64 = C.POINTER(C.c_double)
+
+
+def _sgd_sigs(pfx):
+    return {
+        pfx + "create": (_vp, []),
+        pfx + "destroy": (None, [_vp]),
+        pfx + "init": (_i32, [_vp, C.c_char_p]),
+        pfx + "get_vdim": (_i32, [_vp]),
+        pfx + "initialize_model": (_i32, [_vp, _pf, _i32, _pf, _pf, _i32, _i64, _i32]),
+        pfx + "set_placeholder": (_i32, [_vp, _pi64, _sz]),
+        pfx + "set_cumulative_table": (_i32, [_vp, _pi64]),
+        pfx + "partial_update": (_i32, [_vp, _i32, _i32, _pi64, _pi32, _pf64, _pf64]),
+        pfx + "update_parameters": (_i32, [_vp]),
+        pfx + "synchronize": (_i32, [_vp, _i32]),
+        pfx + "compute_loss": (_i32, [_vp, _i32, _pi32, _pi32, _pi32, _pf64]),
+        pfx + "set_device": (_i32, [_vp, _i32]),
+        pfx + "set_resident_csr": (_i32, [_vp, _pi64, _pi32, _i64]),
+        pfx + "set_mode": (_i32, [_vp, C.c_char_p, _i64]),
+        pfx + "set_shard": (_i32, [_vp, _i64, _i32]),
+        pfx + "device_buffer": (_i32, [_vp, C.c_char_p, C.POINTER(_vp), C.POINTER(_sz)]),
+        pfx + "stream": (_vp, [_vp]),
+        pfx + "get_stats": (_i32, [_vp, C.POINTER(Stats)]),
+        pfx + "reset_stats": (_i32, [_vp]),
+    }
+
+
+SIGNATURES = {
+    "bfh_version": (C.c_char_p, []),
+    "bfh_last_error": (C.c_char_p, [_vp]),
+    "bfh_device_count": (_i32, []),
+    "bfh_bpr_update_triples": (_i32, [_vp, _i64, _pi32, _pi32, _pi32, _f64]),
+    "bfh_als_create": (_vp, []),
+    "bfh_als_destroy": (None, [_vp]),
+    "bfh_als_init": (_i32, [_vp, C.c_char_p]),
+    "bfh_als_get_vdim": (_i32, [_vp]),
+    "bfh_als_initialize_model": (_i32, [_vp, _pf, _i32, _pf, _i32]),
+    "bfh_als_set_placeholder": (_i32, [_vp, _pi64, _pi64, _sz]),
+    "bfh_als_precompute": (_i32, [_vp, _i32]),
+    "bfh_als_partial_update": (_i32, [_vp, _i32, _i32, _pi64, _pi32, _pf, _i32, _pf64, _pf64]),
+    "bfh_als_set_device": (_i32, [_vp, _i32]),
+    "bfh_als_set_resident_csr": (_i32, [_vp, _i32, _pi64, _pi32, _pf, _i64]),
+    "bfh_als_synchronize": (_i32, [_vp, _i32]),
+    "bfh_als_set_mode": (_i32, [_vp, C.c_char_p, _i64]),
+    "bfh_als_device_buffer": (_i32, [_vp, C.c_char_p, C.POINTER(_vp), C.POINTER(_sz)]),
+    "bfh_als_stream": (_vp, [_vp]),
+    "bfh_als_get_stats": (_i32, [_vp, C.POINTER(Stats)]),
+    "bfh_als_reset_stats": (_i32, [_vp]),
+}
+SIGNATURES.update(_sgd_sigs("bfh_bpr_"))
+SIGNATURES.update(_sgd_sigs("bfh_warp_"))
+
+_lib = None
+
+
+def header_symbols():
+    """Every function name declared in include/buffalo_hip.h."""
+    with open(HEADER_PATH) as fin:
+        text = fin.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(bfh_[a-z0-9_]+)\s*\(", text)))
+
+
+def lib():
+    """Load the shared library (no device access happens here)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BuffaloHipError(
+            "libbuffalo_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `python -m buffalo_amd._build`. There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)  # AttributeError here == ABI drift between header and library
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(handle, status):
+    if status is not None and status < 0:
+        msg = lib().bfh_last_error(handle)
+        raise BuffaloHipError("%s (status %d)" % ((msg or b"").decode("utf-8", "replace"), status))
+    return status

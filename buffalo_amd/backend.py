@@ -1,0 +1,232 @@
+"""Accelerator objects with the method surface of buffalo's Cython CUDA bindings, driving
+libbuffalo_hip.so through its C ABI.
+
+* ``CyBPR``  mirrors ``buffalo.algo.cuda._bpr.CyBPR``  (/root/reference/buffalo/algo/cuda/_bpr.pyx:27-80)
+* ``CyALS``  mirrors ``buffalo.algo.cuda._als.CyALS``  (/root/reference/buffalo/algo/cuda/_als.pyx:25-67)
+* ``CyWARP`` gives WARP the same surface as CyBPR, which is what the (unreachable) accelerator
+  scaffold in /root/reference/buffalo/algo/warp.py:212-234 expects.
+
+Same names, argument order and meaning; numpy arrays are handed over as raw pointers and must stay
+alive while the object uses them (the bindings keep references, like the reference's callers do).
+Failures raise ``BuffaloHipError`` where the reference raises the C++ exception through Cython.
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import BuffaloHipError, Stats, check, lib
+
+
+def _arr(a, dtype, ndim, name):
+    # Cython's typed buffer arguments raise ValueError on dtype / ndim mismatch
+    if not isinstance(a, np.ndarray):
+        raise TypeError("Argument '%s' has incorrect type (expected numpy.ndarray, got %s)" % (name, type(a).__name__))
+    if a.dtype != dtype:
+        raise ValueError("Buffer dtype mismatch for '%s', expected '%s' but got '%s'" % (name, np.dtype(dtype), a.dtype))
+    if a.ndim != ndim:
+        raise ValueError("Buffer has wrong number of dimensions for '%s' (expected %d, got %d)" % (name, ndim, a.ndim))
+    if not a.flags["C_CONTIGUOUS"]:
+        raise ValueError("ndarray '%s' is not C-contiguous" % name)
+    return a
+
+
+def _ptr(a, ct):
+    return a.ctypes.data_as(C.POINTER(ct))
+
+
+def _path(p):
+    return p if isinstance(p, bytes) else str(p).encode("utf-8")
+
+
+class _DeviceView:
+    """__cuda_array_interface__ carrier so torch can alias a backend buffer without a copy."""
+
+    def __init__(self, ptr, shape, typestr, owner):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+        self._owner = owner
+
+
+class _Base:
+    _PFX = None
+
+    def __init__(self):
+        self._L = lib()
+        self._h = getattr(self._L, self._PFX + "create")()
+        if not self._h:
+            raise BuffaloHipError((self._L.bfh_last_error(None) or b"create failed").decode())
+        self._keep = {}
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                getattr(self._L, self._PFX + "destroy")(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def _call(self, name, *args):
+        return check(self._h, getattr(self._L, self._PFX + name)(self._h, *args))
+
+    def init(self, opt_path):
+        return bool(self._call("init", _path(opt_path)))
+
+    def get_vdim(self):
+        return self._call("get_vdim")
+
+    # ---- extensions ---------------------------------------------------------------------------
+    def set_device(self, device):
+        self._call("set_device", int(device))
+
+    def set_mode(self, name, value):
+        self._call("set_mode", name.encode(), int(value))
+
+    def stats(self):
+        s = Stats()
+        self._call("get_stats", C.byref(s))
+        return s.as_dict()
+
+    def reset_stats(self):
+        self._call("reset_stats")
+
+    def stream(self):
+        return getattr(self._L, self._PFX + "stream")(self._h)
+
+    def device_buffer(self, name):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._call("device_buffer", name.encode(), C.byref(p), C.byref(n))
+        return p.value, n.value
+
+    def device_tensor(self, name, shape=None, dtype="float32"):
+        """Zero-copy torch view of a backend buffer (for RCCL collectives via torch.distributed)."""
+        import torch
+        ptr, nbytes = self.device_buffer(name)
+        if not ptr:
+            raise BuffaloHipError("device buffer '%s' is not allocated" % name)
+        item = np.dtype(dtype).itemsize
+        if shape is None:
+            shape = (nbytes // item,)
+        typestr = {"float32": "<f4", "int32": "<i4"}[str(np.dtype(dtype))]
+        return torch.as_tensor(_DeviceView(ptr, shape, typestr, self), device="cuda")
+
+
+class _SgdBase(_Base):
+    """Shared by CyBPR and CyWARP (accelerator surface of cuda/_bpr.pyx)."""
+    # drop-in semantics: the reference copies P,Q,Qb back to the numpy arrays after every epoch
+    # (`update_parameters -> synchronize(True)`, cuda/_bpr.pyx:59-61).  Set False to keep the model
+    # in HBM until `synchronize(True)` is called explicitly.
+    sync_every_epoch = True
+
+    def initialize_model(self, P, Q, Qb, num_nnz, set_gpu=False):
+        _arr(P, np.float32, 2, "P"), _arr(Q, np.float32, 2, "Q"), _arr(Qb, np.float32, 2, "Qb")
+        if set_gpu:
+            vdim = self.get_vdim()
+            if P.shape[1] != vdim or Q.shape[1] != vdim:
+                raise ValueError("factor matrices must be padded to vdim=%d columns (got %d / %d)"
+                                 % (vdim, P.shape[1], Q.shape[1]))
+        if Qb.shape[0] != Q.shape[0]:
+            raise ValueError("Qb must have one row per item")
+        self._keep.update(P=P, Q=Q, Qb=Qb)
+        self._call("initialize_model", _ptr(P, C.c_float), P.shape[0], _ptr(Q, C.c_float), _ptr(Qb, C.c_float),
+                   Q.shape[0], int(num_nnz), int(bool(set_gpu)))
+
+    def set_placeholder(self, indptr, batch_size):
+        _arr(indptr, np.int64, 1, "indptr")
+        self._call("set_placeholder", _ptr(indptr, C.c_int64), int(batch_size))
+
+    def set_cumulative_table(self, sampling_table, size):
+        _arr(sampling_table, np.int64, 1, "sampling_table")
+        self._keep["cum"] = (sampling_table, int(size))
+        if "Q" in self._keep:
+            # the CUDA binding passes only the pointer; Q_rows entries are read (bpr.cu:322-327)
+            if sampling_table.shape[0] < self._keep["Q"].shape[0]:
+                raise ValueError("sampling_table shorter than the number of items")
+            self._call("set_cumulative_table", _ptr(sampling_table, C.c_int64))
+
+    def synchronize(self, device_to_host):
+        self._call("synchronize", int(bool(device_to_host)))
+
+    def update_parameters(self):
+        self._call("update_parameters")
+        if self.sync_every_epoch:
+            self.synchronize(True)
+
+    def wait_until_done(self):
+        return
+
+    def add_jobs(self, start_x, next_x, indptr, keys):
+        _arr(indptr, np.int64, 1, "indptr")
+        loss, n = C.c_double(0), C.c_double(0)
+        kp = None
+        if keys is not None:
+            _arr(keys, np.int32, 1, "keys")
+            kp = _ptr(keys, C.c_int32)
+        self._call("partial_update", int(start_x), int(next_x), _ptr(indptr, C.c_int64), kp, C.byref(loss), C.byref(n))
+        return loss.value, n.value
+
+    def compute_loss(self, user, pos, neg):
+        _arr(user, np.int32, 1, "user"), _arr(pos, np.int32, 1, "pos"), _arr(neg, np.int32, 1, "neg")
+        out = C.c_double(0)
+        self._call("compute_loss", user.shape[0], _ptr(user, C.c_int32), _ptr(pos, C.c_int32), _ptr(neg, C.c_int32),
+                   C.byref(out))
+        return out.value
+
+    # ---- extensions ---------------------------------------------------------------------------
+    def set_resident_csr(self, indptr, keys):
+        _arr(indptr, np.int64, 1, "indptr"), _arr(keys, np.int32, 1, "keys")
+        self._call("set_resident_csr", _ptr(indptr, C.c_int64), _ptr(keys, C.c_int32), int(keys.shape[0]))
+
+    def set_shard(self, nnz_offset, num_shards):
+        self._call("set_shard", int(nnz_offset), int(num_shards))
+
+
+class CyBPR(_SgdBase):
+    _PFX = "bfh_bpr_"
+
+    def update_triples(self, users, pos, neg, lr):
+        _arr(users, np.int32, 1, "users"), _arr(pos, np.int32, 1, "pos"), _arr(neg, np.int32, 1, "neg")
+        check(self._h, self._L.bfh_bpr_update_triples(self._h, users.shape[0], _ptr(users, C.c_int32),
+                                                      _ptr(pos, C.c_int32), _ptr(neg, C.c_int32), float(lr)))
+
+
+class CyWARP(_SgdBase):
+    _PFX = "bfh_warp_"
+
+
+class CyALS(_Base):
+    _PFX = "bfh_als_"
+
+    def initialize_model(self, P, Q):
+        _arr(P, np.float32, 2, "P"), _arr(Q, np.float32, 2, "Q")
+        vdim = self.get_vdim()
+        if P.shape[1] != vdim or Q.shape[1] != vdim:
+            raise ValueError("factor matrices must have vdim=%d columns (got %d / %d)" % (vdim, P.shape[1], Q.shape[1]))
+        self._keep.update(P=P, Q=Q)
+        self._call("initialize_model", _ptr(P, C.c_float), P.shape[0], _ptr(Q, C.c_float), Q.shape[0])
+
+    def set_placeholder(self, lindptr, rindptr, batch_size):
+        _arr(lindptr, np.int64, 1, "lindptr"), _arr(rindptr, np.int64, 1, "rindptr")
+        self._call("set_placeholder", _ptr(lindptr, C.c_int64), _ptr(rindptr, C.c_int64), int(batch_size))
+
+    def precompute(self, axis):
+        self._call("precompute", int(axis))
+
+    def partial_update(self, start_x, next_x, indptr, keys, vals, axis):
+        _arr(indptr, np.int64, 1, "indptr")
+        kp = vp = None
+        if keys is not None:
+            _arr(keys, np.int32, 1, "keys"), _arr(vals, np.float32, 1, "vals")
+            kp, vp = _ptr(keys, C.c_int32), _ptr(vals, C.c_float)
+        nume, deno = C.c_double(0), C.c_double(0)
+        self._call("partial_update", int(start_x), int(next_x), _ptr(indptr, C.c_int64), kp, vp, int(axis),
+                   C.byref(nume), C.byref(deno))
+        return nume.value, deno.value
+
+    # ---- extensions ---------------------------------------------------------------------------
+    def set_resident_csr(self, axis, indptr, keys, vals):
+        _arr(indptr, np.int64, 1, "indptr"), _arr(keys, np.int32, 1, "keys"), _arr(vals, np.float32, 1, "vals")
+        self._call("set_resident_csr", int(axis), _ptr(indptr, C.c_int64), _ptr(keys, C.c_int32),
+                   _ptr(vals, C.c_float), int(keys.shape[0]))
+
+    def synchronize(self, device_to_host):
+        self._call("synchronize", int(bool(device_to_host)))

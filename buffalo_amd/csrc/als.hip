@@ -1,0 +1,78 @@
+// ALS on gfx950 -- C ABI + handle.  Kernels live in als_kernels.hpp.
+//
+// Reference semantics: CALS (/root/reference/lib/algo_impl/als/als.cc:30-358) + Algorithm::_leastsquare
+// (/root/reference/lib/algo.cc:39-82) behind CuALS's object surface
+// (/root/reference/include/buffalo/cuda/als/als.hpp:20-35).
+#include "als_kernels.hpp"
+
+using bfh::AlsHandle;
+using bfh::guarded;
+
+extern "C" {
+
+void* bfh_als_create(void) {
+    try {
+        AlsHandle* h = new AlsHandle();
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) {
+            bfh::g_create_error = "no HIP device available (libbuffalo_hip has no CPU fallback)";
+            delete h;
+            return nullptr;
+        }
+        h->device = dev;
+        return h;
+    } catch (const std::exception& e) {
+        bfh::g_create_error = e.what();
+        return nullptr;
+    }
+}
+void bfh_als_destroy(void* h) { delete static_cast<AlsHandle*>(h); }
+int bfh_als_set_device(void* h, int device) {
+    return guarded(h, [&] { static_cast<AlsHandle*>(h)->device = device; BFH_HIP(hipSetDevice(device)); return BFH_OK; });
+}
+int bfh_als_init(void* h, const char* opt_json_path) {
+    int ok = 0;
+    int rc = guarded(h, [&] { ok = static_cast<AlsHandle*>(h)->init(opt_json_path) ? 1 : 0; return BFH_OK; });
+    return rc == BFH_OK ? ok : rc;
+}
+int bfh_als_get_vdim(void* h) { return h ? static_cast<AlsHandle*>(h)->vdim_ : BFH_ERR_INVALID; }
+int bfh_als_initialize_model(void* h, float* P, int P_rows, float* Q, int Q_rows) {
+    return guarded(h, [&] { static_cast<AlsHandle*>(h)->initialize_model(P, P_rows, Q, Q_rows); return BFH_OK; });
+}
+int bfh_als_set_placeholder(void* h, const int64_t* lindptr, const int64_t* rindptr, size_t batch_size) {
+    return guarded(h, [&] { static_cast<AlsHandle*>(h)->set_placeholder(lindptr, rindptr, batch_size); return BFH_OK; });
+}
+int bfh_als_precompute(void* h, int axis) {
+    return guarded(h, [&] { static_cast<AlsHandle*>(h)->precompute(axis); return BFH_OK; });
+}
+int bfh_als_partial_update(void* h, int start_x, int next_x, const int64_t* indptr, const int32_t* keys, const float* vals,
+                           int axis, double* loss_nume, double* loss_deno) {
+    return guarded(h, [&] {
+        double a = 0, b = 0;
+        static_cast<AlsHandle*>(h)->partial_update(start_x, next_x, indptr, keys, vals, axis, &a, &b);
+        if (loss_nume) *loss_nume = a;
+        if (loss_deno) *loss_deno = b;
+        return BFH_OK;
+    });
+}
+int bfh_als_set_resident_csr(void* h, int axis, const int64_t* indptr, const int32_t* keys, const float* vals, int64_t nnz) {
+    return guarded(h, [&] { static_cast<AlsHandle*>(h)->set_resident_csr(axis, indptr, keys, vals, nnz); return BFH_OK; });
+}
+int bfh_als_synchronize(void* h, int device_to_host) {
+    return guarded(h, [&] { static_cast<AlsHandle*>(h)->synchronize(device_to_host != 0); return BFH_OK; });
+}
+int bfh_als_set_mode(void* h, const char* name, int64_t value) {
+    return guarded(h, [&] { static_cast<AlsHandle*>(h)->set_mode(name ? name : "", value); return BFH_OK; });
+}
+int bfh_als_device_buffer(void* h, const char* name, void** dptr, size_t* bytes) {
+    return guarded(h, [&] { static_cast<AlsHandle*>(h)->device_buffer(name ? name : "", dptr, bytes); return BFH_OK; });
+}
+void* bfh_als_stream(void* h) { return h ? static_cast<void*>(static_cast<AlsHandle*>(h)->stream) : nullptr; }
+int bfh_als_get_stats(void* h, bfh_stats* out) {
+    return guarded(h, [&] { *out = static_cast<AlsHandle*>(h)->stats; return BFH_OK; });
+}
+int bfh_als_reset_stats(void* h) {
+    return guarded(h, [&] { static_cast<AlsHandle*>(h)->stats = bfh_stats{}; return BFH_OK; });
+}
+
+}  // extern "C"

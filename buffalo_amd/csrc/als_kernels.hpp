@@ -1,0 +1,860 @@
+// ALS kernels + handle (gfx950).
+//
+// Reference numerics (all paths relative to /root/reference/):
+//   precompute            CALS::precompute                lib/algo_impl/als/als.cc:86-93
+//   dense row update      CALS::_partial_update           lib/algo_impl/als/als.cc:107-209
+//   row solvers           Algorithm::_leastsquare 0,1,2   lib/algo.cc:52-82
+//   iALS++ block update   CALS::_partial_update_ialspp    lib/algo_impl/als/als.cc:211-358
+// Object surface: CuALS   include/buffalo/cuda/als/als.hpp:20-35.
+//
+// Data layout: factor rows are vdim floats; a wave holds a row as K = vdim/64 dwords per lane
+// (element k*64+lane) so every row access is K fully coalesced 256-B transactions and a dot
+// product is K FMAs + a DPP row reduction.  One wave owns one row of the side being solved; rows
+// are handed out through an atomic ticket (the reference uses omp schedule(dynamic,4)).
+#pragma once
+#include "common.hpp"
+
+namespace bfh {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct AlsParams {
+    float* P;              // side being solved   [rows, vdim]
+    const float* Q;        // other side          [op_rows, vdim]
+    const float* FF;       // [vdim, vdim] Gramian of the other side (symmetric)
+    const int64_t* indptr; // full-matrix end offsets of the side being solved
+    const int32_t* keys;   // chunk-local
+    const float* vals;     // chunk-local
+    float* yui;            // chunk-local scratch (iALS++)
+    int64_t shift;
+    int start_x, next_x;
+    int d, vdim, op_rows, block_size;
+    float alpha, reg, eps, cg_tol;
+    int adaptive_reg, compute_loss, axis, num_cg_max_iters;
+    double* loss;          // [0] nume, [1] deno
+    int* ticket;
+};
+
+template <int K>
+struct ARow {
+    float v[K];
+};
+template <int K>
+__device__ __forceinline__ void aload(ARow<K>& r, const float* __restrict__ base, int lane, int vdim) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int e = k * 64 + lane;
+        r.v[k] = (e < vdim) ? base[e] : 0.0f;
+    }
+}
+template <int K>
+__device__ __forceinline__ void astore(const ARow<K>& r, float* __restrict__ base, int lane, int vdim) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int e = k * 64 + lane;
+        if (e < vdim) base[e] = r.v[k];
+    }
+}
+template <int K>
+__device__ __forceinline__ float adot(const ARow<K>& a, const ARow<K>& b) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) s += a.v[k] * b.v[k];
+    return wave_sum(s);
+}
+// element e (uniform) of a row held in K dwords per lane
+template <int K>
+__device__ __forceinline__ float aget(const ARow<K>& r, int e) {
+    float out = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        if ((e >> 6) == k) out = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.v[k]), e & 63));
+    return out;
+}
+// out = x * FF  (row vector times symmetric matrix), d rows of FF streamed (L1/L2 resident)
+template <int K>
+__device__ __forceinline__ void avecmat(ARow<K>& out, const ARow<K>& x, const float* __restrict__ FF, int d, int vdim, int lane) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) out.v[k] = 0.f;
+    for (int i = 0; i < d; ++i) {
+        const float xi = aget<K>(x, i);
+        ARow<K> f;
+        aload<K>(f, FF + static_cast<size_t>(i) * vdim, lane, vdim);
+#pragma unroll
+        for (int k = 0; k < K; ++k) out.v[k] += xi * f.v[k];
+    }
+}
+
+__device__ __forceinline__ int next_row(int* ticket, int lane) {
+    int r = 0;
+    if (lane == 0) r = atomicAdd(ticket, 1);
+    return __builtin_amdgcn_readfirstlane(r);
+}
+
+// ------------------------------------------------------------------------------------------------
+// FF = F^T F on the matrix cores: v_mfma_f32_32x32x2_f32 (exact fp32).  One wave produces a
+// 32 x (32*NT) strip for a slice of rows; A operand = F[row][bi*32 + (lane&31)], row = r + (lane>>5),
+// B operands = the same two rows at column tiles bj..bj+NT-1.  Partials are combined with fp32
+// atomics into a zeroed FF (cublasSgemm in the reference: lib/cuda/als/als.cu:315-317).
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(64) void als_gramian_kernel(const float* __restrict__ F, int rows, int vdim, int rows_per_slice,
+                                                          float* __restrict__ FF) {
+    const int lane = threadIdx.x;
+    const int T = vdim / 32;
+    const int bi = blockIdx.y;
+    const int bj0 = blockIdx.z * NT;
+    const int r0 = blockIdx.x * rows_per_slice;
+    const int r1 = (r0 + rows_per_slice < rows) ? r0 + rows_per_slice : rows;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int g = 0; g < NT; ++g)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
+    const int half = lane >> 5, col = lane & 31;
+    for (int r = r0; r < r1; r += 2) {
+        const int row = r + half;
+        const bool ok = row < r1;
+        const float* fr = F + static_cast<size_t>(ok ? row : r0) * vdim;
+        const float a = ok ? fr[bi * 32 + col] : 0.f;
+#pragma unroll
+        for (int g = 0; g < NT; ++g) {
+            const float b = (ok && bj0 + g < T) ? fr[(bj0 + g) * 32 + col] : 0.f;
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[g], 0, 0, 0);
+        }
+    }
+    // C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int g = 0; g < NT; ++g) {
+        if (bj0 + g >= T) continue;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int i = (e & 3) + 8 * (e >> 2) + 4 * half;
+            atomic_add_f32(FF + static_cast<size_t>(bi * 32 + i) * vdim + (bj0 + g) * 32 + col, acc[g][e]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// manual_cg row update (optimizer "manual_cg", the default for d < 128): als.cc:107-209 with
+// _leastsquare case 2 (algo.cc:58-82, Q-17), matrix-free: the d x d system matrix
+// A = FF + alpha*sum v q q^T + reg*ada*I is applied as x*FF + alpha*sum v (x.q) q + reg*ada*x.
+// ------------------------------------------------------------------------------------------------
+template <int K>
+__device__ __forceinline__ void als_apply(ARow<K>& out, const ARow<K>& x, const AlsParams& p, int64_t beg, int64_t n,
+                                          float regada, int lane, float* dots_first /* optional: x.q_k of first pass */,
+                                          double* nume, double* deno, bool loss_terms) {
+    avecmat<K>(out, x, p.FF, p.d, p.vdim, lane);
+    if (loss_terms) {  // als.cc:175-178
+        *nume += static_cast<double>(adot<K>(x, out));
+        *deno += static_cast<double>(p.op_rows);
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) out.v[k] += regada * x.v[k];
+    for (int64_t k0 = 0; k0 < n; k0 += 64) {
+        const int64_t kk = k0 + lane;
+        int myc = 0;
+        float myv = 0.f;
+        if (kk < n) {
+            myc = p.keys[beg + kk];
+            myv = p.vals[beg + kk];
+        }
+        const int nh = static_cast<int>((n - k0) < 64 ? (n - k0) : 64);
+        for (int j = 0; j < nh; ++j) {
+            const int c = __builtin_amdgcn_readlane(myc, j);
+            const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myv), j));
+            ARow<K> q;
+            aload<K>(q, p.Q + static_cast<size_t>(c) * p.vdim, lane, p.vdim);
+            const float dot = adot<K>(x, q);
+            const float coef = p.alpha * v * dot;
+#pragma unroll
+            for (int k = 0; k < K; ++k) out.v[k] += coef * q.v[k];
+            if (loss_terms) {  // als.cc:187-192
+                *nume -= static_cast<double>(dot * dot);
+                *nume += static_cast<double>((dot - 1) * (dot - 1)) * (1.0 + static_cast<double>(v * p.alpha));
+                *deno += static_cast<double>(v * p.alpha);
+            }
+        }
+    }
+    (void)dots_first;
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void als_cg_kernel(AlsParams p) {
+    const int lane = threadIdx.x & 63;
+    const int vdim = p.vdim;
+    double nume = 0.0, deno = 0.0;
+    const int nrows = p.next_x - p.start_x;
+    for (int i = next_row(p.ticket, lane); i < nrows; i = next_row(p.ticket, lane)) {
+        const int u = p.start_x + i;
+        const int64_t beg = (u == 0 ? 0 : p.indptr[u - 1]) - p.shift;
+        const int64_t n = p.indptr[u] - p.shift - beg;
+        if (n == 0) continue;  // Q-16: empty rows stay unchanged
+        float* Pu = p.P + static_cast<size_t>(u) * vdim;
+        ARow<K> x, y, r, pv, Ap;
+        aload<K>(x, Pu, lane, vdim);
+        const float ada = p.adaptive_reg ? static_cast<float>(n) : 1.0f;
+        const float regada = p.reg * ada;
+        // y = sum (1 + v*alpha) q   (als.cc:183-185)
+#pragma unroll
+        for (int k = 0; k < K; ++k) y.v[k] = 0.f;
+        for (int64_t k0 = 0; k0 < n; k0 += 64) {
+            const int64_t kk = k0 + lane;
+            int myc = 0;
+            float myv = 0.f;
+            if (kk < n) {
+                myc = p.keys[beg + kk];
+                myv = p.vals[beg + kk];
+            }
+            const int nh = static_cast<int>((n - k0) < 64 ? (n - k0) : 64);
+            for (int j = 0; j < nh; ++j) {
+                const int c = __builtin_amdgcn_readlane(myc, j);
+                const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myv), j));
+                ARow<K> q;
+                aload<K>(q, p.Q + static_cast<size_t>(c) * vdim, lane, vdim);
+                const float coef = static_cast<float>(1.0 + static_cast<double>(v * p.alpha));
+#pragma unroll
+                for (int k = 0; k < K; ++k) y.v[k] += q.v[k] * coef;
+            }
+        }
+        if (p.compute_loss) nume += static_cast<double>(ada * p.reg * adot<K>(x, x));  // als.cc:198-200
+        // r = y - x*A   (algo.cc:61)
+        als_apply<K>(Ap, x, p, beg, n, regada, lane, nullptr, &nume, &deno, p.compute_loss && p.axis == 1);
+#pragma unroll
+        for (int k = 0; k < K; ++k) r.v[k] = y.v[k] - Ap.v[k];
+        if (adot<K>(y, y) < adot<K>(r, r)) {  // algo.cc:63-66
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                x.v[k] = 0.f;
+                r.v[k] = y.v[k];
+            }
+        }
+        pv = r;
+        float rs_old = adot<K>(r, r);
+        for (int it = 0; it < p.num_cg_max_iters; ++it) {
+            double dn = 0, dd = 0;
+            als_apply<K>(Ap, pv, p, beg, n, regada, lane, nullptr, &dn, &dd, false);
+            const float a = rs_old / (adot<K>(Ap, pv) + p.eps);
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                x.v[k] += a * pv.v[k];
+                r.v[k] -= a * Ap.v[k];
+            }
+            const float rs_new = adot<K>(r, r);
+            if (rs_new < p.cg_tol) break;
+            const float beta = rs_new / (rs_old + p.eps);
+#pragma unroll
+            for (int k = 0; k < K; ++k) pv.v[k] = r.v[k] + beta * pv.v[k];
+            rs_old = rs_new;
+        }
+        astore<K>(x, Pu, lane, vdim);
+    }
+    if (p.compute_loss && lane == 0) {
+        if (nume != 0.0) atomicAdd(p.loss, nume);
+        if (deno != 0.0) atomicAdd(p.loss + 1, deno);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// llt / ldlt row update: explicit normal equations in LDS + Cholesky by one wave
+// (als.cc:180-204 + algo.cc:52-57).  Used for d < 128 only (d >= 128 is forced to iALS++, Q-13),
+// so A (vdim x vdim, padded stride) fits LDS: 96*97*4 = 37 KB.
+// ------------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(64) void als_chol_kernel(AlsParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x;
+    const int vdim = p.vdim, D = p.d;
+    const int ld = vdim + 1;
+    float* A = lds;            // [vdim][ld]
+    float* z = lds + vdim * ld;  // [vdim]
+    double nume = 0.0, deno = 0.0;
+    const int nrows = p.next_x - p.start_x;
+    for (int i = next_row(p.ticket, lane); i < nrows; i = next_row(p.ticket, lane)) {
+        const int u = p.start_x + i;
+        const int64_t beg = (u == 0 ? 0 : p.indptr[u - 1]) - p.shift;
+        const int64_t n = p.indptr[u] - p.shift - beg;
+        if (n == 0) continue;
+        float* Pu = p.P + static_cast<size_t>(u) * vdim;
+        ARow<K> x, y;
+        aload<K>(x, Pu, lane, vdim);
+        const float ada = p.adaptive_reg ? static_cast<float>(n) : 1.0f;
+        __syncthreads();
+        // A = 0 (the alpha-scaled sum is built first, FF and the ridge are added afterwards: als.cc:194-202)
+        for (int e = lane; e < vdim * ld; e += 64) A[e] = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) y.v[k] = 0.f;
+        if (p.compute_loss && p.axis == 1) {
+            ARow<K> t;
+            avecmat<K>(t, x, p.FF, D, vdim, lane);
+            nume += static_cast<double>(adot<K>(x, t));
+            deno += static_cast<double>(p.op_rows);
+        }
+        __syncthreads();
+        for (int64_t k0 = 0; k0 < n; k0 += 64) {
+            const int64_t kk = k0 + lane;
+            int myc = 0;
+            float myv = 0.f;
+            if (kk < n) {
+                myc = p.keys[beg + kk];
+                myv = p.vals[beg + kk];
+            }
+            const int nh = static_cast<int>((n - k0) < 64 ? (n - k0) : 64);
+            for (int j = 0; j < nh; ++j) {
+                const int c = __builtin_amdgcn_readlane(myc, j);
+                const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myv), j));
+                ARow<K> q;
+                aload<K>(q, p.Q + static_cast<size_t>(c) * vdim, lane, vdim);
+                const float coef = static_cast<float>(1.0 + static_cast<double>(v * p.alpha));
+#pragma unroll
+                for (int k = 0; k < K; ++k) y.v[k] += q.v[k] * coef;
+                // rank-1 update: A[a][e] += (v*q_a) * q_e ; each lane owns columns e = k*64+lane
+                for (int a = 0; a < D; ++a) {
+                    const float va = v * aget<K>(q, a);
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const int e = k * 64 + lane;
+                        if (e < vdim) A[a * ld + e] += va * q.v[k];
+                    }
+                }
+                if (p.compute_loss && p.axis == 1) {
+                    const float dot = adot<K>(x, q);
+                    nume -= static_cast<double>(dot * dot);
+                    nume += static_cast<double>((dot - 1) * (dot - 1)) * (1.0 + static_cast<double>(v * p.alpha));
+                    deno += static_cast<double>(v * p.alpha);
+                }
+            }
+        }
+        if (p.compute_loss) nume += static_cast<double>(ada * p.reg * adot<K>(x, x));
+        // m = FF + FiF*alpha ; m(d,d) += reg*ada
+        for (int a = 0; a < D; ++a) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int e = k * 64 + lane;
+                if (e < D) {
+                    float m = p.FF[static_cast<size_t>(a) * vdim + e] + A[a * ld + e] * p.alpha;
+                    if (a == e) m += p.reg * ada;
+                    A[a * ld + e] = m;
+                }
+            }
+        }
+        // z = y
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int e = k * 64 + lane;
+            if (e < vdim) z[e] = y.v[k];
+        }
+        __syncthreads();
+        // in-place Cholesky (lower), one wave, lanes over rows
+        for (int j = 0; j < D; ++j) {
+            const float ljj = sqrtf(A[j * ld + j]);
+            __syncthreads();
+            for (int r = j + lane; r < D; r += 64) A[r * ld + j] = (r == j) ? ljj : A[r * ld + j] / ljj;
+            __syncthreads();
+            // trailing update of the lower triangle: A[r][c] -= L[r][j]*L[c][j],  j < c <= r
+            for (int r = j + 1 + lane; r < D; r += 64) {
+                const float lrj = A[r * ld + j];
+                for (int c2 = j + 1; c2 <= r; ++c2) A[r * ld + c2] -= lrj * A[c2 * ld + j];
+            }
+            __syncthreads();
+        }
+        // forward substitution L w = y
+        for (int r = 0; r < D; ++r) {
+            float s = 0.f;
+            for (int c2 = lane; c2 < r; c2 += 64) s += A[r * ld + c2] * z[c2];
+            s = wave_sum(s);
+            __syncthreads();
+            if (lane == 0) z[r] = (z[r] - s) / A[r * ld + r];
+            __syncthreads();
+        }
+        // back substitution L^T x = w
+        for (int r = D - 1; r >= 0; --r) {
+            float s = 0.f;
+            for (int c2 = r + 1 + lane; c2 < D; c2 += 64) s += A[c2 * ld + r] * z[c2];
+            s = wave_sum(s);
+            __syncthreads();
+            if (lane == 0) z[r] = (z[r] - s) / A[r * ld + r];
+            __syncthreads();
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int e = k * 64 + lane;
+            if (e < D) Pu[e] = z[e];
+        }
+    }
+    if (p.compute_loss && lane == 0) {
+        if (nume != 0.0) atomicAdd(p.loss, nume);
+        if (deno != 0.0) atomicAdd(p.loss + 1, deno);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// iALS++ (als.cc:211-358, Q-14): per row, Yui = P_u . Q_c for every nnz, then for each block of
+// `block_size` latent dims: gradient b, 3 CG steps on A_blk + sum alpha*v q_blk q_blk^T (matrix
+// free), p_blk -= x, Yui -= q_blk . x.  Block vectors: element j lives in lane j%64, dword j/64.
+// ------------------------------------------------------------------------------------------------
+template <int K, int KB>
+__global__ __launch_bounds__(256) void als_ialspp_kernel(AlsParams p) {
+    const int lane = threadIdx.x & 63;
+    const int vdim = p.vdim, D = p.d;
+    double nume = 0.0, deno = 0.0;
+    const int nrows = p.next_x - p.start_x;
+    const int bs0 = p.block_size < D ? p.block_size : D;
+    for (int i = next_row(p.ticket, lane); i < nrows; i = next_row(p.ticket, lane)) {
+        const int u = p.start_x + i;
+        const int64_t beg = (u == 0 ? 0 : p.indptr[u - 1]) - p.shift;
+        const int64_t n = p.indptr[u] - p.shift - beg;
+        if (n == 0) continue;
+        float* Pu = p.P + static_cast<size_t>(u) * vdim;
+        float* Y = p.yui + beg;
+        ARow<K> x;
+        aload<K>(x, Pu, lane, vdim);
+        const float ada = p.adaptive_reg ? static_cast<float>(n) : 1.0f;
+        if (p.compute_loss && p.axis == 1) {  // als.cc:288-291
+            ARow<K> t;
+            avecmat<K>(t, x, p.FF, D, vdim, lane);
+            nume += static_cast<double>(adot<K>(x, t));
+            deno += static_cast<double>(p.op_rows);
+        }
+        // ---- Yui (als.cc:256-266) + positive-sample loss terms (als.cc:298-303) ----
+        for (int64_t k0 = 0; k0 < n; k0 += 64) {
+            const int64_t kk = k0 + lane;
+            int myc = 0;
+            float myv = 0.f, myy = 0.f;
+            if (kk < n) {
+                myc = p.keys[beg + kk];
+                myv = p.vals[beg + kk];
+            }
+            const int nh = static_cast<int>((n - k0) < 64 ? (n - k0) : 64);
+            for (int j = 0; j < nh; ++j) {
+                const int c = __builtin_amdgcn_readlane(myc, j);
+                ARow<K> q;
+                aload<K>(q, p.Q + static_cast<size_t>(c) * vdim, lane, vdim);
+                const float dot = adot<K>(x, q);
+                if (lane == j) myy = dot;
+                if (p.compute_loss && p.axis == 1) {
+                    const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myv), j));
+                    nume -= static_cast<double>(dot * dot);
+                    nume += static_cast<double>((dot - 1) * (dot - 1)) * (1.0 + static_cast<double>(v * p.alpha));
+                    deno += static_cast<double>(v * p.alpha);
+                }
+            }
+            if (kk < n) Y[kk] = myy;
+        }
+        if (p.compute_loss) nume += static_cast<double>(ada * p.reg * adot<K>(x, x));  // als.cc:306-309
+
+        for (int bb = 0; bb < D; bb += bs0) {
+            int bs = bs0;
+            if (bb + bs >= D) bs = D - bb;
+            // block-layout vectors
+            ARow<KB> b, xs, r, pv, Ap, pblk;
+            bool act[KB];
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                act[k] = (k * 64 + lane) < bs;
+                pblk.v[k] = act[k] ? Pu[bb + k * 64 + lane] : 0.f;
+            }
+            aload<K>(x, Pu, lane, vdim);  // p: the whole row at block start (als.cc:285)
+            // b = p * FF[:, blk] + reg * p_blk   (als.cc:286)
+#pragma unroll
+            for (int k = 0; k < KB; ++k) b.v[k] = 0.f;
+            for (int dd = 0; dd < D; ++dd) {
+                const float pd = aget<K>(x, dd);
+#pragma unroll
+                for (int k = 0; k < KB; ++k)
+                    if (act[k]) b.v[k] += pd * p.FF[static_cast<size_t>(dd) * vdim + bb + k * 64 + lane];
+            }
+#pragma unroll
+            for (int k = 0; k < KB; ++k) b.v[k] += p.reg * pblk.v[k];
+            // b += (Yui - 1) * v * alpha * q_blk   (als.cc:293-297)
+            for (int64_t k0 = 0; k0 < n; k0 += 64) {
+                const int64_t kk = k0 + lane;
+                int myc = 0;
+                float myv = 0.f, myy = 0.f;
+                if (kk < n) {
+                    myc = p.keys[beg + kk];
+                    myv = p.vals[beg + kk];
+                    myy = Y[kk];
+                }
+                const int nh = static_cast<int>((n - k0) < 64 ? (n - k0) : 64);
+                for (int j = 0; j < nh; ++j) {
+                    const int c = __builtin_amdgcn_readlane(myc, j);
+                    const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myv), j));
+                    const float yv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myy), j));
+                    const float coef = (yv - 1.0f) * v * p.alpha;
+                    const float* qb = p.Q + static_cast<size_t>(c) * vdim + bb;
+#pragma unroll
+                    for (int k = 0; k < KB; ++k)
+                        if (act[k]) b.v[k] += coef * qb[k * 64 + lane];
+                }
+            }
+            // ---- CG: 3 hard-coded steps, plain reg, no eps, rs in double (als.cc:313-345) ----
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                xs.v[k] = 0.f;
+                r.v[k] = b.v[k];
+                pv.v[k] = b.v[k];
+            }
+            double rsold = static_cast<double>(adot<KB>(r, r));
+            if (rsold > static_cast<double>(p.cg_tol)) {
+                for (int step = 0; step < 3; ++step) {
+                    // Ap = (FF[blk,blk] + reg I) * pv
+#pragma unroll
+                    for (int k = 0; k < KB; ++k) Ap.v[k] = p.reg * pv.v[k];
+                    for (int c2 = 0; c2 < bs; ++c2) {
+                        const float pc = aget<KB>(pv, c2);
+#pragma unroll
+                        for (int k = 0; k < KB; ++k)
+                            if (act[k]) Ap.v[k] += pc * p.FF[static_cast<size_t>(bb + c2) * vdim + bb + k * 64 + lane];
+                    }
+                    for (int64_t k0 = 0; k0 < n; k0 += 64) {
+                        const int64_t kk = k0 + lane;
+                        int myc = 0;
+                        float myv = 0.f;
+                        if (kk < n) {
+                            myc = p.keys[beg + kk];
+                            myv = p.vals[beg + kk];
+                        }
+                        const int nh = static_cast<int>((n - k0) < 64 ? (n - k0) : 64);
+                        for (int j = 0; j < nh; ++j) {
+                            const int c = __builtin_amdgcn_readlane(myc, j);
+                            const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myv), j));
+                            const float* qb = p.Q + static_cast<size_t>(c) * vdim + bb;
+                            ARow<KB> q;
+#pragma unroll
+                            for (int k = 0; k < KB; ++k) q.v[k] = act[k] ? qb[k * 64 + lane] : 0.f;
+                            const float coef = v * p.alpha * adot<KB>(q, pv);
+#pragma unroll
+                            for (int k = 0; k < KB; ++k) Ap.v[k] += coef * q.v[k];
+                        }
+                    }
+                    const float step_size = static_cast<float>(rsold / static_cast<double>(adot<KB>(pv, Ap)));
+#pragma unroll
+                    for (int k = 0; k < KB; ++k) {
+                        xs.v[k] += step_size * pv.v[k];
+                        r.v[k] -= step_size * Ap.v[k];
+                    }
+                    const double rsnew = static_cast<double>(adot<KB>(r, r));
+                    if (rsnew < static_cast<double>(p.cg_tol)) break;
+                    const float ratio = static_cast<float>(rsnew / rsold);
+#pragma unroll
+                    for (int k = 0; k < KB; ++k) pv.v[k] = r.v[k] + ratio * pv.v[k];
+                    rsold = rsnew;
+                }
+            }
+            // p_blk -= x   (als.cc:346)
+#pragma unroll
+            for (int k = 0; k < KB; ++k)
+                if (act[k]) Pu[bb + k * 64 + lane] = pblk.v[k] - xs.v[k];
+            // Yui -= q_blk . x   (als.cc:347-350)
+            for (int64_t k0 = 0; k0 < n; k0 += 64) {
+                const int64_t kk = k0 + lane;
+                int myc = 0;
+                float myy = 0.f;
+                if (kk < n) {
+                    myc = p.keys[beg + kk];
+                    myy = Y[kk];
+                }
+                const int nh = static_cast<int>((n - k0) < 64 ? (n - k0) : 64);
+                for (int j = 0; j < nh; ++j) {
+                    const int c = __builtin_amdgcn_readlane(myc, j);
+                    const float* qb = p.Q + static_cast<size_t>(c) * vdim + bb;
+                    ARow<KB> q;
+#pragma unroll
+                    for (int k = 0; k < KB; ++k) q.v[k] = act[k] ? qb[k * 64 + lane] : 0.f;
+                    const float dx = adot<KB>(q, xs);
+                    if (lane == j) myy -= dx;
+                }
+                if (kk < n) Y[kk] = myy;
+            }
+        }
+    }
+    if (p.compute_loss && lane == 0) {
+        if (nume != 0.0) atomicAdd(p.loss, nume);
+        if (deno != 0.0) atomicAdd(p.loss + 1, deno);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+class AlsHandle : public HandleBase {
+ public:
+    ~AlsHandle() override {
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+
+    bool init(const char* opt_path) {
+        std::string err;
+        if (!opt_.load(opt_path ? opt_path : "", &err)) {
+            last_error = err;
+            return false;
+        }
+        BFH_HIP(hipSetDevice(device));
+        if (!stream) BFH_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        hipDeviceProp_t prop;
+        BFH_HIP(hipGetDeviceProperties(&prop, device));
+        num_cus_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        d_ = opt_.integer("d");
+        BFH_REQUIRE(d_ > 0, "option d must be positive");
+        vdim_ = vdim_of(d_);
+        BFH_REQUIRE(vdim_ <= 1024, "d > 1024 is not supported by the gfx950 kernels yet");
+        alpha_ = static_cast<float>(opt_.num("alpha"));
+        reg_u_ = static_cast<float>(opt_.num("reg_u"));
+        reg_i_ = static_cast<float>(opt_.num("reg_i"));
+        adaptive_reg_ = opt_.boolean_or("adaptive_reg", false);
+        compute_loss_ = opt_.boolean_or("compute_loss_on_training", false);
+        eps_ = static_cast<float>(opt_.num_or("eps", 1e-10));
+        cg_tol_ = static_cast<float>(opt_.num_or("cg_tolerance", 1e-10));
+        num_cg_max_iters_ = static_cast<int>(opt_.num_or("num_cg_max_iters", 3));
+        block_size_ = static_cast<int>(opt_.num_or("block_size", 32));
+        BFH_REQUIRE(block_size_ > 0, "block_size must be positive");
+        std::string optimizer = opt_.str("optimizer");
+        if (d_ >= 128) optimizer = "ialspp";  // als.cc:46 (Q-13)
+        if (optimizer == "llt") code_ = 0;
+        else if (optimizer == "ldlt") code_ = 1;
+        else if (optimizer == "manual_cg") code_ = 2;
+        else if (optimizer == "ialspp") code_ = 8;
+        else throw Error(BFH_ERR_UNSUPPORTED, "optimizer '" + optimizer + "' is not implemented on gfx950 (supported: llt, ldlt, manual_cg, ialspp)");
+        FF_.resize(static_cast<size_t>(vdim_) * vdim_, true, stream);
+        loss_.resize(2, true, stream);
+        ticket_.resize(1, true, stream);
+        inited_ = true;
+        BFH_HIP(hipStreamSynchronize(stream));
+        return true;
+    }
+
+    void initialize_model(float* P, int P_rows, float* Q, int Q_rows) {
+        BFH_REQUIRE(inited_, "initialize_model called before init");
+        BFH_REQUIRE(P && Q && P_rows > 0 && Q_rows > 0, "initialize_model: null factors or empty shapes");
+        hostP_ = P; hostQ_ = Q; P_rows_ = P_rows; Q_rows_ = Q_rows;
+        const size_t np = static_cast<size_t>(P_rows) * vdim_, nq = static_cast<size_t>(Q_rows) * vdim_;
+        P_.resize(np); Q_.resize(nq);
+        BFH_HIP(hipMemcpyAsync(P_.get(), P, np * sizeof(float), hipMemcpyHostToDevice, stream));
+        BFH_HIP(hipMemcpyAsync(Q_.get(), Q, nq * sizeof(float), hipMemcpyHostToDevice, stream));
+        stats.h2d_bytes += static_cast<double>((np + nq) * sizeof(float));
+        BFH_HIP(hipStreamSynchronize(stream));
+        model_ = true;
+    }
+
+    void set_placeholder(const int64_t* lindptr, const int64_t* rindptr, size_t batch_size) {
+        BFH_REQUIRE(model_, "set_placeholder called before initialize_model");
+        BFH_REQUIRE(lindptr && rindptr, "set_placeholder: null indptr");
+        const int64_t* ip[2] = {lindptr, rindptr};
+        const int rows[2] = {P_rows_, Q_rows_};
+        for (int a = 0; a < 2; ++a) {
+            ax_[a].indptr_host.assign(ip[a], ip[a] + rows[a]);
+            ax_[a].indptr.resize(rows[a]);
+            BFH_HIP(hipMemcpyAsync(ax_[a].indptr.get(), ip[a], rows[a] * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+        }
+        keys_.resize(batch_size);
+        vals_.resize(batch_size);
+        yui_.resize(batch_size);
+        BFH_HIP(hipStreamSynchronize(stream));
+        placeholder_ = true;
+    }
+
+    void set_resident_csr(int axis, const int64_t* indptr, const int32_t* keys, const float* vals, int64_t nnz) {
+        BFH_REQUIRE(model_, "set_resident_csr called before initialize_model");
+        BFH_REQUIRE(axis == 0 || axis == 1, "axis must be 0 or 1");
+        BFH_REQUIRE(indptr && keys && vals, "set_resident_csr: null arrays");
+        const int rows = axis == 0 ? P_rows_ : Q_rows_;
+        BFH_REQUIRE(indptr[rows - 1] == nnz, "set_resident_csr: indptr[-1] != nnz");
+        Axis& A = ax_[axis];
+        A.indptr_host.assign(indptr, indptr + rows);
+        A.indptr.resize(rows);
+        A.keys.resize(static_cast<size_t>(nnz));
+        A.vals.resize(static_cast<size_t>(nnz));
+        BFH_HIP(hipMemcpyAsync(A.indptr.get(), indptr, rows * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+        BFH_HIP(hipMemcpyAsync(A.keys.get(), keys, nnz * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        BFH_HIP(hipMemcpyAsync(A.vals.get(), vals, nnz * sizeof(float), hipMemcpyHostToDevice, stream));
+        stats.h2d_bytes += static_cast<double>(rows * sizeof(int64_t) + nnz * 8);
+        if (yui_.size() < static_cast<size_t>(nnz)) yui_.resize(static_cast<size_t>(nnz));
+        BFH_HIP(hipStreamSynchronize(stream));
+        A.resident = true;
+    }
+
+    void precompute(int axis) {
+        BFH_REQUIRE(model_, "precompute before initialize_model");
+        BFH_REQUIRE(axis == 0 || axis == 1, "axis must be 0 or 1");
+        const float* F = axis == 0 ? Q_.get() : P_.get();
+        const int rows = axis == 0 ? Q_rows_ : P_rows_;
+        BFH_HIP(hipMemsetAsync(FF_.get(), 0, FF_.bytes(), stream));
+        const int T = vdim_ / 32;
+        constexpr int NT = 4;
+        const int TG = (T + NT - 1) / NT;
+        int slices = (num_cus_ * 8) / (T * TG);
+        if (slices < 1) slices = 1;
+        int rps = (rows + slices - 1) / slices;
+        rps = (rps + 1) & ~1;  // even: row pairs never straddle slices
+        if (rps < 2) rps = 2;
+        slices = (rows + rps - 1) / rps;
+        const int slot = t_aux_.begin(stream);
+        hipLaunchKernelGGL(als_gramian_kernel<NT>, dim3(slices, T, TG), dim3(64), 0, stream, F, rows, vdim_, rps, FF_.get());
+        BFH_HIP(hipGetLastError());
+        t_aux_.end(slot, stream);
+        BFH_HIP(hipStreamSynchronize(stream));
+        stats.aux_ms += t_aux_.drain();
+    }
+
+    void partial_update(int start_x, int next_x, const int64_t* indptr, const int32_t* keys, const float* vals, int axis,
+                        double* nume, double* deno) {
+        BFH_REQUIRE(model_, "partial_update before initialize_model");
+        BFH_REQUIRE(axis == 0 || axis == 1, "axis must be 0 or 1");
+        Axis& A = ax_[axis];
+        const int rows = axis == 0 ? P_rows_ : Q_rows_;
+        BFH_REQUIRE(A.resident || placeholder_, "partial_update before set_placeholder");
+        BFH_REQUIRE(0 <= start_x && start_x <= next_x && next_x <= rows, "partial_update: bad row range");
+        *nume = 0.0;
+        *deno = 0.0;
+        if (next_x == start_x) return;  // als.cc:219-222
+        const int64_t* ip = indptr ? indptr : A.indptr_host.data();
+        const int64_t beg = start_x == 0 ? 0 : ip[start_x - 1];
+        const int64_t end = ip[next_x - 1];
+        const int64_t n = end - beg;
+        AlsParams p{};
+        p.P = axis == 0 ? P_.get() : Q_.get();
+        p.Q = axis == 0 ? Q_.get() : P_.get();
+        p.FF = FF_.get();
+        p.indptr = A.indptr.get();
+        p.shift = beg;
+        p.start_x = start_x; p.next_x = next_x;
+        p.d = d_; p.vdim = vdim_;
+        p.op_rows = axis == 0 ? Q_rows_ : P_rows_;
+        p.block_size = block_size_;
+        p.alpha = alpha_;
+        p.reg = axis == 0 ? reg_u_ : reg_i_;
+        p.eps = eps_; p.cg_tol = cg_tol_;
+        p.adaptive_reg = adaptive_reg_; p.compute_loss = compute_loss_; p.axis = axis;
+        p.num_cg_max_iters = num_cg_max_iters_;
+        p.loss = loss_.get();
+        p.ticket = ticket_.get();
+        if (A.resident) {
+            p.keys = A.keys.get() + beg;
+            p.vals = A.vals.get() + beg;
+            p.yui = yui_.get();
+        } else {
+            BFH_REQUIRE(keys && vals, "partial_update: keys/vals == NULL needs bfh_als_set_resident_csr first");
+            BFH_REQUIRE(static_cast<size_t>(n) <= keys_.size(), "partial_update: chunk larger than the placeholder batch_size");
+            if (n) {
+                BFH_HIP(hipMemcpyAsync(keys_.get(), keys, n * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+                BFH_HIP(hipMemcpyAsync(vals_.get(), vals, n * sizeof(float), hipMemcpyHostToDevice, stream));
+                stats.h2d_bytes += static_cast<double>(n * 8);
+            }
+            p.keys = keys_.get();
+            p.vals = vals_.get();
+            p.yui = yui_.get();
+        }
+        BFH_HIP(hipMemsetAsync(loss_.get(), 0, 2 * sizeof(double), stream));
+        BFH_HIP(hipMemsetAsync(ticket_.get(), 0, sizeof(int), stream));
+        const int nrows = next_x - start_x;
+        const int K = (vdim_ + 63) / 64;
+        const int slot = t_main_.begin(stream);
+        if (code_ == 8) {
+            const int bs = block_size_ < d_ ? block_size_ : d_;
+            const int KB = (bs + 63) / 64;
+            int waves = num_cus_ * 16;
+            if (waves > nrows) waves = nrows;
+            dim3 grid((waves + 3) / 4), block(256);
+            launch_ialspp(K, KB, grid, block, p);
+        } else if (code_ == 2) {
+            int waves = num_cus_ * 16;
+            if (waves > nrows) waves = nrows;
+            dim3 grid((waves + 3) / 4), block(256);
+            if (K <= 1) hipLaunchKernelGGL(als_cg_kernel<1>, grid, block, 0, stream, p);
+            else if (K <= 2) hipLaunchKernelGGL(als_cg_kernel<2>, grid, block, 0, stream, p);
+            else throw Error(BFH_ERR_UNSUPPORTED, "manual_cg path expects d < 128");
+        } else {
+            int blocks = num_cus_ * 4;
+            if (blocks > nrows) blocks = nrows;
+            const size_t lds = (static_cast<size_t>(vdim_) * (vdim_ + 1) + vdim_) * sizeof(float);
+            if (K <= 1) hipLaunchKernelGGL(als_chol_kernel<1>, dim3(blocks), dim3(64), lds, stream, p);
+            else if (K <= 2) hipLaunchKernelGGL(als_chol_kernel<2>, dim3(blocks), dim3(64), lds, stream, p);
+            else throw Error(BFH_ERR_UNSUPPORTED, "llt/ldlt path expects d < 128");
+        }
+        BFH_HIP(hipGetLastError());
+        t_main_.end(slot, stream);
+        double l[2] = {0, 0};
+        if (compute_loss_) BFH_HIP(hipMemcpyAsync(l, loss_.get(), 2 * sizeof(double), hipMemcpyDeviceToHost, stream));
+        if (writeback_) {  // als.cu:403: updated rows go back to the caller's array
+            float* hostF = axis == 0 ? hostP_ : hostQ_;
+            const size_t off = static_cast<size_t>(start_x) * vdim_, cnt = static_cast<size_t>(nrows) * vdim_;
+            BFH_HIP(hipMemcpyAsync(hostF + off, p.P + off, cnt * sizeof(float), hipMemcpyDeviceToHost, stream));
+            stats.d2h_bytes += static_cast<double>(cnt * sizeof(float));
+        }
+        BFH_HIP(hipStreamSynchronize(stream));
+        stats.kernel_ms += t_main_.drain();
+        stats.launches += 1;
+        stats.samples += n;
+        *nume = l[0];
+        *deno = l[1];
+    }
+
+    void launch_ialspp(int K, int KB, dim3 grid, dim3 block, const AlsParams& p) {
+#define BFH_IALS(KK, KKB) hipLaunchKernelGGL((als_ialspp_kernel<KK, KKB>), grid, block, 0, stream, p)
+        if (KB <= 1) {
+            if (K <= 1) BFH_IALS(1, 1);
+            else if (K <= 2) BFH_IALS(2, 1);
+            else if (K <= 4) BFH_IALS(4, 1);
+            else if (K <= 8) BFH_IALS(8, 1);
+            else BFH_IALS(16, 1);
+        } else if (KB <= 2) {
+            if (K <= 2) BFH_IALS(2, 2);
+            else if (K <= 4) BFH_IALS(4, 2);
+            else if (K <= 8) BFH_IALS(8, 2);
+            else BFH_IALS(16, 2);
+        } else {
+            throw Error(BFH_ERR_UNSUPPORTED, "block_size > 128 is not implemented on gfx950");
+        }
+#undef BFH_IALS
+    }
+
+    void synchronize(bool d2h) {
+        BFH_REQUIRE(model_, "synchronize before initialize_model");
+        const size_t np = static_cast<size_t>(P_rows_) * vdim_, nq = static_cast<size_t>(Q_rows_) * vdim_;
+        if (d2h) {
+            BFH_HIP(hipMemcpyAsync(hostP_, P_.get(), np * sizeof(float), hipMemcpyDeviceToHost, stream));
+            BFH_HIP(hipMemcpyAsync(hostQ_, Q_.get(), nq * sizeof(float), hipMemcpyDeviceToHost, stream));
+            stats.d2h_bytes += static_cast<double>((np + nq) * sizeof(float));
+        } else {
+            BFH_HIP(hipMemcpyAsync(P_.get(), hostP_, np * sizeof(float), hipMemcpyHostToDevice, stream));
+            BFH_HIP(hipMemcpyAsync(Q_.get(), hostQ_, nq * sizeof(float), hipMemcpyHostToDevice, stream));
+            stats.h2d_bytes += static_cast<double>((np + nq) * sizeof(float));
+        }
+        BFH_HIP(hipStreamSynchronize(stream));
+    }
+
+    void set_mode(const std::string& name, int64_t v) {
+        if (name == "als_writeback") writeback_ = v != 0;
+        else if (name == "timing") timing = v != 0;
+        else throw Error(BFH_ERR_INVALID, "unknown mode '" + name + "'");
+    }
+
+    void device_buffer(const std::string& name, void** p, size_t* bytes) {
+        if (name == "P") { *p = P_.get(); *bytes = P_.bytes(); }
+        else if (name == "Q") { *p = Q_.get(); *bytes = Q_.bytes(); }
+        else if (name == "FF") { *p = FF_.get(); *bytes = FF_.bytes(); }
+        else throw Error(BFH_ERR_INVALID, "unknown device buffer '" + name + "'");
+    }
+
+    struct Axis {
+        std::vector<int64_t> indptr_host;
+        DevBuf<int64_t> indptr;
+        DevBuf<int32_t> keys;
+        DevBuf<float> vals;
+        bool resident = false;
+    };
+
+    Options opt_;
+    bool inited_ = false, model_ = false, placeholder_ = false, writeback_ = true;
+    int d_ = 0, vdim_ = 0, P_rows_ = 0, Q_rows_ = 0, code_ = 2, num_cg_max_iters_ = 3, block_size_ = 32, num_cus_ = 256;
+    float alpha_ = 0, reg_u_ = 0, reg_i_ = 0, eps_ = 1e-10f, cg_tol_ = 1e-10f;
+    bool adaptive_reg_ = false, compute_loss_ = false;
+    float *hostP_ = nullptr, *hostQ_ = nullptr;
+    DevBuf<float> P_, Q_, FF_, vals_, yui_;
+    DevBuf<int32_t> keys_;
+    DevBuf<double> loss_;
+    DevBuf<int> ticket_;
+    Axis ax_[2];
+    EventTimer t_main_, t_aux_;
+};
+
+}  // namespace bfh

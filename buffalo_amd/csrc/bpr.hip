@@ -1,0 +1,534 @@
+// BPRMF on gfx950: fused sampler + pairwise-loss update kernel, loss kernel, C ABI.
+//
+// Reference semantics: CBPRMF::worker (/root/reference/lib/algo_impl/bpr/bpr.cc:72-188) -- the CPU
+// path, as BASELINE.json's north_star asks -- behind CuBPR's object surface
+// (/root/reference/include/buffalo/cuda/bpr/bpr.hpp:29-45).  Not derived from lib/cuda/bpr/bpr.cu:
+// that backend materialises (user,pos,neg) arrays in HBM, spends one 128-thread block and two
+// block-wide barriers per sample and uses expf instead of the CPU's sigmoid table.
+//
+// Kernel shape (wave64):
+//   * the chunk's nnz positions are cut into work items of `chunk` consecutive positions; a wave
+//     owns a work item (perfect load balance on heavy-tailed degrees, coalesced key/row-id loads);
+//   * per 64 positions the lanes sample negatives in parallel (Philox counter draws, verify_neg by
+//     binary search in the user's sorted key run);
+//   * the wave then walks the 64 triples: a latent row is K = vdim/64 dwords per lane (element
+//     k*64+lane), so a row is K fully coalesced 256-B loads and a dot product is K FMAs + a DPP
+//     row reduction -- no LDS, no barrier;
+//   * P[u] lives in registers across the user's run (one load + one store per run instead of per
+//     triple); Q rows / biases are shared between waves: fp32 hardware atomics (default) or racy
+//     plain stores (CPU-Hogwild style), next triple's rows prefetched while the current computes.
+#include "sgd_base.hpp"
+
+namespace bfh {
+
+struct BprConsts {
+    float lr, reg_u, reg_i, reg_j, reg_b;
+    int use_bias, update_i, update_j, verify_neg, uniform, num_neg, pcn, compute_loss, atomic, sequential;
+    int64_t cum_total;
+    const float* exp_table;
+    double* loss_out;
+    int chunk;
+    // injected triples (bfh_bpr_update_triples)
+    const int32_t* inj_u;
+    const int32_t* inj_p;
+    const int32_t* inj_n;
+    int64_t total;  // number of (position, slot) items
+};
+
+// CBPRMF::build_exp_table bpr.cc:57-63 + lookup bpr.cc:124-131 (Q-2: integer 1000/6/2 == 83)
+__device__ __forceinline__ float bpr_logit(float x, const float* __restrict__ table) {
+    if (6.0f < x) return 0.0f;
+    if (x < -6.0f) return 1.0f;
+    const int idx = __builtin_amdgcn_readfirstlane(static_cast<int>((x + 6.0f) * 83.0f));
+    return table[idx];
+}
+
+__device__ __forceinline__ int bpr_sample_negative(const SgdParams& p, const BprConsts& c, uint64_t gpos, uint32_t slot,
+                                                   int64_t ubeg, int64_t uend) {
+    int neg = 0;
+    for (uint32_t attempt = 0; attempt < (1u << 20); ++attempt) {  // the reference loops forever (bpr.cc:106-117)
+        uint32_t o0, o1;
+        counter_draw(p.seed, 0u, gpos, slot, p.epoch, attempt, o0, o1);
+        if (c.uniform) {
+            neg = static_cast<int>((static_cast<uint64_t>(o0) * static_cast<uint32_t>(p.Q_rows)) >> 32);
+        } else {
+            const uint64_t r64 = (static_cast<uint64_t>(o1) << 32) | o0;
+            const int64_t r = static_cast<int64_t>(__umul64hi(r64, static_cast<uint64_t>(c.cum_total)));
+            neg = static_cast<int>(lower_bound_dev<int64_t>(p.cum_table, p.Q_rows, r));  // Q-4: lower_bound
+        }
+        if (!c.verify_neg || !sorted_contains(p.keys, ubeg, uend, neg)) break;
+    }
+    return neg;
+}
+
+template <int K>
+struct Row {
+    float v[K];
+};
+
+template <int K>
+__device__ __forceinline__ void load_row(Row<K>& r, const float* __restrict__ base, int lane, int vdim) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int e = k * 64 + lane;
+        r.v[k] = (e < vdim) ? base[e] : 0.0f;
+    }
+}
+template <int K>
+__device__ __forceinline__ void store_row(const Row<K>& r, float* __restrict__ base, int lane, int vdim) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int e = k * 64 + lane;
+        if (e < vdim) base[e] = r.v[k];
+    }
+}
+template <int K>
+__device__ __forceinline__ void atomic_add_row(const Row<K>& r, float* __restrict__ base, int lane, int vdim) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int e = k * 64 + lane;
+        if (e < vdim) atomic_add_f32(base + e, r.v[k]);
+    }
+}
+
+// SGD: true -> Hogwild SGD branch (bpr.cc:157-172); false -> gradient accumulation branch for
+// adam/adagrad (bpr.cc:138-156,175-181).  PIPE: prefetch the next triple's item rows.
+// INJECT: triples come from arrays instead of CSR + sampler.
+template <int K, bool SGD, bool PIPE, bool INJECT>
+__global__ __launch_bounds__(256) void bpr_update_kernel(SgdParams p, BprConsts c) {
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    const int64_t wave0 = static_cast<int64_t>(blockIdx.x) * wpb + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t nwaves = static_cast<int64_t>(gridDim.x) * wpb;
+    const int vdim = p.vdim;
+    const int64_t n_work = (c.total + c.chunk - 1) / c.chunk;
+
+    int cur_u = -1;
+    bool cur_excl = true;
+    Row<K> pu, p0;     // current / as-loaded user row (SGD) or accumulated / unused (accumulate)
+    Row<K> gacc;       // accumulate mode: gradient of P[u] gathered over the run
+    double loss = 0.0;
+
+    auto flush_user = [&]() {
+        if (cur_u < 0) return;
+        if (SGD) {
+            float* Pu = p.P + static_cast<size_t>(cur_u) * vdim;
+            if (cur_excl) {
+                store_row<K>(pu, Pu, lane, vdim);
+            } else {
+                Row<K> dlt;
+#pragma unroll
+                for (int k = 0; k < K; ++k) dlt.v[k] = pu.v[k] - p0.v[k];
+                atomic_add_row<K>(dlt, Pu, lane, vdim);
+            }
+        } else {
+            atomic_add_row<K>(gacc, p.gradP + static_cast<size_t>(cur_u) * vdim, lane, vdim);
+        }
+        cur_u = -1;
+    };
+
+    for (int64_t w = wave0; w < n_work; w += nwaves) {
+        const int64_t t_beg = w * c.chunk;
+        const int64_t t_end = (t_beg + c.chunk < c.total) ? t_beg + c.chunk : c.total;
+        for (int64_t t0 = t_beg; t0 < t_end; t0 += 64) {
+            // ---------------- lane-parallel: fetch (u,pos) and sample the negative ----------------
+            const int64_t t = t0 + lane;
+            const bool valid = t < t_end;
+            int my_u = 0, my_pos = 0, my_neg = 0, my_excl = 1;
+            if (valid) {
+                if (INJECT) {
+                    my_u = c.inj_u[t];
+                    my_pos = c.inj_p[t];
+                    my_neg = c.inj_n[t];
+                    my_excl = c.sequential;
+                } else {
+                    const int64_t pos_idx = t / c.num_neg;           // chunk-local nnz position
+                    const uint32_t slot = static_cast<uint32_t>(t % c.num_neg);
+                    my_u = p.rows[pos_idx];
+                    my_pos = p.keys[pos_idx];
+                    const int64_t ubeg = (my_u == 0 ? 0 : p.indptr[my_u - 1]) - p.shift;
+                    const int64_t uend = p.indptr[my_u] - p.shift;
+                    my_neg = bpr_sample_negative(p, c, static_cast<uint64_t>(p.nnz_offset + p.shift + pos_idx), slot, ubeg, uend);
+                    // does this wave own the user's whole run?  (then P[u] needs no atomics)
+                    my_excl = c.sequential || (ubeg * c.num_neg >= t_beg && uend * c.num_neg <= t_end);
+                }
+            }
+            const int n_here = static_cast<int>((t_end - t0) < 64 ? (t_end - t0) : 64);
+
+            Row<K> qi, qj, qi_n, qj_n;
+            float bi = 0.f, bj = 0.f, bi_n = 0.f, bj_n = 0.f;
+            int pos = __builtin_amdgcn_readlane(my_pos, 0);
+            int neg = __builtin_amdgcn_readlane(my_neg, 0);
+            if (PIPE) {
+                load_row<K>(qi, p.Q + static_cast<size_t>(pos) * vdim, lane, vdim);
+                load_row<K>(qj, p.Q + static_cast<size_t>(neg) * vdim, lane, vdim);
+                if (c.use_bias) { bi = p.Qb[pos]; bj = p.Qb[neg]; }
+            }
+            for (int j = 0; j < n_here; ++j) {
+                const int u = __builtin_amdgcn_readlane(my_u, j);
+                const int excl = __builtin_amdgcn_readlane(my_excl, j);
+                pos = __builtin_amdgcn_readlane(my_pos, j);
+                neg = __builtin_amdgcn_readlane(my_neg, j);
+                float* Qi = p.Q + static_cast<size_t>(pos) * vdim;
+                float* Qj = p.Q + static_cast<size_t>(neg) * vdim;
+                int pos_n = 0, neg_n = 0;
+                if (PIPE) {
+                    if (j + 1 < n_here) {
+                        pos_n = __builtin_amdgcn_readlane(my_pos, j + 1);
+                        neg_n = __builtin_amdgcn_readlane(my_neg, j + 1);
+                        load_row<K>(qi_n, p.Q + static_cast<size_t>(pos_n) * vdim, lane, vdim);
+                        load_row<K>(qj_n, p.Q + static_cast<size_t>(neg_n) * vdim, lane, vdim);
+                        if (c.use_bias) { bi_n = p.Qb[pos_n]; bj_n = p.Qb[neg_n]; }
+                    }
+                } else {
+                    load_row<K>(qi, Qi, lane, vdim);
+                    load_row<K>(qj, Qj, lane, vdim);
+                    if (c.use_bias) { bi = p.Qb[pos]; bj = p.Qb[neg]; }
+                }
+                if (u != cur_u) {
+                    flush_user();
+                    cur_u = u;
+                    cur_excl = excl != 0;
+                    if (SGD) {
+                        load_row<K>(pu, p.P + static_cast<size_t>(u) * vdim, lane, vdim);
+                        p0 = pu;
+                    } else {
+                        load_row<K>(pu, p.P + static_cast<size_t>(u) * vdim, lane, vdim);
+#pragma unroll
+                        for (int k = 0; k < K; ++k) gacc.v[k] = 0.f;
+                    }
+                }
+                // ---------------- score + sigmoid table (bpr.cc:119-131) ----------------
+                float part = 0.f;
+#pragma unroll
+                for (int k = 0; k < K; ++k) part += pu.v[k] * (qi.v[k] - qj.v[k]);
+                float x = wave_sum(part);
+                if (c.use_bias) x += (bi - bj);
+                const float logit = bpr_logit(x, c.exp_table);
+                if (c.compute_loss) loss += static_cast<double>(log1pf(__expf(-fminf(fmaxf(x, -6.f), 6.f))));
+
+                if (SGD) {
+                    // bpr.cc:157-171 incl. Q-1: the user step sees the already-updated item rows
+                    Row<K> di, dj;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const float idv = logit * pu.v[k];
+                        di.v[k] = c.update_i ? c.lr * (idv - c.reg_i * qi.v[k]) : 0.f;
+                        dj.v[k] = c.update_j ? c.lr * (-idv - c.reg_j * qj.v[k]) : 0.f;
+                        qi.v[k] += di.v[k];
+                        qj.v[k] += dj.v[k];
+                        pu.v[k] += c.lr * (logit * (qi.v[k] - qj.v[k]) - c.reg_u * pu.v[k]);
+                    }
+                    if (c.atomic) {
+                        if (c.update_i) atomic_add_row<K>(di, Qi, lane, vdim);
+                        if (c.update_j) atomic_add_row<K>(dj, Qj, lane, vdim);
+                    } else {
+                        if (c.update_i) store_row<K>(qi, Qi, lane, vdim);
+                        if (c.update_j) store_row<K>(qj, Qj, lane, vdim);
+                    }
+                    if (c.use_bias && lane == 0) {
+                        const float dbi = c.lr * (logit - c.reg_b * bi);
+                        const float dbj = c.lr * (-logit - c.reg_b * bj);
+                        if (c.atomic) {
+                            if (c.update_i) atomic_add_f32(p.Qb + pos, dbi);
+                            if (c.update_j) atomic_add_f32(p.Qb + neg, dbj);
+                        } else {
+                            if (c.update_i) p.Qb[pos] = bi + dbi;
+                            if (c.update_j) p.Qb[neg] = bj + dbj;
+                        }
+                    }
+                } else {
+                    // bpr.cc:138-156: P, Q are frozen during the epoch; gradients are summed
+                    Row<K> gi, gj;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const float idv = logit * pu.v[k];
+                        gacc.v[k] += logit * (qi.v[k] - qj.v[k]);
+                        gi.v[k] = idv;
+                        gj.v[k] = -idv;
+                    }
+                    if (c.update_i) atomic_add_row<K>(gi, p.gradQ + static_cast<size_t>(pos) * vdim, lane, vdim);
+                    if (c.update_j) atomic_add_row<K>(gj, p.gradQ + static_cast<size_t>(neg) * vdim, lane, vdim);
+                    if (lane == 0) {
+                        if (c.use_bias) {
+                            if (c.update_i) atomic_add_f32(p.gradQb + pos, logit);
+                            if (c.update_j) atomic_add_f32(p.gradQb + neg, -logit);
+                        }
+                        if (c.pcn) {  // Q-9 counting rules (bpr.cc:139-143, 175-181)
+                            atomicAdd(p.cntQ + neg, 1);
+                            const bool last_slot = INJECT ? true : (((t0 + j) % c.num_neg) == c.num_neg - 1);
+                            if (last_slot) {
+                                atomicAdd(p.cntP + u, 1);
+                                atomicAdd(p.cntQ + pos, 1);
+                            }
+                        }
+                    }
+                }
+                if (PIPE) {
+                    if (j + 1 < n_here) {
+                        qi = qi_n; qj = qj_n; bi = bi_n; bj = bj_n;
+                        if (SGD && !c.atomic && (pos_n == pos || pos_n == neg || neg_n == pos || neg_n == neg)) {
+                            // racy mode: the prefetch raced with this wave's own stores -> reload
+                            load_row<K>(qi, p.Q + static_cast<size_t>(pos_n) * vdim, lane, vdim);
+                            load_row<K>(qj, p.Q + static_cast<size_t>(neg_n) * vdim, lane, vdim);
+                            if (c.use_bias) { bi = p.Qb[pos_n]; bj = p.Qb[neg_n]; }
+                        }
+                    }
+                }
+            }
+        }
+        if (!c.sequential) flush_user();
+    }
+    flush_user();
+    if (c.compute_loss && lane == 0 && loss != 0.0) atomicAdd(c.loss_out, loss);
+}
+
+// CBPRMF::compute_loss bpr.cc:227-244: mean log(1+exp(-(x_ui - x_uj))) in double; a wave per sample.
+__global__ void bpr_loss_kernel(const float* __restrict__ P, const float* __restrict__ Q, const float* __restrict__ Qb,
+                                const int32_t* __restrict__ users, const int32_t* __restrict__ pos,
+                                const int32_t* __restrict__ neg, int n, int vdim, int use_bias, double* out) {
+    const int lane = threadIdx.x & 63;
+    const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (w >= n) return;
+    const float* pu = P + static_cast<size_t>(users[w]) * vdim;
+    const float* qi = Q + static_cast<size_t>(pos[w]) * vdim;
+    const float* qj = Q + static_cast<size_t>(neg[w]) * vdim;
+    float a = 0.f, b = 0.f;
+    for (int e = lane; e < vdim; e += 64) {
+        a += pu[e] * qi[e];
+        b += pu[e] * qj[e];
+    }
+    float xi = wave_sum(a), xj = wave_sum(b);  // CBPRMF::distance returns float precision
+    if (use_bias) { xi += Qb[pos[w]]; xj += Qb[neg[w]]; }
+    if (lane == 0) {
+        const double x = static_cast<double>(xi) - static_cast<double>(xj);
+        atomicAdd(out, log(1.0 + exp(-x)));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+class BprHandle : public SgdHandle {
+ public:
+    BprHandle() : SgdHandle(0) {}
+    void parse_specific() override {
+        num_neg_ = opt_.integer("num_negative_samples");
+        BFH_REQUIRE(num_neg_ >= 1 && num_neg_ <= 255, "num_negative_samples must be in [1,255]");
+        verify_neg_ = opt_.boolean_or("verify_neg", true);
+        uniform_ = opt_.num_or("sampling_power", 0.0) == 0.0;
+        // CBPRMF::build_exp_table bpr.cc:57-63, evaluated on the host exactly like the CPU path
+        std::vector<float> t(1000);
+        for (int i = 0; i < 1000; ++i) {
+            float e = static_cast<float>(std::exp((i / static_cast<float>(1000) * 2 - 1) * 6));
+            t[i] = static_cast<float>(1.0 / (e + 1));
+        }
+        exp_table_.resize(1000);
+        BFH_HIP(hipMemcpyAsync(exp_table_.get(), t.data(), 1000 * sizeof(float), hipMemcpyHostToDevice, stream));
+        sync_stream();
+    }
+
+    BprConsts consts(double lr) {
+        BprConsts c{};
+        c.lr = static_cast<float>(lr);
+        c.reg_u = reg_u_; c.reg_i = reg_i_; c.reg_j = reg_j_; c.reg_b = reg_b_;
+        c.use_bias = use_bias_; c.update_i = update_i_; c.update_j = update_j_;
+        c.verify_neg = verify_neg_; c.uniform = uniform_; c.num_neg = num_neg_;
+        c.pcn = pcn_; c.compute_loss = compute_loss_;
+        c.atomic = hogwild_atomic_; c.sequential = sequential_;
+        c.cum_total = cum_total_;
+        c.exp_table = exp_table_.get();
+        c.loss_out = scratch_.get();
+        c.chunk = chunk_;
+        return c;
+    }
+
+    template <int K, bool INJECT>
+    void launch_k(const SgdParams& p, const BprConsts& c, dim3 grid, dim3 block) {
+        const bool sgd = optimizer_ == "sgd";
+        const bool pipe = prefetch_ != 0 && !sequential_;
+        if (sgd && pipe) hipLaunchKernelGGL((bpr_update_kernel<K, true, true, INJECT>), grid, block, 0, stream, p, c);
+        else if (sgd) hipLaunchKernelGGL((bpr_update_kernel<K, true, false, INJECT>), grid, block, 0, stream, p, c);
+        else if (pipe) hipLaunchKernelGGL((bpr_update_kernel<K, false, true, INJECT>), grid, block, 0, stream, p, c);
+        else hipLaunchKernelGGL((bpr_update_kernel<K, false, false, INJECT>), grid, block, 0, stream, p, c);
+    }
+
+    template <bool INJECT>
+    void launch(const SgdParams& p, const BprConsts& c) {
+        const int64_t n_work = (c.total + c.chunk - 1) / c.chunk;
+        dim3 block(256), grid(1);
+        if (sequential_) {
+            block = dim3(64);
+        } else {
+            const int wpc = waves_per_cu_ > 0 ? waves_per_cu_ : 32;
+            int64_t waves = static_cast<int64_t>(num_cus_) * wpc;
+            if (waves > n_work) waves = n_work;
+            grid = dim3(static_cast<unsigned>((waves + 3) / 4));
+        }
+        const int slot = t_main_.begin(stream);
+        const int K = (vdim_ + 63) / 64;
+        if (K <= 1) launch_k<1, INJECT>(p, c, grid, block);
+        else if (K <= 2) launch_k<2, INJECT>(p, c, grid, block);
+        else if (K <= 4) launch_k<4, INJECT>(p, c, grid, block);
+        else if (K <= 8) launch_k<8, INJECT>(p, c, grid, block);
+        else launch_k<16, INJECT>(p, c, grid, block);
+        BFH_HIP(hipGetLastError());
+        t_main_.end(slot, stream);
+        stats.launches += 1;
+    }
+
+    void partial_update(int start_x, int next_x, const int64_t* indptr, const int32_t* keys, double* loss_sum, double* n_samples) {
+        SgdParams p;
+        const int64_t n = stage_chunk(start_x, next_x, indptr, keys, &p);
+        *loss_sum = 0.0;
+        *n_samples = static_cast<double>(n) * num_neg_;
+        if (n == 0) return;
+        BFH_REQUIRE(uniform_ || have_cum_, "sampling_power != 0 needs set_cumulative_table");
+        BFH_REQUIRE(uniform_ || cum_total_ > 0, "cumulative table is empty");
+        BprConsts c = consts(current_lr());
+        c.total = n * num_neg_;
+        if (compute_loss_) BFH_HIP(hipMemsetAsync(scratch_.get(), 0, sizeof(double), stream));
+        launch<false>(p, c);
+        if (compute_loss_) BFH_HIP(hipMemcpyAsync(loss_sum, scratch_.get(), sizeof(double), hipMemcpyDeviceToHost, stream));
+        sync_stream();
+        harvest_timers();
+        stats.samples += c.total;
+        advance_progress(start_x, next_x, indptr);
+    }
+
+    void update_triples(int64_t n, const int32_t* users, const int32_t* pos, const int32_t* neg, double lr) {
+        BFH_REQUIRE(model_on_gpu_, "update_triples before initialize_model(..., set_gpu=True)");
+        if (n <= 0) return;
+        inj_.resize(static_cast<size_t>(3 * n));
+        BFH_HIP(hipMemcpyAsync(inj_.get(), users, n * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        BFH_HIP(hipMemcpyAsync(inj_.get() + n, pos, n * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        BFH_HIP(hipMemcpyAsync(inj_.get() + 2 * n, neg, n * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        SgdParams p{};
+        p.P = P_.get(); p.Q = Q_.get(); p.Qb = Qb_.get();
+        p.gradP = gradP_.get(); p.gradQ = gradQ_.get(); p.gradQb = gradQb_.get();
+        p.cntP = cntP_.get(); p.cntQ = cntQ_.get();
+        p.P_rows = P_rows_; p.Q_rows = Q_rows_; p.d = d_; p.vdim = vdim_;
+        BprConsts c = consts(lr);
+        c.compute_loss = 0;
+        c.num_neg = 1;
+        c.total = n;
+        c.inj_u = inj_.get(); c.inj_p = inj_.get() + n; c.inj_n = inj_.get() + 2 * n;
+        launch<true>(p, c);
+        sync_stream();
+        harvest_timers();
+        stats.samples += n;
+    }
+
+    double compute_loss(int n, const int32_t* users, const int32_t* pos, const int32_t* neg) {
+        BFH_REQUIRE(model_on_gpu_, "compute_loss before initialize_model(..., set_gpu=True)");
+        if (n <= 0) return 0.0;  // the reference divides by zero here (bpr.cc:243); callers guard (bpr.py:141)
+        inj_.resize(static_cast<size_t>(3) * n);
+        BFH_HIP(hipMemcpyAsync(inj_.get(), users, n * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        BFH_HIP(hipMemcpyAsync(inj_.get() + n, pos, n * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        BFH_HIP(hipMemcpyAsync(inj_.get() + 2 * n, neg, n * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        BFH_HIP(hipMemsetAsync(scratch_.get(), 0, sizeof(double), stream));
+        const int slot = t_aux_.begin(stream);
+        hipLaunchKernelGGL(bpr_loss_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, P_.get(), Q_.get(), Qb_.get(), inj_.get(),
+                           inj_.get() + n, inj_.get() + 2 * n, n, vdim_, static_cast<int>(use_bias_), scratch_.get());
+        BFH_HIP(hipGetLastError());
+        t_aux_.end(slot, stream);
+        double l = 0.0;
+        BFH_HIP(hipMemcpyAsync(&l, scratch_.get(), sizeof(double), hipMemcpyDeviceToHost, stream));
+        sync_stream();
+        harvest_timers();
+        return l / static_cast<double>(n);
+    }
+
+    int num_neg_ = 1;
+    bool verify_neg_ = true, uniform_ = true;
+    DevBuf<float> exp_table_;
+    DevBuf<int32_t> inj_;
+};
+
+}  // namespace bfh
+
+using bfh::BprHandle;
+using bfh::guarded;
+
+extern "C" {
+
+void* bfh_bpr_create(void) {
+    try {
+        BprHandle* h = new BprHandle();
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) {
+            bfh::g_create_error = "no HIP device available (libbuffalo_hip has no CPU fallback)";
+            delete h;
+            return nullptr;
+        }
+        h->device = dev;
+        return h;
+    } catch (const std::exception& e) {
+        bfh::g_create_error = e.what();
+        return nullptr;
+    }
+}
+void bfh_bpr_destroy(void* h) { delete static_cast<BprHandle*>(h); }
+int bfh_bpr_set_device(void* h, int device) {
+    return guarded(h, [&] { static_cast<BprHandle*>(h)->device = device; BFH_HIP(hipSetDevice(device)); return BFH_OK; });
+}
+int bfh_bpr_init(void* h, const char* opt_json_path) {
+    int ok = 0;
+    int rc = guarded(h, [&] { ok = static_cast<BprHandle*>(h)->init(opt_json_path) ? 1 : 0; return BFH_OK; });
+    return rc == BFH_OK ? ok : rc;
+}
+int bfh_bpr_get_vdim(void* h) { return h ? static_cast<BprHandle*>(h)->get_vdim() : BFH_ERR_INVALID; }
+int bfh_bpr_initialize_model(void* h, float* P, int P_rows, float* Q, float* Qb, int Q_rows, int64_t num_nnz, int set_gpu) {
+    return guarded(h, [&] { static_cast<BprHandle*>(h)->initialize_model(P, P_rows, Q, Qb, Q_rows, num_nnz, set_gpu != 0); return BFH_OK; });
+}
+int bfh_bpr_set_placeholder(void* h, const int64_t* indptr, size_t batch_size) {
+    return guarded(h, [&] { static_cast<BprHandle*>(h)->set_placeholder(indptr, batch_size); return BFH_OK; });
+}
+int bfh_bpr_set_cumulative_table(void* h, const int64_t* table) {
+    return guarded(h, [&] { static_cast<BprHandle*>(h)->set_cumulative_table(table); return BFH_OK; });
+}
+int bfh_bpr_partial_update(void* h, int start_x, int next_x, const int64_t* indptr, const int32_t* keys, double* loss_sum, double* n_samples) {
+    return guarded(h, [&] {
+        double l = 0, n = 0;
+        static_cast<BprHandle*>(h)->partial_update(start_x, next_x, indptr, keys, &l, &n);
+        if (loss_sum) *loss_sum = l;
+        if (n_samples) *n_samples = n;
+        return BFH_OK;
+    });
+}
+int bfh_bpr_update_parameters(void* h) {
+    return guarded(h, [&] { static_cast<BprHandle*>(h)->update_parameters(); return BFH_OK; });
+}
+int bfh_bpr_synchronize(void* h, int device_to_host) {
+    return guarded(h, [&] { static_cast<BprHandle*>(h)->synchronize(device_to_host != 0); return BFH_OK; });
+}
+int bfh_bpr_compute_loss(void* h, int n, const int32_t* users, const int32_t* positives, const int32_t* negatives, double* loss) {
+    return guarded(h, [&] { *loss = static_cast<BprHandle*>(h)->compute_loss(n, users, positives, negatives); return BFH_OK; });
+}
+int bfh_bpr_set_resident_csr(void* h, const int64_t* indptr, const int32_t* keys, int64_t nnz) {
+    return guarded(h, [&] { static_cast<BprHandle*>(h)->set_resident_csr(indptr, keys, nnz); return BFH_OK; });
+}
+int bfh_bpr_set_mode(void* h, const char* name, int64_t value) {
+    return guarded(h, [&] { static_cast<BprHandle*>(h)->set_mode(name ? name : "", value); return BFH_OK; });
+}
+int bfh_bpr_set_shard(void* h, int64_t nnz_offset, int num_shards) {
+    return guarded(h, [&] {
+        BFH_REQUIRE(num_shards >= 1 && nnz_offset >= 0, "set_shard: bad arguments");
+        static_cast<BprHandle*>(h)->nnz_offset_ = nnz_offset;
+        static_cast<BprHandle*>(h)->num_shards_ = num_shards;
+        return BFH_OK;
+    });
+}
+int bfh_bpr_update_triples(void* h, int64_t n, const int32_t* users, const int32_t* positives, const int32_t* negatives, double lr) {
+    return guarded(h, [&] { static_cast<BprHandle*>(h)->update_triples(n, users, positives, negatives, lr); return BFH_OK; });
+}
+int bfh_bpr_device_buffer(void* h, const char* name, void** dptr, size_t* bytes) {
+    return guarded(h, [&] { static_cast<BprHandle*>(h)->device_buffer(name ? name : "", dptr, bytes); return BFH_OK; });
+}
+void* bfh_bpr_stream(void* h) { return h ? static_cast<void*>(static_cast<BprHandle*>(h)->stream) : nullptr; }
+int bfh_bpr_get_stats(void* h, bfh_stats* out) {
+    return guarded(h, [&] { *out = static_cast<BprHandle*>(h)->stats; return BFH_OK; });
+}
+int bfh_bpr_reset_stats(void* h) {
+    return guarded(h, [&] { static_cast<BprHandle*>(h)->stats = bfh_stats{}; return BFH_OK; });
+}
+
+}  // extern "C"

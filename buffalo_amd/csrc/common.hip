@@ -1,0 +1,206 @@
+// Options (JSON) reader + ABI odds and ends.
+#include "common.hpp"
+
+namespace bfh {
+
+thread_local std::string g_create_error;
+
+namespace {
+struct JsonReader {
+    const std::string& s;
+    size_t i = 0;
+    std::string err;
+    explicit JsonReader(const std::string& str) : s(str) {}
+    void ws() {
+        while (i < s.size() && (s[i] == ' ' || s[i] == '\t' || s[i] == '\n' || s[i] == '\r')) ++i;
+    }
+    bool fail(const char* m) {
+        if (err.empty()) err = std::string(m) + " at offset " + std::to_string(i);
+        return false;
+    }
+    bool string(std::string* out) {
+        if (i >= s.size() || s[i] != '"') return fail("expected string");
+        ++i;
+        out->clear();
+        while (i < s.size() && s[i] != '"') {
+            char c = s[i++];
+            if (c == '\\') {
+                if (i >= s.size()) return fail("bad escape");
+                char e = s[i++];
+                switch (e) {
+                    case 'n': out->push_back('\n'); break;
+                    case 't': out->push_back('\t'); break;
+                    case 'r': out->push_back('\r'); break;
+                    case 'b': out->push_back('\b'); break;
+                    case 'f': out->push_back('\f'); break;
+                    case 'u':
+                        if (i + 4 > s.size()) return fail("bad \\u escape");
+                        out->push_back('?');
+                        i += 4;
+                        break;
+                    default: out->push_back(e); break;
+                }
+            } else {
+                out->push_back(c);
+            }
+        }
+        if (i >= s.size()) return fail("unterminated string");
+        ++i;
+        return true;
+    }
+    // kind: 0 number, 1 string, 2 bool, 3 other (null / object / array)
+    bool value(int* kind, double* num, std::string* str, bool* boo) {
+        ws();
+        if (i >= s.size()) return fail("unexpected end");
+        char c = s[i];
+        if (c == '"') {
+            *kind = 1;
+            return string(str);
+        }
+        if (c == '{') {
+            *kind = 3;
+            ++i;
+            ws();
+            if (i < s.size() && s[i] == '}') { ++i; return true; }
+            while (true) {
+                ws();
+                std::string k;
+                if (!string(&k)) return false;
+                ws();
+                if (i >= s.size() || s[i] != ':') return fail("expected ':'");
+                ++i;
+                int kk; double nn; std::string ss; bool bb;
+                if (!value(&kk, &nn, &ss, &bb)) return false;
+                ws();
+                if (i < s.size() && s[i] == ',') { ++i; continue; }
+                if (i < s.size() && s[i] == '}') { ++i; return true; }
+                return fail("expected ',' or '}'");
+            }
+        }
+        if (c == '[') {
+            *kind = 3;
+            ++i;
+            ws();
+            if (i < s.size() && s[i] == ']') { ++i; return true; }
+            while (true) {
+                int kk; double nn; std::string ss; bool bb;
+                if (!value(&kk, &nn, &ss, &bb)) return false;
+                ws();
+                if (i < s.size() && s[i] == ',') { ++i; continue; }
+                if (i < s.size() && s[i] == ']') { ++i; return true; }
+                return fail("expected ',' or ']'");
+            }
+        }
+        if (s.compare(i, 4, "true") == 0) { *kind = 2; *boo = true; i += 4; return true; }
+        if (s.compare(i, 5, "false") == 0) { *kind = 2; *boo = false; i += 5; return true; }
+        if (s.compare(i, 4, "null") == 0) { *kind = 3; i += 4; return true; }
+        // python's json.dumps may emit these for float('inf') / nan
+        if (s.compare(i, 8, "Infinity") == 0) { *kind = 0; *num = INFINITY; i += 8; return true; }
+        if (s.compare(i, 9, "-Infinity") == 0) { *kind = 0; *num = -INFINITY; i += 9; return true; }
+        if (s.compare(i, 3, "NaN") == 0) { *kind = 0; *num = NAN; i += 3; return true; }
+        size_t j = i;
+        while (j < s.size() && (isdigit(static_cast<unsigned char>(s[j])) || s[j] == '-' || s[j] == '+' || s[j] == '.' ||
+                                s[j] == 'e' || s[j] == 'E'))
+            ++j;
+        if (j == i) return fail("unexpected character");
+        try {
+            *num = std::stod(s.substr(i, j - i));
+        } catch (...) {
+            return fail("bad number");
+        }
+        *kind = 0;
+        i = j;
+        return true;
+    }
+};
+}  // namespace
+
+bool Options::load(const std::string& path, std::string* err) {
+    std::ifstream in(path.c_str());
+    if (!in.is_open()) {
+        *err = "File not exists: " + path;
+        return false;
+    }
+    std::string text((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    JsonReader r(text);
+    r.ws();
+    if (r.i >= text.size() || text[r.i] != '{') {
+        *err = "Failed to parse: top-level value is not an object";
+        return false;
+    }
+    ++r.i;
+    r.ws();
+    num_.clear(); str_.clear(); boo_.clear();
+    if (r.i < text.size() && text[r.i] == '}') return true;
+    while (true) {
+        r.ws();
+        std::string k;
+        if (!r.string(&k)) break;
+        r.ws();
+        if (r.i >= text.size() || text[r.i] != ':') { r.fail("expected ':'"); break; }
+        ++r.i;
+        int kind = 3; double num = 0; std::string str; bool boo = false;
+        if (!r.value(&kind, &num, &str, &boo)) break;
+        if (kind == 0) num_[k] = num;
+        else if (kind == 1) str_[k] = str;
+        else if (kind == 2) boo_[k] = boo;
+        r.ws();
+        if (r.i < text.size() && text[r.i] == ',') { ++r.i; continue; }
+        if (r.i < text.size() && text[r.i] == '}') {
+            ++r.i;
+            r.ws();
+            if (r.i != text.size()) r.fail("trailing characters");
+            break;
+        }
+        r.fail("expected ',' or '}'");
+        break;
+    }
+    if (!r.err.empty()) {
+        *err = "Failed to parse: " + r.err;
+        return false;
+    }
+    return true;
+}
+
+double Options::num(const std::string& k) const {
+    auto it = num_.find(k);
+    if (it == num_.end()) throw Error(BFH_ERR_INVALID, "option '" + k + "' missing or not a number");
+    return it->second;
+}
+double Options::num_or(const std::string& k, double dflt) const {
+    auto it = num_.find(k);
+    return it == num_.end() ? dflt : it->second;
+}
+bool Options::boolean(const std::string& k) const {
+    auto it = boo_.find(k);
+    if (it == boo_.end()) throw Error(BFH_ERR_INVALID, "option '" + k + "' missing or not a bool");
+    return it->second;
+}
+bool Options::boolean_or(const std::string& k, bool dflt) const {
+    auto it = boo_.find(k);
+    return it == boo_.end() ? dflt : it->second;
+}
+std::string Options::str(const std::string& k) const {
+    auto it = str_.find(k);
+    if (it == str_.end()) throw Error(BFH_ERR_INVALID, "option '" + k + "' missing or not a string");
+    return it->second;
+}
+
+}  // namespace bfh
+
+extern "C" {
+
+const char* bfh_version(void) { return "buffalo_hip 0.1.0 (gfx950)"; }
+
+const char* bfh_last_error(const void* handle) {
+    if (!handle) return bfh::g_create_error.c_str();
+    return static_cast<const bfh::HandleBase*>(handle)->last_error.c_str();
+}
+
+int bfh_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,260 @@
+// Shared host+device plumbing of libbuffalo_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/buffalo_hip.h"
+
+namespace bfh {
+
+// ------------------------------------------------------------------------------------------------
+// Errors.  The reference throws std::runtime_error from CHECK_CUDA
+// (/root/reference/include/buffalo/cuda/utils.cuh:24-31); here exceptions stop at the C ABI.
+// ------------------------------------------------------------------------------------------------
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+#define BFH_HIP(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess) {                                                                   \
+            std::ostringstream os__;                                                               \
+            os__ << "HIP error " << hipGetErrorString(e__) << " at " << __FILE__ << ":" << __LINE__ \
+                 << " (" #expr ")";                                                                \
+            throw ::bfh::Error(BFH_ERR_HIP, os__.str());                                           \
+        }                                                                                          \
+    } while (0)
+
+#define BFH_REQUIRE(cond, msg)                                                   \
+    do {                                                                         \
+        if (!(cond)) throw ::bfh::Error(BFH_ERR_INVALID, std::string(msg));      \
+    } while (0)
+
+extern thread_local std::string g_create_error;
+
+struct HandleBase {
+    std::string last_error;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bfh_stats stats{};
+    bool timing = true;
+    virtual ~HandleBase() {}
+};
+
+// Runs `fn` and maps exceptions onto the status codes of buffalo_hip.h.
+template <typename F>
+static inline int guarded(void* h, F&& fn) {
+    HandleBase* hb = static_cast<HandleBase*>(h);
+    if (!hb) {
+        g_create_error = "null handle";
+        return BFH_ERR_INVALID;
+    }
+    try {
+        BFH_HIP(hipSetDevice(hb->device));
+        return fn();
+    } catch (const Error& e) {
+        hb->last_error = e.what();
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        hb->last_error = "out of host memory";
+        return BFH_ERR_NOMEM;
+    } catch (const std::exception& e) {
+        hb->last_error = e.what();
+        return BFH_ERR_INVALID;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Options: the reference hands its backends a JSON file path (buffalo/misc/_aux.py:82-89) that is
+// parsed with json11 (lib/algo.cc:19-37, lib/cuda/bpr/bpr.cu:228-243).  Minimal JSON reader; only
+// top-level scalars are kept.  Unlike json11, a key the backend needs but the file lacks is an
+// error (SURVEY section 5 "Config"), except the documented quirks handled by the callers.
+// ------------------------------------------------------------------------------------------------
+class Options {
+ public:
+    bool load(const std::string& path, std::string* err);
+    bool has(const std::string& k) const { return num_.count(k) || str_.count(k) || boo_.count(k); }
+    double num(const std::string& k) const;
+    double num_or(const std::string& k, double dflt) const;
+    int integer(const std::string& k) const { return static_cast<int>(num(k)); }
+    bool boolean(const std::string& k) const;
+    bool boolean_or(const std::string& k, bool dflt) const;
+    std::string str(const std::string& k) const;
+
+ private:
+    std::map<std::string, double> num_;
+    std::map<std::string, std::string> str_;
+    std::map<std::string, bool> boo_;
+};
+
+// ------------------------------------------------------------------------------------------------
+// Device memory
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+class DevBuf {
+ public:
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p_) (void)hipFree(p_);
+        p_ = nullptr;
+        n_ = 0;
+    }
+    // grow-only unless exact is requested
+    void resize(size_t n, bool zero = false, hipStream_t s = nullptr) {
+        if (n != n_) {
+            release();
+            if (n) {
+                hipError_t e = hipMalloc(&p_, n * sizeof(T));
+                if (e != hipSuccess) {
+                    p_ = nullptr;
+                    throw Error(BFH_ERR_NOMEM, std::string("hipMalloc failed: ") + hipGetErrorString(e));
+                }
+            }
+            n_ = n;
+        }
+        if (zero && n_) BFH_HIP(hipMemsetAsync(p_, 0, n_ * sizeof(T), s));
+    }
+    T* get() const { return p_; }
+    size_t size() const { return n_; }
+    size_t bytes() const { return n_ * sizeof(T); }
+
+ private:
+    T* p_ = nullptr;
+    size_t n_ = 0;
+};
+
+// HIP-event stopwatch on the handle's stream; resolved lazily (events are only read after the
+// stream was synchronised by the caller).
+class EventTimer {
+ public:
+    ~EventTimer() {
+        for (auto& p : pool_) {
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
+        }
+    }
+    // returns slot index
+    int begin(hipStream_t s) {
+        if (used_ == pool_.size()) {
+            hipEvent_t a, b;
+            BFH_HIP(hipEventCreate(&a));
+            BFH_HIP(hipEventCreate(&b));
+            pool_.emplace_back(a, b);
+        }
+        BFH_HIP(hipEventRecord(pool_[used_].first, s));
+        return static_cast<int>(used_++);
+    }
+    void end(int slot, hipStream_t s) { BFH_HIP(hipEventRecord(pool_[slot].second, s)); }
+    // call after the stream is idle; returns summed ms and resets
+    double drain() {
+        double ms = 0.0;
+        for (size_t i = 0; i < used_; ++i) {
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, pool_[i].first, pool_[i].second) == hipSuccess) ms += t;
+        }
+        used_ = 0;
+        return ms;
+    }
+
+ private:
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool_;
+    size_t used_ = 0;
+};
+
+static inline int vdim_of(int d) { return ((d + 31) / 32) * 32; }  // bpr.cu:266-267, als.cu:251-252
+
+// ------------------------------------------------------------------------------------------------
+// Device helpers (wave64)
+// ------------------------------------------------------------------------------------------------
+#if defined(__HIPCC__)
+
+// Sum over the 64 lanes of a wavefront; every lane receives the total.
+// 4 DPP row rotations reduce each 16-lane row, then 3 readlanes combine the 4 rows: no LDS, no
+// barrier (the reference needs two __syncthreads per dot: include/buffalo/cuda/utils.cuh:80-114).
+__device__ __forceinline__ float wave_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));  // row_ror:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));  // row_ror:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));  // row_ror:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));  // row_ror:1
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
+__device__ __forceinline__ int lane_id() { return static_cast<int>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))); }
+
+// Philox4x32-10 (Salmon et al., SC'11).  Counter layout shared with the oracle's counter sampler
+// (oracle/buffalo_oracle.cc counter_draw): ctr = (pos_lo, pos_hi, attempt, epoch<<8 | slot),
+// key = (seed, 0x5bf03635 ^ stream).
+__host__ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                       uint32_t k0, uint32_t k1, uint32_t& o0, uint32_t& o1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = static_cast<uint64_t>(0xD2511F53u) * c0;
+        const uint64_t p1 = static_cast<uint64_t>(0xCD9E8D57u) * c2;
+        const uint32_t n0 = static_cast<uint32_t>(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n2 = static_cast<uint32_t>(p0 >> 32) ^ c3 ^ k1;
+        c1 = static_cast<uint32_t>(p1);
+        c3 = static_cast<uint32_t>(p0);
+        c0 = n0;
+        c2 = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    o0 = c0;
+    o1 = c1;
+}
+
+__host__ __device__ __forceinline__ void counter_draw(uint32_t seed, uint32_t stream, uint64_t pos_idx, uint32_t slot,
+                                                      uint32_t epoch, uint32_t attempt, uint32_t& o0, uint32_t& o1) {
+    philox4x32_10(static_cast<uint32_t>(pos_idx), static_cast<uint32_t>(pos_idx >> 32), attempt,
+                  (epoch << 8) | (slot & 0xffu), seed, 0x5bf03635u ^ stream, o0, o1);
+}
+
+// first index in [0,n) with a[idx] >= v  (std::lower_bound)
+template <typename T>
+__device__ __forceinline__ int64_t lower_bound_dev(const T* __restrict__ a, int64_t n, T v) {
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (a[mid] < v) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// membership test in a sorted int32 run [beg,end)
+__device__ __forceinline__ bool sorted_contains(const int32_t* __restrict__ keys, int64_t beg, int64_t end, int32_t v) {
+    int64_t lo = beg, hi = end;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        const int32_t k = keys[mid];
+        if (k < v) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo < end && keys[lo] == v;
+}
+
+// hardware fp32 atomic add without return (global_atomic_add_f32)
+__device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
+
+#endif  // __HIPCC__
+
+}  // namespace bfh

@@ -1,0 +1,463 @@
+// SgdHandle: device-resident model, placeholders, lr schedule and the epoch-end optimizer pass
+// shared by the BPRMF and WARP backends.
+#include "sgd_base.hpp"
+
+namespace bfh {
+
+// ------------------------------------------------------------------------------------------------
+// fill_rows: row id of every nnz of a chunk (cf. fill_rows_kernel, /root/reference/lib/cuda/bpr/
+// bpr.cu:22-33, which runs one thread per block).  One thread per nnz, binary search in indptr.
+// ------------------------------------------------------------------------------------------------
+__global__ void fill_rows_kernel(const int64_t* __restrict__ indptr, int start_x, int next_x, int64_t shift, int64_t n,
+                                 int32_t* __restrict__ rows) {
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int64_t g = shift + t;
+    // first row u in [start_x, next_x) with indptr[u] > g
+    int lo = start_x, hi = next_x;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (indptr[mid] <= g) lo = mid + 1;
+        else hi = mid;
+    }
+    rows[t] = lo;
+}
+
+void launch_fill_rows(const int64_t* indptr, int start_x, int next_x, int64_t shift, int64_t n, int32_t* rows, hipStream_t s) {
+    if (n <= 0) return;
+    const int bs = 256;
+    const int64_t grid = (n + bs - 1) / bs;
+    hipLaunchKernelGGL(fill_rows_kernel, dim3(static_cast<unsigned>(grid)), dim3(bs), 0, s, indptr, start_x, next_x, shift, n, rows);
+    BFH_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// Epoch-end optimizer pass: SGDAlgorithm::update_parameters / update_adam / update_adagrad
+// (/root/reference/lib/algo.cc:365-465) fused with CWARP's unit-ball projection
+// (/root/reference/lib/algo_impl/warp/warp.cc:192-201).  Pure streaming: (3 or 4) arrays read +
+// written once.  Quirks kept: grad keeps the transformed step (Q-6), FEPS outside the sqrt (Q-5).
+// A row is handled by G = 64/RPW lanes, float4 per lane.
+// ------------------------------------------------------------------------------------------------
+struct OptConsts {
+    float reg2, lr, b1, omb1, b2, omb2, c1, c2;
+};
+
+__device__ __forceinline__ float group_sum(float v, int G) {
+    for (int s = 1; s < G; s <<= 1) v += __shfl_xor(v, s, 64);
+    return v;
+}
+
+template <bool ADAM>
+__device__ __forceinline__ void opt_step4(float4& x, float4& g, float4& m, float4& v, bool has_cnt, float cntf,
+                                          const OptConsts& k, float& nrm) {
+    const float FEPS = 1e-10f;
+    float* xp = reinterpret_cast<float*>(&x);
+    float* gp = reinterpret_cast<float*>(&g);
+    float* vp = reinterpret_cast<float*>(&v);
+    float* mp = reinterpret_cast<float*>(&m);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float ge = gp[e];
+        if (has_cnt) ge = ge / cntf;
+        ge = ge - xp[e] * k.reg2;
+        if (ADAM) {
+            mp[e] = k.b1 * mp[e] + k.omb1 * ge;
+            vp[e] = k.b2 * vp[e] + k.omb2 * (ge * ge);
+            const float m_hat = mp[e] / k.c1;
+            const float v_hat = vp[e] / k.c2;
+            ge = m_hat / (sqrtf(v_hat) + FEPS);
+        } else {
+            vp[e] = vp[e] + ge * ge;
+            ge = ge / (sqrtf(vp[e]) + FEPS);
+        }
+        gp[e] = ge;
+        xp[e] = xp[e] + k.lr * ge;
+        nrm += xp[e] * xp[e];
+    }
+}
+
+template <bool ADAM, bool PROJECT>
+__global__ __launch_bounds__(256) void sgd_update_rows_kernel(float* __restrict__ X, float* __restrict__ grad,
+                                                               float* __restrict__ mom, float* __restrict__ vel,
+                                                               const int* __restrict__ cnt, int rows, int vdim, int G,
+                                                               OptConsts k) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int rpw = 64 / G;
+    const int row = wave * rpw + lane / G;
+    const int gl = lane % G;
+    const bool active = row < rows;
+    float nrm = 0.f;
+    float cntf = 1.f;
+    bool has_cnt = false;
+    if (active && cnt) {
+        const int c = cnt[row];
+        has_cnt = c != 0;
+        cntf = static_cast<float>(c);
+    }
+    if (vdim <= G * 4) {
+        // one float4 per lane: the row stays in registers between the step and the projection
+        const bool has = active && gl * 4 < vdim;
+        const size_t o = static_cast<size_t>(active ? row : 0) * vdim + gl * 4;
+        float4 x = make_float4(0, 0, 0, 0), g = x, v = x, m = x;
+        if (has) {
+            x = *reinterpret_cast<float4*>(X + o);
+            g = *reinterpret_cast<float4*>(grad + o);
+            v = *reinterpret_cast<float4*>(vel + o);
+            if (ADAM) m = *reinterpret_cast<float4*>(mom + o);
+            opt_step4<ADAM>(x, g, m, v, has_cnt, cntf, k, nrm);
+            *reinterpret_cast<float4*>(grad + o) = g;
+            *reinterpret_cast<float4*>(vel + o) = v;
+            if (ADAM) *reinterpret_cast<float4*>(mom + o) = m;
+        }
+        if (PROJECT) {
+            nrm = group_sum(nrm, G);
+            const float dn = fmaxf(1.0f, sqrtf(nrm));
+            x.x /= dn; x.y /= dn; x.z /= dn; x.w /= dn;
+        }
+        if (has) *reinterpret_cast<float4*>(X + o) = x;
+        return;
+    }
+    // vdim > 256: G == 64, several float4 per lane; projection needs a second pass over the row
+    if (active) {
+        for (int c = gl * 4; c < vdim; c += G * 4) {
+            const size_t o = static_cast<size_t>(row) * vdim + c;
+            float4 x = *reinterpret_cast<float4*>(X + o);
+            float4 g = *reinterpret_cast<float4*>(grad + o);
+            float4 v = *reinterpret_cast<float4*>(vel + o);
+            float4 m = make_float4(0, 0, 0, 0);
+            if (ADAM) m = *reinterpret_cast<float4*>(mom + o);
+            opt_step4<ADAM>(x, g, m, v, has_cnt, cntf, k, nrm);
+            *reinterpret_cast<float4*>(grad + o) = g;
+            *reinterpret_cast<float4*>(vel + o) = v;
+            if (ADAM) *reinterpret_cast<float4*>(mom + o) = m;
+            *reinterpret_cast<float4*>(X + o) = x;
+        }
+    }
+    if (PROJECT) {
+        nrm = group_sum(nrm, G);
+        if (active) {
+            const float dn = fmaxf(1.0f, sqrtf(nrm));
+            for (int c = gl * 4; c < vdim; c += G * 4) {
+                const size_t o = static_cast<size_t>(row) * vdim + c;
+                float4 x = *reinterpret_cast<float4*>(X + o);
+                x.x /= dn; x.y /= dn; x.z /= dn; x.w /= dn;
+                *reinterpret_cast<float4*>(X + o) = x;
+            }
+        }
+    }
+}
+
+// bias column Qb[I,1]: thread per item (lib/algo.cc:415-419, 448-452)
+template <bool ADAM>
+__global__ void sgd_update_bias_kernel(float* __restrict__ X, float* __restrict__ grad, float* __restrict__ mom,
+                                       float* __restrict__ vel, const int* __restrict__ cnt, int rows, bool use_bias,
+                                       OptConsts k) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    const float FEPS = 1e-10f;
+    float g = grad[i];
+    if (cnt && cnt[i]) g = g / static_cast<float>(cnt[i]);  // Q-9: divided even without use_bias
+    if (use_bias) {
+        g = g - X[i] * k.reg2;
+        if (ADAM) {
+            const float m = k.b1 * mom[i] + k.omb1 * g;
+            const float v = k.b2 * vel[i] + k.omb2 * (g * g);
+            mom[i] = m;
+            vel[i] = v;
+            g = (m / k.c1) / (sqrtf(v / k.c2) + FEPS);
+        } else {
+            const float v = vel[i] + g * g;
+            vel[i] = v;
+            g = g / (sqrtf(v) + FEPS);
+        }
+        X[i] = X[i] + k.lr * g;
+    }
+    grad[i] = g;
+}
+
+// ------------------------------------------------------------------------------------------------
+SgdHandle::~SgdHandle() {
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+bool SgdHandle::init(const char* opt_path) {
+    std::string err;
+    if (!opt_.load(opt_path ? opt_path : "", &err)) {
+        last_error = err;
+        return false;
+    }
+    BFH_HIP(hipSetDevice(device));
+    if (!stream) BFH_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    hipDeviceProp_t prop;
+    BFH_HIP(hipGetDeviceProperties(&prop, device));
+    num_cus_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+
+    d_ = opt_.integer("d");
+    BFH_REQUIRE(d_ > 0, "option d must be positive");
+    vdim_ = vdim_of(d_);
+    BFH_REQUIRE(vdim_ <= 1024, "d > 1024 is not supported by the gfx950 kernels yet");
+    num_iters_ = opt_.integer("num_iters");
+    optimizer_ = opt_.str("optimizer");
+    BFH_REQUIRE(optimizer_ == "sgd" || optimizer_ == "adam" || optimizer_ == "adagrad",
+                "optimizer must be one of sgd, adam, adagrad");
+    lr_ = opt_.num("lr");
+    min_lr_ = opt_.num_or("min_lr", lr_);
+    beta1_ = opt_.num_or("beta1", 0.9);
+    reg_u_ = static_cast<float>(opt_.num("reg_u"));
+    reg_i_ = static_cast<float>(opt_.num("reg_i"));
+    reg_j_ = static_cast<float>(opt_.num("reg_j"));
+    reg_b_ = static_cast<float>(opt_.num_or("reg_b", 0.0));
+    update_i_ = opt_.boolean_or("update_i", true);
+    update_j_ = opt_.boolean_or("update_j", true);
+    use_bias_ = opt_.boolean_or("use_bias", false);
+    pcn_ = opt_.boolean_or("per_coordinate_normalize", false);
+    compute_loss_ = opt_.boolean_or("compute_loss_on_training", false);
+    // the reference's CUDA backend reads a non-existent key "rand_seed" (bpr.cu:262, Q-19);
+    // this backend follows the CPU path and uses "random_seed" (bpr.cc:83).
+    seed_ = static_cast<uint32_t>(opt_.num_or("random_seed", 0));
+    parse_specific();
+    scratch_.resize(8, true, stream);
+    inited_ = true;
+    return true;
+}
+
+void SgdHandle::initialize_model(float* P, int P_rows, float* Q, float* Qb, int Q_rows, int64_t num_nnz, bool set_gpu) {
+    BFH_REQUIRE(inited_, "initialize_model called before init");
+    BFH_REQUIRE(P && Q && Qb && P_rows > 0 && Q_rows > 0, "initialize_model: null factors or empty shapes");
+    hostP_ = P; hostQ_ = Q; hostQb_ = Qb;
+    P_rows_ = P_rows; Q_rows_ = Q_rows;
+    num_nnz_ = num_nnz;
+    if (!set_gpu) return;  // bpr.cu:293-298: only record host pointers
+    const size_t np = static_cast<size_t>(P_rows) * vdim_, nq = static_cast<size_t>(Q_rows) * vdim_;
+    P_.resize(np); Q_.resize(nq); Qb_.resize(Q_rows);
+    BFH_HIP(hipMemcpyAsync(P_.get(), P, np * sizeof(float), hipMemcpyHostToDevice, stream));
+    BFH_HIP(hipMemcpyAsync(Q_.get(), Q, nq * sizeof(float), hipMemcpyHostToDevice, stream));
+    BFH_HIP(hipMemcpyAsync(Qb_.get(), Qb, Q_rows * sizeof(float), hipMemcpyHostToDevice, stream));
+    stats.h2d_bytes += static_cast<double>((np + nq + Q_rows) * sizeof(float));
+    if (optimizer_ != "sgd") {  // lib/algo.cc:221-255
+        gradP_.resize(np, true, stream); gradQ_.resize(nq, true, stream); gradQb_.resize(Q_rows, true, stream);
+        velP_.resize(np, true, stream); velQ_.resize(nq, true, stream); velQb_.resize(Q_rows, true, stream);
+        if (optimizer_ == "adam") {
+            momP_.resize(np, true, stream); momQ_.resize(nq, true, stream); momQb_.resize(Q_rows, true, stream);
+        }
+        if (pcn_) {
+            cntP_.resize(P_rows, true, stream);
+            cntQ_.resize(Q_rows, true, stream);
+        }
+    }
+    iters_ = 0;
+    epoch_ = 0;
+    processed_ = 0;
+    model_on_gpu_ = true;
+    sync_stream();
+}
+
+void SgdHandle::set_placeholder(const int64_t* indptr, size_t batch_size) {
+    BFH_REQUIRE(P_rows_ > 0, "set_placeholder called before initialize_model");
+    BFH_REQUIRE(indptr, "set_placeholder: null indptr");
+    indptr_host_.assign(indptr, indptr + P_rows_);
+    indptr_.resize(P_rows_);
+    BFH_HIP(hipMemcpyAsync(indptr_.get(), indptr, P_rows_ * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+    stats.h2d_bytes += static_cast<double>(P_rows_ * sizeof(int64_t));
+    if (!resident_) {
+        keys_.resize(batch_size);
+        rows_.resize(batch_size);
+    }
+    placeholder_set_ = true;
+    sync_stream();
+}
+
+void SgdHandle::set_resident_csr(const int64_t* indptr, const int32_t* keys, int64_t nnz) {
+    BFH_REQUIRE(P_rows_ > 0, "set_resident_csr called before initialize_model");
+    BFH_REQUIRE(indptr && keys && nnz >= 0, "set_resident_csr: null arrays");
+    BFH_REQUIRE(indptr[P_rows_ - 1] == nnz, "set_resident_csr: indptr[-1] != nnz");
+    indptr_host_.assign(indptr, indptr + P_rows_);
+    indptr_.resize(P_rows_);
+    keys_.resize(static_cast<size_t>(nnz));
+    rows_.resize(static_cast<size_t>(nnz));
+    BFH_HIP(hipMemcpyAsync(indptr_.get(), indptr, P_rows_ * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+    BFH_HIP(hipMemcpyAsync(keys_.get(), keys, nnz * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    stats.h2d_bytes += static_cast<double>(P_rows_ * sizeof(int64_t) + nnz * sizeof(int32_t));
+    launch_fill_rows(indptr_.get(), 0, P_rows_, 0, nnz, rows_.get(), stream);
+    resident_ = true;
+    resident_nnz_ = nnz;
+    placeholder_set_ = true;
+    sync_stream();
+}
+
+void SgdHandle::set_cumulative_table(const int64_t* table) {
+    BFH_REQUIRE(Q_rows_ > 0, "set_cumulative_table called before initialize_model");
+    BFH_REQUIRE(table, "set_cumulative_table: null table");
+    cum_.resize(Q_rows_);
+    BFH_HIP(hipMemcpyAsync(cum_.get(), table, Q_rows_ * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+    cum_total_ = table[Q_rows_ - 1];
+    have_cum_ = true;
+    sync_stream();
+}
+
+int64_t SgdHandle::stage_chunk(int start_x, int next_x, const int64_t* indptr, const int32_t* keys, SgdParams* pr) {
+    BFH_REQUIRE(model_on_gpu_, "partial_update before initialize_model(..., set_gpu=True)");
+    BFH_REQUIRE(placeholder_set_, "partial_update before set_placeholder");
+    BFH_REQUIRE(0 <= start_x && start_x <= next_x && next_x <= P_rows_, "partial_update: bad row range");
+    const int64_t* ip = indptr ? indptr : indptr_host_.data();
+    const int64_t beg = start_x == 0 ? 0 : ip[start_x - 1];
+    const int64_t end = next_x == 0 ? 0 : ip[next_x - 1];
+    const int64_t n = end - beg;
+    std::memset(pr, 0, sizeof(*pr));
+    pr->P = P_.get(); pr->Q = Q_.get(); pr->Qb = Qb_.get();
+    pr->gradP = gradP_.get(); pr->gradQ = gradQ_.get(); pr->gradQb = gradQb_.get();
+    pr->cntP = cntP_.get(); pr->cntQ = cntQ_.get();
+    pr->indptr = indptr_.get();
+    pr->cum_table = have_cum_ ? cum_.get() : nullptr;
+    pr->chunk_nnz = n;
+    pr->shift = beg;
+    pr->nnz_offset = nnz_offset_;
+    pr->P_rows = P_rows_; pr->Q_rows = Q_rows_; pr->d = d_; pr->vdim = vdim_;
+    pr->seed = seed_; pr->epoch = epoch_;
+    if (n == 0) return 0;
+    if (keys) {
+        if (resident_) {
+            // caller insists on passing keys although a resident CSR exists: honour the resident copy
+            pr->keys = keys_.get() + beg;
+            pr->rows = rows_.get() + beg;
+        } else {
+            BFH_REQUIRE(static_cast<size_t>(n) <= keys_.size(), "partial_update: chunk larger than the placeholder batch_size");
+            BFH_HIP(hipMemcpyAsync(keys_.get(), keys, n * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+            stats.h2d_bytes += static_cast<double>(n * sizeof(int32_t));
+            launch_fill_rows(indptr_.get(), start_x, next_x, beg, n, rows_.get(), stream);
+            pr->keys = keys_.get();
+            pr->rows = rows_.get();
+        }
+    } else {
+        BFH_REQUIRE(resident_, "partial_update: keys == NULL needs bfh_*_set_resident_csr first");
+        pr->keys = keys_.get() + beg;
+        pr->rows = rows_.get() + beg;
+    }
+    return n;
+}
+
+// Deterministic form of the reference's lr decay (lib/algo.cc:280-287, Q-8): the lr of a call is
+// the one the progress thread would publish after all previously submitted jobs completed.  Same
+// rule as CuBPR's host-side decay (bpr.cu:399-401) but with the CPU path's progress accounting.
+double SgdHandle::current_lr() const {
+    const double total = static_cast<double>(num_nnz_) * static_cast<double>(num_iters_);
+    const double progress = total > 0 ? processed_ / total : 0.0;
+    double a = lr_ - (lr_ - min_lr_) * progress;
+    return a > min_lr_ ? a : min_lr_;
+}
+
+void SgdHandle::advance_progress(int start_x, int next_x, const int64_t* ip_arg) {
+    const int64_t* ip = ip_arg ? ip_arg : indptr_host_.data();
+    // job.size = 1 (user slot) + n_pos for every non-empty user (include/buffalo/algo.hpp:38-42)
+    int64_t sz = 0;
+    int64_t prev = start_x == 0 ? 0 : ip[start_x - 1];
+    for (int x = start_x; x < next_x; ++x) {
+        const int64_t e = ip[x];
+        if (e > prev) sz += 1 + (e - prev);
+        prev = e;
+    }
+    processed_ += static_cast<double>(sz) * num_shards_;
+}
+
+void SgdHandle::harvest_timers() {
+    stats.kernel_ms += t_main_.drain();
+    stats.optimizer_ms += t_opt_.drain();
+    stats.aux_ms += t_aux_.drain();
+}
+
+void SgdHandle::synchronize(bool device_to_host) {
+    BFH_REQUIRE(hostP_ && model_on_gpu_, "synchronize before initialize_model(..., set_gpu=True)");
+    const size_t np = static_cast<size_t>(P_rows_) * vdim_, nq = static_cast<size_t>(Q_rows_) * vdim_;
+    const hipMemcpyKind kind = device_to_host ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice;
+    if (device_to_host) {
+        BFH_HIP(hipMemcpyAsync(hostP_, P_.get(), np * sizeof(float), kind, stream));
+        BFH_HIP(hipMemcpyAsync(hostQ_, Q_.get(), nq * sizeof(float), kind, stream));
+        BFH_HIP(hipMemcpyAsync(hostQb_, Qb_.get(), Q_rows_ * sizeof(float), kind, stream));
+        stats.d2h_bytes += static_cast<double>((np + nq + Q_rows_) * sizeof(float));
+    } else {
+        BFH_HIP(hipMemcpyAsync(P_.get(), hostP_, np * sizeof(float), kind, stream));
+        BFH_HIP(hipMemcpyAsync(Q_.get(), hostQ_, nq * sizeof(float), kind, stream));
+        BFH_HIP(hipMemcpyAsync(Qb_.get(), hostQb_, Q_rows_ * sizeof(float), kind, stream));
+        stats.h2d_bytes += static_cast<double>((np + nq + Q_rows_) * sizeof(float));
+    }
+    sync_stream();
+}
+
+void SgdHandle::update_parameters() {
+    BFH_REQUIRE(model_on_gpu_, "update_parameters before initialize_model(..., set_gpu=True)");
+    if (optimizer_ != "sgd") {
+        const bool adam = optimizer_ == "adam";
+        const double beta1 = beta1_, beta2 = beta1_;  // Q-5: beta2 is read from "beta1" (lib/algo.cc:396)
+        OptConsts k;
+        k.lr = static_cast<float>(lr_);
+        k.b1 = static_cast<float>(beta1); k.omb1 = static_cast<float>(1.0 - beta1);
+        k.b2 = static_cast<float>(beta2); k.omb2 = static_cast<float>(1.0 - beta2);
+        k.c1 = static_cast<float>(1.0 - std::pow(beta1, iters_ + 1));
+        k.c2 = static_cast<float>(1.0 - std::pow(beta2, iters_ + 1));
+        int G = 8;
+        while (G < 64 && G * 4 < vdim_) G <<= 1;
+        const int rpw = 64 / G;
+        const bool proj = project_unit_ball();
+        auto run = [&](float* X, float* g, float* m, float* v, const int* cnt, int rows, float reg) {
+            k.reg2 = static_cast<float>(2.0 * static_cast<double>(reg));
+            const int waves = (rows + rpw - 1) / rpw;
+            const int blocks = (waves + 3) / 4;
+            if (adam && proj) hipLaunchKernelGGL((sgd_update_rows_kernel<true, true>), dim3(blocks), dim3(256), 0, stream, X, g, m, v, cnt, rows, vdim_, G, k);
+            else if (adam) hipLaunchKernelGGL((sgd_update_rows_kernel<true, false>), dim3(blocks), dim3(256), 0, stream, X, g, m, v, cnt, rows, vdim_, G, k);
+            else if (proj) hipLaunchKernelGGL((sgd_update_rows_kernel<false, true>), dim3(blocks), dim3(256), 0, stream, X, g, m, v, cnt, rows, vdim_, G, k);
+            else hipLaunchKernelGGL((sgd_update_rows_kernel<false, false>), dim3(blocks), dim3(256), 0, stream, X, g, m, v, cnt, rows, vdim_, G, k);
+            BFH_HIP(hipGetLastError());
+        };
+        const int slot = t_opt_.begin(stream);
+        run(P_.get(), gradP_.get(), momP_.get(), velP_.get(), pcn_ ? cntP_.get() : nullptr, P_rows_, reg_u_);
+        // reference order: Q rows, with the bias handled inside the same loop (algo.cc:407-420)
+        {
+            k.reg2 = static_cast<float>(2.0 * static_cast<double>(reg_b_));
+            const int blocks = (Q_rows_ + 255) / 256;
+            if (adam) hipLaunchKernelGGL((sgd_update_bias_kernel<true>), dim3(blocks), dim3(256), 0, stream, Qb_.get(), gradQb_.get(), momQb_.get(), velQb_.get(), pcn_ ? cntQ_.get() : nullptr, Q_rows_, use_bias_, k);
+            else hipLaunchKernelGGL((sgd_update_bias_kernel<false>), dim3(blocks), dim3(256), 0, stream, Qb_.get(), gradQb_.get(), momQb_.get(), velQb_.get(), pcn_ ? cntQ_.get() : nullptr, Q_rows_, use_bias_, k);
+            BFH_HIP(hipGetLastError());
+        }
+        run(Q_.get(), gradQ_.get(), momQ_.get(), velQ_.get(), pcn_ ? cntQ_.get() : nullptr, Q_rows_, reg_i_);
+        if (pcn_) {
+            BFH_HIP(hipMemsetAsync(cntP_.get(), 0, cntP_.bytes(), stream));
+            BFH_HIP(hipMemsetAsync(cntQ_.get(), 0, cntQ_.bytes(), stream));
+        }
+        t_opt_.end(slot, stream);
+    }
+    iters_ += 1;
+    epoch_ += 1;
+    sync_stream();
+    harvest_timers();
+}
+
+void SgdHandle::set_mode(const std::string& name, int64_t v) {
+    if (name == "sequential") sequential_ = static_cast<int>(v);
+    else if (name == "hogwild_atomic") hogwild_atomic_ = static_cast<int>(v);
+    else if (name == "prefetch") prefetch_ = static_cast<int>(v);
+    else if (name == "waves_per_cu") waves_per_cu_ = static_cast<int>(v);
+    else if (name == "chunk") { BFH_REQUIRE(v >= 64 && v % 64 == 0, "chunk must be a positive multiple of 64"); chunk_ = static_cast<int>(v); }
+    else if (name == "timing") timing = v != 0;
+    else if (name == "epoch") epoch_ = static_cast<uint32_t>(v);
+    else throw Error(BFH_ERR_INVALID, "unknown mode '" + name + "'");
+}
+
+void SgdHandle::device_buffer(const std::string& name, void** p, size_t* bytes) {
+    struct { const char* n; void* ptr; size_t b; } tab[] = {
+        {"P", P_.get(), P_.bytes()}, {"Q", Q_.get(), Q_.bytes()}, {"Qb", Qb_.get(), Qb_.bytes()},
+        {"gradP", gradP_.get(), gradP_.bytes()}, {"gradQ", gradQ_.get(), gradQ_.bytes()}, {"gradQb", gradQb_.get(), gradQb_.bytes()},
+        {"countP", cntP_.get(), cntP_.bytes()}, {"countQ", cntQ_.get(), cntQ_.bytes()},
+        {"velP", velP_.get(), velP_.bytes()}, {"velQ", velQ_.get(), velQ_.bytes()},
+        {"momP", momP_.get(), momP_.bytes()}, {"momQ", momQ_.get(), momQ_.bytes()},
+    };
+    for (auto& t : tab)
+        if (name == t.n) {
+            *p = t.ptr;
+            *bytes = t.b;
+            return;
+        }
+    throw Error(BFH_ERR_INVALID, "unknown device buffer '" + name + "'");
+}
+
+}  // namespace bfh

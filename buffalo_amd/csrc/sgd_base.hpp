@@ -1,0 +1,96 @@
+// Device-resident state shared by the BPRMF and WARP backends: the GPU counterpart of
+// SGDAlgorithm (/root/reference/include/buffalo/algo.hpp:93-148, lib/algo.cc:133-492) behind the
+// accelerator surface of CuBPR (/root/reference/include/buffalo/cuda/bpr/bpr.hpp:29-45).
+#pragma once
+#include "common.hpp"
+
+namespace bfh {
+
+struct SgdParams {  // kernel-visible constants
+    float* P;
+    float* Q;
+    float* Qb;
+    float* gradP;
+    float* gradQ;
+    float* gradQb;
+    int* cntP;
+    int* cntQ;
+    const int64_t* indptr;    // [P_rows] end offsets (full matrix)
+    const int32_t* keys;      // chunk keys (chunk-local index)
+    const int32_t* rows;      // chunk row ids (chunk-local index)
+    const int64_t* cum_table; // [Q_rows] or null
+    int64_t chunk_nnz;        // nnz in this chunk
+    int64_t shift;            // global position of the chunk's first nnz (within this shard)
+    int64_t nnz_offset;       // global position of the shard's first nnz
+    int P_rows, Q_rows, d, vdim;
+    uint32_t seed, epoch;
+};
+
+class SgdHandle : public HandleBase {
+ public:
+    explicit SgdHandle(int kind) : kind_(kind) {}
+    ~SgdHandle() override;
+
+    // ---- reference surface -------------------------------------------------------------------
+    bool init(const char* opt_path);
+    int get_vdim() const { return vdim_; }
+    void initialize_model(float* P, int P_rows, float* Q, float* Qb, int Q_rows, int64_t num_nnz, bool set_gpu);
+    void set_placeholder(const int64_t* indptr, size_t batch_size);
+    void set_cumulative_table(const int64_t* table);
+    void synchronize(bool device_to_host);
+    void update_parameters();
+    // ---- extensions --------------------------------------------------------------------------
+    void set_resident_csr(const int64_t* indptr, const int32_t* keys, int64_t nnz);
+    void set_mode(const std::string& name, int64_t v);
+    void device_buffer(const std::string& name, void** p, size_t* bytes);
+    void sync_stream() { BFH_HIP(hipStreamSynchronize(stream)); }
+    void harvest_timers();
+
+ protected:
+    // stage the chunk [start_x,next_x) (keys + row ids) and fill `pr`; returns chunk nnz
+    int64_t stage_chunk(int start_x, int next_x, const int64_t* indptr, const int32_t* keys, SgdParams* pr);
+    double current_lr() const;  // deterministic per-call schedule (see DESIGN.md "learning rate")
+    void advance_progress(int start_x, int next_x, const int64_t* indptr_host);
+    virtual void parse_specific() = 0;
+    virtual bool project_unit_ball() const { return false; }
+
+ public:
+    int kind_;  // 0 bpr, 1 warp
+    Options opt_;
+    bool inited_ = false, model_on_gpu_ = false, placeholder_set_ = false;
+    int d_ = 0, vdim_ = 0, P_rows_ = 0, Q_rows_ = 0;
+    int64_t num_nnz_ = 0;
+    int num_iters_ = 0;
+    std::string optimizer_;
+    bool use_bias_ = false, update_i_ = true, update_j_ = true, pcn_ = false, compute_loss_ = false;
+    float reg_u_ = 0, reg_i_ = 0, reg_j_ = 0, reg_b_ = 0;
+    double lr_ = 0, min_lr_ = 0, beta1_ = 0;
+    uint32_t seed_ = 0, epoch_ = 0;
+    int iters_ = 0;
+    double processed_ = 0;  // sum of job sizes so far (Q-8)
+    int64_t nnz_offset_ = 0;
+    int num_shards_ = 1;
+
+    // knobs
+    int sequential_ = 0, hogwild_atomic_ = 1, prefetch_ = 1, waves_per_cu_ = 0, chunk_ = 256;
+
+    float *hostP_ = nullptr, *hostQ_ = nullptr, *hostQb_ = nullptr;
+    DevBuf<float> P_, Q_, Qb_, gradP_, gradQ_, gradQb_, momP_, momQ_, momQb_, velP_, velQ_, velQb_;
+    DevBuf<int> cntP_, cntQ_;
+    DevBuf<int64_t> indptr_, cum_;
+    std::vector<int64_t> indptr_host_;
+    DevBuf<int32_t> keys_, rows_;
+    DevBuf<double> scratch_;  // loss / counters returned by kernels
+    bool resident_ = false;
+    int64_t resident_nnz_ = 0;
+    bool have_cum_ = false;
+    int64_t cum_total_ = 0;
+    int num_cus_ = 256;
+
+    EventTimer t_main_, t_opt_, t_aux_;
+};
+
+// kernels implemented in sgd_base.hip
+void launch_fill_rows(const int64_t* indptr, int start_x, int next_x, int64_t shift, int64_t n, int32_t* rows, hipStream_t s);
+
+}  // namespace bfh

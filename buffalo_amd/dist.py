@@ -1,0 +1,130 @@
+"""Multi-GPU data parallelism for the SGD family (BPRMF / WARP): one process per GPU,
+`torch.distributed` (backend "nccl" == RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+
+The reference has no multi-device code at all; the scheme below is new:
+
+* users (P rows, their CSR rows, their optimizer state) are sharded into contiguous, nnz-balanced
+  ranges -- one shard per rank; a triple touches one user row and two item rows, so user shards
+  never interact;
+* item factors Q (+Qb) are replicated.  What a rank changed in the replicated tensors during one
+  minibatch (= one `add_jobs` call over its shard) is exchanged as a *delta* with ONE all-reduce:
+      T_new = T_sync + sum_r (T_r - T_sync)
+  - optimizer "sgd" (Hogwild): T = {Q, Qb}  -> local-SGD with summed updates;
+  - adam / adagrad / WARP:     T = {gradQ, gradQb, countQ}; the optimizer step is then computed
+    redundantly and identically on every rank, which is *exactly* the single-GPU result up to fp32
+    summation order (the delta form keeps the never-re-zeroed gradient residue of Q-6 from being
+    counted world_size times).
+  Q is 14 MB at ML-20M/d=128 and 1 GB at the 10M x 1M WARP config: one collective per minibatch
+  keeps the ring all-reduce (per-link bound on xGMI) off the critical path.
+"""
+import numpy as np
+
+
+def shard_bounds(indptr, world_size):
+    """Contiguous user ranges with ~equal nnz (degree distributions are heavy-tailed, so equal
+    row counts would not balance).  Returns world_size+1 row boundaries."""
+    indptr = np.asarray(indptr, dtype=np.int64)
+    U = indptr.shape[0]
+    nnz = int(indptr[-1]) if U else 0
+    bounds = [0]
+    for r in range(1, world_size):
+        target = nnz * r // world_size
+        b = int(np.searchsorted(indptr, target, side="left")) + 1  # first row whose end offset >= target
+        bounds.append(min(max(b, bounds[-1]), U))
+    bounds.append(U)
+    return bounds
+
+
+def shard_csr(indptr, keys, rank, world_size):
+    """Rank-local CSR: rows [u0,u1) with indptr rebased to start at zero.
+    Returns (u0, u1, local_indptr, local_keys, nnz_offset)."""
+    b = shard_bounds(indptr, world_size)
+    u0, u1 = b[rank], b[rank + 1]
+    beg = 0 if u0 == 0 else int(indptr[u0 - 1])
+    end = beg if u1 == u0 else int(indptr[u1 - 1])
+    local_indptr = np.ascontiguousarray(np.asarray(indptr[u0:u1], dtype=np.int64) - beg)
+    return u0, u1, local_indptr, np.ascontiguousarray(keys[beg:end]), beg
+
+
+class DeltaAllReduce:
+    """Keeps replicated tensors consistent across ranks: call `begin()` before the local work and
+    `finish()` after it.  Tensors are torch tensors aliasing the engine's buffers."""
+
+    def __init__(self, tensors, group=None):
+        import torch
+        self.torch = torch
+        self.tensors = [t for t in tensors if t is not None and t.numel() > 0]
+        self.group = group
+        self.snap = [torch.empty_like(t) for t in self.tensors]
+        self.bytes_per_sync = sum(t.numel() * t.element_size() for t in self.tensors)
+
+    def _sync(self):
+        # the backend launches on its own stream and returns idle; torch work on torch's stream has
+        # to be complete before the backend touches the same buffers again (and vice versa)
+        if self.tensors and self.tensors[0].is_cuda:
+            self.torch.cuda.current_stream().synchronize()
+
+    def begin(self):
+        for s, t in zip(self.snap, self.tensors):
+            s.copy_(t)
+        self._sync()
+
+    def finish(self):
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+            return
+        for s, t in zip(self.snap, self.tensors):
+            t.sub_(s)                                   # local delta
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            t.add_(s)                                   # T_sync + sum of deltas
+        self._sync()
+
+
+class DataParallelSGD:
+    """Drives one accelerator object (CyBPR / CyWARP surface) on this rank's user shard.
+
+    `engine` must offer add_jobs / update_parameters plus `replicated_tensors(kind)` returning the
+    torch views to all-reduce; `HipEngine` adapts the HIP backend, the CPU tests plug the oracle in.
+    """
+
+    def __init__(self, engine, optimizer, group=None):
+        self.engine = engine
+        self.sgd = optimizer == "sgd"
+        self.sync = DeltaAllReduce(engine.replicated_tensors("model" if self.sgd else "grad"), group)
+
+    def minibatch(self, start_x, next_x, indptr, keys):
+        """One `add_jobs` over [start_x,next_x) of the local shard + the item-side exchange."""
+        self.sync.begin()
+        out = self.engine.add_jobs(start_x, next_x, indptr, keys)
+        self.engine.wait()
+        self.sync.finish()
+        return out
+
+    def end_epoch(self):
+        self.engine.update_parameters()
+
+
+class HipEngine:
+    """Adapter: buffalo_amd.backend.CyBPR / CyWARP -> DataParallelSGD engine."""
+
+    def __init__(self, obj, num_items, vdim, optimizer, pcn=False):
+        self.obj, self.I, self.vdim, self.optimizer, self.pcn = obj, num_items, vdim, optimizer, pcn
+
+    def replicated_tensors(self, kind):
+        o = self.obj
+        if kind == "model":
+            return [o.device_tensor("Q", (self.I, self.vdim)), o.device_tensor("Qb", (self.I,))]
+        ts = [o.device_tensor("gradQ", (self.I, self.vdim)), o.device_tensor("gradQb", (self.I,))]
+        if self.pcn:
+            ts.append(o.device_tensor("countQ", (self.I,), dtype="int32"))
+        return ts
+
+    def add_jobs(self, start_x, next_x, indptr, keys):
+        return self.obj.add_jobs(start_x, next_x, indptr, keys)
+
+    def wait(self):
+        import torch
+        torch.cuda.synchronize()  # backend calls are synchronous; torch ops run on torch's stream
+
+    def update_parameters(self):
+        self.obj.update_parameters()

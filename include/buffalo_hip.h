@@ -1,0 +1,192 @@
+/*
+ * buffalo_hip.h -- C ABI of libbuffalo_hip.so, the MI355X (gfx950) backend for buffalo's
+ * ALS / BPRMF / WARP training inner loops.
+ *
+ * Drop-in boundary: every object below replaces one C++ class that buffalo's Cython bindings wrap
+ * (paths relative to the kakao/buffalo tree):
+ *
+ *   bfh_bpr_*   <->  cuda_bpr::CuBPR     include/buffalo/cuda/bpr/bpr.hpp:29-45
+ *                    bound by CyBPR      buffalo/algo/cuda/_bpr.pyx:13-80
+ *                    (CPU twin bpr::CBPRMF include/buffalo/algo_impl/bpr/bpr.hpp:21-58,
+ *                     whose numerics this backend follows: lib/algo_impl/bpr/bpr.cc:72-188)
+ *   bfh_warp_*  <->  warp::CWARP         include/buffalo/algo_impl/warp/warp.hpp:20-67
+ *                    bound by CyWARP     buffalo/algo/_warp.pyx; accelerator scaffold
+ *                    buffalo/algo/warp.py:212-234 (the reference has no GPU WARP)
+ *   bfh_als_*   <->  cuda_als::CuALS     include/buffalo/cuda/als/als.hpp:20-35
+ *                    bound by CyALS      buffalo/algo/cuda/_als.pyx:13-67
+ *                    (numerics: als::CALS lib/algo_impl/als/als.cc:86-358)
+ *
+ * Conventions
+ *   - Plain C types only. All array arguments are HOST pointers owned by the caller (numpy memory
+ *     in buffalo); the backend keeps the factor pointers and writes results back into them exactly
+ *     where the reference's CUDA backend does (bpr.cu:334-336, als.cu:403).
+ *   - Factor matrices are C-contiguous float32 [rows, vdim], vdim = ceil(d/32)*32, pad columns zero
+ *     (buffalo/algo/bpr.py:196-204, als.py:146-152).
+ *   - `indptr` is int64[rows] of row END offsets without a leading zero; `keys` / `vals` hold only the
+ *     current chunk, shifted by indptr[start_x-1] (buffalo/data/buffered_data.py:99-118).
+ *   - Return value: BFH_OK (0) on success, a negative bfh_status on failure with the message
+ *     available from bfh_last_error(handle).  `*_init` follows the reference's bool contract:
+ *     1 = options parsed, 0 = file missing / invalid JSON (bpr.cu:245, _bpr.pyx:35).
+ *   - Calls are synchronous (device idle on return), like the reference (bpr.cu:412,427).
+ *   - One handle drives one GPU (the current HIP device at *_create, or bfh_*_set_device).
+ */
+#ifndef BUFFALO_HIP_H_
+#define BUFFALO_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    BFH_OK = 0,
+    BFH_ERR_INVALID = -1,   /* bad argument / call order */
+    BFH_ERR_HIP = -2,       /* a HIP runtime call or kernel failed */
+    BFH_ERR_UNSUPPORTED = -3,
+    BFH_ERR_NOMEM = -4
+} bfh_status;
+
+/* Kernel-level statistics, cumulative since the last bfh_*_reset_stats. */
+typedef struct {
+    int64_t samples;          /* (u,pos[,neg]) updates processed                                */
+    int64_t scored_negatives; /* WARP: negatives actually scored (sum of T)           */
+    int64_t accepted;         /* WARP: positives for which a violator was found                  */
+    int64_t launches;         /* launches of the dominant kernel                                  */
+    double kernel_ms;         /* HIP-event time of the dominant kernel, summed over launches      */
+    double optimizer_ms;      /* HIP-event time of the epoch-end optimizer kernels                */
+    double aux_ms;            /* everything else the backend launched (precompute, loss, ...)     */
+    double h2d_bytes, d2h_bytes;
+} bfh_stats;
+
+const char* bfh_version(void);
+/* Message of the last failure on `handle` (any bfh object), or of the last failed *_create when
+ * handle is NULL.  Never returns NULL. */
+const char* bfh_last_error(const void* handle);
+int bfh_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * BPRMF   (CuBPR: include/buffalo/cuda/bpr/bpr.hpp:29-45)
+ * ---------------------------------------------------------------------------------------------- */
+void* bfh_bpr_create(void);                                        /* CuBPR::CuBPR      bpr.cu:181 */
+void bfh_bpr_destroy(void* h);                                     /* CuBPR::~CuBPR     bpr.cu:222 */
+int bfh_bpr_init(void* h, const char* opt_json_path);              /* CuBPR::init       bpr.cu:245 */
+int bfh_bpr_get_vdim(void* h);                                     /* CuBPR::get_vdim   bpr.cu:346 */
+/* CuBPR::initialize_model bpr.cu:286-308: set_gpu==0 only records the host pointers. */
+int bfh_bpr_initialize_model(void* h, float* P, int P_rows, float* Q, float* Qb, int Q_rows,
+                             int64_t num_nnz, int set_gpu);
+/* CuBPR::set_placeholder bpr.cu:310-320: full rowwise indptr + max chunk nnz. */
+int bfh_bpr_set_placeholder(void* h, const int64_t* indptr, size_t batch_size);
+/* CuBPR::set_cumulative_table bpr.cu:322-327: int64 cumulative item counts [Q_rows]. */
+int bfh_bpr_set_cumulative_table(void* h, const int64_t* table);
+/* CuBPR::partial_update bpr.cu:350-430 (CyBPR.add_jobs).  keys == NULL means "use the CSR made
+ * resident by bfh_bpr_set_resident_csr". Outputs: sum of log(1+e^-x) when
+ * compute_loss_on_training, and the number of (u,pos,neg) samples. */
+int bfh_bpr_partial_update(void* h, int start_x, int next_x, const int64_t* indptr,
+                           const int32_t* keys, double* loss_sum, double* n_samples);
+/* SGDAlgorithm::update_parameters lib/algo.cc:382-465 on the device (no-op for optimizer "sgd"). */
+int bfh_bpr_update_parameters(void* h);
+/* CuBPR::synchronize bpr.cu:330-344: device_to_host != 0 copies P,Q,Qb into the host arrays. */
+int bfh_bpr_synchronize(void* h, int device_to_host);
+/* CBPRMF::compute_loss bpr.cc:227-244 (same contract as CuBPR::compute_loss bpr.cu:432). */
+int bfh_bpr_compute_loss(void* h, int n, const int32_t* users, const int32_t* positives,
+                         const int32_t* negatives, double* loss);
+
+/* ------------------------------------------------------------------------------------------------
+ * WARP   (CWARP: include/buffalo/algo_impl/warp/warp.hpp:20-67; same surface as BPR, as
+ *         buffalo/algo/warp.py:212-234 expects from an accelerator object)
+ * ---------------------------------------------------------------------------------------------- */
+void* bfh_warp_create(void);
+void bfh_warp_destroy(void* h);
+int bfh_warp_init(void* h, const char* opt_json_path);             /* CWARP::init       warp.cc:68 */
+int bfh_warp_get_vdim(void* h);
+int bfh_warp_initialize_model(void* h, float* P, int P_rows, float* Q, float* Qb, int Q_rows,
+                              int64_t num_nnz, int set_gpu);       /* warp.cc:87-94               */
+int bfh_warp_set_placeholder(void* h, const int64_t* indptr, size_t batch_size);
+int bfh_warp_set_cumulative_table(void* h, const int64_t* table);  /* warp.cc:96-100 (unused)     */
+/* CWARP::worker warp.cc:103-173 over one CSR chunk (CyWARP.add_jobs). loss_sum = sum(uj-ui+thr). */
+int bfh_warp_partial_update(void* h, int start_x, int next_x, const int64_t* indptr,
+                            const int32_t* keys, double* loss_sum, double* n_samples);
+int bfh_warp_update_parameters(void* h);                           /* warp.cc:192-201             */
+int bfh_warp_synchronize(void* h, int device_to_host);
+int bfh_warp_compute_loss(void* h, int n, const int32_t* users, const int32_t* positives,
+                          const int32_t* negatives, double* loss); /* warp.cc:205-226             */
+
+/* ------------------------------------------------------------------------------------------------
+ * ALS    (CuALS: include/buffalo/cuda/als/als.hpp:20-35)
+ * ---------------------------------------------------------------------------------------------- */
+void* bfh_als_create(void);                                        /* CuALS::CuALS      als.cu:124 */
+void bfh_als_destroy(void* h);
+int bfh_als_init(void* h, const char* opt_json_path);              /* CuALS::init       als.cu:230 */
+int bfh_als_get_vdim(void* h);                                     /* als.cu:342                   */
+int bfh_als_initialize_model(void* h, float* P, int P_rows, float* Q, int Q_rows); /* als.cu:271 */
+int bfh_als_set_placeholder(void* h, const int64_t* lindptr, const int64_t* rindptr,
+                            size_t batch_size);                    /* als.cu:292                   */
+int bfh_als_precompute(void* h, int axis);                         /* als.cu:310 / als.cc:86       */
+/* CuALS::partial_update als.cu:346-406 with CALS numerics (als.cc:95-358).  Updated rows
+ * [start_x,next_x) are copied back into the host factor array before returning (als.cu:403).
+ * keys/vals == NULL: use the CSR made resident by bfh_als_set_resident_csr(axis). */
+int bfh_als_partial_update(void* h, int start_x, int next_x, const int64_t* indptr,
+                           const int32_t* keys, const float* vals, int axis, double* loss_nume,
+                           double* loss_deno);
+
+/* ------------------------------------------------------------------------------------------------
+ * Extensions (not in the reference): residency, determinism hooks, measurement, multi-GPU plumbing
+ * ---------------------------------------------------------------------------------------------- */
+/* Select the GPU for a handle; call before *_init.  Default: current HIP device at *_create. */
+int bfh_bpr_set_device(void* h, int device);
+int bfh_warp_set_device(void* h, int device);
+int bfh_als_set_device(void* h, int device);
+
+/* Keep the whole CSR in HBM (288 GB) instead of re-sending keys every epoch (bpr.cu:362,
+ * als.cu:361-364).  indptr: int64[rows] end offsets; keys/vals: [nnz]. */
+int bfh_bpr_set_resident_csr(void* h, const int64_t* indptr, const int32_t* keys, int64_t nnz);
+int bfh_warp_set_resident_csr(void* h, const int64_t* indptr, const int32_t* keys, int64_t nnz);
+int bfh_als_set_resident_csr(void* h, int axis, const int64_t* indptr, const int32_t* keys,
+                             const float* vals, int64_t nnz);
+/* With resident CSR the per-call write-back of updated rows (als.cu:403) can be deferred. */
+int bfh_als_synchronize(void* h, int device_to_host);
+
+/* Named integer knobs.  Common: "sequential" (1 = one wave walks the chunk in CSR order: the
+ * deterministic parity mode), "hogwild_atomic" (1 = fp32 atomic adds on shared item rows, 0 = racy
+ * plain stores like CPU Hogwild), "prefetch" (software pipelining depth 0/1), "waves_per_cu",
+ * "chunk" (nnz positions per wave work item), "als_writeback" (0 = defer), "timing" (1 = record
+ * HIP events around every launch).  Unknown names fail with BFH_ERR_INVALID. */
+int bfh_bpr_set_mode(void* h, const char* name, int64_t value);
+int bfh_warp_set_mode(void* h, const char* name, int64_t value);
+int bfh_als_set_mode(void* h, const char* name, int64_t value);
+
+/* Multi-GPU sharding (one process per GPU, users sharded above this ABI): global position of the
+ * shard's first nnz (keeps the counter-based sampler identical to the 1-GPU run) and the number of
+ * shards that advance the lr schedule together. */
+int bfh_bpr_set_shard(void* h, int64_t nnz_offset, int num_shards);
+int bfh_warp_set_shard(void* h, int64_t nnz_offset, int num_shards);
+
+/* Test hook: apply explicit (u,pos,neg) triples with learning rate lr (sgd) or accumulate their
+ * gradients (adam/adagrad), bypassing the sampler. */
+int bfh_bpr_update_triples(void* h, int64_t n, const int32_t* users, const int32_t* positives,
+                           const int32_t* negatives, double lr);
+
+/* Device pointers for collectives (RCCL through torch.distributed) and zero-copy inspection.
+ * BPR/WARP names: "P" "Q" "Qb" "gradP" "gradQ" "gradQb" "countP" "countQ" "velP" "velQ" "momP" "momQ";
+ * ALS names: "P" "Q" "FF".  *dptr is valid until the next initialize_model / destroy. */
+int bfh_bpr_device_buffer(void* h, const char* name, void** dptr, size_t* bytes);
+int bfh_warp_device_buffer(void* h, const char* name, void** dptr, size_t* bytes);
+int bfh_als_device_buffer(void* h, const char* name, void** dptr, size_t* bytes);
+/* hipStream_t the handle launches on (for event timing / stream ordering by the caller). */
+void* bfh_bpr_stream(void* h);
+void* bfh_warp_stream(void* h);
+void* bfh_als_stream(void* h);
+
+int bfh_bpr_get_stats(void* h, bfh_stats* out);
+int bfh_warp_get_stats(void* h, bfh_stats* out);
+int bfh_als_get_stats(void* h, bfh_stats* out);
+int bfh_bpr_reset_stats(void* h);
+int bfh_warp_reset_stats(void* h);
+int bfh_als_reset_stats(void* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BUFFALO_HIP_H_ */

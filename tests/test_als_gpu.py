@@ -1,0 +1,172 @@
+"""ALS parity: HIP backend vs the CPU oracle, per half-epoch and over full epochs.
+
+Tolerance: max-abs error <= 1e-4 x max|value| for the factor matrices (three fp32 CG steps amplify
+summation-order differences; BASELINE.md states rtol 1e-4 for ALS), loss terms to 1e-4 relative."""
+import numpy as np
+import pytest
+
+from conftest import als_opt, tiny_csr
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _vdim(d):
+    return ((d + 31) // 32) * 32
+
+
+def _setup(oracle, csr, d, opt, seed=3, scale=0.2):
+    from buffalo_amd.backend import CyALS
+    vdim = _vdim(d)
+    rng = np.random.default_rng(seed)
+    P = H.pad(np.abs(rng.normal(scale=scale, size=(csr.num_users, d))).astype(np.float32), vdim)
+    Q = H.pad(np.abs(rng.normal(scale=scale, size=(csr.num_items, d))).astype(np.float32), vdim)
+    Po, Qo = P[:, :d].copy(), Q[:, :d].copy()
+    o = oracle.OracleALS()
+    assert o.init(H.write_opt(opt))
+    o.initialize_model(Po, Qo)
+    obj = CyALS()
+    assert obj.init(H.write_opt(dict(opt, accelerator=True)))
+    obj.initialize_model(P, Q)
+    t = csr.transpose()
+    obj.set_placeholder(csr.indptr, t.indptr, csr.nnz + 1)
+    return o, obj, (P, Q), (Po, Qo)
+
+
+def _epoch(o, obj, csr, n_chunks=1):
+    """als.py:165-171: rowwise then colwise half-epoch; returns both backends' (nume, deno)."""
+    tot_o, tot_g = np.zeros(2), np.zeros(2)
+    for axis, mat in ((0, csr), (1, csr.transpose())):
+        o.precompute(axis)
+        obj.precompute(axis)
+        for (a, b) in H.chunks_of(mat, n_chunks):
+            keys, vals = H.chunk_arrays(mat, a, b)
+            tot_o += o.partial_update(a, b, mat.indptr, keys, vals, axis)
+            tot_g += obj.partial_update(a, b, mat.indptr, keys, vals, axis)
+    return tot_o, tot_g
+
+
+def test_precompute_gramian_mfma(oracle):
+    """FF = F^T F on v_mfma_f32_32x32x2_f32; asymmetric input catches a transposed C/D mapping."""
+    from buffalo_amd.backend import CyALS
+    for d, rows in ((20, 7), (128, 1001), (200, 333)):
+        vdim = _vdim(d)
+        rng = np.random.default_rng(d)
+        P = H.pad(rng.normal(size=(5, d)).astype(np.float32), vdim)
+        Q = H.pad((rng.normal(size=(rows, d)) * np.linspace(0.5, 2.0, d)).astype(np.float32), vdim)
+        obj = CyALS()
+        assert obj.init(H.write_opt(als_opt(d=d, accelerator=True)))
+        obj.initialize_model(P, Q)
+        obj.precompute(0)
+        ff = obj.device_tensor("FF", (vdim, vdim)).cpu().numpy()
+        want = Q.astype(np.float64).T @ Q.astype(np.float64)
+        assert H.relerr(ff, want) < 1e-5
+        obj.precompute(1)
+        ff = obj.device_tensor("FF", (vdim, vdim)).cpu().numpy()
+        assert H.relerr(ff, P.astype(np.float64).T @ P.astype(np.float64)) < 1e-5
+
+
+@pytest.mark.parametrize("d,kw", [
+    (20, dict(optimizer="manual_cg")),
+    (20, dict(optimizer="llt")),
+    (40, dict(optimizer="ldlt", adaptive_reg=True)),
+    (70, dict(optimizer="manual_cg", adaptive_reg=True, num_cg_max_iters=5)),
+    (100, dict(optimizer="ialspp", block_size=7)),      # tests/algo/test_als.py:92-101
+    (128, dict(optimizer="manual_cg")),                 # Q-13: silently iALS++
+    (256, dict(optimizer="llt", block_size=32)),        # tests/algo/test_als.py:103-112
+    (160, dict(optimizer="ialspp", block_size=64)),
+])
+def test_epochs_match_oracle(oracle, d, kw):
+    csr = tiny_csr(U=60, I=45, density=0.2, seed=31, counts=True)
+    opt = als_opt(d=d, alpha=4.0, reg_u=0.2, reg_i=0.3, num_iters=2, **kw)
+    o, obj, (P, Q), (Po, Qo) = _setup(oracle, csr, d, opt)
+    for it in range(2):
+        lo, lg = _epoch(o, obj, csr, n_chunks=1 if it else 2)
+        assert abs(lg[0] - lo[0]) <= 1e-4 * max(1.0, abs(lo[0])), (lg, lo)
+        assert abs(lg[1] - lo[1]) <= 1e-4 * max(1.0, abs(lo[1])), (lg, lo)
+        # partial_update writes the updated rows back into the caller's arrays (als.cu:403)
+        assert H.relerr(P[:, :d], Po) < 1e-4, H.relerr(P[:, :d], Po)
+        assert H.relerr(Q[:, :d], Qo) < 1e-4, H.relerr(Q[:, :d], Qo)
+    assert np.all(P[:, d:] == 0) and np.all(Q[:, d:] == 0)
+
+
+def test_empty_rows_unchanged_q16(oracle):
+    from buffalo_amd.synth import CSR
+    csr = CSR(4, 5, [2, 2, 3, 3], [0, 3, 1], [1, 2, 1])
+    for d, optimizer in ((8, "llt"), (8, "manual_cg"), (128, "ialspp")):
+        opt = als_opt(d=d, optimizer=optimizer)
+        o, obj, (P, Q), (Po, Qo) = _setup(oracle, csr, d, opt)
+        before = P.copy()
+        _epoch(o, obj, csr)
+        assert np.array_equal(P[1], before[1]) and np.array_equal(P[3], before[3])
+        assert not np.array_equal(P[0], before[0])
+        assert H.relerr(P[:, :d], Po) < 1e-4
+
+
+def test_resident_csr_and_deferred_writeback(oracle):
+    csr = tiny_csr(U=50, I=40, density=0.25, seed=8, counts=True)
+    d = 128
+    opt = als_opt(d=d, alpha=2.0, compute_loss_on_training=False)
+    o, obj, (P, Q), (Po, Qo) = _setup(oracle, csr, d, opt)
+    t = csr.transpose()
+    obj.set_resident_csr(0, csr.indptr, csr.keys, csr.vals)
+    obj.set_resident_csr(1, t.indptr, t.keys, t.vals)
+    obj.set_mode("als_writeback", 0)
+    P_before = P.copy()
+    for axis, mat in ((0, csr), (1, t)):
+        o.precompute(axis)
+        obj.precompute(axis)
+        o.partial_update(0, mat.num_users, mat.indptr, mat.keys, mat.vals, axis)
+        assert obj.partial_update(0, mat.num_users, mat.indptr, None, None, axis) == (0.0, 0.0)
+    assert np.array_equal(P, P_before)          # nothing written back yet
+    obj.synchronize(True)
+    assert H.relerr(P[:, :d], Po) < 1e-4 and H.relerr(Q[:, :d], Qo) < 1e-4
+
+
+def test_identical_topk_after_training(oracle):
+    """north_star: "identical top-k for fixed seeds" -- ML-100K-shaped config #1 (d=32)."""
+    from buffalo_amd import synth
+    csr = synth.generate(*synth.SHAPES["ml100k"], seed=7, vals="counts")
+    d = 32
+    opt = als_opt(d=d, num_iters=3, compute_loss_on_training=True)
+    np.random.seed(7)
+    o, obj, (P, Q), (Po, Qo) = _setup(oracle, csr, d, opt, seed=7, scale=1.0 / d)
+    for _ in range(3):
+        lo, lg = _epoch(o, obj, csr)
+    assert abs(lg[0] / lg[1] - lo[0] / lo[1]) < 1e-4 * abs(lo[0] / lo[1])
+    so, sg = Po @ Qo.T, P[:, :d] @ Q[:, :d].T
+    for u in range(0, csr.num_users, 37):
+        assert list(np.argsort(-so[u])[:10]) == list(np.argsort(-sg[u])[:10])
+
+
+def test_full_size_properties():
+    """BASELINE config #3 shape (ML-20M, d=128): size-independent checks of one full epoch."""
+    from buffalo_amd import synth
+    from buffalo_amd.backend import CyALS
+    U, I, nnz = synth.SHAPES["ml20m"]
+    csr = synth.generate(U, I, nnz, seed=7, vals="counts")
+    t = csr.transpose()
+    d = 128
+    P, Q, _ = synth.init_factors(U, I, d, seed=7)
+    obj = CyALS()
+    assert obj.init(H.write_opt(als_opt(d=d, accelerator=True, compute_loss_on_training=True)))
+    obj.initialize_model(P, Q)
+    obj.set_resident_csr(0, csr.indptr, csr.keys, csr.vals)
+    obj.set_resident_csr(1, t.indptr, t.keys, t.vals)
+    obj.set_mode("als_writeback", 0)
+    rmse = []
+    for _ in range(2):
+        nume = deno = 0.0
+        for axis, mat in ((0, csr), (1, t)):
+            obj.precompute(axis)
+            a, b = obj.partial_update(0, mat.num_users, mat.indptr, None, None, axis)
+            nume, deno = nume + a, deno + b
+        rmse.append((nume / (deno + 1e-10)) ** 0.5)
+    obj.synchronize(True)
+    assert np.isfinite(P).all() and np.isfinite(Q).all()
+    assert rmse[1] < rmse[0], rmse          # the implicit-feedback objective improves
+    # FF is symmetric and equals P^T P of the final factors
+    obj.precompute(1)
+    ff = obj.device_tensor("FF", (d, d)).cpu().numpy()
+    assert H.relerr(ff, ff.T) < 1e-6
+    assert H.relerr(ff, P.astype(np.float64).T @ P.astype(np.float64)) < 1e-4

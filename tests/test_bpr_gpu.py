@@ -1,0 +1,209 @@
+"""BPRMF parity: HIP backend (through the C ABI) vs the CPU oracle.
+
+Tolerances (fp32; stated per BASELINE.json north_star "same factor matrices within a stated fp32
+tolerance"): deterministic single-stream runs agree to max-abs error <= 1e-5 x max|value| after
+several epochs (summation order inside a dot product is the only difference); gradient-accumulation
+(adam / adagrad) runs agree to 1e-4 because atomics reorder sums; Hogwild runs are compared through
+loss / NDCG@10."""
+import numpy as np
+import pytest
+
+from conftest import bpr_opt, tiny_csr
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _factors(csr, d, vdim, seed=1, scale=0.3, bias=True):
+    rng = np.random.default_rng(seed)
+    P = H.pad(rng.normal(scale=scale, size=(csr.num_users, d)).astype(np.float32), vdim)
+    Q = H.pad(rng.normal(scale=scale, size=(csr.num_items, d)).astype(np.float32), vdim)
+    Qb = rng.normal(scale=0.1, size=(csr.num_items, 1)).astype(np.float32)
+    if not bias:
+        Qb *= 0
+    return P, Q, Qb
+
+
+def _vdim(d):
+    return ((d + 31) // 32) * 32
+
+
+DET = dict(sampler="counter", pos_order="csr", inline=True)
+
+
+@pytest.mark.parametrize("d,kw", [
+    (20, {}),
+    (128, {}),
+    (200, dict(num_negative_samples=2)),
+    (64, dict(use_bias=False, verify_neg=False)),
+    (40, dict(sampling_power=1.0)),
+    (32, dict(update_j=False, reg_u=0.1)),
+    (300, dict(update_i=False)),
+])
+def test_sequential_sgd_matches_oracle(oracle, d, kw):
+    from buffalo_amd.backend import CyBPR
+    csr = tiny_csr(U=40, I=60, density=0.2, seed=13)
+    opt = bpr_opt(d=d, lr=0.05, min_lr=0.002, num_iters=3, random_seed=7, **kw)
+    vdim = _vdim(d)
+    P, Q, Qb = _factors(csr, d, vdim, bias=opt["use_bias"])
+    Po, Qo, Qbo = P[:, :d].copy(), Q[:, :d].copy(), Qb.copy()
+    H.run_oracle_sgd(oracle.OracleBPRMF, opt, csr, Po, Qo, Qbo, epochs=3, n_chunks=2, modes=DET)
+    obj = H.run_hip_sgd(CyBPR, opt, csr, P, Q, Qb, epochs=3, n_chunks=2, modes=dict(sequential=1))
+    assert H.relerr(P[:, :d], Po) < 1e-5, H.relerr(P[:, :d], Po)
+    assert H.relerr(Q[:, :d], Qo) < 1e-5, H.relerr(Q[:, :d], Qo)
+    assert H.relerr(Qb, Qbo) < 1e-5 or not opt["use_bias"]
+    assert np.all(P[:, d:] == 0) and np.all(Q[:, d:] == 0)  # pad columns stay zero
+    assert obj.stats()["samples"] == 3 * csr.nnz * opt["num_negative_samples"]
+
+
+def test_reference_order_replay(oracle):
+    """The oracle in pure reference mode (mt19937 + unordered_set order) records its (u,pos,neg)
+    stream; replaying that stream through the HIP update path must land on the same model."""
+    from buffalo_amd.backend import CyBPR
+    csr = tiny_csr(U=50, I=70, density=0.15, seed=21)
+    d, vdim = 24, 32
+    opt = bpr_opt(d=d, lr=0.04, min_lr=0.04, num_iters=2, random_seed=777)
+    P, Q, Qb = _factors(csr, d, vdim)
+    Po, Qo, Qbo = P[:, :d].copy(), Q[:, :d].copy(), Qb.copy()
+    o = H.run_oracle_sgd(oracle.OracleBPRMF, opt, csr, Po, Qo, Qbo, epochs=2, modes=dict(inline=True), trace=True)
+    tr = o.get_trace()
+    assert len(tr) == 2 * csr.nnz
+    obj = CyBPR()
+    path = H.write_opt(dict(opt, accelerator=True))
+    assert obj.init(path)
+    obj.set_mode("sequential", 1)
+    obj.initialize_model(P, Q, Qb, csr.nnz, True)
+    obj.update_triples(np.ascontiguousarray(tr[:, 0]), np.ascontiguousarray(tr[:, 1]), np.ascontiguousarray(tr[:, 2]), 0.04)
+    obj.synchronize(True)
+    assert H.relerr(P[:, :d], Po) < 1e-5 and H.relerr(Q[:, :d], Qo) < 1e-5 and H.relerr(Qb, Qbo) < 1e-5
+
+
+@pytest.mark.parametrize("optimizer,pcn", [("adagrad", False), ("adam", True), ("adam", False)])
+def test_accumulate_modes_parallel(oracle, optimizer, pcn):
+    """adam / adagrad freeze P,Q inside an epoch, so the fully parallel kernel must agree with the
+    sequential oracle up to fp32 summation order (incl. Q-5, Q-6, Q-9)."""
+    from buffalo_amd.backend import CyBPR
+    csr = tiny_csr(U=64, I=80, density=0.2, seed=5)
+    d, vdim = 48, 64
+    opt = bpr_opt(d=d, lr=0.03, num_iters=3, random_seed=3, optimizer=optimizer, per_coordinate_normalize=pcn,
+                  num_negative_samples=2)
+    P, Q, Qb = _factors(csr, d, vdim)
+    Po, Qo, Qbo = P[:, :d].copy(), Q[:, :d].copy(), Qb.copy()
+    H.run_oracle_sgd(oracle.OracleBPRMF, opt, csr, Po, Qo, Qbo, epochs=3, modes=DET)
+    H.run_hip_sgd(CyBPR, opt, csr, P, Q, Qb, epochs=3, modes=dict(chunk=64))
+    assert H.relerr(P[:, :d], Po) < 1e-4, H.relerr(P[:, :d], Po)
+    assert H.relerr(Q[:, :d], Qo) < 1e-4, H.relerr(Q[:, :d], Qo)
+    assert H.relerr(Qb, Qbo) < 1e-4
+
+
+def test_triples_parallel_disjoint_rows(oracle):
+    """Conflict-free triples (every row touched once) give the same result whatever the schedule."""
+    from buffalo_amd.backend import CyBPR
+    U, I, d, vdim = 300, 600, 128, 128
+    rng = np.random.default_rng(0)
+    users = rng.permutation(U).astype(np.int32)
+    items = rng.permutation(I).astype(np.int32)
+    pos, neg = np.ascontiguousarray(items[:U]), np.ascontiguousarray(items[U:2 * U])
+    opt = bpr_opt(d=d, lr=0.1, min_lr=0.1)
+    outs = []
+    for mode in (dict(sequential=1), dict(hogwild_atomic=1, chunk=64), dict(hogwild_atomic=0, chunk=64, prefetch=0)):
+        rng2 = np.random.default_rng(1)
+        P = rng2.normal(scale=0.3, size=(U, vdim)).astype(np.float32)
+        Q = rng2.normal(scale=0.3, size=(I, vdim)).astype(np.float32)
+        Qb = rng2.normal(scale=0.1, size=(I, 1)).astype(np.float32)
+        obj = CyBPR()
+        assert obj.init(H.write_opt(dict(opt, accelerator=True)))
+        for k, v in mode.items():
+            obj.set_mode(k, v)
+        obj.initialize_model(P, Q, Qb, U, True)
+        obj.update_triples(users, pos, neg, 0.1)
+        obj.synchronize(True)
+        outs.append((P, Q, Qb))
+    for a in outs[1:]:
+        for x, y in zip(a, outs[0]):
+            assert H.relerr(x, y) < 2e-6
+
+
+def test_compute_loss_matches_oracle(oracle):
+    from buffalo_amd.backend import CyBPR
+    csr = tiny_csr(U=30, I=40, seed=2)
+    d, vdim = 20, 32
+    opt = bpr_opt(d=d)
+    P, Q, Qb = _factors(csr, d, vdim, scale=1.0)
+    rng = np.random.default_rng(4)
+    u = rng.integers(0, 30, 17).astype(np.int32)
+    i = rng.integers(0, 40, 17).astype(np.int32)
+    j = rng.integers(0, 40, 17).astype(np.int32)
+    o = oracle.OracleBPRMF()
+    assert o.init(H.write_opt(opt))
+    Po, Qo = P[:, :d].copy(), Q[:, :d].copy()
+    o.initialize_model(Po, Qo, Qb.copy(), csr.nnz)
+    want = o.compute_loss(u, i, j)
+    obj = CyBPR()
+    assert obj.init(H.write_opt(dict(opt, accelerator=True)))
+    obj.initialize_model(P, Q, Qb, csr.nnz, True)
+    got = obj.compute_loss(u, i, j)
+    assert abs(got - want) < 1e-5 * max(1.0, abs(want))
+
+
+@pytest.mark.parametrize("atomic", [1, 0])
+def test_hogwild_statistical_parity(oracle, atomic):
+    """Throughput mode vs the threaded reference path: same loss trajectory and ranking quality on
+    planted low-rank data (mirrors the ndcg threshold test, tests/algo/test_bpr.py:38-47)."""
+    from buffalo_amd import synth
+    from buffalo_amd.backend import CyBPR
+    csr, vali = synth.planted(600, 400, d_true=6, density=0.06, seed=7)
+    d, vdim = 16, 32
+    opt = bpr_opt(d=d, lr=0.05, min_lr=0.01, num_iters=30, random_seed=7, num_workers=4, reg_u=0.01, reg_i=0.01, reg_j=0.01,
+                  reg_b=0.01)
+    P0, Q0, Qb0 = synth.init_factors(600, 400, d, seed=7)
+    Po, Qo, Qbo = P0.copy(), Q0.copy(), Qb0.copy()
+    H.run_oracle_sgd(oracle.OracleBPRMF, opt, csr, Po, Qo, Qbo, epochs=30)
+    P, Q, Qb = H.pad(P0, vdim), H.pad(Q0, vdim), Qb0.copy()
+    H.run_hip_sgd(CyBPR, opt, csr, P, Q, Qb, epochs=30, modes=dict(hogwild_atomic=atomic, chunk=64), resident=True)
+    n_ref = H.ndcg_at_k(Po, Qo, csr, vali, Qb=Qbo)
+    n_hip = H.ndcg_at_k(P[:, :d], Q[:, :d], csr, vali, Qb=Qb)
+    base = H.ndcg_at_k(P0, Q0, csr, vali, Qb=Qb0)
+    assert n_ref > 3 * max(base, 0.01) and n_hip > 3 * max(base, 0.01)
+    assert abs(n_hip - n_ref) < 0.25 * n_ref, (n_hip, n_ref)
+    assert np.isfinite(P).all() and np.isfinite(Q).all()
+
+
+def test_full_size_properties():
+    """BASELINE config #2 shape (138,493 x 27,278, 20,000,263 nnz, d=128): size-independent checks."""
+    from buffalo_amd import synth
+    from buffalo_amd.backend import CyBPR
+    U, I, nnz = synth.SHAPES["ml20m"]
+    csr = synth.generate(U, I, nnz, seed=7)
+    d = vdim = 128
+    opt = bpr_opt(d=d, lr=0.0, min_lr=0.0, num_iters=2, random_seed=7, compute_loss_on_training=True)
+    P, Q, Qb = synth.init_factors(U, I, d, seed=7)
+    P0, Q0, Qb0 = P.copy(), Q.copy(), Qb.copy()
+    obj = CyBPR()
+    assert obj.init(H.write_opt(dict(opt, accelerator=True)))
+    obj.initialize_model(P, Q, Qb, nnz, True)
+    obj.set_cumulative_table(np.zeros(I, np.int64), I)
+    obj.set_resident_csr(csr.indptr, csr.keys)
+    # (a) lr == 0: one epoch is the identity, bit for bit, and every nnz is visited exactly once
+    loss0, n = obj.add_jobs(0, U, csr.indptr, None)
+    obj.update_parameters()
+    assert n == nnz and obj.stats()["samples"] == nnz
+    np.testing.assert_array_equal(P, P0)
+    np.testing.assert_array_equal(Q, Q0)
+    np.testing.assert_array_equal(Qb, Qb0)
+    # the sampled training loss at init is ~ log(2) per sample (scores ~ 0)
+    assert abs(loss0 / n - np.log(2.0)) < 1e-2
+    # (b) a real epoch lowers the sampled loss and keeps everything finite
+    obj2 = CyBPR()
+    opt2 = dict(opt, lr=0.05, min_lr=0.05, accelerator=True)
+    assert obj2.init(H.write_opt(opt2))
+    obj2.initialize_model(P, Q, Qb, nnz, True)
+    obj2.set_cumulative_table(np.zeros(I, np.int64), I)
+    obj2.set_resident_csr(csr.indptr, csr.keys)
+    l1, _ = obj2.add_jobs(0, U, csr.indptr, None)
+    obj2.update_parameters()
+    l2, _ = obj2.add_jobs(0, U, csr.indptr, None)
+    obj2.update_parameters()
+    assert l2 < l1 * 0.98, (l1, l2)
+    assert np.isfinite(P).all() and np.isfinite(Q).all() and np.isfinite(Qb).all()
+    assert not np.array_equal(P, P0) and not np.array_equal(Q, Q0)
