@@ -93,6 +93,29 @@ def header_symbols():
     return sorted(set(re.findall(r"\b(bfh_[a-z0-9_]+)\s*\(", text)))
 
 
+def _preload_shared_hip_runtime():
+    """PyTorch wheels bundle their own libamdhip64.so / libhsa-runtime64.so (SONAME libamdhip64.so.7,
+    same as /opt/rocm's).  Two HSA runtimes in one process cannot both open the GPU, so when torch is
+    installed its runtime is loaded first and libbuffalo_hip.so's DT_NEEDED libamdhip64.so.7 then
+    resolves to it by SONAME; a later `import torch` reuses the same objects.  Without torch the
+    system runtime under /opt/rocm/lib is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    d = os.path.join(os.path.dirname(spec.origin), "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(d, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+
+
 def lib():
     """Load the shared library (no device access happens here)."""
     global _lib
@@ -102,6 +125,7 @@ def lib():
         raise BuffaloHipError(
             "libbuffalo_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; "
             "g.build()'` or `python -m buffalo_amd._build`. There is no CPU fallback." % LIB_PATH)
+    _preload_shared_hip_runtime()
     L = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(L, name)  # AttributeError here == ABI drift between header and library

@@ -210,13 +210,18 @@ __global__ __launch_bounds__(256) void bpr_update_kernel(SgdParams p, BprConsts 
                 if (SGD) {
                     // bpr.cc:157-171 incl. Q-1: the user step sees the already-updated item rows
                     Row<K> di, dj;
+                    // pos == neg can only happen with verify_neg=false or injected triples; the
+                    // reference then updates the one row twice in sequence (bpr.cc:159-169)
+                    const bool same = pos == neg;
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
                         const float idv = logit * pu.v[k];
                         di.v[k] = c.update_i ? c.lr * (idv - c.reg_i * qi.v[k]) : 0.f;
-                        dj.v[k] = c.update_j ? c.lr * (-idv - c.reg_j * qj.v[k]) : 0.f;
                         qi.v[k] += di.v[k];
+                        if (same) qj.v[k] = qi.v[k];
+                        dj.v[k] = c.update_j ? c.lr * (-idv - c.reg_j * qj.v[k]) : 0.f;
                         qj.v[k] += dj.v[k];
+                        if (same) qi.v[k] = qj.v[k];
                         pu.v[k] += c.lr * (logit * (qi.v[k] - qj.v[k]) - c.reg_u * pu.v[k]);
                     }
                     if (c.atomic) {
@@ -227,7 +232,8 @@ __global__ __launch_bounds__(256) void bpr_update_kernel(SgdParams p, BprConsts 
                         if (c.update_j) store_row<K>(qj, Qj, lane, vdim);
                     }
                     if (c.use_bias && lane == 0) {
-                        const float dbi = c.lr * (logit - c.reg_b * bi);
+                        const float dbi = c.update_i ? c.lr * (logit - c.reg_b * bi) : 0.f;
+                        if (same) bj = bi + dbi;
                         const float dbj = c.lr * (-logit - c.reg_b * bj);
                         if (c.atomic) {
                             if (c.update_i) atomic_add_f32(p.Qb + pos, dbi);
