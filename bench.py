@@ -154,9 +154,12 @@ def main():
     assert obj.init(path)
     os.unlink(path)
     obj.sync_every_epoch = False           # keep the model in HBM inside the timed region
+    hog = "1"
     for kv in args.mode:
         k, v = kv.split("=")
         obj.set_mode(k, int(v))
+        if k == "hogwild_atomic":
+            hog = v
     obj.initialize_model(P, Q, Qb, total_nnz, True)
     obj.set_cumulative_table(np.zeros(I, np.int64), I)
     obj.set_resident_csr(ip, keys)        # inputs resident in HBM before the timed region starts
@@ -218,7 +221,7 @@ def main():
                                    % (args.shape, U, I, nnz, "" if args.scaling == "strong" or world == 1 else " per GPU", D),
                        "parallelism": "1 GPU" if world == 1 else "dp%d: users sharded, Q replicated, %d RCCL delta all-reduce/epoch"
                                       % (world, args.minibatches),
-                       "hogwild": "fp32 atomics" if "hogwild_atomic=0" not in args.mode else "racy stores"},
+                       "hogwild": {"0": "write-through (sc1) racy stores on item rows", "1": "fp32 atomics on item rows"}[hog]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "bpr_update_kernel", "kernel_ms": kernel_ms,

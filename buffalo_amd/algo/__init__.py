@@ -1,0 +1,6 @@
+"""buffalo.algo-compatible front: ALS / BPRMF / WARP with the reference's option objects and
+training loops, running on the MI355X backend (buffalo_amd.backend)."""
+from .als import ALS  # noqa: F401
+from .bpr import BPRMF  # noqa: F401
+from .options import ALSOption, BPRMFOption, WARPOption  # noqa: F401
+from .warp import WARP  # noqa: F401

@@ -2,6 +2,8 @@
 // shared by the BPRMF and WARP backends.
 #include "sgd_base.hpp"
 
+#include <algorithm>
+
 namespace bfh {
 
 // ------------------------------------------------------------------------------------------------
@@ -434,7 +436,7 @@ void SgdHandle::update_parameters() {
 
 void SgdHandle::set_mode(const std::string& name, int64_t v) {
     if (name == "sequential") sequential_ = static_cast<int>(v);
-    else if (name == "hogwild_atomic") hogwild_atomic_ = static_cast<int>(v);
+    else if (name == "hogwild_atomic") { BFH_REQUIRE(v == 0 || v == 1, "hogwild_atomic must be 0 (write-through stores) or 1 (fp32 atomics)"); hogwild_atomic_ = static_cast<int>(v); }
     else if (name == "prefetch") prefetch_ = static_cast<int>(v);
     else if (name == "waves_per_cu") waves_per_cu_ = static_cast<int>(v);
     else if (name == "chunk") { BFH_REQUIRE(v >= 64 && v % 64 == 0, "chunk must be a positive multiple of 64"); chunk_ = static_cast<int>(v); }

@@ -149,8 +149,8 @@ int bfh_als_set_resident_csr(void* h, int axis, const int64_t* indptr, const int
 int bfh_als_synchronize(void* h, int device_to_host);
 
 /* Named integer knobs.  Common: "sequential" (1 = one wave walks the chunk in CSR order: the
- * deterministic parity mode), "hogwild_atomic" (1 = fp32 atomic adds on shared item rows, 0 = racy
- * plain stores like CPU Hogwild), "prefetch" (software pipelining depth 0/1), "waves_per_cu",
+ * deterministic parity mode), "hogwild_atomic" (1 = fp32 atomic adds on shared item rows [default], 0 = racy
+ * device-coherent write-through stores like CPU Hogwild), "prefetch" (software pipelining depth 0/1), "waves_per_cu",
  * "chunk" (nnz positions per wave work item), "als_writeback" (0 = defer), "timing" (1 = record
  * HIP events around every launch).  Unknown names fail with BFH_ERR_INVALID. */
 int bfh_bpr_set_mode(void* h, const char* name, int64_t value);

@@ -165,8 +165,11 @@ struct progress_t {
     double loss;
 };
 
+// Eigen evaluates row dot products with packet (8 x float on AVX2) partial sums followed by a
+// horizontal add; `omp simd reduction` makes GCC emit the same shape instead of a serial chain.
 static inline float dotf(const float* a, const float* b, int n) {
     float s = 0.f;
+#pragma omp simd reduction(+ : s)
     for (int i = 0; i < n; ++i) s += a[i] * b[i];
     return s;
 }
@@ -200,6 +203,8 @@ class SGD {
                          //    lr stamped once per add_jobs call from completed progress (deterministic Q-8)
     uint32_t epoch_ = 0;  // counts update_parameters calls (counter sampler)
     long long inl_total_processed_ = 0;
+    int64_t nnz_offset_ = 0;  // multi-GPU tests: global position of this shard's first nnz
+    int num_shards_ = 1;      //                  shards that advance the lr schedule together
     std::vector<std::mt19937> inl_rng_;
     // statistics exported to the tests / bench
     std::atomic<long long> stat_samples_{0}, stat_scored_negs_{0}, stat_updates_{0};
@@ -305,7 +310,7 @@ class SGD {
             j.alpha = lr_;
             if (inline_) {
                 process_job(j, 0, inl_rng_[0]);
-                inl_total_processed_ += j.size;
+                inl_total_processed_ += (long long)j.size * num_shards_;
             } else {
                 job_queue_.push(j);
             }
@@ -320,12 +325,12 @@ class SGD {
             S.push_back(u);
             for (int64_t it = beg; it < end; ++it) S.push_back(positives[it - shifted]);
             if (data_size + job_size <= batch_size) {
-                job.add(S, beg);
+                job.add(S, beg + nnz_offset_);
                 job_size += (int)S.size();
             } else {
                 flush(job);  // with batch_size==0 the very first flush is an empty job (Q-7)
                 job = job_t();
-                job.add(S, beg);
+                job.add(S, beg + nnz_offset_);
                 job_size = (int)S.size();
             }
             S.clear();
@@ -548,6 +553,7 @@ class BPR : public SGD {
                     float* Qp = &Q_[(size_t)pos * D];
                     float* Qn = &Q_[(size_t)neg * D];
                     float x_uij = 0.f;
+#pragma omp simd reduction(+ : x_uij)
                     for (int k = 0; k < D; ++k) x_uij += Pu[k] * (Qp[k] - Qn[k]);
                     if (use_bias) x_uij += (Qb_[pos] - Qb_[neg]);
 
@@ -650,6 +656,7 @@ class WARP : public SGD {
     float score(const float* u, const float* i) const {
         if (!l2_) return dotf(u, i, D_);
         float s = 0.f;
+#pragma omp simd reduction(+ : s)
         for (int k = 0; k < D_; ++k) {
             float df = u[k] - i[k];
             s += df * df;
@@ -1079,6 +1086,7 @@ class ALS {
                     // b = p * gramian + reg * block_p,  gramian = FF_.block(0, block_beg, D, bs)
                     for (int j = 0; j < bs; ++j) {
                         float s = 0.f;
+#pragma omp simd reduction(+ : s)
                         for (int k = 0; k < D; ++k) s += pc[k] * FF_[(size_t)k * D + block_beg + j];
                         b[j] = s + reg * pc[block_beg + j];
                     }
@@ -1118,6 +1126,7 @@ class ALS {
                             // Ap = A * p,  A = FF[blk,blk] + I*reg
                             for (int a = 0; a < bs; ++a) {
                                 float s = 0.f;
+#pragma omp simd reduction(+ : s)
                                 for (int c = 0; c < bs; ++c)
                                     s += (FF_[(size_t)(block_beg + a) * D + block_beg + c] + (a == c ? reg : 0.f)) * pv[c];
                                 Ap[a] = s;
@@ -1193,6 +1202,11 @@ void orc_set_modes(void* hp, int sampler, int pos_order, int inline_mode) {
     h->sgd->sampler_ = sampler;
     h->sgd->pos_order_ = pos_order;
     h->sgd->inline_ = inline_mode;
+}
+void orc_set_shard(void* hp, int64_t nnz_offset, int num_shards) {
+    Handle* h = (Handle*)hp;
+    h->sgd->nnz_offset_ = nnz_offset;
+    h->sgd->num_shards_ = num_shards;
 }
 void orc_trace(void* hp, int on) {
     Handle* h = (Handle*)hp;

@@ -52,6 +52,7 @@ def lib():
         "orc_opt_bool": (None, [vp, C.c_char_p, i32]),
         "orc_init": (i32, [vp]),
         "orc_set_modes": (None, [vp, i32, i32, i32]),
+        "orc_set_shard": (None, [vp, i64, i32]),
         "orc_trace": (None, [vp, i32]),
         "orc_trace_size": (i64, [vp]),
         "orc_trace_copy": (None, [vp, pi32]),
@@ -141,6 +142,16 @@ class _SGDBase(_Base):
         """
         lib().orc_set_modes(self._h, {"mt19937": 0, "counter": 1}[sampler],
                             {"unordered_set": 0, "csr": 1}[pos_order], int(inline))
+
+    def set_shard(self, nnz_offset, num_shards):
+        lib().orc_set_shard(self._h, int(nnz_offset), int(num_shards))
+
+    def state_view(self, name):
+        """Zero-copy numpy view of an optimizer-state vector (used by the multi-process tests)."""
+        idx = ["gradP", "gradQ", "gradQb", "momP", "momQ", "momQb", "velP", "velQ", "velQb"].index(name)
+        n = C.c_int64(0)
+        ptr = lib().orc_sgd_state(self._h, idx, C.byref(n))
+        return np.ctypeslib.as_array(ptr, shape=(n.value,))
 
     def initialize_model(self, P, Q, Qb, num_total_samples):
         _chk(P, np.float32, 2), _chk(Q, np.float32, 2), _chk(Qb, np.float32, 2)

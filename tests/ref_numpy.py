@@ -245,6 +245,82 @@ def ialspp_row(P, Q, FF, u, keys, vals, alpha, reg, block_size, tol=1e-10):
 
 
 # ---------------------------------------------------------------------------------------------
+# float64 ground truth of the same recurrences: fp32 implementations (oracle, HIP) are judged by
+# how far they are from THIS, which separates rounding/conditioning from logic errors.
+# ---------------------------------------------------------------------------------------------
+def ialspp_row_f64(P, Q, FF, u, keys, vals, alpha, reg, block_size, tol=1e-10):
+    D = Q.shape[1]
+    p = P[u].astype(np.float64).copy()
+    Qd, FFd = Q.astype(np.float64), FF.astype(np.float64)
+    Y = np.array([p @ Qd[c] for c in keys])
+    bs0 = min(D, block_size)
+    for bb in range(0, D, bs0):
+        bs = bs0 if bb + bs0 < D else D - bb
+        gram = FFd[:, bb:bb + bs]
+        A = gram[bb:bb + bs, :] + np.eye(bs) * reg
+        b = p @ gram + reg * p[bb:bb + bs]
+        for k, (c, v) in enumerate(zip(keys, vals)):
+            b = b + (Y[k] - 1.0) * v * alpha * Qd[c, bb:bb + bs]
+        x, r = np.zeros(bs), b.copy()
+        pv, rsold = r.copy(), float(b @ b)
+        if rsold > tol:
+            for _ in range(3):
+                Ap = A @ pv
+                for c, v in zip(keys, vals):
+                    qb = Qd[c, bb:bb + bs]
+                    Ap = Ap + v * alpha * (qb @ pv) * qb
+                step = rsold / (pv @ Ap)
+                x, r = x + step * pv, r - step * Ap
+                rsnew = float(r @ r)
+                if rsnew < tol:
+                    break
+                pv, rsold = r + (rsnew / rsold) * pv, rsnew
+        p[bb:bb + bs] -= x
+        for k, c in enumerate(keys):
+            Y[k] -= Qd[c, bb:bb + bs] @ x
+    return p
+
+
+def manual_cg_f64(x0, A, y, iters=3, tol=1e-10, eps=1e-10):
+    x = x0.astype(np.float64).copy()
+    r = y - x @ A
+    if y @ y < r @ r:
+        x[:] = 0
+        r = y.copy()
+    p, rs = r.copy(), float(r @ r)
+    for _ in range(iters):
+        Ap = p @ A
+        a = rs / (Ap @ p + eps)
+        x, r = x + a * p, r - a * Ap
+        rn = float(r @ r)
+        if rn < tol:
+            break
+        p, rs = r + rn / (rs + eps) * p, rn
+    return x
+
+
+def als_half_epoch_f64(P, Q, FF, mat, opt, axis):
+    """float64 result of one half-epoch for every row of `mat` (rows of P are updated)."""
+    d = Q.shape[1]
+    reg = opt["reg_u"] if axis == 0 else opt["reg_i"]
+    optimizer = "ialspp" if d >= 128 else opt["optimizer"]
+    T = P.astype(np.float64).copy()
+    for u in range(mat.num_users):
+        keys, vals = mat.row(u)
+        if len(keys) == 0:
+            continue
+        if optimizer == "ialspp":
+            T[u] = ialspp_row_f64(P, Q, FF, u, keys, vals, opt["alpha"], reg, opt["block_size"])
+            continue
+        A, y = als_normal_equations(P, Q, FF, u, keys, vals, opt["alpha"], reg, opt["adaptive_reg"])
+        if optimizer == "manual_cg":
+            T[u] = manual_cg_f64(P[u], A, y, iters=opt["num_cg_max_iters"], tol=opt["cg_tolerance"], eps=opt["eps"])
+        else:
+            T[u] = np.linalg.solve(A, y)
+    return T
+
+
+# ---------------------------------------------------------------------------------------------
 # Published Philox4x32-10 (Salmon, Moraes, Dror, Shaw; SC'11) -- third, python-int implementation
 # ---------------------------------------------------------------------------------------------
 def philox4x32_10(ctr, key):

@@ -150,8 +150,9 @@ def test_compute_loss_matches_oracle(oracle):
 def test_hogwild_statistical_parity(oracle, atomic):
     """Throughput mode vs the threaded reference path: same ranking quality on planted low-rank data
     (mirrors the ndcg threshold test, tests/algo/test_bpr.py:38-47).  With fp32 atomics no update is
-    lost and the result must track the reference; racy stores (hogwild_atomic=0) drop colliding
-    updates -- thousands of waves hit a 400-item table at once -- so that mode only has to learn."""
+    lost and the result must track the reference; write-through racy stores (hogwild_atomic=0) drop
+    colliding updates -- hundreds of waves hit a 400-item table in lock-step -- so that mode only has
+    to learn something (it is an opt-in)."""
     from buffalo_amd import synth
     from buffalo_amd.backend import CyBPR
     csr, vali = synth.planted(600, 400, d_true=6, density=0.06, seed=7)

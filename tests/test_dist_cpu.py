@@ -1,0 +1,157 @@
+"""Multi-process (world_size 2, gloo, CPU) tests of the data-parallel layer (buffalo_amd/dist.py).
+
+The local engine is the CPU oracle in deterministic mode, so these tests check the *distribution*
+logic the HIP engine relies on: nnz-balanced user sharding, shard offsets that keep the counter
+sampler identical to the single-process run, and the delta all-reduce of the replicated tensors."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class OracleEngine:
+    """DataParallelSGD engine backed by the oracle (tests only)."""
+
+    def __init__(self, o, Q, Qb):
+        self.o, self.Q, self.Qb = o, Q, Qb
+
+    def replicated_tensors(self, kind):
+        import torch
+        if kind == "model":
+            return [torch.from_numpy(self.Q), torch.from_numpy(self.Qb)]
+        return [torch.from_numpy(self.o.state_view("gradQ")), torch.from_numpy(self.o.state_view("gradQb"))]
+
+    def add_jobs(self, a, b, indptr, keys):
+        return self.o.add_jobs(a, b, indptr, keys)
+
+    def wait(self):
+        pass
+
+    def update_parameters(self):
+        self.o.update_parameters()
+
+
+def _make_problem(kind):
+    from conftest import bpr_opt, tiny_csr, warp_opt
+    csr = tiny_csr(U=60, I=50, density=0.15, seed=3)
+    d = 12
+    rng = np.random.default_rng(5)
+    P = rng.normal(scale=0.3, size=(60, d)).astype(np.float32)
+    Q = rng.normal(scale=0.3, size=(50, d)).astype(np.float32)
+    Qb = rng.normal(scale=0.1, size=(50, 1)).astype(np.float32)
+    if kind == "warp":
+        opt = warp_opt(d=d, random_seed=9, max_trials=10, threshold=0.3, num_iters=2, lr=0.05)
+        Qb *= 0
+    elif kind == "bpr_adagrad":
+        opt = bpr_opt(d=d, random_seed=9, optimizer="adagrad", lr=0.05, num_iters=2)
+    else:
+        opt = bpr_opt(d=d, random_seed=9, optimizer="sgd", lr=0.05, min_lr=0.01, num_iters=2)
+    return csr, opt, P, Q, Qb
+
+
+def _oracle(kind, opt, P, Q, Qb, nnz_total):
+    import helpers as H
+    from oracle import oracle as orc
+    o = (orc.OracleWARP if kind == "warp" else orc.OracleBPRMF)()
+    assert o.init(H.write_opt(opt))
+    o.initialize_model(P, Q, Qb, nnz_total)
+    o.set_cumulative_table(np.zeros(Q.shape[0], np.int64), Q.shape[0])
+    o.set_modes(sampler="counter", pos_order="csr", inline=True)
+    o.launch_workers()
+    return o
+
+
+def _worker(rank, world, port, kind, out_dir):
+    import torch.distributed as dist
+    from buffalo_amd.dist import DataParallelSGD, shard_csr
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    csr, opt, P, Q, Qb = _make_problem(kind)
+    u0, u1, ip, keys, off = shard_csr(csr.indptr, csr.keys, rank, world)
+    Pl = np.ascontiguousarray(P[u0:u1])
+    o = _oracle(kind, opt, Pl, Q, Qb, csr.nnz)
+    o.set_shard(off, world)
+    dp = DataParallelSGD(OracleEngine(o, Q, Qb), opt["optimizer"])
+    for _ in range(2):
+        n = u1 - u0
+        for a, b in ((0, n // 2), (n // 2, n)):      # two minibatches per epoch
+            beg = 0 if a == 0 else int(ip[a - 1])
+            end = int(ip[b - 1])
+            dp.minibatch(a, b, ip, np.ascontiguousarray(keys[beg:end]))
+        dp.end_epoch()
+    np.savez(os.path.join(out_dir, "r%d.npz" % rank), P=Pl, Q=Q, Qb=Qb, u0=u0, u1=u1)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_world(kind, tmp_path, world=2):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, kind, str(tmp_path)), nprocs=world, join=True)
+    return [np.load(os.path.join(str(tmp_path), "r%d.npz" % r)) for r in range(world)]
+
+
+def test_shard_bounds_balance_nnz():
+    from buffalo_amd import synth
+    from buffalo_amd.dist import shard_bounds, shard_csr
+    csr = synth.generate(2000, 500, 40000, seed=1)
+    for world in (1, 2, 3, 8):
+        b = shard_bounds(csr.indptr, world)
+        assert b[0] == 0 and b[-1] == 2000 and all(x <= y for x, y in zip(b, b[1:]))
+        sizes, total = [], 0
+        for r in range(world):
+            u0, u1, ip, keys, off = shard_csr(csr.indptr, csr.keys, r, world)
+            assert off == total and (len(ip) == 0 or ip[-1] == keys.shape[0])
+            total += keys.shape[0]
+            sizes.append(keys.shape[0])
+        assert total == csr.nnz
+        assert max(sizes) - min(sizes) <= 2 * int(np.diff(np.concatenate([[0], csr.indptr])).max())
+
+
+@pytest.mark.parametrize("kind", ["bpr_adagrad", "warp"])
+def test_gradient_allreduce_equals_single_process(kind, tmp_path):
+    """adam/adagrad/WARP: P,Q frozen inside an epoch => 2 ranks == 1 process up to summation order."""
+    import helpers as H
+    outs = _run_world(kind, tmp_path)
+    csr, opt, P, Q, Qb = _make_problem(kind)
+    o = _oracle(kind, opt, P, Q, Qb, csr.nnz)
+    for _ in range(2):
+        o.add_jobs(0, csr.num_users, csr.indptr, csr.keys)
+        o.update_parameters()
+    Pm = np.concatenate([z["P"] for z in outs])
+    assert H.relerr(Pm, P) < 1e-5
+    for z in outs:                                   # replicas stay identical and match
+        assert H.relerr(z["Q"], Q) < 1e-5 and H.relerr(z["Qb"], Qb) < 1e-5 + (kind == "warp")
+    np.testing.assert_array_equal(outs[0]["Q"], outs[1]["Q"])
+
+
+def test_sgd_delta_allreduce_keeps_replicas_consistent(tmp_path):
+    """Hogwild sgd across ranks is local-SGD with summed item deltas: replicas must be identical
+    after every exchange, every rank must have moved Q, and the result stays near the sequential one."""
+    import helpers as H
+    outs = _run_world("bpr_sgd", tmp_path)
+    csr, opt, P, Q, Qb = _make_problem("bpr_sgd")
+    Q0 = Q.copy()
+    o = _oracle("bpr_sgd", opt, P, Q, Qb, csr.nnz)
+    for _ in range(2):
+        o.add_jobs(0, csr.num_users, csr.indptr, csr.keys)
+        o.update_parameters()
+    np.testing.assert_array_equal(outs[0]["Q"], outs[1]["Q"])
+    np.testing.assert_array_equal(outs[0]["Qb"], outs[1]["Qb"])
+    assert not np.array_equal(outs[0]["Q"], Q0)
+    # same negatives are drawn (shard offsets), only the visibility of the other rank's item updates differs
+    assert H.relerr(outs[0]["Q"], Q) < 0.05
+    assert H.relerr(np.concatenate([z["P"] for z in outs]), P) < 0.05
