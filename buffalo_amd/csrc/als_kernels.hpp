@@ -12,6 +12,11 @@
 // product is K FMAs + a DPP row reduction.  One wave owns one row of the side being solved; rows
 // are handed out through an atomic ticket (the reference uses omp schedule(dynamic,4)).
 #pragma once
+#include <algorithm>
+#include <map>
+#include <memory>
+#include <tuple>
+
 #include "common.hpp"
 
 namespace bfh {
@@ -575,6 +580,472 @@ __global__ __launch_bounds__(256) void als_ialspp_kernel(AlsParams p) {
     }
 }
 
+// ================================================================================================
+// Gramian-on-MFMA path (vdim <= 128: every d <= 128, i.e. BASELINE config #3 and all d < 128 solvers)
+//
+// One workgroup (4 waves) owns a row (or a 4096-nnz chunk of a heavy row).  ONE pass over the row's
+// nnz builds, on the matrix cores (v_mfma_f32_32x32x2_f32, exact fp32),
+//     G = alpha * sum_k v_k q_k q_k^T   (vdim x vdim; wave w accumulates tile-row w: T tiles x 16 regs)
+//     g = sum_k coef_k q_k              (coef = alpha*v for iALS++, 1 + alpha*v for the dense solvers)
+// with q rows streamed straight from HBM/L2 into the MFMA operand layout (lane = (k&1)*32 + i reads
+// q_k[32*bj + i]: a 128-byte segment per half-wave, no LDS staging, no transposition).  M = FF + G then
+// lands in LDS and wave 0 runs the small dense algebra:
+//   * iALS++ (als.cc:269-352): the reference tracks Yui_k = p.q_k incrementally; with the explicit
+//     Gramian, sum_k alpha v_k (Yui_k - 1) q_k == r0 + G (p - p0) where p0 is the row at entry and
+//     r0 = sum_k alpha v_k (p0.q_k - 1) q_k is gathered in the same pass, so the block gradient is
+//     b = M[blk,:](p - p0) + (FF p0)_blk + reg p_blk + r0_blk and the CG matrix M[blk,blk] + reg I:
+//     the same recurrence without the reference's 5 passes over the nnz per block, and without the
+//     cancellation a naive G p - g would introduce in fp32;
+//   * manual_cg / llt / ldlt (als.cc:180-204 + algo.cc:52-82): A = M + reg*ada*I explicitly.
+// Heavy rows (item "Star Wars" has 10^5 users) are cut into chunks whose partial G/g are combined
+// with fp32 atomics in a scratch slot and solved by a second, tiny launch.
+// ================================================================================================
+struct AlsWork {
+    int row;
+    int kbeg, kend;  // chunk-local nnz range
+    int slot;        // -1: whole row in this item (solve in place); >= 0: partial of heavy row `slot`
+};
+
+constexpr int ALS_LD_PAD = 1;
+
+// the dense phase runs on ONE wave whose lanes exchange data through LDS: order the DS traffic
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// dense phase, executed by ONE wave on LDS-resident M (ld = vdim+1), g, p.  `mode`: 8 ialspp, 2 manual_cg, 0/1 cholesky
+__device__ __forceinline__ void als_dense_solve(float* M, float* gv, float* pv_lds, const float* p0, const float* f0, float* w0, float* w1,
+                                                float* w2, float* w3, float* w4, const AlsParams& p, int lane, float regada, int mode) {
+    const int D = p.d, ld = p.vdim + ALS_LD_PAD;
+    if (mode == 8) {
+        const int bs0 = p.block_size < D ? p.block_size : D;
+        if (bs0 <= 32) {
+            // fast path (default block_size 32): lane = (i, h) -- row i of the block, h = column parity.
+            // x, r, pv live in registers; only pv is exchanged through LDS.  delta = p - p0 is non-zero
+            // only in the blocks already solved, so the gradient touches bb columns, not D.
+            const int i = lane & 31, h = lane >> 5;
+            float* pvs = w3;
+            for (int bb = 0; bb < D; bb += bs0) {
+                int bs = bs0;
+                if (bb + bs >= D) bs = D - bb;
+                const bool act = i < bs;
+                const float* Mi = M + (bb + (act ? i : 0)) * ld;
+                float sum = 0.f;
+#pragma unroll 8
+                for (int j = h; j < bb; j += 2) sum += Mi[j] * (pv_lds[j] - p0[j]);
+                sum += __shfl_xor(sum, 32, 64);
+                float bi = act ? sum + f0[bb + i] + p.reg * pv_lds[bb + i] + gv[bb + i] : 0.f;
+                float xr = 0.f, rr = bi, pvr = bi;
+                double rsold = static_cast<double>(wave_sum(h == 0 ? rr * rr : 0.f));
+                if (rsold > static_cast<double>(p.cg_tol)) {
+                    for (int step = 0; step < 3; ++step) {
+                        wave_lds_sync();
+                        if (h == 0 && act) pvs[i] = pvr;
+                        wave_lds_sync();
+                        float ap = 0.f;
+#pragma unroll 8
+                        for (int j = h; j < bs; j += 2) ap += Mi[bb + j] * pvs[j];
+                        ap += __shfl_xor(ap, 32, 64);
+                        ap = act ? ap + p.reg * pvr : 0.f;
+                        const float pap = wave_sum(h == 0 ? pvr * ap : 0.f);
+                        const float step_size = static_cast<float>(rsold / static_cast<double>(pap));
+                        xr += step_size * pvr;
+                        rr -= step_size * ap;
+                        const double rsnew = static_cast<double>(wave_sum(h == 0 ? rr * rr : 0.f));
+                        if (rsnew < static_cast<double>(p.cg_tol)) break;
+                        pvr = rr + static_cast<float>(rsnew / rsold) * pvr;
+                        rsold = rsnew;
+                    }
+                }
+                wave_lds_sync();
+                if (h == 0 && act) pv_lds[bb + i] -= xr;
+                wave_lds_sync();
+            }
+            return;
+        }
+        for (int bb = 0; bb < D; bb += bs0) {
+            int bs = bs0;
+            if (bb + bs >= D) bs = D - bb;
+            float* b = w0; float* x = w1; float* r = w2; float* pv = w3; float* ap = w4;
+            // b = M[blk,:] (p - p0) + (FF p0)_blk + reg p_blk + r0_blk   -- delta form: no G p - g cancellation
+            float rs = 0.f;
+            for (int i = lane; i < bs; i += 64) {
+                const float* Mi = M + (bb + i) * ld;
+                float sum = 0.f;
+#pragma unroll 8
+                for (int j = 0; j < bb; ++j) sum += Mi[j] * (pv_lds[j] - p0[j]);
+                sum += f0[bb + i] + p.reg * pv_lds[bb + i] + gv[bb + i];
+                b[i] = sum; r[i] = sum; pv[i] = sum; x[i] = 0.f;
+                rs += sum * sum;
+            }
+            (void)b;
+            double rsold = static_cast<double>(wave_sum(rs));
+            wave_lds_sync();
+            if (rsold > static_cast<double>(p.cg_tol)) {
+                for (int step = 0; step < 3; ++step) {
+                    float pap = 0.f;
+                    for (int i = lane; i < bs; i += 64) {
+                        const float* Mi = M + (bb + i) * ld + bb;
+                        float sum = p.reg * pv[i];
+#pragma unroll 8
+                        for (int j = 0; j < bs; ++j) sum += Mi[j] * pv[j];
+                        ap[i] = sum;
+                        pap += pv[i] * sum;
+                    }
+                    pap = wave_sum(pap);
+                    const float step_size = static_cast<float>(rsold / static_cast<double>(pap));
+                    float rn = 0.f;
+                    for (int i = lane; i < bs; i += 64) {
+                        x[i] += step_size * pv[i];
+                        const float ri = r[i] - step_size * ap[i];
+                        r[i] = ri;
+                        rn += ri * ri;
+                    }
+                    const double rsnew = static_cast<double>(wave_sum(rn));
+                    if (rsnew < static_cast<double>(p.cg_tol)) break;
+                    const float ratio = static_cast<float>(rsnew / rsold);
+                    wave_lds_sync();
+                    for (int i = lane; i < bs; i += 64) pv[i] = r[i] + ratio * pv[i];
+                    wave_lds_sync();
+                    rsold = rsnew;
+                }
+            }
+            for (int i = lane; i < bs; i += 64) pv_lds[bb + i] -= x[i];
+            wave_lds_sync();
+        }
+        return;
+    }
+    // explicit system A = M + regada I (in place)
+    for (int i = lane; i < D; i += 64) M[i * ld + i] += regada;
+    wave_lds_sync();
+    if (mode == 2) {  // manual_cg, algo.cc:58-82 (Q-17); x = pv_lds, y = gv
+        float* r = w0; float* q = w1; float* Ap = w2;
+        auto matvec = [&](const float* v, float* out) {  // out = v * A (A symmetric)
+            for (int i = lane; i < D; i += 64) {
+                const float* Ai = M + i * ld;
+                float sum = 0.f;
+#pragma unroll 8
+                for (int j = 0; j < D; ++j) sum += Ai[j] * v[j];
+                out[i] = sum;
+            }
+            wave_lds_sync();
+        };
+        matvec(pv_lds, Ap);
+        float yy = 0.f, rr = 0.f;
+        for (int i = lane; i < D; i += 64) {
+            const float ri = gv[i] - Ap[i];
+            r[i] = ri;
+            yy += gv[i] * gv[i];
+            rr += ri * ri;
+        }
+        yy = wave_sum(yy);
+        rr = wave_sum(rr);
+        if (yy < rr) {
+            for (int i = lane; i < D; i += 64) { pv_lds[i] = 0.f; r[i] = gv[i]; }
+            rr = yy;
+        }
+        for (int i = lane; i < D; i += 64) q[i] = r[i];
+        wave_lds_sync();
+        float rs_old = rr;
+        for (int it = 0; it < p.num_cg_max_iters; ++it) {
+            matvec(q, Ap);
+            float pap = 0.f;
+            for (int i = lane; i < D; i += 64) pap += Ap[i] * q[i];
+            pap = wave_sum(pap);
+            const float a = rs_old / (pap + p.eps);
+            float rn = 0.f;
+            for (int i = lane; i < D; i += 64) {
+                pv_lds[i] += a * q[i];
+                const float ri = r[i] - a * Ap[i];
+                r[i] = ri;
+                rn += ri * ri;
+            }
+            const float rs_new = wave_sum(rn);
+            if (rs_new < p.cg_tol) break;
+            const float beta = rs_new / (rs_old + p.eps);
+            for (int i = lane; i < D; i += 64) q[i] = r[i] + beta * q[i];
+            wave_lds_sync();
+            rs_old = rs_new;
+        }
+        return;
+    }
+    // llt / ldlt: in-place Cholesky of A, then two triangular solves on z = y
+    float* z = w0;
+    for (int i = lane; i < D; i += 64) z[i] = gv[i];
+    wave_lds_sync();
+    for (int j = 0; j < D; ++j) {
+        const float ljj = sqrtf(M[j * ld + j]);
+        wave_lds_sync();
+        for (int r = j + lane; r < D; r += 64) M[r * ld + j] = (r == j) ? ljj : M[r * ld + j] / ljj;
+        wave_lds_sync();
+        for (int r = j + 1 + lane; r < D; r += 64) {
+            const float lrj = M[r * ld + j];
+            for (int c2 = j + 1; c2 <= r; ++c2) M[r * ld + c2] -= lrj * M[c2 * ld + j];
+        }
+        wave_lds_sync();
+    }
+    for (int r = 0; r < D; ++r) {
+        float sum = 0.f;
+        for (int c2 = lane; c2 < r; c2 += 64) sum += M[r * ld + c2] * z[c2];
+        sum = wave_sum(sum);
+        wave_lds_sync();
+        if (lane == 0) z[r] = (z[r] - sum) / M[r * ld + r];
+        wave_lds_sync();
+    }
+    for (int r = D - 1; r >= 0; --r) {
+        float sum = 0.f;
+        for (int c2 = r + 1 + lane; c2 < D; c2 += 64) sum += M[c2 * ld + r] * z[c2];
+        sum = wave_sum(sum);
+        wave_lds_sync();
+        if (lane == 0) z[r] = (z[r] - sum) / M[r * ld + r];
+        wave_lds_sync();
+    }
+    for (int i = lane; i < D; i += 64) pv_lds[i] = z[i];
+    wave_lds_sync();
+}
+
+// LDS carve: M[vdim][vdim+1] | g[vdim] | p[vdim] | 4 work vectors[vdim]
+__host__ __device__ inline size_t als_gs_lds_bytes(int vdim) { return (static_cast<size_t>(vdim) * (vdim + ALS_LD_PAD) + 9 * vdim + 4) * sizeof(float); }
+
+template <int T>
+__global__ __launch_bounds__(256, 2) void als_gram_solve_kernel(AlsParams p, const AlsWork* __restrict__ work, int n_work, float* __restrict__ scratch,
+                                                             int mode) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int vdim = p.vdim, D = p.d, ld = vdim + ALS_LD_PAD;
+    float* M = lds;
+    float* gv = lds + vdim * ld;
+    float* pl = gv + vdim;
+    float* w0 = pl + vdim; float* w1 = w0 + vdim; float* w2 = w1 + vdim; float* w3 = w2 + vdim; float* w4 = w3 + vdim;
+    float* p0 = w4 + vdim; float* f0 = p0 + vdim;
+    int* s_item = reinterpret_cast<int*>(f0 + vdim);   // all LDS lives in the dynamic region (16-B aligned base)
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // tile row of this wave
+    const int half = lane >> 5, col = lane & 31;
+    const bool ialspp = mode == 8;
+    double nume = 0.0, deno = 0.0;      // row-level terms (identical in every lane of wave 0)
+    double nume_k = 0.0, deno_k = 0.0;  // per-nnz terms (lanes 0 and 32 of wave 0 hold the two k-parities)
+
+    while (true) {
+        __syncthreads();
+        if (threadIdx.x == 0) *s_item = atomicAdd(p.ticket, 1);
+        __syncthreads();
+        const int item = *s_item;
+        if (item >= n_work) break;
+        const AlsWork wk = work[item];
+        const int u = wk.row;
+        float* Pu = p.P + static_cast<size_t>(u) * vdim;
+        // current row -> LDS (the loss terms and the solve read it)
+        for (int e = threadIdx.x; e < vdim; e += blockDim.x) { pl[e] = Pu[e]; p0[e] = Pu[e]; }
+        __syncthreads();
+        if (ialspp && wk.slot < 0 && wv < T) {   // f0 = FF p0 (wave w: rows 32w..32w+31, the two half-waves split the columns)
+            float sum = 0.f;
+            const float* Fr = p.FF + static_cast<size_t>(wv * 32 + col) * vdim + half * (vdim / 2);
+            for (int j = 0; j < vdim / 2; ++j) sum += Fr[j] * p0[half * (vdim / 2) + j];
+            sum += __shfl_xor(sum, 32, 64);
+            if (half == 0) f0[wv * 32 + col] = sum;
+        }
+
+        f32x16 acc[T];
+#pragma unroll
+        for (int g = 0; g < T; ++g)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
+        float gpart = 0.f;   // this lane's share of g[wv*32 + col]
+        float pcol[T];
+#pragma unroll
+        for (int g = 0; g < T; ++g) pcol[g] = pl[g * 32 + col];
+        const bool lossk = p.compute_loss && p.axis == 1 && wv == 0;
+
+        const int64_t n = wk.kend - wk.kbeg;
+        for (int64_t k0 = 0; k0 < n; k0 += 64) {
+            const int64_t kk = k0 + lane;
+            int myc = 0;
+            float myv = 0.f;
+            if (kk < n) {
+                myc = p.keys[wk.kbeg + kk];
+                myv = p.vals[wk.kbeg + kk];
+            }
+            const int nh = static_cast<int>((n - k0) < 64 ? (n - k0) : 64);
+            constexpr int UP = 4;   // nnz pairs in flight per iteration (software pipelining by hand)
+            for (int j = 0; j < nh; j += 2 * UP) {
+                float qv[UP][T], vv[UP];
+                bool okk[UP];
+#pragma unroll
+                for (int uu = 0; uu < UP; ++uu) {
+                    const int src = j + 2 * uu + half;      // this half-wave's nnz of pair uu
+                    okk[uu] = src < nh;
+                    // cross-lane reads stay OUTSIDE any lane-divergent expression: a shuffle executed under a
+                    // partial exec mask returns 0 for source lanes that are masked off
+                    const int c = __shfl(myc, src & 63, 64);
+                    const float vsh = __shfl(myv, src & 63, 64);
+                    vv[uu] = okk[uu] ? vsh : 0.f;
+                    const float* q = p.Q + static_cast<size_t>(okk[uu] ? c : 0) * vdim;
+#pragma unroll
+                    for (int g = 0; g < T; ++g) qv[uu][g] = okk[uu] ? q[g * 32 + col] : 0.f;
+                }
+#pragma unroll
+                for (int uu = 0; uu < UP; ++uu) {
+                    const float v = vv[uu];
+                    const float wgt = p.alpha * v;
+                    float dp = 0.f;   // y0 = p0 . q_k, reduced inside each half-wave (row_ror butterfly + one cross-row hop)
+                    if (ialspp || lossk) {
+#pragma unroll
+                        for (int g = 0; g < T; ++g) dp += qv[uu][g] * pcol[g];
+                        dp += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, dp), 0x128, 0xf, 0xf, false));
+                        dp += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, dp), 0x124, 0xf, 0xf, false));
+                        dp += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, dp), 0x122, 0xf, 0xf, false));
+                        dp += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, dp), 0x121, 0xf, 0xf, false));
+                        dp += __shfl_xor(dp, 16, 64);
+                    }
+                    if (wv < T) {
+                        float qsel = 0.f;   // qv[wv] with compile-time indices (runtime-indexed arrays spill to scratch)
+#pragma unroll
+                        for (int g = 0; g < T; ++g) qsel = (g == wv) ? qv[uu][g] : qsel;
+                        const float a = wgt * qsel;
+#pragma unroll
+                        for (int g = 0; g < T; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, qv[uu][g], acc[g], 0, 0, 0);
+                        // iALS++: r0 += alpha v (y0 - 1) q ; dense solvers: y += (1 + alpha v) q
+                        const float coef = ialspp ? wgt * (dp - 1.0f) : static_cast<float>(1.0 + static_cast<double>(v * p.alpha));
+                        gpart += (okk[uu] ? coef : 0.f) * qsel;
+                    }
+                    if (lossk && col == 0 && okk[uu]) {  // als.cc:187-192 / 298-303 on the ORIGINAL row
+                        nume_k -= static_cast<double>(dp * dp);
+                        nume_k += static_cast<double>((dp - 1) * (dp - 1)) * (1.0 + static_cast<double>(v * p.alpha));
+                        deno_k += static_cast<double>(v * p.alpha);
+                    }
+                }
+            }
+        }
+        gpart += __shfl_xor(gpart, 32, 64);  // both halves hold k-parities of the same element
+
+        if (wk.slot >= 0) {
+            // heavy row: add this chunk's partial into the scratch slot, solved by als_solve_heavy_kernel
+            float* S = scratch + static_cast<size_t>(wk.slot) * (vdim * vdim + vdim);
+            if (wv < T) {
+#pragma unroll
+                for (int g = 0; g < T; ++g)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int i = (e & 3) + 8 * (e >> 2) + 4 * half;
+                        atomic_add_f32(S + static_cast<size_t>(wv * 32 + i) * vdim + g * 32 + col, acc[g][e]);
+                    }
+                if (half == 0) atomic_add_f32(S + vdim * vdim + wv * 32 + col, gpart);
+            }
+            continue;
+        }
+        // M = FF + G, g -> LDS
+        if (wv < T) {
+#pragma unroll
+            for (int g = 0; g < T; ++g)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int i = (e & 3) + 8 * (e >> 2) + 4 * half;
+                    const int rr = wv * 32 + i, cc = g * 32 + col;
+                    M[rr * ld + cc] = acc[g][e] + p.FF[static_cast<size_t>(rr) * vdim + cc];
+                }
+            if (half == 0) gv[wv * 32 + col] = gpart;
+        }
+        __syncthreads();
+        if (wv == 0) {
+            const float ada = p.adaptive_reg ? static_cast<float>(n) : 1.0f;
+            if (p.compute_loss) {
+                float pp = 0.f, pfp = 0.f;
+                for (int i = lane; i < D; i += 64) {
+                    pp += pl[i] * pl[i];
+                    if (p.axis == 1) {
+                        float sum = 0.f;
+                        for (int j = 0; j < D; ++j) sum += p.FF[static_cast<size_t>(i) * vdim + j] * pl[j];
+                        pfp += pl[i] * sum;
+                    }
+                }
+                pp = wave_sum(pp);
+                nume += static_cast<double>(ada * p.reg * pp);
+                if (p.axis == 1) {
+                    pfp = wave_sum(pfp);
+                    nume += static_cast<double>(pfp);
+                    deno += static_cast<double>(p.op_rows);
+                }
+            }
+            als_dense_solve(M, gv, pl, p0, f0, w0, w1, w2, w3, w4, p, lane, p.reg * ada, mode);
+            for (int i = lane; i < D; i += 64) Pu[i] = pl[i];
+        }
+    }
+    if (p.compute_loss && wv == 0) {
+        nume_k += __shfl_xor(nume_k, 32, 64);
+        deno_k += __shfl_xor(deno_k, 32, 64);
+        if (lane == 0) {
+            if (nume + nume_k != 0.0) atomicAdd(p.loss, nume + nume_k);
+            if (deno + deno_k != 0.0) atomicAdd(p.loss + 1, deno + deno_k);
+        }
+    }
+}
+
+struct AlsHeavy {
+    int row, slot;
+    int64_t n;
+};
+
+__global__ __launch_bounds__(64) void als_solve_heavy_kernel(AlsParams p, const AlsHeavy* __restrict__ heavy, int n_heavy, const float* __restrict__ scratch,
+                                                             int mode) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int vdim = p.vdim, D = p.d, ld = vdim + ALS_LD_PAD;
+    float* M = lds;
+    float* gv = lds + vdim * ld;
+    float* pl = gv + vdim;
+    float* w0 = pl + vdim; float* w1 = w0 + vdim; float* w2 = w1 + vdim; float* w3 = w2 + vdim; float* w4 = w3 + vdim;
+    float* p0 = w4 + vdim; float* f0 = p0 + vdim;
+    const int lane = threadIdx.x;
+    const int h = blockIdx.x;
+    if (h >= n_heavy) return;
+    const AlsHeavy hv = heavy[h];
+    const float* S = scratch + static_cast<size_t>(hv.slot) * (vdim * vdim + vdim);
+    float* Pu = p.P + static_cast<size_t>(hv.row) * vdim;
+    for (int e = lane; e < vdim * vdim; e += 64) {
+        const int rr = e / vdim, cc = e % vdim;
+        M[rr * ld + cc] = S[e] + p.FF[e];
+    }
+    for (int e = lane; e < vdim; e += 64) {
+        gv[e] = S[vdim * vdim + e];
+        pl[e] = Pu[e];
+        p0[e] = Pu[e];
+    }
+    __syncthreads();
+    for (int i = lane; i < vdim; i += 64) {
+        float sum = 0.f;
+        for (int j = 0; j < vdim; ++j) sum += p.FF[static_cast<size_t>(i) * vdim + j] * p0[j];
+        f0[i] = sum;
+    }
+    __syncthreads();
+    const float ada = p.adaptive_reg ? static_cast<float>(hv.n) : 1.0f;
+    double nume = 0.0, deno = 0.0;
+    if (p.compute_loss) {
+        float pp = 0.f, pfp = 0.f;
+        for (int i = lane; i < D; i += 64) {
+            pp += pl[i] * pl[i];
+            if (p.axis == 1) {
+                float sum = 0.f;
+                for (int j = 0; j < D; ++j) sum += p.FF[static_cast<size_t>(i) * vdim + j] * pl[j];
+                pfp += pl[i] * sum;
+            }
+        }
+        pp = wave_sum(pp);
+        nume += static_cast<double>(ada * p.reg * pp);
+        if (p.axis == 1) {
+            pfp = wave_sum(pfp);
+            nume += static_cast<double>(pfp);
+            deno += static_cast<double>(p.op_rows);
+        }
+    }
+    als_dense_solve(M, gv, pl, p0, f0, w0, w1, w2, w3, w4, p, lane, p.reg * ada, mode);
+    for (int i = lane; i < D; i += 64) Pu[i] = pl[i];
+    if (p.compute_loss && lane == 0) {
+        if (nume != 0.0) atomicAdd(p.loss, nume);
+        if (deno != 0.0) atomicAdd(p.loss + 1, deno);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 class AlsHandle : public HandleBase {
  public:
@@ -649,6 +1120,7 @@ class AlsHandle : public HandleBase {
         vals_.resize(batch_size);
         yui_.resize(batch_size);
         BFH_HIP(hipStreamSynchronize(stream));
+        work_cache_.clear();
         placeholder_ = true;
     }
 
@@ -669,6 +1141,7 @@ class AlsHandle : public HandleBase {
         stats.h2d_bytes += static_cast<double>(rows * sizeof(int64_t) + nnz * 8);
         if (yui_.size() < static_cast<size_t>(nnz)) yui_.resize(static_cast<size_t>(nnz));
         BFH_HIP(hipStreamSynchronize(stream));
+        work_cache_.clear();
         A.resident = true;
     }
 
@@ -747,8 +1220,41 @@ class AlsHandle : public HandleBase {
         BFH_HIP(hipMemsetAsync(ticket_.get(), 0, sizeof(int), stream));
         const int nrows = next_x - start_x;
         const int K = (vdim_ + 63) / 64;
+        const bool gram_path = vdim_ <= 128 && !force_v1_;
+        const WorkList* wl = nullptr;
+        if (gram_path) {
+            wl = &work_list(axis, start_x, next_x, ip, beg);
+            if (wl->n_heavy) BFH_HIP(hipMemsetAsync(scratch_.get(), 0, static_cast<size_t>(wl->n_heavy) * (vdim_ * vdim_ + vdim_) * sizeof(float), stream));
+        }
         const int slot = t_main_.begin(stream);
-        if (code_ == 8) {
+        if (gram_path) {
+            // Gramian on the matrix cores + dense LDS solve (see als_gram_solve_kernel)
+            const size_t lds = als_gs_lds_bytes(vdim_);
+            const int T = vdim_ / 32;
+            int blocks = num_cus_ * static_cast<int>(std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds)));
+            if (blocks > wl->n_work) blocks = wl->n_work;
+            if (blocks > 0) {
+#define BFH_GS(TT)                                                                                                            \
+    do {                                                                                                                      \
+        BFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(als_gram_solve_kernel<TT>),                                \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));                      \
+        hipLaunchKernelGGL(als_gram_solve_kernel<TT>, dim3(blocks), dim3(256), lds, stream, p, wl->work.get(), wl->n_work,    \
+                           scratch_.get(), static_cast<int>(code_));                                                         \
+    } while (0)
+                if (T <= 1) BFH_GS(1);
+                else if (T <= 2) BFH_GS(2);
+                else if (T <= 3) BFH_GS(3);
+                else BFH_GS(4);
+#undef BFH_GS
+                BFH_HIP(hipGetLastError());
+            }
+            if (wl->n_heavy) {
+                BFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(als_solve_heavy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            static_cast<int>(lds)));
+                hipLaunchKernelGGL(als_solve_heavy_kernel, dim3(wl->n_heavy), dim3(64), lds, stream, p, wl->heavy.get(), wl->n_heavy,
+                                   scratch_.get(), static_cast<int>(code_));
+            }
+        } else if (code_ == 8) {
             const int bs = block_size_ < d_ ? block_size_ : d_;
             const int KB = (bs + 63) / 64;
             int waves = num_cus_ * 16;
@@ -788,6 +1294,53 @@ class AlsHandle : public HandleBase {
         *deno = l[1];
     }
 
+    struct WorkList {
+        DevBuf<AlsWork> work;
+        DevBuf<AlsHeavy> heavy;
+        int n_work = 0, n_heavy = 0;
+    };
+    // Work items of one partial_update call: one per non-empty row, rows above HEAVY nnz cut into
+    // chunks; longest first (dynamic ticket order) so the tail is short.  Cached per (axis, range).
+    const WorkList& work_list(int axis, int start_x, int next_x, const int64_t* ip, int64_t shift) {
+        const auto key = std::make_tuple(axis, start_x, next_x);
+        auto it = work_cache_.find(key);
+        if (it != work_cache_.end()) return *it->second;
+        constexpr int64_t HEAVY = 4096;
+        std::vector<AlsWork> w;
+        std::vector<AlsHeavy> h;
+        w.reserve(next_x - start_x);
+        int64_t prev = start_x == 0 ? 0 : ip[start_x - 1];
+        for (int x = start_x; x < next_x; ++x) {
+            const int64_t e = ip[x], n = e - prev;
+            if (n > 0) {  // Q-16: empty rows are left untouched
+                const int64_t kb = prev - shift;
+                if (n <= HEAVY) {
+                    w.push_back({x, static_cast<int>(kb), static_cast<int>(kb + n), -1});
+                } else {
+                    const int slot = static_cast<int>(h.size());
+                    h.push_back({x, slot, n});
+                    const int64_t nch = (n + HEAVY - 1) / HEAVY, per = ((n + nch - 1) / nch + 1) & ~int64_t(1);
+                    for (int64_t c0 = 0; c0 < n; c0 += per)
+                        w.push_back({x, static_cast<int>(kb + c0), static_cast<int>(kb + std::min(n, c0 + per)), slot});
+                }
+            }
+            prev = e;
+        }
+        std::stable_sort(w.begin(), w.end(), [](const AlsWork& a, const AlsWork& b) { return (a.kend - a.kbeg) > (b.kend - b.kbeg); });
+        auto wl = std::make_unique<WorkList>();
+        wl->n_work = static_cast<int>(w.size());
+        wl->n_heavy = static_cast<int>(h.size());
+        wl->work.resize(std::max<size_t>(1, w.size()));
+        wl->heavy.resize(std::max<size_t>(1, h.size()));
+        if (!w.empty()) BFH_HIP(hipMemcpyAsync(wl->work.get(), w.data(), w.size() * sizeof(AlsWork), hipMemcpyHostToDevice, stream));
+        if (!h.empty()) BFH_HIP(hipMemcpyAsync(wl->heavy.get(), h.data(), h.size() * sizeof(AlsHeavy), hipMemcpyHostToDevice, stream));
+        BFH_HIP(hipStreamSynchronize(stream));
+        const size_t need = std::max<size_t>(1, h.size()) * (static_cast<size_t>(vdim_) * vdim_ + vdim_);
+        if (scratch_.size() < need) scratch_.resize(need);
+        if (work_cache_.size() > 64) work_cache_.clear();
+        return *(work_cache_[key] = std::move(wl));
+    }
+
     void launch_ialspp(int K, int KB, dim3 grid, dim3 block, const AlsParams& p) {
 #define BFH_IALS(KK, KKB) hipLaunchKernelGGL((als_ialspp_kernel<KK, KKB>), grid, block, 0, stream, p)
         if (KB <= 1) {
@@ -824,6 +1377,7 @@ class AlsHandle : public HandleBase {
 
     void set_mode(const std::string& name, int64_t v) {
         if (name == "als_writeback") writeback_ = v != 0;
+        else if (name == "als_v1") force_v1_ = v != 0;   // matrix-free reference kernels (debug / d > 128)
         else if (name == "timing") timing = v != 0;
         else throw Error(BFH_ERR_INVALID, "unknown mode '" + name + "'");
     }
@@ -854,6 +1408,9 @@ class AlsHandle : public HandleBase {
     DevBuf<double> loss_;
     DevBuf<int> ticket_;
     Axis ax_[2];
+    bool force_v1_ = false;
+    DevBuf<float> scratch_;
+    std::map<std::tuple<int, int, int>, std::unique_ptr<WorkList>> work_cache_;
     EventTimer t_main_, t_aux_;
 };
 

@@ -1,0 +1,131 @@
+"""Secondary measurements for DESIGN.md / profiles (not the driver's bench contract):
+ALS (config #3), WARP (config #5 scaled to one GPU), BPR adagrad, and the PCIe-inclusive BPR rate
+when the boundary hands over host keys every epoch like the reference does."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import bpr_options, load_matrix, write_opt  # noqa: E402
+from buffalo_amd import synth  # noqa: E402
+from buffalo_amd.backend import CyALS, CyBPR, CyWARP  # noqa: E402
+
+out = {}
+csr = load_matrix("ml20m", 7)
+U, I, nnz = csr.num_users, csr.num_items, csr.nnz
+which = sys.argv[1:] or ["als", "warp", "bpr_adagrad", "bpr_pcie"]
+
+if "als" in which:
+    rng = np.random.default_rng(7)
+    vals = (1 + rng.poisson(1.0, size=nnz)).astype(np.float32)
+    c2 = synth.CSR(U, I, csr.indptr, csr.keys, vals)
+    t = c2.transpose()
+    for d in (128, 32):
+        P, Q, _ = synth.init_factors(U, I, d, seed=7)
+        opt = {"evaluation_on_learning": False, "compute_loss_on_training": False, "early_stopping_rounds": 0, "save_best": False,
+               "evaluation_period": 1, "save_period": 10, "random_seed": 7, "validation": {}, "adaptive_reg": False,
+               "save_factors": False, "accelerator": True, "d": d, "num_iters": 10, "num_workers": 8, "hyper_threads": 256,
+               "num_cg_max_iters": 3, "reg_u": 0.1, "reg_i": 0.1, "alpha": 8.0, "optimizer": "manual_cg", "cg_tolerance": 1e-10,
+               "block_size": 32, "eps": 1e-10, "model_path": "", "data_opt": {}}
+        g = CyALS()
+        assert g.init(write_opt(opt))
+        g.initialize_model(P, Q)
+        g.set_resident_csr(0, c2.indptr, c2.keys, c2.vals)
+        g.set_resident_csr(1, t.indptr, t.keys, t.vals)
+        g.set_mode("als_writeback", 0)
+
+        def epoch():
+            for axis, mat in ((0, c2), (1, t)):
+                g.precompute(axis)
+                g.partial_update(0, mat.num_users, mat.indptr, None, None, axis)
+        epoch()
+        g.reset_stats()
+        t0 = time.perf_counter()
+        n = 3
+        for _ in range(n):
+            epoch()
+        dt = (time.perf_counter() - t0) / n
+        st = g.stats()
+        out["als_d%d" % d] = {"epoch_ms": dt * 1e3, "kernel_ms_per_epoch": st["kernel_ms"] / n, "gramian_ms_per_epoch": st["aux_ms"] / n,
+                              "interactions_per_s": 2 * nnz / dt, "optimizer": "ialspp(bs=32)" if d >= 128 else "manual_cg(3)"}
+        print("als", d, out["als_d%d" % d], flush=True)
+
+if "warp" in which:
+    d = 256
+    P, Q, Qb = synth.init_factors(U, I, d, seed=7, signed=True)
+    Qb *= 0
+    opt = {"evaluation_on_learning": False, "compute_loss_on_training": False, "early_stopping_rounds": 0, "save_best": False,
+           "evaluation_period": 5, "save_period": 10, "random_seed": 7, "validation": {}, "accelerator": True, "num_workers": 8,
+           "hyper_threads": 256, "num_iters": 10, "d": d, "threshold": 1.0, "score_func": "dot", "max_trials": 500, "update_i": True,
+           "update_j": True, "reg_u": 0.0, "reg_i": 0.0, "reg_j": 0.0, "optimizer": "adagrad", "lr": 0.05, "min_lr": 0.0001,
+           "beta1": 0.9, "beta2": 0.999, "eps": 1e-10, "per_coordinate_normalize": False, "model_path": "", "data_opt": {}}
+    g = CyWARP()
+    assert g.init(write_opt(opt))
+    g.sync_every_epoch = False
+    g.initialize_model(P, Q, Qb, nnz, True)
+    g.set_resident_csr(csr.indptr, csr.keys)
+    ep = []
+    for e in range(4):
+        g.reset_stats()
+        t0 = time.perf_counter()
+        g.add_jobs(0, U, csr.indptr, None)
+        t1 = time.perf_counter()
+        g.update_parameters()
+        t2 = time.perf_counter()
+        st = g.stats()
+        T = st["scored_negatives"] / nnz
+        alg = st["accepted"] * ((8 + st["scored_negatives"] / max(st["accepted"], 1)) * 4 * d + 4) \
+            + (nnz - st["accepted"]) * (2 * 4 * d + 4)   # rough: SURVEY 8(d) formula with measured T
+        ep.append({"epoch": e, "trial_kernel_ms": st["kernel_ms"], "optimizer_ms": st["optimizer_ms"], "wall_ms": (t2 - t0) * 1e3,
+                   "positives_per_s": nnz / (t1 - t0), "mean_scored_negatives_T": T, "accepted_frac": st["accepted"] / nnz,
+                   "algorithmic_GBps": alg / (st["kernel_ms"] * 1e-3) / 1e9})
+        print("warp", ep[-1], flush=True)
+    out["warp_ml20m_d256"] = ep
+
+if "bpr_adagrad" in which:
+    P, Q, Qb = synth.init_factors(U, I, 128, seed=7)
+    g = CyBPR()
+    assert g.init(write_opt(bpr_options(10, optimizer="adagrad", lr=0.05)))
+    g.sync_every_epoch = False
+    g.initialize_model(P, Q, Qb, nnz, True)
+    g.set_cumulative_table(np.zeros(I, np.int64), I)
+    g.set_resident_csr(csr.indptr, csr.keys)
+    g.add_jobs(0, U, csr.indptr, None)
+    g.update_parameters()
+    g.reset_stats()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        g.add_jobs(0, U, csr.indptr, None)
+        g.update_parameters()
+    dt = (time.perf_counter() - t0) / 3
+    st = g.stats()
+    out["bpr_adagrad"] = {"epoch_ms": dt * 1e3, "accumulate_kernel_ms": st["kernel_ms"] / 3, "optimizer_ms": st["optimizer_ms"] / 3,
+                          "optimizer_GBps": (U + I) * 128 * 4 * 6 / (st["optimizer_ms"] / 3 * 1e-3) / 1e9}
+    print("bpr_adagrad", out["bpr_adagrad"], flush=True)
+
+if "bpr_pcie" in which:
+    # drop-in call pattern of the reference: host keys handed over every epoch + P,Q,Qb copied back
+    P, Q, Qb = synth.init_factors(U, I, 128, seed=7)
+    g = CyBPR()
+    assert g.init(write_opt(bpr_options(10)))
+    g.initialize_model(P, Q, Qb, nnz)
+    g.set_cumulative_table(np.zeros(I, np.int64), I)
+    g.set_placeholder(csr.indptr, nnz + 1)
+    g.initialize_model(P, Q, Qb, nnz, True)
+    g.add_jobs(0, U, csr.indptr, csr.keys)
+    g.update_parameters()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        g.add_jobs(0, U, csr.indptr, csr.keys)
+        g.update_parameters()          # device optimizer step + D2H of P,Q,Qb (sync_every_epoch=True)
+    dt = (time.perf_counter() - t0) / 3
+    out["bpr_host_buffers_every_epoch"] = {"epoch_ms": dt * 1e3, "updates_per_s": nnz / dt,
+                                           "note": "80 MB keys H2D (pageable numpy) + fill_rows + kernel + 85 MB D2H per epoch"}
+    print("bpr_pcie", out["bpr_host_buffers_every_epoch"], flush=True)
+
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "bench_extra.json"), "w"), indent=1)

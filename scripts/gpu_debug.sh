@@ -1,3 +1,5 @@
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-./scripts/micro/atomics > gpurun_out/micro_atomics.log 2>&1; cat gpurun_out/micro_atomics.log
+timeout 900 python -m pytest tests/test_als_gpu.py -m gpu -q --timeout 600 -p no:cacheprovider > gpurun_out/pytest_als.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_als.log
+timeout 600 python scripts/bench_extra.py als > gpurun_out/bench_extra_als.log 2>&1
+grep -E "^E  +Assert|^E  +assert|FAILED|passed|failed" gpurun_out/pytest_als.log | cut -c1-300 | tail -30; tail -3 gpurun_out/bench_extra_als.log
