@@ -125,10 +125,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    # test hooks (1-GPU boxes): BFH_DEVICE_OVERRIDE pins every rank to one device, BFH_DIST_BACKEND=gloo
+    # replaces RCCL (which refuses two ranks on one GPU); the driver's runs set neither
+    if "BFH_DEVICE_OVERRIDE" in os.environ:
+        local_rank = int(os.environ["BFH_DEVICE_OVERRIDE"])
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("BFH_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, "WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus)
 
     csr = load_matrix(args.shape, args.seed)

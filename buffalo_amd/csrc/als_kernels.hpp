@@ -38,6 +38,7 @@ struct AlsParams {
     int adaptive_reg, compute_loss, axis, num_cg_max_iters;
     double* loss;          // [0] nume, [1] deno
     int* ticket;
+    int debug;             // profiling ablations: 1 skip dense solve, 2 skip MFMA, 4 skip M/FF staging
 };
 
 template <int K>
@@ -839,7 +840,7 @@ __global__ __launch_bounds__(256, 2) void als_gram_solve_kernel(AlsParams p, con
         // current row -> LDS (the loss terms and the solve read it)
         for (int e = threadIdx.x; e < vdim; e += blockDim.x) { pl[e] = Pu[e]; p0[e] = Pu[e]; }
         __syncthreads();
-        if (ialspp && wk.slot < 0 && wv < T) {   // f0 = FF p0 (wave w: rows 32w..32w+31, the two half-waves split the columns)
+        if (ialspp && wk.slot < 0 && wv < T && !(p.debug & 4)) {   // f0 = FF p0 (wave w: rows 32w..32w+31, the two half-waves split the columns)
             float sum = 0.f;
             const float* Fr = p.FF + static_cast<size_t>(wv * 32 + col) * vdim + half * (vdim / 2);
             for (int j = 0; j < vdim / 2; ++j) sum += Fr[j] * p0[half * (vdim / 2) + j];
@@ -859,40 +860,59 @@ __global__ __launch_bounds__(256, 2) void als_gram_solve_kernel(AlsParams p, con
         const bool lossk = p.compute_loss && p.axis == 1 && wv == 0;
 
         const int64_t n = wk.kend - wk.kbeg;
-        for (int64_t k0 = 0; k0 < n; k0 += 64) {
-            const int64_t kk = k0 + lane;
-            int myc = 0;
-            float myv = 0.f;
-            if (kk < n) {
-                myc = p.keys[wk.kbeg + kk];
-                myv = p.vals[wk.kbeg + kk];
+        // nnz are consumed in groups of UP pairs; the operand rows of group g+1 are in flight while the
+        // MFMAs of group g run (register double buffer), and the keys/vals of the next 64-nnz chunk are
+        // fetched one chunk ahead, so the only exposed latency is the very first group of a row.
+        constexpr int UP = 4;
+        const int64_t nchunks = (n + 63) / 64;
+        int myc = 0, myc_n = 0;
+        float myv = 0.f, myv_n = 0.f;
+        auto fetch_keys = [&](int64_t chunk, int& cc, float& vvv) {
+            const int64_t kk = chunk * 64 + lane;
+            cc = 0;
+            vvv = 0.f;
+            if (chunk < nchunks && kk < n) {
+                cc = p.keys[wk.kbeg + kk];
+                vvv = p.vals[wk.kbeg + kk];
             }
-            const int nh = static_cast<int>((n - k0) < 64 ? (n - k0) : 64);
-            constexpr int UP = 4;   // nnz pairs in flight per iteration (software pipelining by hand)
+        };
+        fetch_keys(0, myc, myv);
+        fetch_keys(1, myc_n, myv_n);
+        float qa[UP][T], va[UP];   // group being consumed
+        bool oka[UP];
+        auto load_group = [&](int cc_reg, float vv_reg, int j, int nh, float (&q)[UP][T], float (&v)[UP], bool (&ok)[UP]) {
+#pragma unroll
+            for (int uu = 0; uu < UP; ++uu) {
+                const int src = j + 2 * uu + half;      // this half-wave's nnz of pair uu
+                ok[uu] = src < nh;
+                // cross-lane reads stay OUTSIDE any lane-divergent expression: a shuffle executed under a
+                // partial exec mask returns 0 for source lanes that are masked off
+                const int c = __shfl(cc_reg, src & 63, 64);
+                const float vsh = __shfl(vv_reg, src & 63, 64);
+                v[uu] = ok[uu] ? vsh : 0.f;
+                const float* q_ = p.Q + static_cast<size_t>(ok[uu] ? c : 0) * vdim;
+#pragma unroll
+                for (int g = 0; g < T; ++g) q[uu][g] = ok[uu] ? q_[g * 32 + col] : 0.f;
+            }
+        };
+        if (n > 0) load_group(myc, myv, 0, static_cast<int>(n < 64 ? n : 64), qa, va, oka);
+        for (int64_t ch = 0; ch < nchunks; ++ch) {
+            const int nh = static_cast<int>((n - ch * 64) < 64 ? (n - ch * 64) : 64);
+            const int nh_next = (ch + 1 < nchunks) ? static_cast<int>((n - (ch + 1) * 64) < 64 ? (n - (ch + 1) * 64) : 64) : 0;
             for (int j = 0; j < nh; j += 2 * UP) {
-                float qv[UP][T], vv[UP];
-                bool okk[UP];
+                float qb[UP][T], vb[UP];   // next group, loads issued before this group's MFMAs
+                bool okb[UP];
+                const bool more_here = j + 2 * UP < nh;
+                if (more_here) load_group(myc, myv, j + 2 * UP, nh, qb, vb, okb);
+                else load_group(myc_n, myv_n, 0, nh_next, qb, vb, okb);   // nh_next == 0: every lane masked, zeros
 #pragma unroll
                 for (int uu = 0; uu < UP; ++uu) {
-                    const int src = j + 2 * uu + half;      // this half-wave's nnz of pair uu
-                    okk[uu] = src < nh;
-                    // cross-lane reads stay OUTSIDE any lane-divergent expression: a shuffle executed under a
-                    // partial exec mask returns 0 for source lanes that are masked off
-                    const int c = __shfl(myc, src & 63, 64);
-                    const float vsh = __shfl(myv, src & 63, 64);
-                    vv[uu] = okk[uu] ? vsh : 0.f;
-                    const float* q = p.Q + static_cast<size_t>(okk[uu] ? c : 0) * vdim;
-#pragma unroll
-                    for (int g = 0; g < T; ++g) qv[uu][g] = okk[uu] ? q[g * 32 + col] : 0.f;
-                }
-#pragma unroll
-                for (int uu = 0; uu < UP; ++uu) {
-                    const float v = vv[uu];
+                    const float v = va[uu];
                     const float wgt = p.alpha * v;
                     float dp = 0.f;   // y0 = p0 . q_k, reduced inside each half-wave (row_ror butterfly + one cross-row hop)
                     if (ialspp || lossk) {
 #pragma unroll
-                        for (int g = 0; g < T; ++g) dp += qv[uu][g] * pcol[g];
+                        for (int g = 0; g < T; ++g) dp += qa[uu][g] * pcol[g];
                         dp += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, dp), 0x128, 0xf, 0xf, false));
                         dp += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, dp), 0x124, 0xf, 0xf, false));
                         dp += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, dp), 0x122, 0xf, 0xf, false));
@@ -900,23 +920,37 @@ __global__ __launch_bounds__(256, 2) void als_gram_solve_kernel(AlsParams p, con
                         dp += __shfl_xor(dp, 16, 64);
                     }
                     if (wv < T) {
-                        float qsel = 0.f;   // qv[wv] with compile-time indices (runtime-indexed arrays spill to scratch)
+                        float qsel = 0.f;   // qa[uu][wv] with compile-time indices (runtime-indexed arrays spill to scratch)
 #pragma unroll
-                        for (int g = 0; g < T; ++g) qsel = (g == wv) ? qv[uu][g] : qsel;
+                        for (int g = 0; g < T; ++g) qsel = (g == wv) ? qa[uu][g] : qsel;
                         const float a = wgt * qsel;
+                        if (!(p.debug & 2)) {
 #pragma unroll
-                        for (int g = 0; g < T; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, qv[uu][g], acc[g], 0, 0, 0);
+                            for (int g = 0; g < T; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, qa[uu][g], acc[g], 0, 0, 0);
+                        } else {
+                            acc[0][0] += a * qa[uu][0];
+                        }
                         // iALS++: r0 += alpha v (y0 - 1) q ; dense solvers: y += (1 + alpha v) q
                         const float coef = ialspp ? wgt * (dp - 1.0f) : static_cast<float>(1.0 + static_cast<double>(v * p.alpha));
-                        gpart += (okk[uu] ? coef : 0.f) * qsel;
+                        gpart += (oka[uu] ? coef : 0.f) * qsel;
                     }
-                    if (lossk && col == 0 && okk[uu]) {  // als.cc:187-192 / 298-303 on the ORIGINAL row
+                    if (lossk && col == 0 && oka[uu]) {  // als.cc:187-192 / 298-303 on the ORIGINAL row
                         nume_k -= static_cast<double>(dp * dp);
                         nume_k += static_cast<double>((dp - 1) * (dp - 1)) * (1.0 + static_cast<double>(v * p.alpha));
                         deno_k += static_cast<double>(v * p.alpha);
                     }
                 }
+#pragma unroll
+                for (int uu = 0; uu < UP; ++uu) {
+                    va[uu] = vb[uu];
+                    oka[uu] = okb[uu];
+#pragma unroll
+                    for (int g = 0; g < T; ++g) qa[uu][g] = qb[uu][g];
+                }
             }
+            myc = myc_n;
+            myv = myv_n;
+            fetch_keys(ch + 2, myc_n, myv_n);
         }
         gpart += __shfl_xor(gpart, 32, 64);  // both halves hold k-parities of the same element
 
@@ -936,7 +970,7 @@ __global__ __launch_bounds__(256, 2) void als_gram_solve_kernel(AlsParams p, con
             continue;
         }
         // M = FF + G, g -> LDS
-        if (wv < T) {
+        if (wv < T && !(p.debug & 4)) {
 #pragma unroll
             for (int g = 0; g < T; ++g)
 #pragma unroll
@@ -968,7 +1002,7 @@ __global__ __launch_bounds__(256, 2) void als_gram_solve_kernel(AlsParams p, con
                     deno += static_cast<double>(p.op_rows);
                 }
             }
-            als_dense_solve(M, gv, pl, p0, f0, w0, w1, w2, w3, w4, p, lane, p.reg * ada, mode);
+            if (!(p.debug & 1)) als_dense_solve(M, gv, pl, p0, f0, w0, w1, w2, w3, w4, p, lane, p.reg * ada, mode);
             for (int i = lane; i < D; i += 64) Pu[i] = pl[i];
         }
     }
@@ -1200,6 +1234,7 @@ class AlsHandle : public HandleBase {
         p.num_cg_max_iters = num_cg_max_iters_;
         p.loss = loss_.get();
         p.ticket = ticket_.get();
+        p.debug = debug_;
         if (A.resident) {
             p.keys = A.keys.get() + beg;
             p.vals = A.vals.get() + beg;
@@ -1377,7 +1412,8 @@ class AlsHandle : public HandleBase {
 
     void set_mode(const std::string& name, int64_t v) {
         if (name == "als_writeback") writeback_ = v != 0;
-        else if (name == "als_v1") force_v1_ = v != 0;   // matrix-free reference kernels (debug / d > 128)
+        else if (name == "als_v1") force_v1_ = v != 0;
+        else if (name == "als_debug") debug_ = static_cast<int>(v);   // matrix-free reference kernels (debug / d > 128)
         else if (name == "timing") timing = v != 0;
         else throw Error(BFH_ERR_INVALID, "unknown mode '" + name + "'");
     }
@@ -1409,6 +1445,7 @@ class AlsHandle : public HandleBase {
     DevBuf<int> ticket_;
     Axis ax_[2];
     bool force_v1_ = false;
+    int debug_ = 0;
     DevBuf<float> scratch_;
     std::map<std::tuple<int, int, int>, std::unique_ptr<WorkList>> work_cache_;
     EventTimer t_main_, t_aux_;

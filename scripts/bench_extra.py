@@ -37,6 +37,8 @@ if "als" in which:
         g.set_resident_csr(0, c2.indptr, c2.keys, c2.vals)
         g.set_resident_csr(1, t.indptr, t.keys, t.vals)
         g.set_mode("als_writeback", 0)
+        if os.environ.get("ALS_DEBUG"):
+            g.set_mode("als_debug", int(os.environ["ALS_DEBUG"]))
 
         def epoch():
             for axis, mat in ((0, c2), (1, t)):
