@@ -38,7 +38,8 @@ struct AlsParams {
     int adaptive_reg, compute_loss, axis, num_cg_max_iters;
     double* loss;          // [0] nume, [1] deno
     int* ticket;
-    int debug;             // profiling ablations: 1 skip dense solve, 2 skip MFMA, 4 skip M/FF staging
+    int debug;             // profiling ablations: 1 skip dense solve, 4 skip M/FF staging
+    int solver;            // 0 llt, 1 ldlt, 2 manual_cg, 8 ialspp
 };
 
 template <int K>
@@ -100,12 +101,15 @@ __device__ __forceinline__ int next_row(int* ticket, int lane) {
 // ------------------------------------------------------------------------------------------------
 // FF = F^T F on the matrix cores: v_mfma_f32_32x32x2_f32 (exact fp32).  One wave produces a
 // 32 x (32*NT) strip for a slice of rows; A operand = F[row][bi*32 + (lane&31)], row = r + (lane>>5),
-// B operands = the same two rows at column tiles bj..bj+NT-1.  Partials are combined with fp32
-// atomics into a zeroed FF (cublasSgemm in the reference: lib/cuda/als/als.cu:315-317).
+// B operands = the same two rows at column tiles bj..bj+NT-1.  The slices' partials are combined with
+// fp64 atomics into a zeroed accumulator and rounded to fp32 once (als_gramian_round_kernel): the order
+// the slices arrive in then perturbs the sum at the 1e-16 level, i.e. FF is reproducible run to run
+// (cublasSgemm in the reference, lib/cuda/als/als.cu:315-317, is deterministic too; fp32 atomics were
+// not, and iALS++ amplifies a 1e-7 wobble of FF through the cancellation in its gradient).
 // ------------------------------------------------------------------------------------------------
 template <int NT>
 __global__ __launch_bounds__(64) void als_gramian_kernel(const float* __restrict__ F, int rows, int vdim, int rows_per_slice,
-                                                          float* __restrict__ FF) {
+                                                          double* __restrict__ FF) {
     const int lane = threadIdx.x;
     const int T = vdim / 32;
     const int bi = blockIdx.y;
@@ -136,9 +140,14 @@ __global__ __launch_bounds__(64) void als_gramian_kernel(const float* __restrict
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int i = (e & 3) + 8 * (e >> 2) + 4 * half;
-            atomic_add_f32(FF + static_cast<size_t>(bi * 32 + i) * vdim + (bj0 + g) * 32 + col, acc[g][e]);
+            atomicAdd(FF + static_cast<size_t>(bi * 32 + i) * vdim + (bj0 + g) * 32 + col, static_cast<double>(acc[g][e]));
         }
     }
+}
+
+__global__ __launch_bounds__(256) void als_gramian_round_kernel(const double* __restrict__ acc, float* __restrict__ FF, int n) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) FF[e] = static_cast<float>(acc[e]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -810,11 +819,186 @@ __device__ __forceinline__ void als_dense_solve(float* M, float* gv, float* pv_l
 // LDS carve: M[vdim][vdim+1] | g[vdim] | p[vdim] | 4 work vectors[vdim]
 __host__ __device__ inline size_t als_gs_lds_bytes(int vdim) { return (static_cast<size_t>(vdim) * (vdim + ALS_LD_PAD) + 9 * vdim + 4) * sizeof(float); }
 
+// ------------------------------------------------------------------------------------------------
+// Gramian pass of ONE wave over the nnz of one work item: acc[g] += (alpha v q[tw-block])^T q[g-block]
+// on the matrix cores (v_mfma_f32_32x32x2_f32: one instruction eats TWO nnz, k-index = lane>>5), and
+// gpart += c q[tw*32+col] with c = alpha v (iALS++: g = sum alpha v q) or 1 + alpha v (dense solvers: y).
+// The 64 keys/vals of a chunk sit one-per-lane; a pair's two row ids are wave-uniform so they come out
+// with v_readlane (SALU), the operand rows are plain dword loads (half-wave = one 128-B line per tile),
+// and the loop is register double-buffered: the rows of group j+1 (UP pairs) are in flight while group j
+// feeds the MFMAs.  Steady state per pair: 4 readlane, 2 cndmask, 1 address mad, T+1 loads, 2 mul, 1 fma.
+// ------------------------------------------------------------------------------------------------
+template <int T, bool IALS>
+__device__ __forceinline__ void als_gram_rowpass(const AlsParams& p, const AlsWork& wk, int tw, int lane, int half, int col, bool lossk,
+                                                 const float (&pcol)[T], f32x16 (&acc)[T], float& gpart, double& nume_k, double& deno_k) {
+    const int vdim = p.vdim;
+    const int64_t n = wk.kend - wk.kbeg;
+    constexpr int UP = 4;
+    const int64_t nchunks = (n + 63) / 64;
+    auto fetch_keys = [&](int64_t chunk, int& cc, float& vvv) {
+        const int64_t kk = chunk * 64 + lane;
+        cc = 0;        // padding lanes: row 0 of the other factor with weight 0
+        vvv = 0.f;
+        if (kk < n) {
+            cc = p.keys[wk.kbeg + kk];
+            vvv = p.vals[wk.kbeg + kk];
+        }
+    };
+    auto load_pair = [&](int myc, float myv, int pr, float (&q)[T], float& qs, float& v) {
+        const int c0 = __builtin_amdgcn_readlane(myc, 2 * pr), c1 = __builtin_amdgcn_readlane(myc, 2 * pr + 1);
+        const float v0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myv), 2 * pr));
+        const float v1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myv), 2 * pr + 1));
+        v = half ? v1 : v0;
+        const float* q_ = p.Q + static_cast<size_t>(half ? c1 : c0) * vdim + col;
+#pragma unroll
+        for (int g = 0; g < T; ++g) q[g] = q_[g * 32];
+        qs = q_[tw * 32];   // A-operand column block (same cache line as q[tw]; tw is wave-uniform but not a compile-time index)
+    };
+    auto consume = [&](const float (&q)[T], float qs, float v, float one) {
+        const float wgt = p.alpha * v;
+        const float a = wgt * qs;
+#pragma unroll
+        for (int g = 0; g < T; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, q[g], acc[g], 0, 0, 0);
+        // als.cc:184: float(1.0 + double(v*alpha)) == 1.0f + v*alpha (the exact sum rounded once either way)
+        gpart += (IALS ? wgt : (one + wgt)) * qs;
+        if (lossk) {  // als.cc:187-192 / 298-303 on the ORIGINAL row
+            float dp = 0.f;
+#pragma unroll
+            for (int g = 0; g < T; ++g) dp += q[g] * pcol[g];
+            for (int sft = 1; sft < 32; sft <<= 1) dp += __shfl_xor(dp, sft, 64);
+            if (col == 0 && one != 0.f) {
+                nume_k -= static_cast<double>(dp * dp);
+                nume_k += static_cast<double>((dp - 1) * (dp - 1)) * (1.0 + static_cast<double>(wgt));
+                deno_k += static_cast<double>(wgt);
+            }
+        }
+    };
+    auto nnz_of = [&](int64_t ch) { return ch < nchunks ? static_cast<int>((n - ch * 64) < 64 ? (n - ch * 64) : 64) : 0; };
+    auto groups_of = [&](int64_t ch) { return (nnz_of(ch) >> 1) / UP; };   // groups hold COMPLETE pairs only (no padding lane)
+    int myc, myc_n;
+    float myv, myv_n;
+    fetch_keys(0, myc, myv);
+    fetch_keys(1, myc_n, myv_n);
+    float qa[UP][T], qsa[UP], va[UP];
+    if (groups_of(0) > 0) {
+#pragma unroll
+        for (int uu = 0; uu < UP; ++uu) load_pair(myc, myv, uu, qa[uu], qsa[uu], va[uu]);
+    }
+    for (int64_t ch = 0; ch < nchunks; ++ch) {
+        const int npairs = (nnz_of(ch) + 1) >> 1;
+        const int ngroups = groups_of(ch);
+        const bool next_has_group = groups_of(ch + 1) > 0;
+        for (int gidx = 0; gidx < ngroups; ++gidx) {
+            float qb[UP][T], qsb[UP], vb[UP];
+            const bool here = gidx + 1 < ngroups;
+            if (here) {
+#pragma unroll
+                for (int uu = 0; uu < UP; ++uu) load_pair(myc, myv, (gidx + 1) * UP + uu, qb[uu], qsb[uu], vb[uu]);
+            } else if (next_has_group) {   // first group of the next chunk
+#pragma unroll
+                for (int uu = 0; uu < UP; ++uu) load_pair(myc_n, myv_n, uu, qb[uu], qsb[uu], vb[uu]);
+            }
+#pragma unroll
+            for (int uu = 0; uu < UP; ++uu) consume(qa[uu], qsa[uu], va[uu], 1.0f);
+            if (here || next_has_group) {
+#pragma unroll
+                for (int uu = 0; uu < UP; ++uu) {
+                    qsa[uu] = qsb[uu];
+                    va[uu] = vb[uu];
+#pragma unroll
+                    for (int g = 0; g < T; ++g) qa[uu][g] = qb[uu][g];
+                }
+            }
+        }
+        // <= UP leftover pairs: only the last chunk of the item has them; its last pair may be half padding
+        for (int pr = ngroups * UP; pr < npairs; ++pr) {
+            float q1[T], qs1, v1;
+            load_pair(myc, myv, pr, q1, qs1, v1);
+            consume(q1, qs1, v1, (ch * 64 + 2 * pr + half < n) ? 1.0f : 0.f);
+        }
+        myc = myc_n;
+        myv = myv_n;
+        fetch_keys(ch + 2, myc_n, myv_n);
+    }
+    gpart += __shfl_xor(gpart, 32, 64);   // the two halves hold the k-parities of the same element
+}
+
+// Everything after the Gramian pass of one work item: heavy-row partial -> scratch, or M = FF + G into LDS
+// and the dense solve by wave 0.  Shared by the register-operand and the LDS-tile kernels.
 template <int T>
-__global__ __launch_bounds__(256, 2) void als_gram_solve_kernel(AlsParams p, const AlsWork* __restrict__ work, int n_work, float* __restrict__ scratch,
-                                                             int mode) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+__device__ __forceinline__ void als_finish_item(const AlsParams& p, const AlsWork& wk, f32x16 (&acc)[T], float gpart, float* __restrict__ scratch,
+                                                float* M, float* gv, float* pl, float* p0, float* f0, float* w0, float* w1, float* w2, float* w3,
+                                                float* w4, float* Pu, int64_t n, int mode, int lane, int wv, int half, int col, double& nume,
+                                                double& deno) {
     const int vdim = p.vdim, D = p.d, ld = vdim + ALS_LD_PAD;
+    if (wk.slot >= 0) {
+        // heavy row: add this chunk's partial into the scratch slot, solved by als_solve_kernel
+        float* S = scratch + static_cast<size_t>(wk.slot) * (vdim * vdim + vdim);
+#pragma unroll
+        for (int g = 0; g < T; ++g)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int i = (e & 3) + 8 * (e >> 2) + 4 * half;
+                atomic_add_f32(S + static_cast<size_t>(wv * 32 + i) * vdim + g * 32 + col, acc[g][e]);
+            }
+        if (half == 0) atomic_add_f32(S + vdim * vdim + wv * 32 + col, gpart);
+        return;
+    }
+    // M = FF + G -> LDS; iALS++ keeps -g (see als_dense_solve: b = M[blk,:] delta + f0 + gv + reg p with f0 = M p0)
+    if (!(p.debug & 4)) {
+#pragma unroll
+        for (int g = 0; g < T; ++g)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int i = (e & 3) + 8 * (e >> 2) + 4 * half;
+                const int rr = wv * 32 + i, cc = g * 32 + col;
+                M[rr * ld + cc] = acc[g][e] + p.FF[static_cast<size_t>(rr) * vdim + cc];
+            }
+        if (half == 0) gv[wv * 32 + col] = mode == 8 ? -gpart : gpart;
+    }
+    __syncthreads();
+    if (mode == 8 && !(p.debug & 4)) {   // f0 = M p0: wave w rows 32w..32w+31, the half-waves split the columns
+        const float* Mi = M + (wv * 32 + col) * ld + half * (vdim / 2);
+        const float* pp = p0 + half * (vdim / 2);
+        float sum = 0.f;
+#pragma unroll 8
+        for (int j = 0; j < vdim / 2; ++j) sum += Mi[j] * pp[j];
+        sum += __shfl_xor(sum, 32, 64);
+        if (half == 0) f0[wv * 32 + col] = sum;
+        __syncthreads();
+    }
+    if (wv == 0) {
+        const float ada = p.adaptive_reg ? static_cast<float>(n) : 1.0f;
+        if (p.compute_loss) {
+            float pp = 0.f, pfp = 0.f;
+            for (int i = lane; i < D; i += 64) {
+                pp += pl[i] * pl[i];
+                if (p.axis == 1) {
+                    float sum = 0.f;
+                    for (int j = 0; j < D; ++j) sum += p.FF[static_cast<size_t>(i) * vdim + j] * pl[j];
+                    pfp += pl[i] * sum;
+                }
+            }
+            pp = wave_sum(pp);
+            nume += static_cast<double>(ada * p.reg * pp);
+            if (p.axis == 1) {
+                pfp = wave_sum(pfp);
+                nume += static_cast<double>(pfp);
+                deno += static_cast<double>(p.op_rows);
+            }
+        }
+        if (!(p.debug & 1)) als_dense_solve(M, gv, pl, p0, f0, w0, w1, w2, w3, w4, p, lane, p.reg * ada, mode);
+        for (int i = lane; i < D; i += 64) Pu[i] = pl[i];
+    }
+}
+
+// Fused design: one 64*T-thread block per row; wave w accumulates tile-row w of G in registers, the block
+// assembles M = FF + G in LDS and wave 0 runs the dense phase in place -- G never touches HBM.
+template <int T, bool IALS>
+__global__ __launch_bounds__(64 * T, 2) void als_gram_solve_kernel(AlsParams p, const AlsWork* __restrict__ work, int n_work, float* __restrict__ scratch) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int vdim = p.vdim, ld = vdim + ALS_LD_PAD;
+    constexpr int mode_ials = 8;
     float* M = lds;
     float* gv = lds + vdim * ld;
     float* pl = gv + vdim;
@@ -824,7 +1008,7 @@ __global__ __launch_bounds__(256, 2) void als_gram_solve_kernel(AlsParams p, con
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // tile row of this wave
     const int half = lane >> 5, col = lane & 31;
-    const bool ialspp = mode == 8;
+    const int mode = IALS ? mode_ials : p.solver;
     double nume = 0.0, deno = 0.0;      // row-level terms (identical in every lane of wave 0)
     double nume_k = 0.0, deno_k = 0.0;  // per-nnz terms (lanes 0 and 32 of wave 0 hold the two k-parities)
 
@@ -835,176 +1019,22 @@ __global__ __launch_bounds__(256, 2) void als_gram_solve_kernel(AlsParams p, con
         const int item = *s_item;
         if (item >= n_work) break;
         const AlsWork wk = work[item];
-        const int u = wk.row;
-        float* Pu = p.P + static_cast<size_t>(u) * vdim;
+        float* Pu = p.P + static_cast<size_t>(wk.row) * vdim;
         // current row -> LDS (the loss terms and the solve read it)
         for (int e = threadIdx.x; e < vdim; e += blockDim.x) { pl[e] = Pu[e]; p0[e] = Pu[e]; }
-        __syncthreads();
-        if (ialspp && wk.slot < 0 && wv < T && !(p.debug & 4)) {   // f0 = FF p0 (wave w: rows 32w..32w+31, the two half-waves split the columns)
-            float sum = 0.f;
-            const float* Fr = p.FF + static_cast<size_t>(wv * 32 + col) * vdim + half * (vdim / 2);
-            for (int j = 0; j < vdim / 2; ++j) sum += Fr[j] * p0[half * (vdim / 2) + j];
-            sum += __shfl_xor(sum, 32, 64);
-            if (half == 0) f0[wv * 32 + col] = sum;
-        }
-
         f32x16 acc[T];
 #pragma unroll
         for (int g = 0; g < T; ++g)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
-        float gpart = 0.f;   // this lane's share of g[wv*32 + col]
+        float gpart = 0.f;
+        const bool lossk = p.compute_loss && p.axis == 1 && wv == 0;
         float pcol[T];
 #pragma unroll
-        for (int g = 0; g < T; ++g) pcol[g] = pl[g * 32 + col];
-        const bool lossk = p.compute_loss && p.axis == 1 && wv == 0;
-
-        const int64_t n = wk.kend - wk.kbeg;
-        // nnz are consumed in groups of UP pairs; the operand rows of group g+1 are in flight while the
-        // MFMAs of group g run (register double buffer), and the keys/vals of the next 64-nnz chunk are
-        // fetched one chunk ahead, so the only exposed latency is the very first group of a row.
-        constexpr int UP = 4;
-        const int64_t nchunks = (n + 63) / 64;
-        int myc = 0, myc_n = 0;
-        float myv = 0.f, myv_n = 0.f;
-        auto fetch_keys = [&](int64_t chunk, int& cc, float& vvv) {
-            const int64_t kk = chunk * 64 + lane;
-            cc = 0;
-            vvv = 0.f;
-            if (chunk < nchunks && kk < n) {
-                cc = p.keys[wk.kbeg + kk];
-                vvv = p.vals[wk.kbeg + kk];
-            }
-        };
-        fetch_keys(0, myc, myv);
-        fetch_keys(1, myc_n, myv_n);
-        float qa[UP][T], va[UP];   // group being consumed
-        bool oka[UP];
-        auto load_group = [&](int cc_reg, float vv_reg, int j, int nh, float (&q)[UP][T], float (&v)[UP], bool (&ok)[UP]) {
-#pragma unroll
-            for (int uu = 0; uu < UP; ++uu) {
-                const int src = j + 2 * uu + half;      // this half-wave's nnz of pair uu
-                ok[uu] = src < nh;
-                // cross-lane reads stay OUTSIDE any lane-divergent expression: a shuffle executed under a
-                // partial exec mask returns 0 for source lanes that are masked off
-                const int c = __shfl(cc_reg, src & 63, 64);
-                const float vsh = __shfl(vv_reg, src & 63, 64);
-                v[uu] = ok[uu] ? vsh : 0.f;
-                const float* q_ = p.Q + static_cast<size_t>(ok[uu] ? c : 0) * vdim;
-#pragma unroll
-                for (int g = 0; g < T; ++g) q[uu][g] = ok[uu] ? q_[g * 32 + col] : 0.f;
-            }
-        };
-        if (n > 0) load_group(myc, myv, 0, static_cast<int>(n < 64 ? n : 64), qa, va, oka);
-        for (int64_t ch = 0; ch < nchunks; ++ch) {
-            const int nh = static_cast<int>((n - ch * 64) < 64 ? (n - ch * 64) : 64);
-            const int nh_next = (ch + 1 < nchunks) ? static_cast<int>((n - (ch + 1) * 64) < 64 ? (n - (ch + 1) * 64) : 64) : 0;
-            for (int j = 0; j < nh; j += 2 * UP) {
-                float qb[UP][T], vb[UP];   // next group, loads issued before this group's MFMAs
-                bool okb[UP];
-                const bool more_here = j + 2 * UP < nh;
-                if (more_here) load_group(myc, myv, j + 2 * UP, nh, qb, vb, okb);
-                else load_group(myc_n, myv_n, 0, nh_next, qb, vb, okb);   // nh_next == 0: every lane masked, zeros
-#pragma unroll
-                for (int uu = 0; uu < UP; ++uu) {
-                    const float v = va[uu];
-                    const float wgt = p.alpha * v;
-                    float dp = 0.f;   // y0 = p0 . q_k, reduced inside each half-wave (row_ror butterfly + one cross-row hop)
-                    if (ialspp || lossk) {
-#pragma unroll
-                        for (int g = 0; g < T; ++g) dp += qa[uu][g] * pcol[g];
-                        dp += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, dp), 0x128, 0xf, 0xf, false));
-                        dp += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, dp), 0x124, 0xf, 0xf, false));
-                        dp += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, dp), 0x122, 0xf, 0xf, false));
-                        dp += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, dp), 0x121, 0xf, 0xf, false));
-                        dp += __shfl_xor(dp, 16, 64);
-                    }
-                    if (wv < T) {
-                        float qsel = 0.f;   // qa[uu][wv] with compile-time indices (runtime-indexed arrays spill to scratch)
-#pragma unroll
-                        for (int g = 0; g < T; ++g) qsel = (g == wv) ? qa[uu][g] : qsel;
-                        const float a = wgt * qsel;
-                        if (!(p.debug & 2)) {
-#pragma unroll
-                            for (int g = 0; g < T; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, qa[uu][g], acc[g], 0, 0, 0);
-                        } else {
-                            acc[0][0] += a * qa[uu][0];
-                        }
-                        // iALS++: r0 += alpha v (y0 - 1) q ; dense solvers: y += (1 + alpha v) q
-                        const float coef = ialspp ? wgt * (dp - 1.0f) : static_cast<float>(1.0 + static_cast<double>(v * p.alpha));
-                        gpart += (oka[uu] ? coef : 0.f) * qsel;
-                    }
-                    if (lossk && col == 0 && oka[uu]) {  // als.cc:187-192 / 298-303 on the ORIGINAL row
-                        nume_k -= static_cast<double>(dp * dp);
-                        nume_k += static_cast<double>((dp - 1) * (dp - 1)) * (1.0 + static_cast<double>(v * p.alpha));
-                        deno_k += static_cast<double>(v * p.alpha);
-                    }
-                }
-#pragma unroll
-                for (int uu = 0; uu < UP; ++uu) {
-                    va[uu] = vb[uu];
-                    oka[uu] = okb[uu];
-#pragma unroll
-                    for (int g = 0; g < T; ++g) qa[uu][g] = qb[uu][g];
-                }
-            }
-            myc = myc_n;
-            myv = myv_n;
-            fetch_keys(ch + 2, myc_n, myv_n);
-        }
-        gpart += __shfl_xor(gpart, 32, 64);  // both halves hold k-parities of the same element
-
-        if (wk.slot >= 0) {
-            // heavy row: add this chunk's partial into the scratch slot, solved by als_solve_heavy_kernel
-            float* S = scratch + static_cast<size_t>(wk.slot) * (vdim * vdim + vdim);
-            if (wv < T) {
-#pragma unroll
-                for (int g = 0; g < T; ++g)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int i = (e & 3) + 8 * (e >> 2) + 4 * half;
-                        atomic_add_f32(S + static_cast<size_t>(wv * 32 + i) * vdim + g * 32 + col, acc[g][e]);
-                    }
-                if (half == 0) atomic_add_f32(S + vdim * vdim + wv * 32 + col, gpart);
-            }
-            continue;
-        }
-        // M = FF + G, g -> LDS
-        if (wv < T && !(p.debug & 4)) {
-#pragma unroll
-            for (int g = 0; g < T; ++g)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int i = (e & 3) + 8 * (e >> 2) + 4 * half;
-                    const int rr = wv * 32 + i, cc = g * 32 + col;
-                    M[rr * ld + cc] = acc[g][e] + p.FF[static_cast<size_t>(rr) * vdim + cc];
-                }
-            if (half == 0) gv[wv * 32 + col] = gpart;
-        }
-        __syncthreads();
-        if (wv == 0) {
-            const float ada = p.adaptive_reg ? static_cast<float>(n) : 1.0f;
-            if (p.compute_loss) {
-                float pp = 0.f, pfp = 0.f;
-                for (int i = lane; i < D; i += 64) {
-                    pp += pl[i] * pl[i];
-                    if (p.axis == 1) {
-                        float sum = 0.f;
-                        for (int j = 0; j < D; ++j) sum += p.FF[static_cast<size_t>(i) * vdim + j] * pl[j];
-                        pfp += pl[i] * sum;
-                    }
-                }
-                pp = wave_sum(pp);
-                nume += static_cast<double>(ada * p.reg * pp);
-                if (p.axis == 1) {
-                    pfp = wave_sum(pfp);
-                    nume += static_cast<double>(pfp);
-                    deno += static_cast<double>(p.op_rows);
-                }
-            }
-            if (!(p.debug & 1)) als_dense_solve(M, gv, pl, p0, f0, w0, w1, w2, w3, w4, p, lane, p.reg * ada, mode);
-            for (int i = lane; i < D; i += 64) Pu[i] = pl[i];
-        }
+        for (int g = 0; g < T; ++g) pcol[g] = lossk ? Pu[g * 32 + col] : 0.f;
+        als_gram_rowpass<T, IALS>(p, wk, wv, lane, half, col, lossk, pcol, acc, gpart, nume_k, deno_k);
+        als_finish_item<T>(p, wk, acc, gpart, scratch, M, gv, pl, p0, f0, w0, w1, w2, w3, w4, Pu, wk.kend - wk.kbeg, mode, lane, wv, half, col, nume,
+                           deno);
     }
     if (p.compute_loss && wv == 0) {
         nume_k += __shfl_xor(nume_k, 32, 64);
@@ -1016,12 +1046,80 @@ __global__ __launch_bounds__(256, 2) void als_gram_solve_kernel(AlsParams p, con
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Split design: Gramian pass and dense solve as two launches.
+//   als_gram_kernel   -- no LDS, <= 168 VGPRs: 3 waves per SIMD stream q rows into the matrix cores; a
+//                        64*T-thread block shares a row so its q rows reach the CU's L1 once.  G and g go
+//                        to an HBM scratch slot per row (row-major [vdim][vdim] + [vdim]); chunks of heavy
+//                        rows add with fp32 atomics into the (zeroed) slot.
+//   als_solve_kernel  -- one wave per row: M = FF + G from the scratch into LDS, then als_dense_solve.
+// Costs 2 * vdim^2 * 4 B of HBM traffic per row, which is nothing at vdim <= 96 (where the fused kernel's
+// low occupancy hurts most) and ~5 ms per ML-20M epoch at vdim = 128 -- hence the per-vdim default.
+// ------------------------------------------------------------------------------------------------
+template <int T, bool IALS>
+__global__ __launch_bounds__(64 * T, 3) void als_gram_kernel(AlsParams p, const AlsWork* __restrict__ work, int n_items, float* __restrict__ scratch) {
+    const int vdim = p.vdim;
+    const int lane = threadIdx.x & 63;
+    const int half = lane >> 5, col = lane & 31;
+    double nume_k = 0.0, deno_k = 0.0;
+    __shared__ int s_item;
+    const int tw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // tile-row of G this wave accumulates
+    while (true) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_item = atomicAdd(p.ticket, 1);
+        __syncthreads();
+        const int item = s_item;
+        if (item >= n_items) break;
+        const AlsWork wk = work[item];
+        const int u = wk.row;
+        f32x16 acc[T];
+#pragma unroll
+        for (int g = 0; g < T; ++g)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
+        float gpart = 0.f;
+        const bool lossk = p.compute_loss && p.axis == 1 && tw == 0;
+        float pcol[T];
+#pragma unroll
+        for (int g = 0; g < T; ++g) pcol[g] = lossk ? p.P[static_cast<size_t>(u) * vdim + g * 32 + col] : 0.f;
+        als_gram_rowpass<T, IALS>(p, wk, tw, lane, half, col, lossk, pcol, acc, gpart, nume_k, deno_k);
+        float* S = scratch + static_cast<size_t>(u - p.start_x) * (static_cast<size_t>(vdim) * vdim + vdim);
+        if (wk.slot >= 0) {   // chunk of a heavy row: partials are summed (the slot was zeroed by the host)
+#pragma unroll
+            for (int g = 0; g < T; ++g)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int i = (e & 3) + 8 * (e >> 2) + 4 * half;
+                    atomic_add_f32(S + static_cast<size_t>(tw * 32 + i) * vdim + g * 32 + col, acc[g][e]);
+                }
+            if (half == 0) atomic_add_f32(S + static_cast<size_t>(vdim) * vdim + tw * 32 + col, gpart);
+        } else {
+#pragma unroll
+            for (int g = 0; g < T; ++g)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int i = (e & 3) + 8 * (e >> 2) + 4 * half;
+                    S[static_cast<size_t>(tw * 32 + i) * vdim + g * 32 + col] = acc[g][e];
+                }
+            if (half == 0) S[static_cast<size_t>(vdim) * vdim + tw * 32 + col] = gpart;
+        }
+    }
+    if (p.compute_loss && p.axis == 1) {
+        nume_k += __shfl_xor(nume_k, 32, 64);
+        deno_k += __shfl_xor(deno_k, 32, 64);
+        if (lane == 0) {
+            if (nume_k != 0.0) atomicAdd(p.loss, nume_k);
+            if (deno_k != 0.0) atomicAdd(p.loss + 1, deno_k);
+        }
+    }
+}
+
 struct AlsHeavy {
     int row, slot;
     int64_t n;
 };
 
-__global__ __launch_bounds__(64) void als_solve_heavy_kernel(AlsParams p, const AlsHeavy* __restrict__ heavy, int n_heavy, const float* __restrict__ scratch,
+__global__ __launch_bounds__(64) void als_solve_kernel(AlsParams p, const AlsHeavy* __restrict__ heavy, int n_heavy, const float* __restrict__ scratch,
                                                              int mode) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int vdim = p.vdim, D = p.d, ld = vdim + ALS_LD_PAD;
@@ -1031,25 +1129,38 @@ __global__ __launch_bounds__(64) void als_solve_heavy_kernel(AlsParams p, const 
     float* w0 = pl + vdim; float* w1 = w0 + vdim; float* w2 = w1 + vdim; float* w3 = w2 + vdim; float* w4 = w3 + vdim;
     float* p0 = w4 + vdim; float* f0 = p0 + vdim;
     const int lane = threadIdx.x;
-    const int h = blockIdx.x;
-    if (h >= n_heavy) return;
+    for (int h = blockIdx.x; h < n_heavy; h += gridDim.x) {
     const AlsHeavy hv = heavy[h];
-    const float* S = scratch + static_cast<size_t>(hv.slot) * (vdim * vdim + vdim);
+    __syncthreads();
+    const float* S = scratch + static_cast<size_t>(hv.slot) * (static_cast<size_t>(vdim) * vdim + vdim);
     float* Pu = p.P + static_cast<size_t>(hv.row) * vdim;
     for (int e = lane; e < vdim * vdim; e += 64) {
         const int rr = e / vdim, cc = e % vdim;
         M[rr * ld + cc] = S[e] + p.FF[e];
     }
     for (int e = lane; e < vdim; e += 64) {
-        gv[e] = S[vdim * vdim + e];
+        gv[e] = mode == 8 ? -S[vdim * vdim + e] : S[vdim * vdim + e];   // iALS++: -g, see als_finish_item
         pl[e] = Pu[e];
         p0[e] = Pu[e];
+        f0[e] = 0.f;
     }
     __syncthreads();
-    for (int i = lane; i < vdim; i += 64) {
-        float sum = 0.f;
-        for (int j = 0; j < vdim; ++j) sum += p.FF[static_cast<size_t>(i) * vdim + j] * p0[j];
-        f0[i] = sum;
+    if (mode == 8) {   // f0 = M p0 (row i of M per lane: stride ld = vdim+1 words, conflict-free)
+        for (int i = lane; i < vdim; i += 64) {
+            const float* Mi = M + i * ld;
+            float sum = 0.f;
+#pragma unroll 8
+            for (int j = 0; j < vdim; ++j) sum += Mi[j] * p0[j];
+            f0[i] = sum;
+        }
+    }
+    if (p.compute_loss && p.axis == 1) {
+        for (int i = lane; i < vdim; i += 64) {   // FF p0 for the p FF p loss term (FF symmetric: column i read as FF[j][i])
+            float sum = 0.f;
+#pragma unroll 8
+            for (int j = 0; j < vdim; ++j) sum += p.FF[static_cast<size_t>(j) * vdim + i] * p0[j];
+            w1[i] = sum;
+        }
     }
     __syncthreads();
     const float ada = p.adaptive_reg ? static_cast<float>(hv.n) : 1.0f;
@@ -1058,11 +1169,7 @@ __global__ __launch_bounds__(64) void als_solve_heavy_kernel(AlsParams p, const 
         float pp = 0.f, pfp = 0.f;
         for (int i = lane; i < D; i += 64) {
             pp += pl[i] * pl[i];
-            if (p.axis == 1) {
-                float sum = 0.f;
-                for (int j = 0; j < D; ++j) sum += p.FF[static_cast<size_t>(i) * vdim + j] * pl[j];
-                pfp += pl[i] * sum;
-            }
+            if (p.axis == 1) pfp += pl[i] * w1[i];     // p (FF p)
         }
         pp = wave_sum(pp);
         nume += static_cast<double>(ada * p.reg * pp);
@@ -1072,12 +1179,13 @@ __global__ __launch_bounds__(64) void als_solve_heavy_kernel(AlsParams p, const 
             deno += static_cast<double>(p.op_rows);
         }
     }
-    als_dense_solve(M, gv, pl, p0, f0, w0, w1, w2, w3, w4, p, lane, p.reg * ada, mode);
+    if (!(p.debug & 1)) als_dense_solve(M, gv, pl, p0, f0, w0, w1, w2, w3, w4, p, lane, p.reg * ada, mode);
     for (int i = lane; i < D; i += 64) Pu[i] = pl[i];
     if (p.compute_loss && lane == 0) {
         if (nume != 0.0) atomicAdd(p.loss, nume);
         if (deno != 0.0) atomicAdd(p.loss + 1, deno);
     }
+    }  // rows
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1120,6 +1228,7 @@ class AlsHandle : public HandleBase {
         else if (optimizer == "ialspp") code_ = 8;
         else throw Error(BFH_ERR_UNSUPPORTED, "optimizer '" + optimizer + "' is not implemented on gfx950 (supported: llt, ldlt, manual_cg, ialspp)");
         FF_.resize(static_cast<size_t>(vdim_) * vdim_, true, stream);
+        FF64_.resize(static_cast<size_t>(vdim_) * vdim_, true, stream);
         loss_.resize(2, true, stream);
         ticket_.resize(1, true, stream);
         inited_ = true;
@@ -1184,7 +1293,7 @@ class AlsHandle : public HandleBase {
         BFH_REQUIRE(axis == 0 || axis == 1, "axis must be 0 or 1");
         const float* F = axis == 0 ? Q_.get() : P_.get();
         const int rows = axis == 0 ? Q_rows_ : P_rows_;
-        BFH_HIP(hipMemsetAsync(FF_.get(), 0, FF_.bytes(), stream));
+        BFH_HIP(hipMemsetAsync(FF64_.get(), 0, FF64_.bytes(), stream));
         const int T = vdim_ / 32;
         constexpr int NT = 4;
         const int TG = (T + NT - 1) / NT;
@@ -1195,7 +1304,10 @@ class AlsHandle : public HandleBase {
         if (rps < 2) rps = 2;
         slices = (rows + rps - 1) / rps;
         const int slot = t_aux_.begin(stream);
-        hipLaunchKernelGGL(als_gramian_kernel<NT>, dim3(slices, T, TG), dim3(64), 0, stream, F, rows, vdim_, rps, FF_.get());
+        hipLaunchKernelGGL(als_gramian_kernel<NT>, dim3(slices, T, TG), dim3(64), 0, stream, F, rows, vdim_, rps, FF64_.get());
+        BFH_HIP(hipGetLastError());
+        const int nff = vdim_ * vdim_;
+        hipLaunchKernelGGL(als_gramian_round_kernel, dim3((nff + 255) / 256), dim3(256), 0, stream, FF64_.get(), FF_.get(), nff);
         BFH_HIP(hipGetLastError());
         t_aux_.end(slot, stream);
         BFH_HIP(hipStreamSynchronize(stream));
@@ -1235,6 +1347,7 @@ class AlsHandle : public HandleBase {
         p.loss = loss_.get();
         p.ticket = ticket_.get();
         p.debug = debug_;
+        p.solver = static_cast<int>(code_);
         if (A.resident) {
             p.keys = A.keys.get() + beg;
             p.vals = A.vals.get() + beg;
@@ -1262,31 +1375,72 @@ class AlsHandle : public HandleBase {
             if (wl->n_heavy) BFH_HIP(hipMemsetAsync(scratch_.get(), 0, static_cast<size_t>(wl->n_heavy) * (vdim_ * vdim_ + vdim_) * sizeof(float), stream));
         }
         const int slot = t_main_.begin(stream);
-        if (gram_path) {
-            // Gramian on the matrix cores + dense LDS solve (see als_gram_solve_kernel)
-            const size_t lds = als_gs_lds_bytes(vdim_);
+        const bool split = design_ < 0 ? vdim_ < 128 : design_ == 0;   // see als_gram_kernel: G round trip through HBM only pays below vdim 128
+        if (gram_path && split) {
+            // split design: Gramian pass at full occupancy -> HBM scratch -> dense solve (see als_gram_kernel)
             const int T = vdim_ / 32;
-            int blocks = num_cus_ * static_cast<int>(std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds)));
+            const size_t per_row = static_cast<size_t>(vdim_) * vdim_ + vdim_;
+            const size_t need = static_cast<size_t>(nrows) * per_row;
+            if (gscratch_.size() < need) gscratch_.resize(need);
+            for (int hr : wl->heavy_rows)
+                BFH_HIP(hipMemsetAsync(gscratch_.get() + static_cast<size_t>(hr - start_x) * per_row, 0, per_row * sizeof(float), stream));
+            const int items = wl->n_work;
+            if (items > 0) {
+                int blocks = items;
+                const int per_cu = (12 / T) > 0 ? (12 / T) : 1;       // <= 166 VGPRs -> 3 waves per SIMD = 12 waves per CU
+                if (blocks > num_cus_ * per_cu) blocks = num_cus_ * per_cu;
+#define BFH_GK(TT)                                                                                                                  \
+    do {                                                                                                                            \
+        if (code_ == 8) hipLaunchKernelGGL((als_gram_kernel<TT, true>), dim3(blocks), dim3(64 * TT), 0, stream, p, wl->work.get(), items, gscratch_.get()); \
+        else hipLaunchKernelGGL((als_gram_kernel<TT, false>), dim3(blocks), dim3(64 * TT), 0, stream, p, wl->work.get(), items, gscratch_.get());          \
+    } while (0)
+                if (T <= 1) BFH_GK(1);
+                else if (T <= 2) BFH_GK(2);
+                else if (T <= 3) BFH_GK(3);
+                else BFH_GK(4);
+#undef BFH_GK
+                BFH_HIP(hipGetLastError());
+                const size_t lds_h = als_gs_lds_bytes(vdim_);
+                int sblocks = num_cus_ * static_cast<int>(std::max<size_t>(1, std::min<size_t>(16, (160 * 1024) / lds_h)));
+                if (sblocks > wl->n_solve) sblocks = wl->n_solve;
+                BFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(als_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            static_cast<int>(lds_h)));
+                hipLaunchKernelGGL(als_solve_kernel, dim3(sblocks), dim3(64), lds_h, stream, p, wl->solve.get(), wl->n_solve,
+                                   gscratch_.get(), static_cast<int>(code_));
+                BFH_HIP(hipGetLastError());
+            }
+        } else if (gram_path) {
+            // fused design: Gramian on the matrix cores + dense LDS solve in one launch
+            const int T = vdim_ / 32;
+            const size_t lds = als_gs_lds_bytes(vdim_);
+            int blocks = num_cus_ * static_cast<int>(std::max<size_t>(1, std::min<size_t>(2, (160 * 1024) / lds)));
             if (blocks > wl->n_work) blocks = wl->n_work;
             if (blocks > 0) {
-#define BFH_GS(TT)                                                                                                            \
+#define BFH_GS1(TT, II)                                                                                                        \
     do {                                                                                                                      \
-        BFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(als_gram_solve_kernel<TT>),                                \
+        BFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(als_gram_solve_kernel<TT, II>),                            \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));                      \
-        hipLaunchKernelGGL(als_gram_solve_kernel<TT>, dim3(blocks), dim3(256), lds, stream, p, wl->work.get(), wl->n_work,    \
-                           scratch_.get(), static_cast<int>(code_));                                                         \
+        hipLaunchKernelGGL((als_gram_solve_kernel<TT, II>), dim3(blocks), dim3(64 * TT), lds, stream, p, wl->work.get(),      \
+                           wl->n_work, scratch_.get());                                                                       \
+    } while (0)
+#define BFH_GS(TT)                      \
+    do {                                \
+        if (code_ == 8) BFH_GS1(TT, true); \
+        else BFH_GS1(TT, false);        \
     } while (0)
                 if (T <= 1) BFH_GS(1);
                 else if (T <= 2) BFH_GS(2);
                 else if (T <= 3) BFH_GS(3);
                 else BFH_GS(4);
 #undef BFH_GS
+#undef BFH_GS1
                 BFH_HIP(hipGetLastError());
             }
             if (wl->n_heavy) {
-                BFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(als_solve_heavy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            static_cast<int>(lds)));
-                hipLaunchKernelGGL(als_solve_heavy_kernel, dim3(wl->n_heavy), dim3(64), lds, stream, p, wl->heavy.get(), wl->n_heavy,
+                const size_t lds_h = als_gs_lds_bytes(vdim_);
+                BFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(als_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            static_cast<int>(lds_h)));
+                hipLaunchKernelGGL(als_solve_kernel, dim3(wl->n_heavy), dim3(64), lds_h, stream, p, wl->heavy.get(), wl->n_heavy,
                                    scratch_.get(), static_cast<int>(code_));
             }
         } else if (code_ == 8) {
@@ -1331,8 +1485,10 @@ class AlsHandle : public HandleBase {
 
     struct WorkList {
         DevBuf<AlsWork> work;
-        DevBuf<AlsHeavy> heavy;
-        int n_work = 0, n_heavy = 0;
+        DevBuf<AlsHeavy> heavy;   // fused kernels: heavy rows only (slot = scratch slot)
+        DevBuf<AlsHeavy> solve;   // split design: every non-empty row, longest first (slot = row - start_x)
+        std::vector<int> heavy_rows;
+        int n_work = 0, n_heavy = 0, n_solve = 0;
     };
     // Work items of one partial_update call: one per non-empty row, rows above HEAVY nnz cut into
     // chunks; longest first (dynamic ticket order) so the tail is short.  Cached per (axis, range).
@@ -1342,12 +1498,14 @@ class AlsHandle : public HandleBase {
         if (it != work_cache_.end()) return *it->second;
         constexpr int64_t HEAVY = 4096;
         std::vector<AlsWork> w;
-        std::vector<AlsHeavy> h;
+        std::vector<AlsHeavy> h, sv;
         w.reserve(next_x - start_x);
+        sv.reserve(next_x - start_x);
         int64_t prev = start_x == 0 ? 0 : ip[start_x - 1];
         for (int x = start_x; x < next_x; ++x) {
             const int64_t e = ip[x], n = e - prev;
             if (n > 0) {  // Q-16: empty rows are left untouched
+                sv.push_back({x, x - start_x, n});
                 const int64_t kb = prev - shift;
                 if (n <= HEAVY) {
                     w.push_back({x, static_cast<int>(kb), static_cast<int>(kb + n), -1});
@@ -1362,9 +1520,14 @@ class AlsHandle : public HandleBase {
             prev = e;
         }
         std::stable_sort(w.begin(), w.end(), [](const AlsWork& a, const AlsWork& b) { return (a.kend - a.kbeg) > (b.kend - b.kbeg); });
+        std::stable_sort(sv.begin(), sv.end(), [](const AlsHeavy& a, const AlsHeavy& b) { return a.n > b.n; });
         auto wl = std::make_unique<WorkList>();
         wl->n_work = static_cast<int>(w.size());
         wl->n_heavy = static_cast<int>(h.size());
+        wl->n_solve = static_cast<int>(sv.size());
+        for (const auto& hh : h) wl->heavy_rows.push_back(hh.row);
+        wl->solve.resize(std::max<size_t>(1, sv.size()));
+        if (!sv.empty()) BFH_HIP(hipMemcpyAsync(wl->solve.get(), sv.data(), sv.size() * sizeof(AlsHeavy), hipMemcpyHostToDevice, stream));
         wl->work.resize(std::max<size_t>(1, w.size()));
         wl->heavy.resize(std::max<size_t>(1, h.size()));
         if (!w.empty()) BFH_HIP(hipMemcpyAsync(wl->work.get(), w.data(), w.size() * sizeof(AlsWork), hipMemcpyHostToDevice, stream));
@@ -1413,7 +1576,8 @@ class AlsHandle : public HandleBase {
     void set_mode(const std::string& name, int64_t v) {
         if (name == "als_writeback") writeback_ = v != 0;
         else if (name == "als_v1") force_v1_ = v != 0;
-        else if (name == "als_debug") debug_ = static_cast<int>(v);   // matrix-free reference kernels (debug / d > 128)
+        else if (name == "als_debug") debug_ = static_cast<int>(v);
+        else if (name == "als_fused") design_ = v < 0 ? -1 : (v != 0);   // 1 fused Gramian+solve kernel, 0 split design, -1 per-vdim default
         else if (name == "timing") timing = v != 0;
         else throw Error(BFH_ERR_INVALID, "unknown mode '" + name + "'");
     }
@@ -1440,12 +1604,15 @@ class AlsHandle : public HandleBase {
     bool adaptive_reg_ = false, compute_loss_ = false;
     float *hostP_ = nullptr, *hostQ_ = nullptr;
     DevBuf<float> P_, Q_, FF_, vals_, yui_;
+    DevBuf<double> FF64_;   // fp64 accumulator of the Gramian slices (see als_gramian_kernel)
     DevBuf<int32_t> keys_;
     DevBuf<double> loss_;
     DevBuf<int> ticket_;
     Axis ax_[2];
     bool force_v1_ = false;
     int debug_ = 0;
+    int design_ = -1;
+    DevBuf<float> gscratch_;
     DevBuf<float> scratch_;
     std::map<std::tuple<int, int, int>, std::unique_ptr<WorkList>> work_cache_;
     EventTimer t_main_, t_aux_;

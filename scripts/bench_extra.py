@@ -39,6 +39,8 @@ if "als" in which:
         g.set_mode("als_writeback", 0)
         if os.environ.get("ALS_DEBUG"):
             g.set_mode("als_debug", int(os.environ["ALS_DEBUG"]))
+        if os.environ.get("ALS_FUSED"):
+            g.set_mode("als_fused", int(os.environ["ALS_FUSED"]))
 
         def epoch():
             for axis, mat in ((0, c2), (1, t)):

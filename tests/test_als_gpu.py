@@ -81,7 +81,8 @@ CASES = [
 @pytest.mark.parametrize("d,kw,shape", [(d, kw, "tiny") for d, kw in CASES] +
                          [(32, dict(optimizer="llt"), "ml100k"), (32, dict(optimizer="manual_cg"), "ml100k"),
                           (128, dict(optimizer="ialspp"), "ml100k")])
-def test_half_epochs_match_oracle(oracle, d, kw, shape):
+@pytest.mark.parametrize("design", ["split", "fused"])
+def test_half_epochs_match_oracle(oracle, d, kw, shape, design):
     """Every half-epoch starts from bit-identical factors (the GPU model is re-synchronised to the
     oracle's after each comparison), so differences are the kernels' own.  Truncated fp32 CG is
     sensitive to summation order (cond(A) ~ 1e3..1e4): the HIP result has to sit inside the oracle's
@@ -89,12 +90,15 @@ def test_half_epochs_match_oracle(oracle, d, kw, shape):
         err(hip, f64) <= max(5 * err(oracle, f64), 5e-5)   and   err(hip, oracle) <= 4 * max(...)."""
     import ref_numpy as rn
     from buffalo_amd import synth
+    if _vdim(d) > 128 and design == "fused":
+        pytest.skip("vdim > 128 runs the matrix-free kernels; the Gramian designs do not apply")
     if shape == "tiny":
         csr = tiny_csr(U=320, I=280, density=0.06, seed=31, counts=True)   # every row shorter than a wave
     else:
         csr = synth.generate(*synth.SHAPES["ml100k"], seed=7, vals="counts")  # row lengths 1..900: odd, > 64, > 128
     opt = als_opt(d=d, alpha=4.0, reg_u=0.2, reg_i=0.3, num_iters=2, **kw)
     o, obj, (P, Q), (Po, Qo) = _setup(oracle, csr, d, opt, scale=0.1)
+    obj.set_mode("als_fused", int(design == "fused"))   # both Gramian designs exist for every vdim <= 128
     t = csr.transpose()
     for it in range(2 if shape == "tiny" else 1):
         for axis, mat in ((0, csr), (1, t)):
@@ -102,16 +106,22 @@ def test_half_epochs_match_oracle(oracle, d, kw, shape):
             obj.precompute(axis)
             X, Xo, Yo = (P, Po, Qo) if axis == 0 else (Q, Qo, Po)
             truth = rn.als_half_epoch_f64(Xo.copy(), Yo, o.get_ff(d), mat, opt, axis)
+            # each backend is held to the float64 recurrence started from ITS OWN Gramian: FF's own rounding
+            # (checked in test_precompute_gramian_mfma) is amplified by the cancellation in the iALS++
+            # gradient and would otherwise be charged to the row solver
+            ff_hip = obj.device_tensor("FF", (_vdim(d), _vdim(d))).cpu().numpy()[:d, :d].copy()
+            truth_hip = rn.als_half_epoch_f64(Xo.copy(), Yo, ff_hip, mat, opt, axis)
             lo, lg = np.zeros(2), np.zeros(2)
             for (a, b) in H.chunks_of(mat, 2 if it == 0 else 1):
                 keys, vals = H.chunk_arrays(mat, a, b)
                 lo += o.partial_update(a, b, mat.indptr, keys, vals, axis)
                 lg += obj.partial_update(a, b, mat.indptr, keys, vals, axis)
             # partial_update wrote the updated rows back into the caller's arrays (als.cu:403)
-            e_or, e_hip, e_pair = H.relerr(Xo, truth), H.relerr(X[:, :d], truth), H.relerr(X[:, :d], Xo)
+            e_or, e_hip, e_pair = H.relerr(Xo, truth), H.relerr(X[:, :d], truth_hip), H.relerr(X[:, :d], Xo)
             env = max(5 * e_or, 5e-5)
             assert e_hip <= env, (it, axis, e_hip, e_or)
-            assert e_pair <= 4 * env, (it, axis, e_pair, e_or)
+            gap = H.relerr(truth_hip, truth)     # what the two Gramians' roundings alone do to the exact recurrence
+            assert e_pair <= 4 * env + 2 * gap, (it, axis, e_pair, e_or, gap)
             assert abs(lg[0] - lo[0]) <= 2e-4 * max(1.0, abs(lo[0])), (lg, lo)
             assert abs(lg[1] - lo[1]) <= 1e-5 * max(1.0, abs(lo[1])), (lg, lo)
             X[:, :d] = Xo                     # re-synchronise
