@@ -593,22 +593,22 @@ __global__ __launch_bounds__(256) void als_ialspp_kernel(AlsParams p) {
 // ================================================================================================
 // Gramian-on-MFMA path (vdim <= 128: every d <= 128, i.e. BASELINE config #3 and all d < 128 solvers)
 //
-// One workgroup (4 waves) owns a row (or a 4096-nnz chunk of a heavy row).  ONE pass over the row's
-// nnz builds, on the matrix cores (v_mfma_f32_32x32x2_f32, exact fp32),
-//     G = alpha * sum_k v_k q_k q_k^T   (vdim x vdim; wave w accumulates tile-row w: T tiles x 16 regs)
+// One WAVE owns a row (or a 4096-nnz chunk of a heavy row).  ONE pass over the row's nnz builds, on the
+// matrix cores (v_mfma_f32_32x32x2_f32, exact fp32), the upper triangle of
+//     G = alpha * sum_k v_k q_k q_k^T   (vdim x vdim: T(T+1)/2 tiles of 32x32, 16 accumulator registers each)
 //     g = sum_k coef_k q_k              (coef = alpha*v for iALS++, 1 + alpha*v for the dense solvers)
 // with q rows streamed straight from HBM/L2 into the MFMA operand layout (lane = (k&1)*32 + i reads
-// q_k[32*bj + i]: a 128-byte segment per half-wave, no LDS staging, no transposition).  M = FF + G then
-// lands in LDS and wave 0 runs the small dense algebra:
-//   * iALS++ (als.cc:269-352): the reference tracks Yui_k = p.q_k incrementally; with the explicit
-//     Gramian, sum_k alpha v_k (Yui_k - 1) q_k == r0 + G (p - p0) where p0 is the row at entry and
-//     r0 = sum_k alpha v_k (p0.q_k - 1) q_k is gathered in the same pass, so the block gradient is
-//     b = M[blk,:](p - p0) + (FF p0)_blk + reg p_blk + r0_blk and the CG matrix M[blk,blk] + reg I:
-//     the same recurrence without the reference's 5 passes over the nnz per block, and without the
-//     cancellation a naive G p - g would introduce in fp32;
-//   * manual_cg / llt / ldlt (als.cc:180-204 + algo.cc:52-82): A = M + reg*ada*I explicitly.
+// q_k[32*b + i]: a 128-byte segment per half-wave, no LDS staging, no transposition) -- als_gram_kernel.
+//   * iALS++ (als.cc:269-352), block_size 32, d % 32 == 0 (the d >= 128 default, BASELINE config #3):
+//     the reference tracks Yui_k = p.q_k incrementally over 5 passes of the nnz per block; with
+//     M = FF + G in hand, sum_k alpha v_k (Yui_k - 1) q_k == G p - g, so the block gradient is
+//     (M p)_blk - g_blk + reg p_blk and the CG matrix M[blk,blk] + reg I -- the same recurrence, evaluated
+//     from the accumulator registers without M ever leaving the wave (als_ialspp_inreg);
+//   * everything else (manual_cg / llt / ldlt, als.cc:180-204 + algo.cc:52-82: A = M + reg*ada*I; iALS++
+//     with other block sizes): the tiles go to an HBM scratch slot and als_solve_kernel runs the dense
+//     algebra from LDS (als_dense_solve).
 // Heavy rows (item "Star Wars" has 10^5 users) are cut into chunks whose partial G/g are combined
-// with fp32 atomics in a scratch slot and solved by a second, tiny launch.
+// with fp32 atomics in a scratch slot and solved by als_solve_kernel.
 // ================================================================================================
 struct AlsWork {
     int row;
@@ -819,294 +819,379 @@ __device__ __forceinline__ void als_dense_solve(float* M, float* gv, float* pv_l
 // LDS carve: M[vdim][vdim+1] | g[vdim] | p[vdim] | 4 work vectors[vdim]
 __host__ __device__ inline size_t als_gs_lds_bytes(int vdim) { return (static_cast<size_t>(vdim) * (vdim + ALS_LD_PAD) + 9 * vdim + 4) * sizeof(float); }
 
-// ------------------------------------------------------------------------------------------------
-// Gramian pass of ONE wave over the nnz of one work item: acc[g] += (alpha v q[tw-block])^T q[g-block]
-// on the matrix cores (v_mfma_f32_32x32x2_f32: one instruction eats TWO nnz, k-index = lane>>5), and
-// gpart += c q[tw*32+col] with c = alpha v (iALS++: g = sum alpha v q) or 1 + alpha v (dense solvers: y).
-// The 64 keys/vals of a chunk sit one-per-lane; a pair's two row ids are wave-uniform so they come out
-// with v_readlane (SALU), the operand rows are plain dword loads (half-wave = one 128-B line per tile),
-// and the loop is register double-buffered: the rows of group j+1 (UP pairs) are in flight while group j
-// feeds the MFMAs.  Steady state per pair: 4 readlane, 2 cndmask, 1 address mad, T+1 loads, 2 mul, 1 fma.
-// ------------------------------------------------------------------------------------------------
-template <int T, bool IALS>
-__device__ __forceinline__ void als_gram_rowpass(const AlsParams& p, const AlsWork& wk, int tw, int lane, int half, int col, bool lossk,
-                                                 const float (&pcol)[T], f32x16 (&acc)[T], float& gpart, double& nume_k, double& deno_k) {
-    const int vdim = p.vdim;
-    const int64_t n = wk.kend - wk.kbeg;
-    constexpr int UP = 4;
-    const int64_t nchunks = (n + 63) / 64;
-    auto fetch_keys = [&](int64_t chunk, int& cc, float& vvv) {
-        const int64_t kk = chunk * 64 + lane;
-        cc = 0;        // padding lanes: row 0 of the other factor with weight 0
-        vvv = 0.f;
-        if (kk < n) {
-            cc = p.keys[wk.kbeg + kk];
-            vvv = p.vals[wk.kbeg + kk];
-        }
-    };
-    auto load_pair = [&](int myc, float myv, int pr, float (&q)[T], float& qs, float& v) {
-        const int c0 = __builtin_amdgcn_readlane(myc, 2 * pr), c1 = __builtin_amdgcn_readlane(myc, 2 * pr + 1);
-        const float v0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myv), 2 * pr));
-        const float v1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myv), 2 * pr + 1));
-        v = half ? v1 : v0;
-        const float* q_ = p.Q + static_cast<size_t>(half ? c1 : c0) * vdim + col;
-#pragma unroll
-        for (int g = 0; g < T; ++g) q[g] = q_[g * 32];
-        qs = q_[tw * 32];   // A-operand column block (same cache line as q[tw]; tw is wave-uniform but not a compile-time index)
-    };
-    auto consume = [&](const float (&q)[T], float qs, float v, float one) {
-        const float wgt = p.alpha * v;
-        const float a = wgt * qs;
-#pragma unroll
-        for (int g = 0; g < T; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, q[g], acc[g], 0, 0, 0);
-        // als.cc:184: float(1.0 + double(v*alpha)) == 1.0f + v*alpha (the exact sum rounded once either way)
-        gpart += (IALS ? wgt : (one + wgt)) * qs;
-        if (lossk) {  // als.cc:187-192 / 298-303 on the ORIGINAL row
-            float dp = 0.f;
-#pragma unroll
-            for (int g = 0; g < T; ++g) dp += q[g] * pcol[g];
-            for (int sft = 1; sft < 32; sft <<= 1) dp += __shfl_xor(dp, sft, 64);
-            if (col == 0 && one != 0.f) {
-                nume_k -= static_cast<double>(dp * dp);
-                nume_k += static_cast<double>((dp - 1) * (dp - 1)) * (1.0 + static_cast<double>(wgt));
-                deno_k += static_cast<double>(wgt);
-            }
-        }
-    };
-    auto nnz_of = [&](int64_t ch) { return ch < nchunks ? static_cast<int>((n - ch * 64) < 64 ? (n - ch * 64) : 64) : 0; };
-    auto groups_of = [&](int64_t ch) { return (nnz_of(ch) >> 1) / UP; };   // groups hold COMPLETE pairs only (no padding lane)
-    int myc, myc_n;
-    float myv, myv_n;
-    fetch_keys(0, myc, myv);
-    fetch_keys(1, myc_n, myv_n);
-    float qa[UP][T], qsa[UP], va[UP];
-    if (groups_of(0) > 0) {
-#pragma unroll
-        for (int uu = 0; uu < UP; ++uu) load_pair(myc, myv, uu, qa[uu], qsa[uu], va[uu]);
-    }
-    for (int64_t ch = 0; ch < nchunks; ++ch) {
-        const int npairs = (nnz_of(ch) + 1) >> 1;
-        const int ngroups = groups_of(ch);
-        const bool next_has_group = groups_of(ch + 1) > 0;
-        for (int gidx = 0; gidx < ngroups; ++gidx) {
-            float qb[UP][T], qsb[UP], vb[UP];
-            const bool here = gidx + 1 < ngroups;
-            if (here) {
-#pragma unroll
-                for (int uu = 0; uu < UP; ++uu) load_pair(myc, myv, (gidx + 1) * UP + uu, qb[uu], qsb[uu], vb[uu]);
-            } else if (next_has_group) {   // first group of the next chunk
-#pragma unroll
-                for (int uu = 0; uu < UP; ++uu) load_pair(myc_n, myv_n, uu, qb[uu], qsb[uu], vb[uu]);
-            }
-#pragma unroll
-            for (int uu = 0; uu < UP; ++uu) consume(qa[uu], qsa[uu], va[uu], 1.0f);
-            if (here || next_has_group) {
-#pragma unroll
-                for (int uu = 0; uu < UP; ++uu) {
-                    qsa[uu] = qsb[uu];
-                    va[uu] = vb[uu];
-#pragma unroll
-                    for (int g = 0; g < T; ++g) qa[uu][g] = qb[uu][g];
-                }
-            }
-        }
-        // <= UP leftover pairs: only the last chunk of the item has them; its last pair may be half padding
-        for (int pr = ngroups * UP; pr < npairs; ++pr) {
-            float q1[T], qs1, v1;
-            load_pair(myc, myv, pr, q1, qs1, v1);
-            consume(q1, qs1, v1, (ch * 64 + 2 * pr + half < n) ? 1.0f : 0.f);
-        }
-        myc = myc_n;
-        myv = myv_n;
-        fetch_keys(ch + 2, myc_n, myv_n);
-    }
-    gpart += __shfl_xor(gpart, 32, 64);   // the two halves hold the k-parities of the same element
+// floats per scratch slot: G [vdim][vdim] | g [vdim] | g1 = sum q (loss only) [vdim]
+__host__ __device__ inline size_t als_slot_floats(int vdim) { return static_cast<size_t>(vdim) * vdim + 2 * static_cast<size_t>(vdim); }
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+    for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
+    return v;
 }
 
-// Everything after the Gramian pass of one work item: heavy-row partial -> scratch, or M = FF + G into LDS
-// and the dense solve by wave 0.  Shared by the register-operand and the LDS-tile kernels.
+// row-level loss terms by one wave: reg*ada*|p|^2 (both half-epochs, als.cc:306-309) and, on the item
+// half-epoch, p^T M p - 2 p.(g_w + g_1) (see als_gram_kernel) + one count of the other side's rows.
+// Mp = M p; gsum_a - gsum_b = g_w + g_1 (gsum_b == nullptr: gsum_a alone).
+__device__ __forceinline__ void als_row_loss(const AlsParams& p, const float* pl, const float* Mp, const float* gsum_a, const float* gsum_b, float ada,
+                                             int lane, double& nume, double& deno) {
+    float pp = 0.f, pmp = 0.f, pg = 0.f;
+    for (int i = lane; i < p.vdim; i += 64) {
+        pp += pl[i] * pl[i];
+        if (p.axis == 1) {
+            pmp += pl[i] * Mp[i];
+            pg += pl[i] * (gsum_b ? gsum_a[i] - gsum_b[i] : gsum_a[i]);
+        }
+    }
+    pp = wave_sum(pp);
+    nume += static_cast<double>(ada * p.reg * pp);
+    if (p.axis == 1) {
+        pmp = wave_sum(pmp);
+        pg = wave_sum(pg);
+        nume += static_cast<double>(pmp) - 2.0 * static_cast<double>(pg);
+        deno += static_cast<double>(p.op_rows);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// In-register iALS++ (als.cc:269-352) for the wave-per-row Gramian kernel: when the pass over the nnz
+// ends, the wave holds the upper triangle of M = FF + G in its accumulators (they were initialised with
+// the FF tiles) in the MFMA C layout  tile[e] @ lane (half, col) = M[32a + r(e) + 4 half][32b + col],
+// r(e) = (e&3) + 8(e>>2).  Both products the block recurrence needs come straight out of that layout:
+//   * "column" product  y[col] = sum_r tile[r][col] x[r]   -- 16 FMAs per lane against an LDS-broadcast
+//     x, then one cross-half add: used for tiles above the diagonal block (M[blk][j<blk] = M[j][blk]^T)
+//     and for the symmetric diagonal tile (the CG matrix);
+//   * "row" product     y[r]   = sum_col tile[r][col] x[col] -- 16 per-lane products, then a transpose-
+//     reduce over the 32 lanes of each half (16+8+4+2+1 shuffles) that leaves row (lane>>1)&15 in each
+//     lane pair: used for the tiles right of the diagonal block.
+// So M never goes to LDS or HBM: no scratch round trip, no second kernel, and the solve of one wave
+// overlaps the Gramian passes of the other waves on the CU.  Needs block_size == 32 and d % 32 == 0.
+// ------------------------------------------------------------------------------------------------
 template <int T>
-__device__ __forceinline__ void als_finish_item(const AlsParams& p, const AlsWork& wk, f32x16 (&acc)[T], float gpart, float* __restrict__ scratch,
-                                                float* M, float* gv, float* pl, float* p0, float* f0, float* w0, float* w1, float* w2, float* w3,
-                                                float* w4, float* Pu, int64_t n, int mode, int lane, int wv, int half, int col, double& nume,
-                                                double& deno) {
-    const int vdim = p.vdim, D = p.d, ld = vdim + ALS_LD_PAD;
-    if (wk.slot >= 0) {
-        // heavy row: add this chunk's partial into the scratch slot, solved by als_solve_kernel
-        float* S = scratch + static_cast<size_t>(wk.slot) * (vdim * vdim + vdim);
+__host__ __device__ constexpr int als_tri(int a, int b) { return a * T - a * (a - 1) / 2 + (b - a); }   // index of tile (a, b), a <= b
+
+__device__ __forceinline__ float als_tile_colpart(const f32x16& t, const float* x /* LDS, 32 floats, 16-B aligned */, int half) {
+    float s = 0.f;
 #pragma unroll
-        for (int g = 0; g < T; ++g)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int i = (e & 3) + 8 * (e >> 2) + 4 * half;
-                atomic_add_f32(S + static_cast<size_t>(wv * 32 + i) * vdim + g * 32 + col, acc[g][e]);
-            }
-        if (half == 0) atomic_add_f32(S + vdim * vdim + wv * 32 + col, gpart);
-        return;
+    for (int k = 0; k < 4; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(x + 8 * k + 4 * half);
+        s += t[4 * k + 0] * v.x + t[4 * k + 1] * v.y + t[4 * k + 2] * v.z + t[4 * k + 3] * v.w;
     }
-    // M = FF + G -> LDS; iALS++ keeps -g (see als_dense_solve: b = M[blk,:] delta + f0 + gv + reg p with f0 = M p0)
-    if (!(p.debug & 4)) {
+    return s;   // caller adds the other half's share (rows 4..7 mod 8)
+}
+
+// z[e] = per-lane products; leaves sum over the 32 lanes of this half of row (lane>>1)&15 (in e-numbering) in every lane
+__device__ __forceinline__ float als_rows_reduce(float (&z)[16], int lane) {
+    const bool b4 = lane & 16, b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
 #pragma unroll
-        for (int g = 0; g < T; ++g)
+    for (int e = 0; e < 8; ++e) {
+        const float keep = b4 ? z[e + 8] : z[e], send = b4 ? z[e] : z[e + 8];
+        z[e] = keep + __shfl_xor(send, 16, 64);
+    }
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int i = (e & 3) + 8 * (e >> 2) + 4 * half;
-                const int rr = wv * 32 + i, cc = g * 32 + col;
-                M[rr * ld + cc] = acc[g][e] + p.FF[static_cast<size_t>(rr) * vdim + cc];
-            }
-        if (half == 0) gv[wv * 32 + col] = mode == 8 ? -gpart : gpart;
+    for (int e = 0; e < 4; ++e) {
+        const float keep = b3 ? z[e + 4] : z[e], send = b3 ? z[e] : z[e + 4];
+        z[e] = keep + __shfl_xor(send, 8, 64);
     }
-    __syncthreads();
-    if (mode == 8 && !(p.debug & 4)) {   // f0 = M p0: wave w rows 32w..32w+31, the half-waves split the columns
-        const float* Mi = M + (wv * 32 + col) * ld + half * (vdim / 2);
-        const float* pp = p0 + half * (vdim / 2);
-        float sum = 0.f;
-#pragma unroll 8
-        for (int j = 0; j < vdim / 2; ++j) sum += Mi[j] * pp[j];
-        sum += __shfl_xor(sum, 32, 64);
-        if (half == 0) f0[wv * 32 + col] = sum;
-        __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const float keep = b2 ? z[e + 2] : z[e], send = b2 ? z[e] : z[e + 2];
+        z[e] = keep + __shfl_xor(send, 4, 64);
     }
-    if (wv == 0) {
-        const float ada = p.adaptive_reg ? static_cast<float>(n) : 1.0f;
-        if (p.compute_loss) {
-            float pp = 0.f, pfp = 0.f;
-            for (int i = lane; i < D; i += 64) {
-                pp += pl[i] * pl[i];
-                if (p.axis == 1) {
-                    float sum = 0.f;
-                    for (int j = 0; j < D; ++j) sum += p.FF[static_cast<size_t>(i) * vdim + j] * pl[j];
-                    pfp += pl[i] * sum;
+    {
+        const float keep = b1 ? z[1] : z[0], send = b1 ? z[0] : z[1];
+        z[0] = keep + __shfl_xor(send, 2, 64);
+    }
+    return z[0] + __shfl_xor(z[0], 1, 64);
+}
+
+// `pc`: LDS copy of the row (vdim floats), `tmp`: 64 LDS floats.  On return pc holds the updated row.
+template <int T>
+__device__ __forceinline__ void als_ialspp_inreg(const f32x16 (&acc)[T * (T + 1) / 2], const float (&g)[T], const float (&g1)[T], const AlsParams& p,
+                                                 float* pc, float* tmp, int lane, int half, int col, float ada, double& nume, double& deno) {
+    float* out = tmp;        // 32: row-product results
+    float* pvs = tmp + 32;   // 32: CG direction
+    // (M x)[32 blk + col] for x = pc
+    auto block_matvec = [&](int blk) {
+        float part = 0.f;
+#pragma unroll
+        for (int ja = 0; ja < T; ++ja)
+            if (ja <= blk) part += als_tile_colpart(acc[als_tri<T>(ja < blk ? ja : blk, blk)], pc + ja * 32, half);
+        float s = part + __shfl_xor(part, 32, 64);
+        if (blk < T - 1) {
+            float z[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) z[e] = 0.f;
+#pragma unroll
+            for (int jb = 1; jb < T; ++jb)
+                if (jb > blk) {
+                    const float xv = pc[jb * 32 + col];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) z[e] += acc[als_tri<T>(blk < jb ? blk : jb, jb)][e] * xv;
                 }
-            }
-            pp = wave_sum(pp);
-            nume += static_cast<double>(ada * p.reg * pp);
+            const float y = als_rows_reduce(z, lane);
+            const int es = (lane >> 1) & 15;
+            wave_lds_sync();
+            if (!(lane & 1)) out[(es & 3) + 8 * (es >> 2) + 4 * half] = y;
+            wave_lds_sync();
+            s += out[col];
+        }
+        return s;
+    };
+    if (p.compute_loss) {   // als.cc:288-309 on the row at entry (see als_gram_kernel for the algebra)
+        float pp = 0.f, pmp = 0.f, pg = 0.f;
+#pragma unroll
+        for (int blk = 0; blk < T; ++blk) {
+            const float pv = pc[blk * 32 + col];
+            pp += pv * pv;
             if (p.axis == 1) {
-                pfp = wave_sum(pfp);
-                nume += static_cast<double>(pfp);
-                deno += static_cast<double>(p.op_rows);
+                pmp += pv * block_matvec(blk);
+                pg += pv * (g[blk] + g1[blk]);
             }
         }
-        if (!(p.debug & 1)) als_dense_solve(M, gv, pl, p0, f0, w0, w1, w2, w3, w4, p, lane, p.reg * ada, mode);
-        for (int i = lane; i < D; i += 64) Pu[i] = pl[i];
-    }
-}
-
-// Fused design: one 64*T-thread block per row; wave w accumulates tile-row w of G in registers, the block
-// assembles M = FF + G in LDS and wave 0 runs the dense phase in place -- G never touches HBM.
-template <int T, bool IALS>
-__global__ __launch_bounds__(64 * T, 2) void als_gram_solve_kernel(AlsParams p, const AlsWork* __restrict__ work, int n_work, float* __restrict__ scratch) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int vdim = p.vdim, ld = vdim + ALS_LD_PAD;
-    constexpr int mode_ials = 8;
-    float* M = lds;
-    float* gv = lds + vdim * ld;
-    float* pl = gv + vdim;
-    float* w0 = pl + vdim; float* w1 = w0 + vdim; float* w2 = w1 + vdim; float* w3 = w2 + vdim; float* w4 = w3 + vdim;
-    float* p0 = w4 + vdim; float* f0 = p0 + vdim;
-    int* s_item = reinterpret_cast<int*>(f0 + vdim);   // all LDS lives in the dynamic region (16-B aligned base)
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // tile row of this wave
-    const int half = lane >> 5, col = lane & 31;
-    const int mode = IALS ? mode_ials : p.solver;
-    double nume = 0.0, deno = 0.0;      // row-level terms (identical in every lane of wave 0)
-    double nume_k = 0.0, deno_k = 0.0;  // per-nnz terms (lanes 0 and 32 of wave 0 hold the two k-parities)
-
-    while (true) {
-        __syncthreads();
-        if (threadIdx.x == 0) *s_item = atomicAdd(p.ticket, 1);
-        __syncthreads();
-        const int item = *s_item;
-        if (item >= n_work) break;
-        const AlsWork wk = work[item];
-        float* Pu = p.P + static_cast<size_t>(wk.row) * vdim;
-        // current row -> LDS (the loss terms and the solve read it)
-        for (int e = threadIdx.x; e < vdim; e += blockDim.x) { pl[e] = Pu[e]; p0[e] = Pu[e]; }
-        f32x16 acc[T];
-#pragma unroll
-        for (int g = 0; g < T; ++g)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
-        float gpart = 0.f;
-        const bool lossk = p.compute_loss && p.axis == 1 && wv == 0;
-        float pcol[T];
-#pragma unroll
-        for (int g = 0; g < T; ++g) pcol[g] = lossk ? Pu[g * 32 + col] : 0.f;
-        als_gram_rowpass<T, IALS>(p, wk, wv, lane, half, col, lossk, pcol, acc, gpart, nume_k, deno_k);
-        als_finish_item<T>(p, wk, acc, gpart, scratch, M, gv, pl, p0, f0, w0, w1, w2, w3, w4, Pu, wk.kend - wk.kbeg, mode, lane, wv, half, col, nume,
-                           deno);
-    }
-    if (p.compute_loss && wv == 0) {
-        nume_k += __shfl_xor(nume_k, 32, 64);
-        deno_k += __shfl_xor(deno_k, 32, 64);
-        if (lane == 0) {
-            if (nume + nume_k != 0.0) atomicAdd(p.loss, nume + nume_k);
-            if (deno + deno_k != 0.0) atomicAdd(p.loss + 1, deno + deno_k);
+        pp = wave_sum(half == 0 ? pp : 0.f);
+        nume += static_cast<double>(ada * p.reg * pp);
+        if (p.axis == 1) {
+            pmp = wave_sum(half == 0 ? pmp : 0.f);
+            pg = wave_sum(half == 0 ? pg : 0.f);
+            nume += static_cast<double>(pmp) - 2.0 * static_cast<double>(pg);
+            deno += static_cast<double>(p.op_rows);
         }
     }
+#pragma unroll
+    for (int blk = 0; blk < T; ++blk) {
+        const float pblk = pc[blk * 32 + col];
+        const float bi = block_matvec(blk) - g[blk] + p.reg * pblk;   // als.cc:286-297: gradient of the block at the current row
+        float xr = 0.f, rr = bi, pvr = bi;
+        double rsold = static_cast<double>(wave_sum(half == 0 ? rr * rr : 0.f));
+        if (rsold > static_cast<double>(p.cg_tol)) {   // als.cc:313-345: 3 CG steps on M[blk,blk] + reg I
+            for (int step = 0; step < 3; ++step) {
+                wave_lds_sync();
+                if (half == 0) pvs[col] = pvr;
+                wave_lds_sync();
+                float ap = als_tile_colpart(acc[als_tri<T>(blk, blk)], pvs, half);
+                ap += __shfl_xor(ap, 32, 64);
+                ap += p.reg * pvr;
+                const float pap = wave_sum(half == 0 ? pvr * ap : 0.f);
+                const float step_size = static_cast<float>(rsold / static_cast<double>(pap));
+                xr += step_size * pvr;
+                rr -= step_size * ap;
+                const double rsnew = static_cast<double>(wave_sum(half == 0 ? rr * rr : 0.f));
+                if (rsnew < static_cast<double>(p.cg_tol)) break;
+                pvr = rr + static_cast<float>(rsnew / rsold) * pvr;
+                rsold = rsnew;
+            }
+        }
+        wave_lds_sync();
+        if (half == 0) pc[blk * 32 + col] = pblk - xr;   // als.cc:346
+        wave_lds_sync();
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
-// Split design: Gramian pass and dense solve as two launches.
-//   als_gram_kernel   -- no LDS, <= 168 VGPRs: 3 waves per SIMD stream q rows into the matrix cores; a
-//                        64*T-thread block shares a row so its q rows reach the CU's L1 once.  G and g go
-//                        to an HBM scratch slot per row (row-major [vdim][vdim] + [vdim]); chunks of heavy
-//                        rows add with fp32 atomics into the (zeroed) slot.
-//   als_solve_kernel  -- one wave per row: M = FF + G from the scratch into LDS, then als_dense_solve.
-// Costs 2 * vdim^2 * 4 B of HBM traffic per row, which is nothing at vdim <= 96 (where the fused kernel's
-// low occupancy hurts most) and ~5 ms per ML-20M epoch at vdim = 128 -- hence the per-vdim default.
+// als_gram_kernel -- ONE WAVE PER ROW, no big LDS.  The wave holds the whole upper triangle of G
+// (T(T+1)/2 tiles x 16 accumulator registers: 160 at vdim 128) and streams each q row through the matrix
+// cores exactly once:
+//     acc[(a,b)] += (alpha v q[block a])^T q[block b]     v_mfma_f32_32x32x2_f32: one instruction eats TWO nnz
+//     gpart[a]   += c q[32a + col],  c = alpha v (iALS++: g_w = sum alpha v q) or 1 + alpha v (dense solvers: y)
+// The 64 keys/vals of a chunk sit one-per-lane; a pair's two row ids are wave-uniform so they come out
+// with v_readlane (SALU), the operand rows are plain dword loads (half-wave = one 128-B line per tile, a
+// 32-bit per-lane row offset off one SGPR base), and the loop is register double-buffered: the T loads
+// of each of the UP pairs of group j+1 are in flight while group j feeds UP * T(T+1)/2 MFMAs (~2.5k
+// cycles at vdim 128) -- enough to hide an Infinity-Cache round trip with 2 waves per SIMD -- and no q
+// row is fetched twice.
+//
+// Loss (als.cc:187-192 / 298-303, item half-epoch only): sum_k [-y_k^2 + (y_k-1)^2 (1+w_k)] with
+// y_k = p.q_k, w_k = alpha v_k equals  p^T G p - 2 p.(g_w + g_1) + sum_k (1 + w_k)  (g_1 = sum q), so
+// nothing per-nnz is needed beyond one more FMA (g1part, iALS++ only: the dense solvers' y is
+// g_w + g_1 already); the constant and the denominator sum_k w_k are added where the vals are read, the
+// quadratic form (with p^T FF p, as p^T M p) by whoever holds M.
+//
+// INREG (iALS++ with block_size 32, d == vdim): the accumulators start from the FF tiles, rows that fit
+// one work item are SOLVED IN PLACE (als_ialspp_inreg) and only the chunks of heavy rows go to scratch
+// (slot_base = 0).  Otherwise the computed tiles of G, g (and g1) go to the row's HBM scratch slot
+// (row - start_x; heavy rows: slot_base + wk.slot, zeroed by the host, fp32 atomics) and als_solve_kernel
+// -- a 256-thread block per row -- rebuilds M = FF + G in LDS and runs als_dense_solve.
 // ------------------------------------------------------------------------------------------------
-template <int T, bool IALS>
-__global__ __launch_bounds__(64 * T, 3) void als_gram_kernel(AlsParams p, const AlsWork* __restrict__ work, int n_items, float* __restrict__ scratch) {
-    const int vdim = p.vdim;
+template <int T, bool IALS, bool INREG>
+__global__ __launch_bounds__(256, 2) void als_gram_kernel(AlsParams p, const AlsWork* __restrict__ work, int n_items, float* __restrict__ scratch,
+                                                          int slot_base) {
+    static_assert(!INREG || IALS, "the in-register solve is the iALS++ recurrence");
+    __shared__ __attribute__((aligned(16))) float s_vec[INREG ? 4 * (32 * T + 64) : 4];
+    constexpr int NT = T * (T + 1) / 2;
+    constexpr int UP = 4;
+    constexpr unsigned row_bytes = 32u * T * 4u;   // vdim == 32*T
     const int lane = threadIdx.x & 63;
     const int half = lane >> 5, col = lane & 31;
+    const bool lossk = p.compute_loss && p.axis == 1;
     double nume_k = 0.0, deno_k = 0.0;
-    __shared__ int s_item;
-    const int tw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // tile-row of G this wave accumulates
+    const char* qbase = reinterpret_cast<const char*>(p.Q);
     while (true) {
-        __syncthreads();
-        if (threadIdx.x == 0) s_item = atomicAdd(p.ticket, 1);
-        __syncthreads();
-        const int item = s_item;
+        int item = 0;
+        if (lane == 0) item = atomicAdd(p.ticket, 1);
+        item = __builtin_amdgcn_readfirstlane(item);
         if (item >= n_items) break;
         const AlsWork wk = work[item];
-        const int u = wk.row;
-        f32x16 acc[T];
+        const bool solve_here = INREG && wk.slot < 0;
+        f32x16 acc[NT];
 #pragma unroll
-        for (int g = 0; g < T; ++g)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
-        float gpart = 0.f;
-        const bool lossk = p.compute_loss && p.axis == 1 && tw == 0;
-        float pcol[T];
+            for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+        if (solve_here) {   // M = FF + G: start the accumulators from the FF tiles (64 KB, L2-resident)
+            const float* Fl = p.FF + half * 4 * (32 * T) + col;
+            asm volatile("" : "+v"(Fl));   // keep the 10 tiles' address arithmetic inside the item loop (hoisted, it spills)
+            int t = 0;
 #pragma unroll
-        for (int g = 0; g < T; ++g) pcol[g] = lossk ? p.P[static_cast<size_t>(u) * vdim + g * 32 + col] : 0.f;
-        als_gram_rowpass<T, IALS>(p, wk, tw, lane, half, col, lossk, pcol, acc, gpart, nume_k, deno_k);
-        float* S = scratch + static_cast<size_t>(u - p.start_x) * (static_cast<size_t>(vdim) * vdim + vdim);
-        if (wk.slot >= 0) {   // chunk of a heavy row: partials are summed (the slot was zeroed by the host)
+            for (int a = 0; a < T; ++a)
 #pragma unroll
-            for (int g = 0; g < T; ++g)
+                for (int b = a; b < T; ++b, ++t)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[t][e] = Fl[(a * 32 + (e & 3) + 8 * (e >> 2)) * (32 * T) + b * 32];
+        }
+        float gpart[T], g1part[T];
+#pragma unroll
+        for (int a = 0; a < T; ++a) { gpart[a] = 0.f; g1part[a] = 0.f; }
+        const int64_t n = wk.kend - wk.kbeg;
+        const int64_t nchunks = (n + 63) / 64;
+        auto fetch_keys = [&](int64_t chunk, int& cc, float& vvv) {
+            const int64_t kk = chunk * 64 + lane;
+            cc = 0;        // padding lanes: row 0 of the other factor with weight 0
+            vvv = 0.f;
+            if (kk < n) {
+                cc = p.keys[wk.kbeg + kk];
+                vvv = p.vals[wk.kbeg + kk];
+                if (lossk) {   // constant and denominator of the loss, see als_gram_kernel
+                    const double w = static_cast<double>(vvv * p.alpha);
+                    deno_k += w;
+                    nume_k += 1.0 + w;
+                }
+            }
+        };
+        auto load_pair = [&](int myc, float myv, int pr, float (&q)[T], float& v) {
+            const int c0 = __builtin_amdgcn_readlane(myc, 2 * pr), c1 = __builtin_amdgcn_readlane(myc, 2 * pr + 1);
+            const float v0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myv), 2 * pr));
+            const float v1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myv), 2 * pr + 1));
+            v = half ? v1 : v0;
+            const unsigned voff = static_cast<unsigned>(half ? c1 : c0) * row_bytes + static_cast<unsigned>(col) * 4u;   // host guarantees < 4 GiB
+            const float* q_ = reinterpret_cast<const float*>(qbase + voff);
+#pragma unroll
+            for (int b = 0; b < T; ++b) q[b] = q_[b * 32];
+        };
+        auto consume = [&](const float (&q)[T], float v, float one) {
+            const float wgt = p.alpha * v;
+            int t = 0;
+#pragma unroll
+            for (int a = 0; a < T; ++a) {
+                const float av = wgt * q[a];
+#pragma unroll
+                for (int b = a; b < T; ++b, ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, q[b], acc[t], 0, 0, 0);
+                // als.cc:184: float(1.0 + double(v*alpha)) == 1.0f + v*alpha (the exact sum rounded once either way)
+                gpart[a] += (IALS ? wgt : (one + wgt)) * q[a];
+                if (IALS && lossk) g1part[a] += one * q[a];
+            }
+        };
+        auto nnz_of = [&](int64_t ch) { return ch < nchunks ? static_cast<int>((n - ch * 64) < 64 ? (n - ch * 64) : 64) : 0; };
+        auto groups_of = [&](int64_t ch) { return (nnz_of(ch) >> 1) / UP; };   // groups hold COMPLETE pairs only (no padding lane)
+        int myc, myc_n;
+        float myv, myv_n;
+        fetch_keys(0, myc, myv);
+        fetch_keys(1, myc_n, myv_n);
+        float qa[UP][T], va[UP];
+        if (groups_of(0) > 0) {
+#pragma unroll
+            for (int uu = 0; uu < UP; ++uu) load_pair(myc, myv, uu, qa[uu], va[uu]);
+        }
+        for (int64_t ch = 0; ch < nchunks; ++ch) {
+            const int npairs = (nnz_of(ch) + 1) >> 1;
+            const int ngroups = groups_of(ch);
+            const bool next_has_group = groups_of(ch + 1) > 0;
+            for (int gidx = 0; gidx < ngroups; ++gidx) {
+                float qb[UP][T], vb[UP];
+                const bool here = gidx + 1 < ngroups;
+                if (here) {
+#pragma unroll
+                    for (int uu = 0; uu < UP; ++uu) load_pair(myc, myv, (gidx + 1) * UP + uu, qb[uu], vb[uu]);
+                } else if (next_has_group) {   // first group of the next chunk
+#pragma unroll
+                    for (int uu = 0; uu < UP; ++uu) load_pair(myc_n, myv_n, uu, qb[uu], vb[uu]);
+                }
+#pragma unroll
+                for (int uu = 0; uu < UP; ++uu) consume(qa[uu], va[uu], 1.0f);
+                if (here || next_has_group) {
+#pragma unroll
+                    for (int uu = 0; uu < UP; ++uu) {
+                        va[uu] = vb[uu];
+#pragma unroll
+                        for (int b = 0; b < T; ++b) qa[uu][b] = qb[uu][b];
+                    }
+                }
+            }
+            // <= UP leftover pairs: only the last chunk of the item has them; its last pair may be half padding
+            for (int pr = ngroups * UP; pr < npairs; ++pr) {
+                float q1[T], v1;
+                load_pair(myc, myv, pr, q1, v1);
+                consume(q1, v1, (ch * 64 + 2 * pr + half < n) ? 1.0f : 0.f);
+            }
+            myc = myc_n;
+            myv = myv_n;
+            fetch_keys(ch + 2, myc_n, myv_n);
+        }
+        constexpr int VD = 32 * T;   // vdim == 32*T on this path
+        if (solve_here) {
+            float* pc = s_vec + (threadIdx.x >> 6) * (VD + 64);
+            float* Pu = p.P + static_cast<size_t>(wk.row) * VD;
+            float gs[T], g1s[T];
+#pragma unroll
+            for (int a = 0; a < T; ++a) {   // the two halves hold the k-parities of the same element
+                gs[a] = gpart[a] + __shfl_xor(gpart[a], 32, 64);
+                g1s[a] = g1part[a] + __shfl_xor(g1part[a], 32, 64);
+            }
+            wave_lds_sync();
+            for (int e = lane; e < VD; e += 64) pc[e] = Pu[e];
+            wave_lds_sync();
+            double nume = 0.0, deno = 0.0;
+            if (!(p.debug & 1)) {
+                als_ialspp_inreg<T>(acc, gs, g1s, p, pc, pc + VD, lane, half, col, p.adaptive_reg ? static_cast<float>(n) : 1.0f, nume, deno);
+                for (int e = lane; e < VD; e += 64) Pu[e] = pc[e];
+            }
+            if (p.compute_loss && lane == 0) {   // row-level terms ride on lane 0's share of the per-nnz sums
+                nume_k += nume;
+                deno_k += deno;
+            }
+            continue;
+        }
+        // upper-triangle tiles, g, g1 -> the row's scratch slot
+        // (every element offset below is a compile-time constant off ONE lane base)
+        float* S = scratch + static_cast<size_t>(wk.slot >= 0 ? slot_base + wk.slot : wk.row - p.start_x) * als_slot_floats(VD);
+        float* Sl = S + half * 4 * VD + col;
+        const bool atomic = wk.slot >= 0;   // chunk of a heavy row: partials are summed (the slot was zeroed by the host)
+        int t = 0;
+#pragma unroll
+        for (int a = 0; a < T; ++a) {
+#pragma unroll
+            for (int b = a; b < T; ++b, ++t) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int i = (e & 3) + 8 * (e >> 2) + 4 * half;
-                    atomic_add_f32(S + static_cast<size_t>(tw * 32 + i) * vdim + g * 32 + col, acc[g][e]);
+                    float* dst = Sl + (a * 32 + (e & 3) + 8 * (e >> 2)) * VD + b * 32;
+                    if (atomic) atomic_add_f32(dst, acc[t][e]);
+                    else *dst = acc[t][e];
                 }
-            if (half == 0) atomic_add_f32(S + static_cast<size_t>(vdim) * vdim + tw * 32 + col, gpart);
-        } else {
-#pragma unroll
-            for (int g = 0; g < T; ++g)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int i = (e & 3) + 8 * (e >> 2) + 4 * half;
-                    S[static_cast<size_t>(tw * 32 + i) * vdim + g * 32 + col] = acc[g][e];
+            }
+            const float gs = gpart[a] + __shfl_xor(gpart[a], 32, 64);   // the two halves hold the k-parities of the same element
+            const float g1s = g1part[a] + __shfl_xor(g1part[a], 32, 64);
+            if (half == 0) {
+                float* gdst = S + VD * VD + a * 32 + col;
+                if (atomic) {
+                    atomic_add_f32(gdst, gs);
+                    if (IALS && lossk) atomic_add_f32(gdst + VD, g1s);
+                } else {
+                    *gdst = gs;
+                    if (IALS && lossk) gdst[VD] = g1s;
                 }
-            if (half == 0) S[static_cast<size_t>(vdim) * vdim + tw * 32 + col] = gpart;
+            }
         }
     }
-    if (p.compute_loss && p.axis == 1) {
-        nume_k += __shfl_xor(nume_k, 32, 64);
-        deno_k += __shfl_xor(deno_k, 32, 64);
+    if (lossk || (INREG && p.compute_loss)) {
+        nume_k = wave_sum_f64(nume_k);
+        deno_k = wave_sum_f64(deno_k);
         if (lane == 0) {
             if (nume_k != 0.0) atomicAdd(p.loss, nume_k);
             if (deno_k != 0.0) atomicAdd(p.loss + 1, deno_k);
@@ -1119,73 +1204,81 @@ struct AlsHeavy {
     int64_t n;
 };
 
-__global__ __launch_bounds__(64) void als_solve_kernel(AlsParams p, const AlsHeavy* __restrict__ heavy, int n_heavy, const float* __restrict__ scratch,
-                                                             int mode) {
+// Dense phase of the split design: a 256-thread block per row.  The four waves pull the row's tiles of G
+// (+ FF) from the scratch slot into LDS with 32 independent loads in flight each -- the phase is pure
+// latency otherwise, LDS holds two rows per CU at vdim 128 -- mirror the missing triangle, share the
+// M p0 matvec, then wave 0 runs als_dense_solve.
+__global__ __launch_bounds__(256) void als_solve_kernel(AlsParams p, const AlsHeavy* __restrict__ heavy, int n_heavy, const float* __restrict__ scratch,
+                                                        int mode) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int vdim = p.vdim, D = p.d, ld = vdim + ALS_LD_PAD;
+    const int vdim = p.vdim, D = p.d, ld = vdim + ALS_LD_PAD, T = vdim / 32;
     float* M = lds;
     float* gv = lds + vdim * ld;
     float* pl = gv + vdim;
     float* w0 = pl + vdim; float* w1 = w0 + vdim; float* w2 = w1 + vdim; float* w3 = w2 + vdim; float* w4 = w3 + vdim;
     float* p0 = w4 + vdim; float* f0 = p0 + vdim;
-    const int lane = threadIdx.x;
-    for (int h = blockIdx.x; h < n_heavy; h += gridDim.x) {
-    const AlsHeavy hv = heavy[h];
-    __syncthreads();
-    const float* S = scratch + static_cast<size_t>(hv.slot) * (static_cast<size_t>(vdim) * vdim + vdim);
-    float* Pu = p.P + static_cast<size_t>(hv.row) * vdim;
-    for (int e = lane; e < vdim * vdim; e += 64) {
-        const int rr = e / vdim, cc = e % vdim;
-        M[rr * ld + cc] = S[e] + p.FF[e];
-    }
-    for (int e = lane; e < vdim; e += 64) {
-        gv[e] = mode == 8 ? -S[vdim * vdim + e] : S[vdim * vdim + e];   // iALS++: -g, see als_finish_item
-        pl[e] = Pu[e];
-        p0[e] = Pu[e];
-        f0[e] = 0.f;
-    }
-    __syncthreads();
-    if (mode == 8) {   // f0 = M p0 (row i of M per lane: stride ld = vdim+1 words, conflict-free)
-        for (int i = lane; i < vdim; i += 64) {
-            const float* Mi = M + i * ld;
-            float sum = 0.f;
-#pragma unroll 8
-            for (int j = 0; j < vdim; ++j) sum += Mi[j] * p0[j];
-            f0[i] = sum;
-        }
-    }
-    if (p.compute_loss && p.axis == 1) {
-        for (int i = lane; i < vdim; i += 64) {   // FF p0 for the p FF p loss term (FF symmetric: column i read as FF[j][i])
-            float sum = 0.f;
-#pragma unroll 8
-            for (int j = 0; j < vdim; ++j) sum += p.FF[static_cast<size_t>(j) * vdim + i] * p0[j];
-            w1[i] = sum;
-        }
-    }
-    __syncthreads();
-    const float ada = p.adaptive_reg ? static_cast<float>(hv.n) : 1.0f;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5, col = lane & 31;
+    const bool lossk = p.compute_loss && p.axis == 1;
     double nume = 0.0, deno = 0.0;
-    if (p.compute_loss) {
-        float pp = 0.f, pfp = 0.f;
-        for (int i = lane; i < D; i += 64) {
-            pp += pl[i] * pl[i];
-            if (p.axis == 1) pfp += pl[i] * w1[i];     // p (FF p)
+    for (int h = blockIdx.x; h < n_heavy; h += gridDim.x) {
+        const AlsHeavy hv = heavy[h];
+        __syncthreads();
+        const float* S = scratch + static_cast<size_t>(hv.slot) * als_slot_floats(vdim);
+        float* Pu = p.P + static_cast<size_t>(hv.row) * vdim;
+        int k = 0;
+        for (int ta = 0; ta < T; ++ta)
+            for (int tb = 0; tb < T; ++tb) {
+                const int j = tb - ta;
+                if (j < 0) continue;                     // the slot holds the upper triangle of tiles
+                if ((k++ & 3) != wv) continue;   // tiles are dealt round-robin to the four waves
+                const size_t base = static_cast<size_t>(ta * 32 + half) * vdim + tb * 32 + col;
+                float sv[16], fv[16];
+#pragma unroll
+                for (int it = 0; it < 16; ++it) {
+                    sv[it] = S[base + static_cast<size_t>(2 * it) * vdim];
+                    fv[it] = p.FF[base + static_cast<size_t>(2 * it) * vdim];
+                }
+#pragma unroll
+                for (int it = 0; it < 16; ++it) {
+                    const int rr = ta * 32 + 2 * it + half, cc = tb * 32 + col;
+                    const float m = sv[it] + fv[it];
+                    M[rr * ld + cc] = m;
+                    if (j != 0) M[cc * ld + rr] = m;   // mirrored tile (FF is symmetric)
+                }
+            }
+        for (int e = threadIdx.x; e < vdim; e += blockDim.x) {
+            gv[e] = mode == 8 ? -S[vdim * vdim + e] : S[vdim * vdim + e];   // iALS++: als_dense_solve wants -g (b = M[blk,:] delta + f0 + gv + reg p with f0 = M p0)
+            if (lossk && mode == 8) w1[e] = S[vdim * vdim + vdim + e];
+            pl[e] = Pu[e];
+            p0[e] = Pu[e];
+            f0[e] = 0.f;
         }
-        pp = wave_sum(pp);
-        nume += static_cast<double>(ada * p.reg * pp);
-        if (p.axis == 1) {
-            pfp = wave_sum(pfp);
-            nume += static_cast<double>(pfp);
-            deno += static_cast<double>(p.op_rows);
+        __syncthreads();
+        if (mode == 8 || lossk) {   // f0 = M p0: the row's 32-row blocks are dealt to the waves, the half-waves split the columns
+            for (int blk = wv; blk < T; blk += 4) {
+                const float* Mi = M + (blk * 32 + col) * ld + half * (vdim / 2);
+                const float* pp = p0 + half * (vdim / 2);
+                float sum = 0.f;
+#pragma unroll 8
+                for (int j = 0; j < vdim / 2; ++j) sum += Mi[j] * pp[j];
+                sum += __shfl_xor(sum, 32, 64);
+                if (half == 0) f0[blk * 32 + col] = sum;
+            }
+            __syncthreads();
+        }
+        if (wv == 0) {
+            const float ada = p.adaptive_reg ? static_cast<float>(hv.n) : 1.0f;
+            if (p.compute_loss) als_row_loss(p, pl, f0, mode == 8 ? w1 : gv, mode == 8 ? gv : nullptr, ada, lane, nume, deno);
+            if (!(p.debug & 1)) als_dense_solve(M, gv, pl, p0, f0, w0, w1, w2, w3, w4, p, lane, p.reg * ada, mode);
+            for (int i = lane; i < D; i += 64) Pu[i] = pl[i];
         }
     }
-    if (!(p.debug & 1)) als_dense_solve(M, gv, pl, p0, f0, w0, w1, w2, w3, w4, p, lane, p.reg * ada, mode);
-    for (int i = lane; i < D; i += 64) Pu[i] = pl[i];
-    if (p.compute_loss && lane == 0) {
+    if (p.compute_loss && threadIdx.x == 0) {
         if (nume != 0.0) atomicAdd(p.loss, nume);
         if (deno != 0.0) atomicAdd(p.loss + 1, deno);
     }
-    }  // rows
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1368,31 +1461,48 @@ class AlsHandle : public HandleBase {
         BFH_HIP(hipMemsetAsync(ticket_.get(), 0, sizeof(int), stream));
         const int nrows = next_x - start_x;
         const int K = (vdim_ + 63) / 64;
-        const bool gram_path = vdim_ <= 128 && !force_v1_;
+        // the Gramian kernels address the other factor with 32-bit byte offsets
+        const bool gram_path = vdim_ <= 128 && !force_v1_ && static_cast<uint64_t>(p.op_rows) * vdim_ * 4 < (1ull << 32);
         const WorkList* wl = nullptr;
         if (gram_path) {
             wl = &work_list(axis, start_x, next_x, ip, beg);
-            if (wl->n_heavy) BFH_HIP(hipMemsetAsync(scratch_.get(), 0, static_cast<size_t>(wl->n_heavy) * (vdim_ * vdim_ + vdim_) * sizeof(float), stream));
+            if (wl->n_heavy) BFH_HIP(hipMemsetAsync(scratch_.get(), 0, static_cast<size_t>(wl->n_heavy) * als_slot_floats(vdim_) * sizeof(float), stream));
         }
         const int slot = t_main_.begin(stream);
-        const bool split = design_ < 0 ? vdim_ < 128 : design_ == 0;   // see als_gram_kernel: G round trip through HBM only pays below vdim 128
-        if (gram_path && split) {
-            // split design: Gramian pass at full occupancy -> HBM scratch -> dense solve (see als_gram_kernel)
+        if (gram_path) {
+            // wave-per-row Gramian pass; rows are solved from the accumulators (iALS++, block_size 32, d == vdim) or
+            // go through an HBM scratch slot to the dense-solve kernel (see als_gram_kernel)
             const int T = vdim_ / 32;
-            const size_t per_row = static_cast<size_t>(vdim_) * vdim_ + vdim_;
-            const size_t need = static_cast<size_t>(nrows) * per_row;
-            if (gscratch_.size() < need) gscratch_.resize(need);
-            for (int hr : wl->heavy_rows)
-                BFH_HIP(hipMemsetAsync(gscratch_.get() + static_cast<size_t>(hr - start_x) * per_row, 0, per_row * sizeof(float), stream));
+            const bool inreg = code_ == 8 && block_size_ == 32 && d_ == vdim_ && !no_inreg_;
+            const size_t per_row = als_slot_floats(vdim_);
+            const size_t lds_h = als_gs_lds_bytes(vdim_);
+            BFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(als_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        static_cast<int>(lds_h)));
             const int items = wl->n_work;
-            if (items > 0) {
-                int blocks = items;
-                const int per_cu = (12 / T) > 0 ? (12 / T) : 1;       // <= 166 VGPRs -> 3 waves per SIMD = 12 waves per CU
-                if (blocks > num_cus_ * per_cu) blocks = num_cus_ * per_cu;
+            int blocks = (items + 3) / 4;                           // 4 independent waves per block, one work item each
+            if (blocks > num_cus_ * 4) blocks = num_cus_ * 4;       // persistent: residency is set by the kernel's VGPR count
+            if (items > 0 && inreg) {
+#define BFH_GK(TT) hipLaunchKernelGGL((als_gram_kernel<TT, true, true>), dim3(blocks), dim3(256), 0, stream, p, wl->work.get(), items, scratch_.get(), 0)
+                if (T <= 1) BFH_GK(1);
+                else if (T <= 2) BFH_GK(2);
+                else if (T <= 3) BFH_GK(3);
+                else BFH_GK(4);
+#undef BFH_GK
+                BFH_HIP(hipGetLastError());
+                if (wl->n_heavy)   // heavy rows: chunk partials were summed in scratch_ (zeroed above)
+                    hipLaunchKernelGGL(als_solve_kernel, dim3(wl->n_heavy), dim3(256), lds_h, stream, p, wl->heavy.get(), wl->n_heavy, scratch_.get(),
+                                       static_cast<int>(code_));
+                BFH_HIP(hipGetLastError());
+            } else if (items > 0) {
+                // scratch: one slot per row of the chunk, then one (zeroed) accumulation slot per heavy row
+                const size_t need = (static_cast<size_t>(nrows) + wl->n_heavy) * per_row;
+                if (gscratch_.size() < need) gscratch_.resize(need);
+                if (wl->n_heavy)
+                    BFH_HIP(hipMemsetAsync(gscratch_.get() + static_cast<size_t>(nrows) * per_row, 0, wl->n_heavy * per_row * sizeof(float), stream));
 #define BFH_GK(TT)                                                                                                                  \
     do {                                                                                                                            \
-        if (code_ == 8) hipLaunchKernelGGL((als_gram_kernel<TT, true>), dim3(blocks), dim3(64 * TT), 0, stream, p, wl->work.get(), items, gscratch_.get()); \
-        else hipLaunchKernelGGL((als_gram_kernel<TT, false>), dim3(blocks), dim3(64 * TT), 0, stream, p, wl->work.get(), items, gscratch_.get());          \
+        if (code_ == 8) hipLaunchKernelGGL((als_gram_kernel<TT, true, false>), dim3(blocks), dim3(256), 0, stream, p, wl->work.get(), items, gscratch_.get(), nrows); \
+        else hipLaunchKernelGGL((als_gram_kernel<TT, false, false>), dim3(blocks), dim3(256), 0, stream, p, wl->work.get(), items, gscratch_.get(), nrows);          \
     } while (0)
                 if (T <= 1) BFH_GK(1);
                 else if (T <= 2) BFH_GK(2);
@@ -1400,48 +1510,11 @@ class AlsHandle : public HandleBase {
                 else BFH_GK(4);
 #undef BFH_GK
                 BFH_HIP(hipGetLastError());
-                const size_t lds_h = als_gs_lds_bytes(vdim_);
-                int sblocks = num_cus_ * static_cast<int>(std::max<size_t>(1, std::min<size_t>(16, (160 * 1024) / lds_h)));
+                int sblocks = num_cus_ * static_cast<int>(std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_h)));
                 if (sblocks > wl->n_solve) sblocks = wl->n_solve;
-                BFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(als_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            static_cast<int>(lds_h)));
-                hipLaunchKernelGGL(als_solve_kernel, dim3(sblocks), dim3(64), lds_h, stream, p, wl->solve.get(), wl->n_solve,
-                                   gscratch_.get(), static_cast<int>(code_));
+                hipLaunchKernelGGL(als_solve_kernel, dim3(sblocks), dim3(256), lds_h, stream, p, wl->solve.get(), wl->n_solve, gscratch_.get(),
+                                   static_cast<int>(code_));
                 BFH_HIP(hipGetLastError());
-            }
-        } else if (gram_path) {
-            // fused design: Gramian on the matrix cores + dense LDS solve in one launch
-            const int T = vdim_ / 32;
-            const size_t lds = als_gs_lds_bytes(vdim_);
-            int blocks = num_cus_ * static_cast<int>(std::max<size_t>(1, std::min<size_t>(2, (160 * 1024) / lds)));
-            if (blocks > wl->n_work) blocks = wl->n_work;
-            if (blocks > 0) {
-#define BFH_GS1(TT, II)                                                                                                        \
-    do {                                                                                                                      \
-        BFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(als_gram_solve_kernel<TT, II>),                            \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));                      \
-        hipLaunchKernelGGL((als_gram_solve_kernel<TT, II>), dim3(blocks), dim3(64 * TT), lds, stream, p, wl->work.get(),      \
-                           wl->n_work, scratch_.get());                                                                       \
-    } while (0)
-#define BFH_GS(TT)                      \
-    do {                                \
-        if (code_ == 8) BFH_GS1(TT, true); \
-        else BFH_GS1(TT, false);        \
-    } while (0)
-                if (T <= 1) BFH_GS(1);
-                else if (T <= 2) BFH_GS(2);
-                else if (T <= 3) BFH_GS(3);
-                else BFH_GS(4);
-#undef BFH_GS
-#undef BFH_GS1
-                BFH_HIP(hipGetLastError());
-            }
-            if (wl->n_heavy) {
-                const size_t lds_h = als_gs_lds_bytes(vdim_);
-                BFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(als_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            static_cast<int>(lds_h)));
-                hipLaunchKernelGGL(als_solve_kernel, dim3(wl->n_heavy), dim3(64), lds_h, stream, p, wl->heavy.get(), wl->n_heavy,
-                                   scratch_.get(), static_cast<int>(code_));
             }
         } else if (code_ == 8) {
             const int bs = block_size_ < d_ ? block_size_ : d_;
@@ -1487,7 +1560,6 @@ class AlsHandle : public HandleBase {
         DevBuf<AlsWork> work;
         DevBuf<AlsHeavy> heavy;   // fused kernels: heavy rows only (slot = scratch slot)
         DevBuf<AlsHeavy> solve;   // split design: every non-empty row, longest first (slot = row - start_x)
-        std::vector<int> heavy_rows;
         int n_work = 0, n_heavy = 0, n_solve = 0;
     };
     // Work items of one partial_update call: one per non-empty row, rows above HEAVY nnz cut into
@@ -1505,12 +1577,13 @@ class AlsHandle : public HandleBase {
         for (int x = start_x; x < next_x; ++x) {
             const int64_t e = ip[x], n = e - prev;
             if (n > 0) {  // Q-16: empty rows are left untouched
-                sv.push_back({x, x - start_x, n});
                 const int64_t kb = prev - shift;
                 if (n <= HEAVY) {
                     w.push_back({x, static_cast<int>(kb), static_cast<int>(kb + n), -1});
+                    sv.push_back({x, x - start_x, n});
                 } else {
                     const int slot = static_cast<int>(h.size());
+                    sv.push_back({x, (next_x - start_x) + slot, n});   // split design: heavy slots follow the per-row slots
                     h.push_back({x, slot, n});
                     const int64_t nch = (n + HEAVY - 1) / HEAVY, per = ((n + nch - 1) / nch + 1) & ~int64_t(1);
                     for (int64_t c0 = 0; c0 < n; c0 += per)
@@ -1525,7 +1598,6 @@ class AlsHandle : public HandleBase {
         wl->n_work = static_cast<int>(w.size());
         wl->n_heavy = static_cast<int>(h.size());
         wl->n_solve = static_cast<int>(sv.size());
-        for (const auto& hh : h) wl->heavy_rows.push_back(hh.row);
         wl->solve.resize(std::max<size_t>(1, sv.size()));
         if (!sv.empty()) BFH_HIP(hipMemcpyAsync(wl->solve.get(), sv.data(), sv.size() * sizeof(AlsHeavy), hipMemcpyHostToDevice, stream));
         wl->work.resize(std::max<size_t>(1, w.size()));
@@ -1533,7 +1605,7 @@ class AlsHandle : public HandleBase {
         if (!w.empty()) BFH_HIP(hipMemcpyAsync(wl->work.get(), w.data(), w.size() * sizeof(AlsWork), hipMemcpyHostToDevice, stream));
         if (!h.empty()) BFH_HIP(hipMemcpyAsync(wl->heavy.get(), h.data(), h.size() * sizeof(AlsHeavy), hipMemcpyHostToDevice, stream));
         BFH_HIP(hipStreamSynchronize(stream));
-        const size_t need = std::max<size_t>(1, h.size()) * (static_cast<size_t>(vdim_) * vdim_ + vdim_);
+        const size_t need = std::max<size_t>(1, h.size()) * als_slot_floats(vdim_);
         if (scratch_.size() < need) scratch_.resize(need);
         if (work_cache_.size() > 64) work_cache_.clear();
         return *(work_cache_[key] = std::move(wl));
@@ -1577,7 +1649,7 @@ class AlsHandle : public HandleBase {
         if (name == "als_writeback") writeback_ = v != 0;
         else if (name == "als_v1") force_v1_ = v != 0;
         else if (name == "als_debug") debug_ = static_cast<int>(v);
-        else if (name == "als_fused") design_ = v < 0 ? -1 : (v != 0);   // 1 fused Gramian+solve kernel, 0 split design, -1 per-vdim default
+        else if (name == "als_inreg") no_inreg_ = v == 0;                 // 0: iALS++ rows go through the scratch + solve kernel instead of the in-register solve
         else if (name == "timing") timing = v != 0;
         else throw Error(BFH_ERR_INVALID, "unknown mode '" + name + "'");
     }
@@ -1611,7 +1683,7 @@ class AlsHandle : public HandleBase {
     Axis ax_[2];
     bool force_v1_ = false;
     int debug_ = 0;
-    int design_ = -1;
+    bool no_inreg_ = false;
     DevBuf<float> gscratch_;
     DevBuf<float> scratch_;
     std::map<std::tuple<int, int, int>, std::unique_ptr<WorkList>> work_cache_;

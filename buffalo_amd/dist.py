@@ -1,4 +1,4 @@
-"""Multi-GPU data parallelism for the SGD family (BPRMF / WARP): one process per GPU,
+"""Multi-GPU data parallelism (BPRMF / WARP: DataParallelSGD, ALS: DataParallelALS): one process per GPU,
 `torch.distributed` (backend "nccl" == RCCL over xGMI on ROCm; "gloo" in the CPU tests).
 
 The reference has no multi-device code at all; the scheme below is new:
@@ -128,3 +128,74 @@ class HipEngine:
 
     def update_parameters(self):
         self.obj.update_parameters()
+
+
+class DataParallelALS:
+    """ALS across ranks: rows inside a half-epoch are independent given the
+    other side's factors, so the rows being solved are cut into contiguous nnz-balanced shards, both
+    factor matrices are replicated, and after each half-epoch every rank publishes the rows it solved.
+    The result is the single-GPU result bit for bit: every row is solved by exactly one rank from
+    identical inputs, and FF = F^T F is recomputed by every rank from the (identical) replica -- a
+    0.1 ms kernel at ML-20M/d=128, cheaper than all-reducing partial Gramians and free of a second
+    summation order.
+
+    Exchange: one broadcast per rank of its contiguous row block (P: 71 MB / world at ML-20M d=128,
+    Q: 14 MB / world) -- the uneven-size all-gather written as `world` broadcasts, which RCCL runs as
+    direct xGMI copies.  `engine` offers precompute(axis), partial_update(a, b, axis) -> (nume, deno)
+    over the FULL-matrix row range [a, b) and factor_tensor(axis) -> torch view [rows, vdim] of the side
+    being solved; `HipAlsEngine` adapts CyALS, the CPU tests plug the oracle in."""
+
+    def __init__(self, engine, indptrs, group=None):
+        import torch.distributed as dist
+        self.engine, self.group = engine, group
+        on = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if on else 1
+        self.rank = dist.get_rank(group) if on else 0
+        self.bounds = [shard_bounds(ip, self.world) for ip in indptrs]   # [axis] -> world+1 row boundaries
+
+    def half_epoch(self, axis):
+        import torch
+        self.engine.precompute(axis)
+        b = self.bounds[axis]
+        loss = self.engine.partial_update(b[self.rank], b[self.rank + 1], axis)
+        if self.world == 1:
+            return loss
+        import torch.distributed as dist
+        self.engine.wait()
+        F = self.engine.factor_tensor(axis)
+        for r in range(self.world):
+            if b[r + 1] > b[r]:
+                dist.broadcast(F[b[r]:b[r + 1]], src=dist.get_global_rank(self.group, r) if self.group is not None else r, group=self.group)
+        l = torch.tensor(loss, dtype=torch.float64, device=F.device)
+        dist.all_reduce(l, op=dist.ReduceOp.SUM, group=self.group)
+        if F.is_cuda:
+            torch.cuda.current_stream().synchronize()
+        return float(l[0]), float(l[1])
+
+    def epoch(self):
+        """als.py:165-171: rowwise then colwise half-epoch; returns the summed (nume, deno)."""
+        n0, d0 = self.half_epoch(0)
+        n1, d1 = self.half_epoch(1)
+        return n0 + n1, d0 + d1
+
+
+class HipAlsEngine:
+    """Adapter: buffalo_amd.backend.CyALS with both CSR orientations resident -> DataParallelALS engine."""
+
+    def __init__(self, obj, num_users, num_items, vdim, lindptr, rindptr):
+        self.obj, self.rows, self.vdim = obj, (num_users, num_items), vdim
+        self.indptr = (lindptr, rindptr)
+        obj.set_mode("als_writeback", 0)      # rows stay in HBM; synchronize(True) copies the model out once
+
+    def precompute(self, axis):
+        self.obj.precompute(axis)
+
+    def partial_update(self, a, b, axis):
+        return self.obj.partial_update(a, b, self.indptr[axis], None, None, axis)
+
+    def factor_tensor(self, axis):
+        return self.obj.device_tensor("P" if axis == 0 else "Q", (self.rows[axis], self.vdim))
+
+    def wait(self):
+        import torch
+        torch.cuda.synchronize()

@@ -24,9 +24,9 @@ if "als" in which:
     vals = (1 + rng.poisson(1.0, size=nnz)).astype(np.float32)
     c2 = synth.CSR(U, I, csr.indptr, csr.keys, vals)
     t = c2.transpose()
-    for d in (128, 32):
+    for d, with_loss in ((128, False), (128, True), (32, False), (32, True)):
         P, Q, _ = synth.init_factors(U, I, d, seed=7)
-        opt = {"evaluation_on_learning": False, "compute_loss_on_training": False, "early_stopping_rounds": 0, "save_best": False,
+        opt = {"evaluation_on_learning": False, "compute_loss_on_training": with_loss, "early_stopping_rounds": 0, "save_best": False,
                "evaluation_period": 1, "save_period": 10, "random_seed": 7, "validation": {}, "adaptive_reg": False,
                "save_factors": False, "accelerator": True, "d": d, "num_iters": 10, "num_workers": 8, "hyper_threads": 256,
                "num_cg_max_iters": 3, "reg_u": 0.1, "reg_i": 0.1, "alpha": 8.0, "optimizer": "manual_cg", "cg_tolerance": 1e-10,
@@ -39,8 +39,8 @@ if "als" in which:
         g.set_mode("als_writeback", 0)
         if os.environ.get("ALS_DEBUG"):
             g.set_mode("als_debug", int(os.environ["ALS_DEBUG"]))
-        if os.environ.get("ALS_FUSED"):
-            g.set_mode("als_fused", int(os.environ["ALS_FUSED"]))
+        if os.environ.get("ALS_INREG"):
+            g.set_mode("als_inreg", int(os.environ["ALS_INREG"]))
 
         def epoch():
             for axis, mat in ((0, c2), (1, t)):
@@ -54,9 +54,11 @@ if "als" in which:
             epoch()
         dt = (time.perf_counter() - t0) / n
         st = g.stats()
-        out["als_d%d" % d] = {"epoch_ms": dt * 1e3, "kernel_ms_per_epoch": st["kernel_ms"] / n, "gramian_ms_per_epoch": st["aux_ms"] / n,
+        name = "als_d%d%s" % (d, "_loss" if with_loss else "")
+        mfma_flop = 2 * nnz * (d // 32) * (d // 32 + 1) // 2 * 2 * 32 * 32      # issued: upper-triangle tiles, both half-epochs
+        out[name] = {"epoch_ms": dt * 1e3, "mfma_issued_TFLOPs": mfma_flop / (st["kernel_ms"] / n * 1e-3) / 1e12, "kernel_ms_per_epoch": st["kernel_ms"] / n, "gramian_ms_per_epoch": st["aux_ms"] / n,
                               "interactions_per_s": 2 * nnz / dt, "optimizer": "ialspp(bs=32)" if d >= 128 else "manual_cg(3)"}
-        print("als", d, out["als_d%d" % d], flush=True)
+        print("als", name, out[name], flush=True)
 
 if "warp" in which:
     d = 256

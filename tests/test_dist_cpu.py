@@ -155,3 +155,87 @@ def test_sgd_delta_allreduce_keeps_replicas_consistent(tmp_path):
     # same negatives are drawn (shard offsets), only the visibility of the other rank's item updates differs
     assert H.relerr(outs[0]["Q"], Q) < 0.05
     assert H.relerr(np.concatenate([z["P"] for z in outs]), P) < 0.05
+
+
+# ------------------------------------------------------------------------------------------------
+# ALS: row shards + broadcast of the solved rows
+# ------------------------------------------------------------------------------------------------
+class OracleAlsEngine:
+    """DataParallelALS engine backed by the oracle (tests only)."""
+
+    def __init__(self, o, P, Q, csr, t):
+        self.o, self.F, self.mats = o, (P, Q), (csr, t)
+
+    def precompute(self, axis):
+        self.o.precompute(axis)
+
+    def partial_update(self, a, b, axis):
+        import helpers as H
+        m = self.mats[axis]
+        if a == b:
+            return 0.0, 0.0
+        keys, vals = H.chunk_arrays(m, a, b)
+        return tuple(self.o.partial_update(a, b, m.indptr, keys, vals, axis))
+
+    def factor_tensor(self, axis):
+        import torch
+        return torch.from_numpy(self.F[axis])
+
+    def wait(self):
+        pass
+
+
+def _als_problem(optimizer, d):
+    from conftest import als_opt, tiny_csr
+    csr = tiny_csr(U=70, I=45, density=0.2, seed=11, counts=True)
+    rng = np.random.default_rng(2)
+    P = np.abs(rng.normal(scale=0.2, size=(70, d))).astype(np.float32)
+    Q = np.abs(rng.normal(scale=0.2, size=(45, d))).astype(np.float32)
+    opt = als_opt(d=d, optimizer=optimizer, num_iters=2, alpha=4.0, reg_u=0.1, reg_i=0.2, block_size=8)
+    return csr, opt, P, Q
+
+
+def _als_oracle(opt, P, Q):
+    import helpers as H
+    from oracle import oracle as orc
+    o = orc.OracleALS()
+    assert o.init(H.write_opt(opt))
+    o.initialize_model(P, Q)
+    return o
+
+
+def _als_worker(rank, world, port, optimizer, d, out_dir):
+    import torch.distributed as dist
+    from buffalo_amd.dist import DataParallelALS
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    csr, opt, P, Q = _als_problem(optimizer, d)
+    t = csr.transpose()
+    dp = DataParallelALS(OracleAlsEngine(_als_oracle(opt, P, Q), P, Q, csr, t), (csr.indptr, t.indptr))
+    losses = [dp.epoch() for _ in range(2)]
+    np.savez(os.path.join(out_dir, "als%d.npz" % rank), P=P, Q=Q, losses=np.array(losses))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("optimizer,d", [("manual_cg", 12), ("ialspp", 20)])
+def test_als_row_shards_equal_single_process(optimizer, d, tmp_path):
+    """Every row is solved by exactly one rank from identical inputs => the 2-rank factors equal the
+    1-process factors bit for bit; the (nume, deno) loss pairs agree to summation order."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_als_worker, args=(2, port, optimizer, d, str(tmp_path)), nprocs=2, join=True)
+    outs = [np.load(os.path.join(str(tmp_path), "als%d.npz" % r)) for r in range(2)]
+    csr, opt, P, Q = _als_problem(optimizer, d)
+    t = csr.transpose()
+    eng = OracleAlsEngine(_als_oracle(opt, P, Q), P, Q, csr, t)
+    losses = []
+    for _ in range(2):
+        tot = np.zeros(2)
+        for axis, m in ((0, csr), (1, t)):
+            eng.precompute(axis)
+            tot += eng.partial_update(0, m.num_users, axis)
+        losses.append(tot)
+    for z in outs:
+        np.testing.assert_array_equal(z["P"], P)
+        np.testing.assert_array_equal(z["Q"], Q)
+        np.testing.assert_allclose(z["losses"], np.array(losses), rtol=1e-9)
