@@ -78,6 +78,15 @@ SIGNATURES = {
     "bfh_als_stream": (_vp, [_vp]),
     "bfh_als_get_stats": (_i32, [_vp, C.POINTER(Stats)]),
     "bfh_als_reset_stats": (_i32, [_vp]),
+    "bfh_topk_create": (_vp, []),
+    "bfh_topk_destroy": (None, [_vp]),
+    "bfh_topk_set_device": (_i32, [_vp, _i32]),
+    "bfh_topk_dot_topn": (_i32, [_vp, _pi32, _i32, _pf, _i32, _i32, _pf, _i32, _i32, _pf, _i32, _pi32, _pf, _pi32, _i32, _i32]),
+    "bfh_topk_dot_topn_device": (_i32, [_vp, _pi32, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _pi32, _pf, _pi32, _i32, _i32]),
+    "bfh_topk_quickselect": (_i32, [_vp, _pf, _i32, _i32, _pi32, _i32, _i32]),
+    "bfh_topk_set_mode": (_i32, [_vp, C.c_char_p, _i64]),
+    "bfh_topk_get_stats": (_i32, [_vp, C.POINTER(Stats)]),
+    "bfh_topk_reset_stats": (_i32, [_vp]),
 }
 SIGNATURES.update(_sgd_sigs("bfh_bpr_"))
 SIGNATURES.update(_sgd_sigs("bfh_warp_"))

@@ -1,9 +1,9 @@
 """Thin re-creation of the pieces of buffalo.algo.base / buffalo.evaluate.base the three training
 classes need (/root/reference/buffalo/algo/base.py:12-318, buffalo/evaluate/base.py:9-148).
 
-Inference helpers (top-k, most_similar), id maps and the pickle-framed model format are NEXT rows of
-the scope table; only what `train()` touches is reproduced here, plus a plain
-numpy `topk_recommendation` so examples and parity checks can rank."""
+Only what `train()` touches is reproduced here.  Ranking (validation, `topk_recommendation`) runs on the
+GPU through `buffalo_amd.parallel`; id maps and the pickle-framed model format
+are later rows of the scope table."""
 import logging
 import pickle
 import struct
@@ -58,20 +58,47 @@ class Algo:
         self.__early_stopping["min_loss"] = loss
         return self.__early_stopping["round"] >= self.opt.early_stopping_rounds
 
-    def get_topk(self, scores, k):
-        k = min(k, scores.shape[-1])
-        part = np.argpartition(-scores, k - 1, axis=-1)[..., :k]
-        order = np.argsort(-np.take_along_axis(scores, part, axis=-1), axis=-1)
-        return np.take_along_axis(part, order, axis=-1)
+    def get_topk(self, scores, k, sorted=True, num_threads=4):
+        """evaluate/base.py:31-42 (Evaluable.get_topk): column indices of the k best scores per row, on the GPU."""
+        from ..parallel import quickselect
+        scores = np.ascontiguousarray(scores, dtype=np.float32)
+        many = scores.ndim == 2
+        if not many:
+            scores = scores.reshape(1, -1)
+        k = min(k, scores.shape[1])
+        assert k > 0, f"k({k}) or cols({scores.shape[1]}) should be greater than 0"
+        result = np.empty((scores.shape[0], k), dtype=np.int32)
+        quickselect(scores, result, sorted, num_threads)
+        return result if many else result[0]
 
-    def topk_recommendation(self, rows, topk=10):
-        """Index-based top-k (no id maps): {row: [item indices]}."""
-        rows = list(rows)
-        scores = self.P[rows] @ self.Q.T
+    def _ranker(self):
+        """TopK engine that admits every score -- what numpy scores + quickselect give in algo/base.py:40-55."""
+        eng = getattr(self, "_topk_engine", None)
+        if eng is None:
+            from ..parallel import TopK
+            eng = self._topk_engine = TopK()
+            eng.set_mode("flt_min_rule", 0)
+        return eng
+
+    def _get_topk_recommendation(self, rows, topk, pool=None):
+        """algo/base.py:40-55: (row, [item indices best first]) for every row; scores = P Q^T (+ Qb), fused with the selection."""
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        d = self.opt.d
+        P = np.ascontiguousarray(self.P[:, :d], dtype=np.float32)
+        Q = np.ascontiguousarray(self.Q[:, :d], dtype=np.float32)
         Qb = getattr(self, "Qb", None)
-        if Qb is not None and getattr(self.opt, "use_bias", False):
-            scores = scores + Qb.reshape(1, -1)
-        return dict(zip(rows, self.get_topk(scores, topk)))
+        Qb = np.ascontiguousarray(Qb, dtype=np.float32).reshape(-1, 1) if Qb is not None and getattr(self.opt, "use_bias", False) \
+            else np.array([[]], dtype=np.float32)
+        pool = np.array([], dtype=np.int32) if pool is None else np.ascontiguousarray(pool, dtype=np.int32)
+        k = min(int(topk), Q.shape[0])
+        keys = np.empty((len(rows), k), dtype=np.int32)
+        scores = np.empty((len(rows), k), dtype=np.float32)
+        self._ranker().dot_topn(rows, P, Q, Qb, keys, scores, pool, k)
+        return list(zip(rows.tolist(), keys))
+
+    def topk_recommendation(self, rows, topk=10, pool=None):
+        """Index-based top-k (no id maps): {row: [item indices]}."""
+        return {r: t for r, t in self._get_topk_recommendation(list(rows), topk, pool)}
 
     # -- Serializable (base.py:271-318): u64 count, then (u64 len, name, u64 len, pickle) frames ----
     def save(self, path):
@@ -98,41 +125,80 @@ class Algo:
 
 
 class Evaluable:
-    """Ranking metrics on the held-out `vali` group (evaluate/base.py:44-148, numpy restatement)."""
+    """Ranking / score metrics on the held-out `vali` group: evaluate/base.py:44-148 with the ranking done by
+    the GPU top-k (`_get_topk_recommendation`) instead of numpy scores + OpenMP quickselect."""
 
     def __init__(self, *args, **kwargs):
         pass
 
-    def get_validation_results(self, topk=10):
+    def get_validation_results(self, topk=None):
         if not self.data.has_group("vali"):
             return {}
+        results = {}
+        results.update(self._evaluate_ranking_metrics(topk))
+        results.update(self._evaluate_score_metrics())
+        return results
+
+    def _validation_sets(self):
+        """mm.py / base.py `_prepare_validation_data`: ground truth and already-seen items per validation row."""
         g = self.data.get_group("vali")
-        rows, cols = g["row"], g["col"]
-        users = np.unique(rows)
-        scores = self.P[users][:, :self.opt.d] @ self.Q[:, :self.opt.d].T
+        gt = {}
+        for r, c in zip(g["row"], g["col"]):
+            gt.setdefault(int(r), set()).add(int(c))
+        tr = self.data.get_group("rowwise")
+        seen = {}
+        for u in gt:
+            beg = 0 if u == 0 else int(tr["indptr"][u - 1])
+            seen[u] = set(int(x) for x in tr["key"][beg:int(tr["indptr"][u])])
+        return gt, seen, max((len(s) for s in seen.values()), default=0)
+
+    def _evaluate_ranking_metrics(self, topk=None):  # evaluate/base.py:44-128
+        validation = self.opt.validation or {}
+        batch_size = validation.get("batch", 128)
+        topk = int(topk or validation.get("topk", 10))
+        gt, validation_seen, max_seen = self._validation_sets()
+        rows = np.array(sorted(gt), dtype=np.int32)
+        num_items = self.data.get_header()["num_items"]
+        NDCG = AP = HIT = AUC = N = 0.0
+        idcgs = np.cumsum(1.0 / np.log2(np.arange(2, topk + 2)))
+        dcgs = 1.0 / np.log2(np.arange(2, topk + 2))
+        for index in range(0, len(rows), batch_size):
+            recs = self._get_topk_recommendation(rows[index:index + batch_size], topk=topk + max_seen)
+            for row, cand in recs:
+                seen = validation_seen.get(row, set())
+                if len(seen) == 0:
+                    continue
+                _topk = [int(t) for t in cand if int(t) not in seen][:topk]     # filter_seen_items
+                _gt = gt[row]
+                HIT += len(set(_topk) & _gt) / len(_gt)
+                idcg = idcgs[min(len(_gt), topk) - 1]
+                dcg = hit = miss = ap = auc = 0.0
+                num_pos_items = len(_gt)
+                num_neg_items = num_items - num_pos_items
+                for i, r in enumerate(_topk):
+                    if r in _gt:
+                        hit += 1
+                        ap += hit / (i + 1.0)
+                        dcg += dcgs[i]
+                    else:
+                        miss += 1
+                        auc += hit
+                auc += ((hit + num_pos_items) / 2.0) * (num_neg_items - miss)
+                auc /= (num_pos_items * num_neg_items)
+                NDCG += dcg / idcg
+                AP += ap / min(len(_gt), topk)
+                AUC += auc
+                N += 1.0
+        if N == 0:
+            return {}
+        return {"ndcg": NDCG / N, "map": AP / N, "accuracy": HIT / N, "auc": AUC / N}
+
+    def _evaluate_score_metrics(self):  # evaluate/base.py:130-148
+        g = self.data.get_group("vali")
+        d = self.opt.d
+        pred = np.einsum("ij,ij->i", self.P[g["row"], :d], self.Q[g["col"], :d])
         Qb = getattr(self, "Qb", None)
         if Qb is not None and getattr(self.opt, "use_bias", False):
-            scores = scores + Qb.reshape(1, -1)
-        tr = self.data.get_group("rowwise")
-        pos = {u: i for i, u in enumerate(users)}
-        for u in users:  # seen items never get recommended
-            beg = 0 if u == 0 else int(tr["indptr"][u - 1])
-            scores[pos[u], tr["key"][beg:int(tr["indptr"][u])]] = -np.inf
-        top = self.get_topk(scores, topk)
-        truth = {}
-        for r, c in zip(rows, cols):
-            truth.setdefault(int(r), set()).add(int(c))
-        ndcg = mapk = acc = 0.0
-        idcgs = np.cumsum(1.0 / np.log2(np.arange(2, topk + 2)))
-        for u in users:
-            gt, rec = truth[int(u)], top[pos[u]]
-            hits = np.array([int(x) in gt for x in rec], dtype=np.float64)
-            dcg = (hits / np.log2(np.arange(2, len(rec) + 2))).sum()
-            ndcg += dcg / idcgs[min(len(gt), topk) - 1]
-            prec = np.cumsum(hits) / np.arange(1, len(rec) + 1)
-            mapk += (prec * hits).sum() / min(len(gt), topk)
-            acc += hits.sum() / min(len(gt), topk)
-        n = float(len(users))
-        pred = np.array([self.P[r, :self.opt.d] @ self.Q[c, :self.opt.d] for r, c in zip(rows, cols)])
-        rmse = float(np.sqrt(np.mean((pred - g["val"]) ** 2)))
-        return {"ndcg": ndcg / n, "map": mapk / n, "accuracy": acc / n, "rmse": rmse, "error": rmse}
+            pred = pred + Qb.reshape(-1)[g["col"]]
+        err = pred - g["val"]
+        return {"rmse": float(np.sqrt(np.mean(err * err))), "error": float(np.mean(np.abs(err)))}

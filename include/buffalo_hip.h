@@ -186,6 +186,42 @@ int bfh_bpr_reset_stats(void* h);
 int bfh_warp_reset_stats(void* h);
 int bfh_als_reset_stats(void* h);
 
+/* ------------------------------------------------------------------------------------------------
+ * Top-k selection over factor products   (buffalo/parallel/_core.hpp)
+ * The consumer of P, Q right after training: ParALS/ParBPRMF.topk_recommendation, most_similar
+ * (parallel/base.py:21-28, 46-60) and the validation ranking loop (evaluate/base.py:31-42, 80-82).
+ * ---------------------------------------------------------------------------------------------- */
+void* bfh_topk_create(void);
+void bfh_topk_destroy(void* h);
+int bfh_topk_set_device(void* h, int device);
+/* parallel::dot_topn _core.hpp:89-142 (Cython dot_topn _core.pyx:39-56; the num_threads argument has no
+ * meaning here).  Host arrays in, host arrays out: out_keys/out_scores are [num_queries, k], C order.
+ * Candidates j == indexes[i] are skipped when P == Q (same pointer), a non-empty pool restricts the
+ * candidates, qb_rows == 0 means "no bias".  Admission rule, tie order and padding follow the
+ * reference: only scores > FLT_MIN are ever admitted, kept set = first k by (score desc, index asc),
+ * listed by (score desc, index desc); unfilled slots below min(k, q_rows[, pool_size]) read
+ * (-1, FLT_MIN), the slots above it (-1, 0.0).  k <= 16384. */
+int bfh_topk_dot_topn(void* h, const int32_t* indexes, int num_queries, const float* P, int p_rows, int p_cols,
+                      const float* Q, int q_rows, int q_cols, const float* Qb, int qb_rows, int32_t* out_keys,
+                      float* out_scores, const int32_t* pool, int pool_size, int k);
+/* Same selection with the factor matrices already in HBM (e.g. the "P"/"Q"/"Qb" buffers a training
+ * handle returns from bfh_*_device_buffer): no PCIe traffic except indexes/pool in and results out.
+ * dP/dQ are device pointers to row-major [rows, ld] floats with ld % 8 == 0 and columns >= d zero
+ * (the training layout: ld = vdim); `same` != 0 applies the P == Q self-exclusion. */
+int bfh_topk_dot_topn_device(void* h, const int32_t* indexes, int num_queries, const float* dP, int p_rows, const float* dQ,
+                             int q_rows, int d, int ld, const float* dQb, int qb_rows, int same, int32_t* out_keys,
+                             float* out_scores, const int32_t* pool, int pool_size, int k);
+/* parallel::quickselect _core.hpp:69-87 (evaluate/base.py:31-42): column indices of the k largest
+ * scores of every row of the host matrix scores[rows, cols]; always returned in descending score
+ * order (the reference leaves the order unspecified when sorted == 0).  Ties are broken by the
+ * higher column index first (std::nth_element leaves that unspecified). */
+int bfh_topk_quickselect(void* h, const float* scores, int rows, int cols, int32_t* result, int k, int sorted);
+/* "flt_min_rule" (default 1): 0 admits every score in bfh_topk_dot_topn[_device] -- the selection the
+ * validation loop gets from numpy scores + quickselect (algo/base.py:40-55 of the reference). */
+int bfh_topk_set_mode(void* h, const char* name, int64_t value);
+int bfh_topk_get_stats(void* h, bfh_stats* out);
+int bfh_topk_reset_stats(void* h);
+
 #ifdef __cplusplus
 }
 #endif

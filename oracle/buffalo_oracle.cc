@@ -30,6 +30,7 @@
 #include <cstdint>
 #include <cstring>
 #include <deque>
+#include <limits>
 #include <map>
 #include <mutex>
 #include <numeric>
@@ -1174,6 +1175,81 @@ struct Handle {
 // ============================================================================
 // C ABI consumed by oracle/oracle.py (ctypes)
 // ============================================================================
+// ------------------------------------------------------------------------------------------------
+// Inference-side selection, restating buffalo/parallel/_core.hpp.
+//
+// orc_dot_topn  ~ parallel::dot_topn (_core.hpp:89-142): per query q = indexes[i], candidates j are
+//   visited in ascending order; skipped when the two factor matrices are the same array and j == q
+//   (:117-118) or when a pool is given and j is not in it (:119-120); score = P[q].Q[j] (+ Qb[j]).
+//   The running list (topn_t, :37-67) is kept sorted by descending score in `correct_k` slots that
+//   start as (key -1, val FLT_MIN).  A candidate is admitted only if score > last slot's val
+//   (strict, :124) -- since FLT_MIN is the smallest POSITIVE normal float, non-positive scores are
+//   never admitted -- and is placed in front of the first slot whose val is not greater than it
+//   (lower_bound with `val > that`, :53), i.e. BEFORE earlier candidates of equal score.
+//   Net effect: the kept set is the first k by (score desc, j asc), listed by (score desc, j desc).
+//   Slots correct_k..k-1 are written as (-1, 0.0) (:134-137).
+// orc_quickselect ~ parallel::quickselect (_core.hpp:69-87): std::nth_element over column indices
+//   with `scores[l] > scores[r]`, then std::sort of the first k when `sorted`.
+// ------------------------------------------------------------------------------------------------
+static void dot_topn_ref(const int32_t* indexes, int num_queries, const float* P, int p_rows, int p_cols, const float* Q, int q_rows,
+                         int q_cols, const float* Qb, int qb_rows, int32_t* out_keys, float* out_scores, const int32_t* pool,
+                         int pool_size, int k, int same) {
+    (void)p_rows;
+    std::unordered_set<int32_t> allowed(pool, pool + pool_size);
+    int kk = std::min(q_rows, k);
+    if (pool_size) kk = std::min(pool_size, kk);
+    const int d = std::min(p_cols, q_cols);
+#pragma omp parallel for schedule(guided)
+    for (int i = 0; i < num_queries; ++i) {
+        std::vector<int32_t> keys(std::max(kk, 1), -1);
+        std::vector<float> vals(std::max(kk, 1), std::numeric_limits<float>::min());
+        float last = std::numeric_limits<float>::min();
+        const int q = indexes[i];
+        const float* pq = P + (size_t)q * p_cols;
+        for (int j = 0; j < q_rows && kk > 0; ++j) {
+            if (same && q == j) continue;
+            if (pool_size && !allowed.count(j)) continue;
+            const float* qj = Q + (size_t)j * q_cols;
+            float score = 0.f;
+#pragma omp simd reduction(+ : score)
+            for (int c = 0; c < d; ++c) score += pq[c] * qj[c];
+            if (qb_rows) score += Qb[j];
+            if (!(score > last)) continue;
+            int pos = 0;   // first slot whose value is not greater than the candidate
+            while (pos < kk && vals[pos] > score) ++pos;
+            if (pos >= kk) continue;
+            for (int t = kk - 1; t > pos; --t) {
+                keys[t] = keys[t - 1];
+                vals[t] = vals[t - 1];
+            }
+            keys[pos] = j;
+            vals[pos] = score;
+            last = vals[kk - 1];
+        }
+        for (int t = 0; t < kk; ++t) {
+            out_keys[(size_t)i * k + t] = keys[t];
+            out_scores[(size_t)i * k + t] = vals[t];
+        }
+        for (int t = kk; t < k; ++t) {
+            out_keys[(size_t)i * k + t] = -1;
+            out_scores[(size_t)i * k + t] = 0.0f;
+        }
+    }
+}
+
+static void quickselect_ref(const float* scores, int rows, int cols, int32_t* result, int k, int sorted) {
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int i = 0; i < rows; ++i) {
+        const float* srow = scores + (size_t)i * cols;
+        std::vector<int> order(cols);
+        std::iota(order.begin(), order.end(), 0);
+        auto higher = [&](int l, int r) { return srow[l] > srow[r]; };
+        std::nth_element(order.begin(), order.begin() + k - 1, order.end(), higher);
+        if (sorted) std::sort(order.begin(), order.begin() + k, higher);
+        std::copy(order.begin(), order.begin() + k, result + (size_t)i * k);
+    }
+}
+
 extern "C" {
 
 void* orc_create(int kind) {
@@ -1277,6 +1353,14 @@ void orc_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
 void orc_counter_draw(uint32_t seed, uint32_t stream, uint64_t pos_idx, uint32_t slot, uint32_t epoch,
                       uint32_t attempt, uint32_t* out) {
     counter_draw(seed, stream, pos_idx, slot, epoch, attempt, out);
+}
+
+void orc_dot_topn(const int32_t* indexes, int num_queries, const float* P, int p_rows, int p_cols, const float* Q, int q_rows, int q_cols,
+                  const float* Qb, int qb_rows, int32_t* out_keys, float* out_scores, const int32_t* pool, int pool_size, int k, int same) {
+    dot_topn_ref(indexes, num_queries, P, p_rows, p_cols, Q, q_rows, q_cols, Qb, qb_rows, out_keys, out_scores, pool, pool_size, k, same);
+}
+void orc_quickselect(const float* scores, int rows, int cols, int32_t* result, int k, int sorted) {
+    quickselect_ref(scores, rows, cols, result, k, sorted);
 }
 
 }  // extern "C"

@@ -74,6 +74,8 @@ def lib():
         "orc_philox": (None, [C.c_uint32] * 6 + [pu32]),
         "orc_counter_draw": (None, [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32,
                                     C.c_uint32, pu32]),
+        "orc_dot_topn": (None, [pi32, i32, pf, i32, i32, pf, i32, i32, pf, i32, pi32, pf, pi32, i32, i32, i32]),
+        "orc_quickselect": (None, [pf, i32, i32, pi32, i32, i32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -259,3 +261,21 @@ def counter_draw(seed, stream, pos_idx, slot, epoch, attempt):
     out = (C.c_uint32 * 4)()
     lib().orc_counter_draw(seed, stream, pos_idx, slot, epoch, attempt, out)
     return [int(x) for x in out]
+
+
+def dot_topn(indexes, P, Q, Qb, out_keys, out_scores, pool, k, num_threads=0):
+    """buffalo.parallel._core.dot_topn (_core.pyx:39-56) on the oracle; `P is Q` means "same matrix"."""
+    for a, dt in ((indexes, np.int32), (P, np.float32), (Q, np.float32), (Qb, np.float32), (out_keys, np.int32),
+                  (out_scores, np.float32), (pool, np.int32)):
+        assert a.dtype == dt and a.flags["C_CONTIGUOUS"]
+    qb_rows = Qb.shape[0] if Qb.shape[1] != 0 else 0
+    same = int(P.ctypes.data == Q.ctypes.data)
+    lib().orc_dot_topn(_p(indexes, C.c_int32), indexes.shape[0], _p(P, C.c_float), P.shape[0], P.shape[1],
+                       _p(Q, C.c_float), Q.shape[0], Q.shape[1], _p(Qb, C.c_float), qb_rows,
+                       _p(out_keys, C.c_int32), _p(out_scores, C.c_float), _p(pool, C.c_int32), pool.shape[0], int(k), same)
+
+
+def quickselect(scores, result, sorted, num_threads=0):
+    """buffalo.parallel._core.quickselect (_core.pyx:30-35) on the oracle."""
+    assert scores.dtype == np.float32 and result.dtype == np.int32
+    lib().orc_quickselect(_p(scores, C.c_float), scores.shape[0], scores.shape[1], _p(result, C.c_int32), result.shape[1], int(bool(sorted)))

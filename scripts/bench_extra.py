@@ -133,5 +133,38 @@ if "bpr_pcie" in which:
                                            "note": "80 MB keys H2D (pageable numpy) + fill_rows + kernel + 85 MB D2H per epoch"}
     print("bpr_pcie", out["bpr_host_buffers_every_epoch"], flush=True)
 
+if "topk" in which:
+    # the consumer right after training: top-100 of every user over all items (validation / ParALS.topk_recommendation)
+    from buffalo_amd import parallel as par
+    rng = np.random.default_rng(0)
+    d, k = 128, 100
+    P = rng.normal(scale=0.1, size=(U, d)).astype(np.float32)
+    Q = rng.normal(scale=0.1, size=(I, d)).astype(np.float32)
+    eng = par.TopK()
+    nob, nop = np.array([[]], np.float32), np.array([], np.int32)
+    res = {}
+    for nq in (128, 4096, U):
+        idx = np.arange(nq, dtype=np.int32)
+        ok, osc = np.empty((nq, k), np.int32), np.empty((nq, k), np.float32)
+        eng.dot_topn(idx, P, Q, nob, ok, osc, nop, k)
+        eng.reset_stats()
+        t0 = time.perf_counter()
+        eng.dot_topn(idx, P, Q, nob, ok, osc, nop, k)
+        dt = time.perf_counter() - t0
+        st = eng.stats()
+        res["nq%d" % nq] = {"wall_ms_host_arrays": dt * 1e3, "scores_kernel_ms": st["kernel_ms"], "select_kernel_ms": st["aux_ms"],
+                            "scores_TFLOPs": 2.0 * nq * I * d / (st["kernel_ms"] * 1e-3) / 1e12, "queries_per_s": nq / dt}
+        print("topk", nq, res["nq%d" % nq], flush=True)
+    from oracle import oracle as orc     # CPU restatement of parallel::dot_topn, all host cores (OpenMP), bounded sample
+    nq = 4096
+    idx = np.arange(nq, dtype=np.int32)
+    ok, osc = np.empty((nq, k), np.int32), np.empty((nq, k), np.float32)
+    t0 = time.perf_counter()
+    orc.dot_topn(idx, P, Q, nob, ok, osc, nop, k)
+    dt = time.perf_counter() - t0
+    res["cpu_oracle"] = {"queries": nq, "wall_ms": dt * 1e3, "queries_per_s": nq / dt, "cores": os.cpu_count()}
+    print("topk cpu", res["cpu_oracle"], flush=True)
+    out["topk_ml20m_d128_k100"] = res
+
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "bench_extra.json"), "w"), indent=1)

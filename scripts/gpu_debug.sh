@@ -1,5 +1,5 @@
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
-grep -E "^E  +Assert|^E  +assert|FAILED|passed|failed|rc=" gpurun_out/pytest_gpu.log | cut -c1-300 | tail -30
-timeout 300 python scripts/bench_extra.py als 2>&1 | grep "^als" | cut -c1-330
+timeout 1200 python -m pytest tests/test_topk_gpu.py tests/test_front_gpu.py -m gpu -q --timeout 600 -p no:cacheprovider > gpurun_out/pytest_topk.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_topk.log
+grep -E "^E  +|FAILED|passed|failed|rc=|Error" gpurun_out/pytest_topk.log | cut -c1-300 | tail -40
+timeout 600 python scripts/bench_extra.py topk 2>&1 | grep "^topk" | cut -c1-300

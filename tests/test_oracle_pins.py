@@ -313,3 +313,66 @@ def test_ialspp_matches_transliteration(oracle, opt_file, d, block):
         want = rn.ialspp_row(P0, Q0, FF, u, keys, vals, 3.0, 0.15, block)
         assert np.abs(P[u] - want).max() <= 3e-4 * np.abs(want).max()  # 3 fp32 CG steps per block
     assert not np.allclose(P, P0)
+
+
+# ------------------------------------------------------------------------------------------------
+# parallel::dot_topn / quickselect restatement -- pinned on the reference's
+# own parallel tests (tests/parallel/test_base.py:38-101, numpy argsort as the known answer) and on
+# exact-arithmetic cases for the admission / tie rules of _core.hpp:37-67,115-137
+# ------------------------------------------------------------------------------------------------
+def test_topn_reference_test01_most_similar(oracle):
+    import topk_cases as tc
+    Q = tc.unit_factors(128, 5, seed=1)
+    indexes = np.array([0, 1, 2, 3, 4], dtype=np.int32)
+    keys, scores = tc.run(oracle.dot_topn, indexes, Q, Q, tc.NO_BIAS, tc.EMPTY_POOL, 10)
+    wk, ws = tc.numpy_most_similar(indexes, Q, 10)
+    assert np.array_equal(keys, wk) and np.allclose(scores, ws, atol=1e-7)
+
+
+def test_topn_reference_test03_pool(oracle):
+    import topk_cases as tc
+    Q = tc.unit_factors(128, 5, seed=2)
+    keys, scores = tc.run(oracle.dot_topn, np.arange(5, dtype=np.int32), Q, Q, tc.NO_BIAS, np.array([5, 6, 7], np.int32), 10)
+    assert set(keys.reshape(-1)) == {5, 6, 7, -1}
+    assert np.all(keys[:, 3:] == -1) and np.all(scores[:, 3:] == 0.0)       # slots >= correct_k: (-1, 0.0)
+    assert np.all(np.diff(scores[:, :3], axis=1) <= 0)
+
+
+def test_topn_reference_test04_topk(oracle):
+    import topk_cases as tc
+    P, Q = tc.unit_factors(512, 5, seed=3), tc.unit_factors(128, 5, seed=4)
+    idx = np.array([312, 313, 314, 315, 316], dtype=np.int32)
+    keys, scores = tc.run(oracle.dot_topn, idx, P, Q, tc.NO_BIAS, tc.EMPTY_POOL, 10)
+    wk, ws = tc.numpy_topk(idx, P, Q, 10)
+    assert np.array_equal(keys, wk) and np.allclose(scores, ws, atol=1e-7)
+
+
+@pytest.mark.parametrize("same,bias,pool,k", [(False, False, [], 7), (True, False, [], 7), (False, True, [], 40),
+                                              (True, True, [1, 2, 3, 5, 8, 13, 21, 34], 5), (False, False, [0, 4], 6)])
+def test_topn_admission_and_tie_rules_exact(oracle, same, bias, pool, k):
+    """Integer factors => exact scores with many ties, zeros and negatives: non-positive scores are never
+    admitted (FLT_MIN start value), unfilled slots read (-1, FLT_MIN), equal scores are listed by DESCENDING
+    index, and boundary ties follow the admit-early / evict-oldest rule spelled out in topk_cases.spec_dot_topn."""
+    import topk_cases as tc
+    Q = tc.integer_factors(37, 6, seed=5)
+    P = Q if same else tc.integer_factors(9, 6, seed=6)
+    Qb = tc.integer_factors(37, 1, seed=7, lo=-1, hi=2) if bias else tc.NO_BIAS
+    idx = np.arange(P.shape[0] if not same else 9, dtype=np.int32)
+    keys, scores = tc.run(oracle.dot_topn, idx, P, Q, Qb, np.array(pool, np.int32), k)
+    wk, ws = tc.spec_dot_topn(idx, P, Q, Qb, pool, k, same)
+    assert np.array_equal(keys, wk)
+    assert np.array_equal(scores, ws)
+    assert (keys == -1).any() or k <= 7        # the cases do exercise unfilled slots
+
+
+def test_quickselect_matches_numpy_on_distinct_scores(oracle):
+    rng = np.random.default_rng(11)
+    scores = rng.permutation(64 * 200).reshape(64, 200).astype(np.float32)   # all distinct
+    for k, srt in ((1, True), (10, True), (200, True), (25, False)):
+        res = np.empty((64, k), np.int32)
+        oracle.quickselect(scores, res, srt)
+        want = np.argsort(-scores, axis=1)[:, :k]
+        if srt:
+            assert np.array_equal(res, want)
+        else:
+            assert np.array_equal(np.sort(res, axis=1), np.sort(want, axis=1))
