@@ -11,6 +11,10 @@
 // therefore pinned only by (a) line-by-line correspondence with the reference
 // sources cited on every function and (b) the independent numpy
 // transliterations + analytic micro-cases in tests/test_oracle_pins.py.
+// The inference-side selection (dot_topn / quickselect, bottom of this file)
+// IS pinned by the reference: its own tests compare those functions with numpy
+// argsort (tests/parallel/test_base.py:38-101) and are restated as
+// test_topn_reference_test01/03/04 in tests/test_oracle_pins.py.
 //
 // All citations are relative to /root/reference/.
 // Quirk numbers (Q-n) refer to SURVEY.md section 7.4.
