@@ -78,6 +78,7 @@ SIGNATURES = {
     "bfh_als_stream": (_vp, [_vp]),
     "bfh_als_get_stats": (_i32, [_vp, C.POINTER(Stats)]),
     "bfh_als_reset_stats": (_i32, [_vp]),
+    "bfh_coo_to_csr": (_i32, [_pi32, _pi32, _pf, _i64, _i32, _i32, C.POINTER(_i64), _pi32, _pf, C.POINTER(Stats)]),
     "bfh_topk_create": (_vp, []),
     "bfh_topk_destroy": (None, [_vp]),
     "bfh_topk_set_device": (_i32, [_vp, _i32]),

@@ -63,13 +63,10 @@ class StreamOptions(DataOption):
         return True
 
 
-def _group(num_rows, rows, cols, vals):
-    """(row, col)-sorted CSR group in the reference layout (fileio.hpp:330-378)."""
-    order = np.lexsort((cols, rows))
-    rows, cols, vals = rows[order], cols[order], vals[order]
-    indptr = np.cumsum(np.bincount(rows, minlength=num_rows), dtype=np.int64)
-    return {"indptr": indptr, "key": np.ascontiguousarray(cols, dtype=np.int32),
-            "val": np.ascontiguousarray(vals, dtype=np.float32)}
+def _group(num_rows, num_cols, rows, cols, vals):
+    """(row, col)-sorted CSR group in the reference layout (fileio.hpp:263-420), built on the device."""
+    from ..ingest import coo_to_csr
+    return coo_to_csr(rows, cols, vals, num_rows, num_cols)
 
 
 def _read_ids(src, n, what):
@@ -123,8 +120,8 @@ class Data:
         rows = np.asarray(rows, dtype=np.int64)
         cols = np.asarray(cols, dtype=np.int64)
         vals = np.asarray(vals, dtype=np.float32)
-        self.groups["rowwise"] = _group(num_users, rows, cols, vals)
-        self.groups["colwise"] = _group(num_items, cols, rows, vals)
+        self.groups["rowwise"] = _group(num_users, num_items, rows, cols, vals)
+        self.groups["colwise"] = _group(num_items, num_users, cols, rows, vals)
         if vali is not None and len(vali[0]):
             self.groups["vali"] = {"row": np.asarray(vali[0], dtype=np.int32), "col": np.asarray(vali[1], dtype=np.int32),
                                    "val": np.asarray(vali[2], dtype=np.float32)}

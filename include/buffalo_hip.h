@@ -222,6 +222,17 @@ int bfh_topk_set_mode(void* h, const char* name, int64_t value);
 int bfh_topk_get_stats(void* h, bfh_stats* out);
 int bfh_topk_reset_stats(void* h);
 
+/* ------------------------------------------------------------------------------------------------
+ * COO -> compressed rows on the device   (buffalo/data/fileio.hpp:263-420)
+ * The step right before the training path: _sort_and_compressed_binarization, run once per orientation.
+ * Records are stable-sorted by (major, minor) -- duplicates are kept, in input order -- and come back as
+ * indptr[num_major] (END offsets: records with major id <= k, no leading zero), out_minor[nnz],
+ * out_vals[nnz].  Ids are 0-based here (the reference parses 1-based text and subtracts 1, :396,:401).
+ * Stateless; failures are reported through bfh_last_error(NULL).  `stats` may be NULL.
+ * ---------------------------------------------------------------------------------------------- */
+int bfh_coo_to_csr(const int32_t* major, const int32_t* minor, const float* vals, int64_t nnz, int num_major,
+                   int num_minor, int64_t* indptr, int32_t* out_minor, float* out_vals, bfh_stats* stats);
+
 #ifdef __cplusplus
 }
 #endif

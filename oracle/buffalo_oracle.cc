@@ -1366,5 +1366,25 @@ void orc_dot_topn(const int32_t* indexes, int num_queries, const float* P, int p
 void orc_quickselect(const float* scores, int rows, int cols, int32_t* result, int k, int sorted) {
     quickselect_ref(scores, rows, cols, result, k, sorted);
 }
+// _sort_and_compressed_binarization (buffalo/data/fileio.hpp:263-420) on 0-based in-memory records: stable sort by
+// (major, minor) (:328-339), END-offset indptr (:359-379), minor ids and values in sorted order (:389-410).
+void orc_coo_to_csr(const int32_t* major, const int32_t* minor, const float* vals, int64_t nnz, int num_major, int64_t* indptr,
+                    int32_t* out_minor, float* out_vals) {
+    std::vector<int64_t> order(nnz);
+    std::iota(order.begin(), order.end(), (int64_t)0);
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
+        if (major[a] == major[b]) return minor[a] < minor[b];
+        return major[a] < major[b];
+    });
+    int64_t pos = 0;
+    for (int m = 0; m < num_major; ++m) {
+        while (pos < nnz && major[order[pos]] <= m) ++pos;
+        indptr[m] = pos;
+    }
+    for (int64_t i = 0; i < nnz; ++i) {
+        out_minor[i] = minor[order[i]];
+        out_vals[i] = vals[order[i]];
+    }
+}
 
 }  // extern "C"

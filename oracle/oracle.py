@@ -76,6 +76,7 @@ def lib():
                                     C.c_uint32, pu32]),
         "orc_dot_topn": (None, [pi32, i32, pf, i32, i32, pf, i32, i32, pf, i32, pi32, pf, pi32, i32, i32, i32]),
         "orc_quickselect": (None, [pf, i32, i32, pi32, i32, i32]),
+        "orc_coo_to_csr": (None, [pi32, pi32, pf, i64, i32, pi64, pi32, pf]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -279,3 +280,17 @@ def quickselect(scores, result, sorted, num_threads=0):
     """buffalo.parallel._core.quickselect (_core.pyx:30-35) on the oracle."""
     assert scores.dtype == np.float32 and result.dtype == np.int32
     lib().orc_quickselect(_p(scores, C.c_float), scores.shape[0], scores.shape[1], _p(result, C.c_int32), result.shape[1], int(bool(sorted)))
+
+
+def coo_to_csr(major, minor, vals, num_major, num_minor=None):
+    """fileio.hpp:263-420 on the oracle: same return layout as buffalo_amd.ingest.coo_to_csr."""
+    major = np.ascontiguousarray(major, dtype=np.int32)
+    minor = np.ascontiguousarray(minor, dtype=np.int32)
+    vals = np.ascontiguousarray(vals, dtype=np.float32)
+    nnz = major.shape[0]
+    indptr = np.empty(int(num_major), dtype=np.int64)
+    key = np.empty(nnz, dtype=np.int32)
+    val = np.empty(nnz, dtype=np.float32)
+    lib().orc_coo_to_csr(_p(major, C.c_int32), _p(minor, C.c_int32), _p(vals, C.c_float), nnz, int(num_major),
+                         _p(indptr, C.c_int64), _p(key, C.c_int32), _p(val, C.c_float))
+    return {"indptr": indptr, "key": key, "val": val}

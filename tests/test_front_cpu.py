@@ -10,6 +10,16 @@ from buffalo_amd.data import BufferedDataMatrix, MatrixMarket, MatrixMarketOptio
 from buffalo_amd.misc import Option
 
 
+@pytest.fixture(autouse=True)
+def _oracle_builds_the_groups(monkeypatch, oracle):
+    """The loaders hand their (row, col, val) records to the device (`buffalo_amd.ingest`); there is no GPU in
+    this suite, so the CPU oracle's restatement of the same step stands in for it.  What is under test here
+    is the host logic around it (parsing, hold-out, chunking); tests/test_ingest_gpu.py runs the same loader
+    checks against the real device path."""
+    import buffalo_amd.data as D
+    monkeypatch.setattr(D, "_group", lambda nr, nc, r, c, v: oracle.coo_to_csr(r, c, v, nr, nc))
+
+
 def test_option_defaults_and_validation():
     for cls, key, val in ((ALSOption, "alpha", 8.0), (BPRMFOption, "lr", 0.002), (WARPOption, "max_trials", 500)):
         o = cls()

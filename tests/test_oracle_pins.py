@@ -376,3 +376,23 @@ def test_quickselect_matches_numpy_on_distinct_scores(oracle):
             assert np.array_equal(res, want)
         else:
             assert np.array_equal(np.sort(res, axis=1), np.sort(want, axis=1))
+
+
+def test_coo_to_csr_matches_scipy_and_is_stable(oracle):
+    """fileio.hpp:263-420: stable (row, col) sort keeping duplicates, END-offset indptr."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(4)
+    n, R, Cc = 5000, 70, 40
+    r = rng.integers(0, R, n).astype(np.int32)
+    r[r == 13] = 14                                   # an empty row in the middle; rows 0.. may be empty at the ends too
+    c = rng.integers(0, Cc, n).astype(np.int32)
+    v = np.arange(n, dtype=np.float32)               # distinct values make the record order visible
+    g = oracle.coo_to_csr(r, c, v, R + 3, Cc)         # three trailing empty rows
+    order = np.lexsort((np.arange(n), c, r))          # stable: input order breaks (row, col) ties
+    assert np.array_equal(g["key"], c[order]) and np.array_equal(g["val"], v[order])
+    want = np.cumsum(np.bincount(r, minlength=R + 3))
+    assert np.array_equal(g["indptr"], want) and g["indptr"][13] == g["indptr"][12] and g["indptr"][-1] == n
+    M = sp.coo_matrix((np.ones(n, np.float32), (r, c)), shape=(R + 3, Cc)).tocsr()   # scipy sums duplicates: compare the pattern
+    M.sort_indices()
+    assert np.array_equal(np.unique(np.stack([np.repeat(np.arange(R + 3), np.diff(np.concatenate([[0], g["indptr"]]))), g["key"]]), axis=1),
+                          np.stack([np.repeat(np.arange(R + 3), np.diff(M.indptr)), M.indices]))
