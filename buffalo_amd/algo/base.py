@@ -5,8 +5,6 @@ Only what `train()` touches is reproduced here.  Ranking (validation, `topk_reco
 GPU through `buffalo_amd.parallel`; id maps and the pickle-framed model format
 are later rows of the scope table."""
 import logging
-import pickle
-import struct
 
 import numpy as np
 
@@ -100,25 +98,43 @@ class Algo:
         """Index-based top-k (no id maps): {row: [item indices]}."""
         return {r: t for r, t in self._get_topk_recommendation(list(rows), topk, pool)}
 
-    # -- Serializable (base.py:271-318): u64 count, then (u64 len, name, u64 len, pickle) frames ----
-    def save(self, path):
+    # -- id maps (base.py:157-180) ----------------------------------------------------------------
+    def build_itemid_map(self):
+        ids = list(getattr(self.data, "itemids", None) or map(str, range(self.data.get_header()["num_items"])))
+        self._idmanager.itemids = ids
+        self._idmanager.itemid_map = {v: idx for idx, v in enumerate(ids)}
+        self._idmanager.itemid_mapped = True
+
+    def build_userid_map(self):
+        ids = list(getattr(self.data, "userids", None) or map(str, range(self.data.get_header()["num_users"])))
+        self._idmanager.userids = ids
+        self._idmanager.userid_map = {v: idx for idx, v in enumerate(ids)}
+        self._idmanager.userid_mapped = True
+
+    # -- Serializable (base.py:271-318): files are byte-compatible with stock buffalo, see buffalo_amd/serialize.py
+    def save(self, path=None, with_itemid_map=True, with_userid_map=True, data_fields=()):
+        from ..serialize import dump_objects
+        if path is None:
+            path = self.opt.model_path
+        if with_itemid_map and not self._idmanager.itemid_mapped and getattr(self, "data", None) is not None:
+            self.build_itemid_map()
+        if with_userid_map and not self._idmanager.userid_mapped and getattr(self, "data", None) is not None:
+            self.build_userid_map()
         data = self._get_data()
-        with open(path, "wb") as fout:
-            fout.write(struct.pack("Q", len(data)))
-            for name, obj in data:
-                nb, ob = name.encode("utf8"), pickle.dumps(obj, protocol=4)
-                fout.write(struct.pack("Q", len(nb)) + nb + struct.pack("Q", len(ob)) + ob)
+        if data_fields:
+            data = [(k, v) for k, v in data if k in data_fields]
+        dump_objects(path, data)
 
     def load(self, path, data_fields=()):
-        with open(path, "rb") as fin:
-            (n,) = struct.unpack("Q", fin.read(8))
-            for _ in range(n):
-                (ln,) = struct.unpack("Q", fin.read(8))
-                name = fin.read(ln).decode("utf8")
-                (lo,) = struct.unpack("Q", fin.read(8))
-                blob = fin.read(lo)
-                if not data_fields or name in data_fields:
-                    setattr(self, name, pickle.loads(blob))
+        from ..serialize import load_objects
+        for name, obj in load_objects(path, data_fields):
+            setattr(self, name, obj)
+
+    @classmethod
+    def instantiate(cls, cls_opt, path, data_fields=()):   # base.py:313-318
+        c = cls(cls_opt().get_default_option())
+        c.load(path, data_fields)
+        return c
 
     def _get_data(self):
         return [("_idmanager", self._idmanager)]
