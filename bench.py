@@ -56,8 +56,10 @@ def load_matrix(shape_name, seed):
         z = np.load(cache)
         return synth.CSR(U, I, z["indptr"], z["keys"], np.ones(z["keys"].shape[0], np.float32))
     csr = synth.generate(U, I, nnz, seed=seed)
-    try:
-        np.savez(cache, indptr=csr.indptr, keys=csr.keys)
+    try:   # written under a private name and renamed: N ranks may get here at the same time
+        tmp = "%s.%d.tmp.npz" % (cache, os.getpid())
+        np.savez(tmp, indptr=csr.indptr, keys=csr.keys)
+        os.replace(tmp, cache)
     except OSError:
         pass
     return csr
