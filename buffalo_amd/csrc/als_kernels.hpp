@@ -17,6 +17,8 @@
 #include <memory>
 #include <tuple>
 
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace bfh {
@@ -1206,6 +1208,341 @@ __global__ __launch_bounds__(256, 2) void als_gram_kernel(AlsParams p, const Als
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 128 < vdim <= 256 (iALS++ at d = 160 ... 256, block_size 32, d % 32 == 0): the upper triangle of M has
+// T(T+1)/2 = 15 ... 36 tiles -- too many accumulators for one wave, and M (up to 263 KB) does not fit LDS.
+// A block of W = ceil(T/2) waves owns the row: wave w keeps tile-rows w and T-1-w (T+1 tiles, <= 144
+// accumulator registers; the middle row alone when T is odd), loads only the column blocks w..T-1 of each
+// q row, and the block recurrence of als_ialspp_inreg runs across the waves: for block blk every wave adds
+// the products of ITS tiles in column blk / row blk into an LDS vector, the wave that owns the diagonal tile
+// runs the three CG steps, the new p_blk goes back through LDS.  Two barriers per block, M never leaves the
+// registers.  Heavy rows: their chunks add into a scratch slot and a second launch (`finalize`) starts from
+// FF + slot instead of the nnz pass.  The wave index picks one of W instantiations so that every tile,
+// operand and accumulator index is a compile-time constant.
+// ------------------------------------------------------------------------------------------------
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void als_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        als_static_for<N, I + 1>(f);
+    }
+}
+
+template <int T, int WV>
+struct AlsWide {
+    static constexpr int W = (T + 1) / 2;
+    static constexpr int R0 = WV, R1 = T - 1 - WV;
+    static constexpr bool TWO = R1 != R0;
+    static constexpr int N0 = T - R0;                 // tiles of row R0: columns R0 .. T-1
+    static constexpr int N1 = TWO ? T - R1 : 0;       // tiles of row R1: columns R1 .. T-1
+    static constexpr int NTW = N0 + N1;
+    static constexpr int NB = T - R0;                 // column blocks R0 .. T-1 are loaded (R1 >= R0)
+    // slot of tile (a, b), a in {R0, R1}, b >= a
+    static constexpr int slot(int a, int b) { return a == R0 ? b - R0 : N0 + (b - R1); }
+    static constexpr bool owns_row(int a) { return a == R0 || (TWO && a == R1); }
+};
+
+struct AlsWideLds {          // carved from dynamic LDS: vdim | W*32 | 32 | 32 | 8 floats
+    float* pc;               // the row (current iterate)
+    float* contrib;          // [W][32] column-product partials of the waves
+    float* rowres;           // [32] row-product result of the diagonal tile's owner
+    float* pvs;              // [32] CG direction
+    float* red;              // [8] loss partials
+};
+
+template <int T, int WV>
+__device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork& wk, bool finalize, float* __restrict__ scratch, const AlsWideLds& L,
+                                              int lane, int half, int col, double& nume_k, double& deno_k) {
+    using C = AlsWide<T, WV>;
+    constexpr int NTW = C::NTW, NB = C::NB, R0 = C::R0, R1 = C::R1, VD = 32 * T, W = C::W;
+    constexpr bool TWO = C::TWO;
+    constexpr int UP = 4;
+    constexpr unsigned row_bytes = VD * 4u;
+    const bool lossk = p.compute_loss && p.axis == 1;
+    const bool partial = !finalize && wk.slot >= 0;   // chunk of a heavy row: tiles go to the scratch slot, no solve
+    float* Pu = p.P + static_cast<size_t>(wk.row) * VD;
+
+    f32x16 acc[NTW];
+    float gp0 = 0.f, gp1 = 0.f, g10 = 0.f, g11 = 0.f;   // g / g1 shares of rows R0, R1
+    {   // accumulators start from FF (+ the heavy row's summed chunk tiles when finalizing); zero for a chunk
+        const float* Fl = p.FF + half * 4 * VD + col;
+        const float* Sl = scratch + static_cast<size_t>(wk.slot >= 0 ? wk.slot : 0) * als_slot_floats(VD) + half * 4 * VD + col;
+        asm volatile("" : "+v"(Fl));
+#pragma unroll
+        for (int s = 0; s < NTW; ++s) {
+            const int a = s < C::N0 ? R0 : R1, b = s < C::N0 ? R0 + s : R1 + (s - C::N0);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int off = (a * 32 + (e & 3) + 8 * (e >> 2)) * VD + b * 32;
+                acc[s][e] = partial ? 0.f : Fl[off] + (finalize ? Sl[off] : 0.f);
+            }
+        }
+    }
+    if (!finalize) {
+        const int64_t n = wk.kend - wk.kbeg;
+        const int64_t nchunks = (n + 63) / 64;
+        const char* qbase = reinterpret_cast<const char*>(p.Q + R0 * 32);   // blocks R0 .. T-1
+        auto fetch_keys = [&](int64_t chunk, int& cc, float& vvv) {
+            const int64_t kk = chunk * 64 + lane;
+            cc = 0;
+            vvv = 0.f;
+            if (kk < n) {
+                cc = p.keys[wk.kbeg + kk];
+                vvv = p.vals[wk.kbeg + kk];
+                if (lossk && WV == 0) {
+                    const double w = static_cast<double>(vvv * p.alpha);
+                    deno_k += w;
+                    nume_k += 1.0 + w;
+                }
+            }
+        };
+        auto load_pair = [&](int myc, float myv, int pr, float (&q)[NB], float& v) {
+            const int c0 = __builtin_amdgcn_readlane(myc, 2 * pr), c1 = __builtin_amdgcn_readlane(myc, 2 * pr + 1);
+            const float v0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myv), 2 * pr));
+            const float v1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myv), 2 * pr + 1));
+            v = half ? v1 : v0;
+            const unsigned voff = static_cast<unsigned>(half ? c1 : c0) * row_bytes + static_cast<unsigned>(col) * 4u;
+            const float* q_ = reinterpret_cast<const float*>(qbase + voff);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) q[b] = q_[b * 32];
+        };
+        auto consume = [&](const float (&q)[NB], float v, float one) {
+            const float wgt = p.alpha * v;
+            const float lo = lossk ? one : 0.f;
+            const float a0 = wgt * q[0];                       // block R0
+#pragma unroll
+            for (int s = 0; s < C::N0; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, q[s], acc[s], 0, 0, 0);
+            gp0 += wgt * q[0];
+            g10 += lo * q[0];
+            if (TWO) {
+                const float a1 = wgt * q[R1 - R0];             // block R1
+#pragma unroll
+                for (int s = 0; s < C::N1; ++s)
+                    acc[C::N0 + s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, q[R1 - R0 + s], acc[C::N0 + s], 0, 0, 0);
+                gp1 += wgt * q[R1 - R0];
+                g11 += lo * q[R1 - R0];
+            }
+        };
+        auto nnz_of = [&](int64_t ch) { return ch < nchunks ? static_cast<int>((n - ch * 64) < 64 ? (n - ch * 64) : 64) : 0; };
+        auto groups_of = [&](int64_t ch) { return (nnz_of(ch) >> 1) / UP; };
+        int myc, myc_n;
+        float myv, myv_n;
+        fetch_keys(0, myc, myv);
+        fetch_keys(1, myc_n, myv_n);
+        float qa[UP][NB], va[UP];
+        if (groups_of(0) > 0) {
+#pragma unroll
+            for (int uu = 0; uu < UP; ++uu) load_pair(myc, myv, uu, qa[uu], va[uu]);
+        }
+        for (int64_t ch = 0; ch < nchunks; ++ch) {
+            const int npairs = (nnz_of(ch) + 1) >> 1;
+            const int ngroups = groups_of(ch);
+            for (int gidx = 0; gidx < ngroups; ++gidx) {   // same pipelining as als_gram_kernel
+                float qb[UP][NB], vb[UP];
+                const bool here = gidx + 1 < ngroups;
+                const int src_c = here ? myc : myc_n;
+                const float src_v = here ? myv : myv_n;
+                const int pr0 = here ? (gidx + 1) * UP : 0;
+#pragma unroll
+                for (int uu = 0; uu < UP; ++uu) load_pair(src_c, src_v, pr0 + uu, qb[uu], vb[uu]);
+#pragma unroll
+                for (int uu = 0; uu < UP; ++uu) consume(qa[uu], va[uu], 1.0f);
+#pragma unroll
+                for (int uu = 0; uu < UP; ++uu) {
+                    va[uu] = vb[uu];
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) qa[uu][b] = qb[uu][b];
+                }
+#pragma unroll
+                for (int i = 0; i < UP * NTW; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x006, 2, 0);
+                    if (i % 2 == 0 && i / 2 < UP * NB) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+            }
+            for (int pr = ngroups * UP; pr < npairs; ++pr) {
+                float q1[NB], v1;
+                load_pair(myc, myv, pr, q1, v1);
+                consume(q1, v1, (ch * 64 + 2 * pr + half < n) ? 1.0f : 0.f);
+            }
+            myc = myc_n;
+            myv = myv_n;
+            fetch_keys(ch + 2, myc_n, myv_n);
+        }
+    }
+    // the two halves hold the k-parities of the same element
+    gp0 += __shfl_xor(gp0, 32, 64); gp1 += __shfl_xor(gp1, 32, 64);
+    g10 += __shfl_xor(g10, 32, 64); g11 += __shfl_xor(g11, 32, 64);
+
+    float* S = scratch + static_cast<size_t>(wk.slot >= 0 ? wk.slot : 0) * als_slot_floats(VD);
+    if (partial) {   // add this chunk's tiles / vector shares into the (zeroed) slot
+        float* Sl = S + half * 4 * VD + col;
+#pragma unroll
+        for (int s = 0; s < NTW; ++s) {
+            const int a = s < C::N0 ? R0 : R1, b = s < C::N0 ? R0 + s : R1 + (s - C::N0);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) atomic_add_f32(Sl + (a * 32 + (e & 3) + 8 * (e >> 2)) * VD + b * 32, acc[s][e]);
+        }
+        if (half == 0) {
+            atomic_add_f32(S + VD * VD + R0 * 32 + col, gp0);
+            if (lossk) atomic_add_f32(S + VD * VD + VD + R0 * 32 + col, g10);
+            if (TWO) {
+                atomic_add_f32(S + VD * VD + R1 * 32 + col, gp1);
+                if (lossk) atomic_add_f32(S + VD * VD + VD + R1 * 32 + col, g11);
+            }
+        }
+        return;
+    }
+    if (finalize) {   // g, g1 were summed in the slot
+        gp0 = S[VD * VD + R0 * 32 + col];
+        g10 = lossk ? S[VD * VD + VD + R0 * 32 + col] : 0.f;
+        if (TWO) {
+            gp1 = S[VD * VD + R1 * 32 + col];
+            g11 = lossk ? S[VD * VD + VD + R1 * 32 + col] : 0.f;
+        }
+    }
+
+    // ---------------- iALS++ across the W waves (als.cc:269-352, see als_ialspp_inreg) ----------------
+    for (int e = threadIdx.x; e < VD; e += 64 * W) L.pc[e] = Pu[e];
+    __syncthreads();
+    // this wave's share of (M x)[32 blk + col] for x = pc: column products of its tiles in column blk go to
+    // contrib[WV], the row products of row blk (if it owns it) to rowres; the caller sums after a barrier
+    auto block_partials = [&](auto blk_c) {
+        constexpr int blk = decltype(blk_c)::value;
+        float part = 0.f;
+        if constexpr (R0 <= blk) part += als_tile_colpart(acc[C::slot(R0, blk)], L.pc + R0 * 32, half);
+        if constexpr (TWO && R1 <= blk) part += als_tile_colpart(acc[C::slot(R1, blk)], L.pc + R1 * 32, half);
+        part += __shfl_xor(part, 32, 64);
+        if (half == 0) L.contrib[WV * 32 + col] = part;
+        if constexpr (C::owns_row(blk)) {
+            float y = 0.f;
+            if constexpr (blk < T - 1) {
+                float z[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) z[e] = 0.f;
+#pragma unroll
+                for (int jb = blk + 1; jb < T; ++jb) {
+                    const float xv = L.pc[jb * 32 + col];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) z[e] += acc[C::slot(blk, jb)][e] * xv;
+                }
+                y = als_rows_reduce(z, lane);
+            }
+            const int es = (lane >> 1) & 15;
+            if (!(lane & 1)) L.rowres[(es & 3) + 8 * (es >> 2) + 4 * half] = y;
+        }
+    };
+    auto block_sum = [&]() {
+        float s = L.rowres[col];
+#pragma unroll
+        for (int w = 0; w < W; ++w) s += L.contrib[w * 32 + col];
+        return s;
+    };
+    const float ada = p.adaptive_reg ? static_cast<float>(wk.kend - wk.kbeg) : 1.0f;
+    (void)ada;
+    if (p.compute_loss) {   // als.cc:288-309 on the row at entry: reg*ada*|p|^2 (+ p^T M p - 2 p.(g_w + g_1) on the item side)
+        float pp = 0.f, pmp = 0.f, pg = 0.f;
+        als_static_for<T>([&](auto blk_c) {
+            constexpr int blk = decltype(blk_c)::value;
+            if (p.axis == 1) {
+                block_partials(blk_c);
+                __syncthreads();
+                if (WV == 0) pmp += L.pc[blk * 32 + col] * block_sum();
+                __syncthreads();
+            }
+            if constexpr (C::owns_row(blk)) {
+                const float pv = L.pc[blk * 32 + col];
+                pp += pv * pv;
+                pg += pv * (blk == R0 ? gp0 + g10 : gp1 + g11);
+            }
+        });
+        pp = wave_sum(half == 0 ? pp : 0.f);
+        pg = wave_sum(half == 0 ? pg : 0.f);
+        pmp = wave_sum(half == 0 ? pmp : 0.f);
+        if (lane == 0) {
+            // heavy rows: ada uses the full row length, which the finalize item carries in kend - kbeg
+            nume_k += static_cast<double>(ada * p.reg * pp);
+            if (p.axis == 1) {
+                nume_k += static_cast<double>(pmp) - 2.0 * static_cast<double>(pg);
+                if (WV == 0) deno_k += static_cast<double>(p.op_rows);
+            }
+        }
+    }
+    als_static_for<T>([&](auto blk_c) {
+        constexpr int blk = decltype(blk_c)::value;
+        block_partials(blk_c);
+        __syncthreads();
+        if constexpr (C::owns_row(blk)) {   // this wave holds the diagonal tile and g_blk: gradient + 3 CG steps (als.cc:286-346)
+            const float pblk = L.pc[blk * 32 + col];
+            const float gblk = blk == R0 ? gp0 : gp1;
+            const float bi = block_sum() - gblk + p.reg * pblk;
+            float xr = 0.f, rr = bi, pvr = bi;
+            double rsold = static_cast<double>(wave_sum(half == 0 ? rr * rr : 0.f));
+            if (rsold > static_cast<double>(p.cg_tol)) {
+                for (int step = 0; step < 3; ++step) {
+                    wave_lds_sync();
+                    if (half == 0) L.pvs[col] = pvr;
+                    wave_lds_sync();
+                    float ap = als_tile_colpart(acc[C::slot(blk, blk)], L.pvs, half);
+                    ap += __shfl_xor(ap, 32, 64);
+                    ap += p.reg * pvr;
+                    const float pap = wave_sum(half == 0 ? pvr * ap : 0.f);
+                    const float step_size = static_cast<float>(rsold / static_cast<double>(pap));
+                    xr += step_size * pvr;
+                    rr -= step_size * ap;
+                    const double rsnew = static_cast<double>(wave_sum(half == 0 ? rr * rr : 0.f));
+                    if (rsnew < static_cast<double>(p.cg_tol)) break;
+                    pvr = rr + static_cast<float>(rsnew / rsold) * pvr;
+                    rsold = rsnew;
+                }
+            }
+            if (half == 0 && !(p.debug & 1)) L.pc[blk * 32 + col] = pblk - xr;
+        }
+        __syncthreads();
+    });
+    for (int e = threadIdx.x; e < VD; e += 64 * W) Pu[e] = L.pc[e];
+    __syncthreads();
+}
+
+template <int T>
+__global__ __launch_bounds__(64 * ((T + 1) / 2), 2) void als_wide_kernel(AlsParams p, const AlsWork* __restrict__ work, int n_items,
+                                                                         float* __restrict__ scratch, int finalize) {
+    constexpr int W = (T + 1) / 2, VD = 32 * T;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    AlsWideLds L;
+    L.pc = lds;
+    L.contrib = lds + VD;
+    L.rowres = L.contrib + W * 32;
+    L.pvs = L.rowres + 32;
+    L.red = L.pvs + 32;
+    int* s_item = reinterpret_cast<int*>(L.red + 8);
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5, col = lane & 31;
+    double nume_k = 0.0, deno_k = 0.0;
+    while (true) {
+        __syncthreads();
+        if (threadIdx.x == 0) *s_item = atomicAdd(p.ticket, 1);
+        __syncthreads();
+        const int item = *s_item;
+        if (item >= n_items) break;
+        const AlsWork wk = work[item];
+        if (wv == 0) als_wide_item<T, 0>(p, wk, finalize != 0, scratch, L, lane, half, col, nume_k, deno_k);
+        else if (wv == 1) als_wide_item<T, 1>(p, wk, finalize != 0, scratch, L, lane, half, col, nume_k, deno_k);
+        else if (wv == 2) als_wide_item<T, 2>(p, wk, finalize != 0, scratch, L, lane, half, col, nume_k, deno_k);
+        else als_wide_item<T, (W > 3 ? 3 : 0)>(p, wk, finalize != 0, scratch, L, lane, half, col, nume_k, deno_k);
+    }
+    if (p.compute_loss) {
+        nume_k = wave_sum_f64(nume_k);
+        deno_k = wave_sum_f64(deno_k);
+        if (lane == 0) {
+            if (nume_k != 0.0) atomicAdd(p.loss, nume_k);
+            if (deno_k != 0.0) atomicAdd(p.loss + 1, deno_k);
+        }
+    }
+}
+__host__ __device__ inline size_t als_wide_lds_bytes(int vdim) { return (static_cast<size_t>(vdim) + 4 * 32 + 32 + 32 + 8 + 4) * sizeof(float); }
+
 struct AlsHeavy {
     int row, slot;
     int64_t n;
@@ -1470,8 +1807,11 @@ class AlsHandle : public HandleBase {
         const int K = (vdim_ + 63) / 64;
         // the Gramian kernels address the other factor with 32-bit byte offsets
         const bool gram_path = vdim_ <= 128 && !force_v1_ && static_cast<uint64_t>(p.op_rows) * vdim_ * 4 < (1ull << 32);
+        // 128 < vdim <= 256: block-per-row kernel with the tiles spread over ceil(T/2) waves (als_wide_kernel)
+        const bool wide_path = !gram_path && !force_v1_ && vdim_ > 128 && vdim_ <= 256 && code_ == 8 && block_size_ == 32 && d_ == vdim_ &&
+                               static_cast<uint64_t>(p.op_rows) * vdim_ * 4 < (1ull << 32);
         const WorkList* wl = nullptr;
-        if (gram_path) {
+        if (gram_path || wide_path) {
             wl = &work_list(axis, start_x, next_x, ip, beg);
             if (wl->n_heavy) BFH_HIP(hipMemsetAsync(scratch_.get(), 0, static_cast<size_t>(wl->n_heavy) * als_slot_floats(vdim_) * sizeof(float), stream));
         }
@@ -1523,6 +1863,30 @@ class AlsHandle : public HandleBase {
                                    static_cast<int>(code_));
                 BFH_HIP(hipGetLastError());
             }
+        } else if (wide_path) {
+            const int T = vdim_ / 32;
+            const size_t lds = als_wide_lds_bytes(vdim_);
+            int blocks = std::min(wl->n_work, num_cus_ * 2);
+#define BFH_WIDE(TT, ITEMS, N, FIN)                                                                                              \
+    hipLaunchKernelGGL(als_wide_kernel<TT>, dim3(std::max(1, std::min(N, num_cus_ * 2))), dim3(64 * ((TT + 1) / 2)), lds, stream, p, ITEMS, N, \
+                       scratch_.get(), FIN)
+#define BFH_WIDE_T(ITEMS, N, FIN)                  \
+    do {                                           \
+        if (T == 5) BFH_WIDE(5, ITEMS, N, FIN);    \
+        else if (T == 6) BFH_WIDE(6, ITEMS, N, FIN); \
+        else if (T == 7) BFH_WIDE(7, ITEMS, N, FIN); \
+        else BFH_WIDE(8, ITEMS, N, FIN);           \
+    } while (0)
+            (void)blocks;
+            if (wl->n_work > 0) BFH_WIDE_T(wl->work.get(), wl->n_work, 0);
+            BFH_HIP(hipGetLastError());
+            if (wl->n_heavy) {   // heavy rows: FF + summed chunk tiles -> solve
+                BFH_HIP(hipMemsetAsync(ticket_.get(), 0, sizeof(int), stream));
+                BFH_WIDE_T(wl->heavy_work.get(), wl->n_heavy, 1);
+                BFH_HIP(hipGetLastError());
+            }
+#undef BFH_WIDE_T
+#undef BFH_WIDE
         } else if (code_ == 8) {
             const int bs = block_size_ < d_ ? block_size_ : d_;
             const int KB = (bs + 63) / 64;
@@ -1567,6 +1931,7 @@ class AlsHandle : public HandleBase {
         DevBuf<AlsWork> work;
         DevBuf<AlsHeavy> heavy;   // fused kernels: heavy rows only (slot = scratch slot)
         DevBuf<AlsHeavy> solve;   // split design: every non-empty row, longest first (slot = row - start_x)
+        DevBuf<AlsWork> heavy_work;   // wide kernel's finalize launch: one item per heavy row (kend - kbeg = its nnz)
         int n_work = 0, n_heavy = 0, n_solve = 0;
     };
     // Work items of one partial_update call: one per non-empty row, rows above HEAVY nnz cut into
@@ -1609,6 +1974,12 @@ class AlsHandle : public HandleBase {
         if (!sv.empty()) BFH_HIP(hipMemcpyAsync(wl->solve.get(), sv.data(), sv.size() * sizeof(AlsHeavy), hipMemcpyHostToDevice, stream));
         wl->work.resize(std::max<size_t>(1, w.size()));
         wl->heavy.resize(std::max<size_t>(1, h.size()));
+        {
+            std::vector<AlsWork> hw;
+            for (const auto& hh : h) hw.push_back({hh.row, 0, static_cast<int>(hh.n), hh.slot});
+            wl->heavy_work.resize(std::max<size_t>(1, hw.size()));
+            if (!hw.empty()) BFH_HIP(hipMemcpyAsync(wl->heavy_work.get(), hw.data(), hw.size() * sizeof(AlsWork), hipMemcpyHostToDevice, stream));
+        }
         if (!w.empty()) BFH_HIP(hipMemcpyAsync(wl->work.get(), w.data(), w.size() * sizeof(AlsWork), hipMemcpyHostToDevice, stream));
         if (!h.empty()) BFH_HIP(hipMemcpyAsync(wl->heavy.get(), h.data(), h.size() * sizeof(AlsHeavy), hipMemcpyHostToDevice, stream));
         BFH_HIP(hipStreamSynchronize(stream));

@@ -24,7 +24,7 @@ if "als" in which:
     vals = (1 + rng.poisson(1.0, size=nnz)).astype(np.float32)
     c2 = synth.CSR(U, I, csr.indptr, csr.keys, vals)
     t = c2.transpose()
-    for d, with_loss in ((128, False), (128, True), (32, False), (32, True)):
+    for d, with_loss in ((128, False), (128, True), (32, False), (32, True), (256, False)):
         P, Q, _ = synth.init_factors(U, I, d, seed=7)
         opt = {"evaluation_on_learning": False, "compute_loss_on_training": with_loss, "early_stopping_rounds": 0, "save_best": False,
                "evaluation_period": 1, "save_period": 10, "random_seed": 7, "validation": {}, "adaptive_reg": False,
@@ -55,7 +55,10 @@ if "als" in which:
         dt = (time.perf_counter() - t0) / n
         st = g.stats()
         name = "als_d%d%s" % (d, "_loss" if with_loss else "")
-        mfma_flop = 2 * nnz * (d // 32) * (d // 32 + 1) // 2 * 2 * 32 * 32      # issued: upper-triangle tiles, both half-epochs
+        T_ = d // 32
+
+        tiles = T_ * (T_ + 1) // 2
+        mfma_flop = 2 * nnz * tiles * 2 * 32 * 32      # issued: upper-triangle tiles, both half-epochs
         out[name] = {"epoch_ms": dt * 1e3, "mfma_issued_TFLOPs": mfma_flop / (st["kernel_ms"] / n * 1e-3) / 1e12, "kernel_ms_per_epoch": st["kernel_ms"] / n, "gramian_ms_per_epoch": st["aux_ms"] / n,
                               "interactions_per_s": 2 * nnz / dt, "optimizer": "ialspp(bs=32)" if d >= 128 else "manual_cg(3)"}
         print("als", name, out[name], flush=True)

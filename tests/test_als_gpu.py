@@ -76,26 +76,35 @@ CASES = [
     (100, dict(optimizer="ialspp", block_size=7)),      # tests/algo/test_als.py:92-101
     (128, dict(optimizer="manual_cg")),                 # Q-13: silently iALS++
     (256, dict(optimizer="llt", block_size=32)),        # tests/algo/test_als.py:103-112
-    (160, dict(optimizer="ialspp", block_size=64)),
+    (160, dict(optimizer="ialspp", block_size=64)),     # vdim > 128 with block_size != 32: matrix-free kernels
+    (160, dict(optimizer="ialspp")),                    # 128 < vdim <= 256, block_size 32: als_wide_kernel, T = 5 (3 waves, middle row alone)
+    (192, dict(optimizer="manual_cg")),                 # T = 6
+    (224, dict(optimizer="ialspp", adaptive_reg=True)), # T = 7
 ]
 
 
 @pytest.mark.parametrize("d,kw,shape", [(d, kw, "tiny") for d, kw in CASES] +
                          [(32, dict(optimizer="llt"), "ml100k"), (32, dict(optimizer="manual_cg"), "ml100k"),
-                          (128, dict(optimizer="ialspp"), "ml100k")])
+                          (128, dict(optimizer="ialspp"), "ml100k"), (256, dict(optimizer="ialspp"), "ml100k"),
+                          # rows above 4096 nnz are cut into chunks whose tiles are summed in a scratch slot
+                          (32, dict(optimizer="manual_cg"), "heavy"), (128, dict(optimizer="ialspp"), "heavy"),
+                          (256, dict(optimizer="ialspp"), "heavy")])
 @pytest.mark.parametrize("design", ["inreg", "scratch"])
 def test_half_epochs_match_oracle(oracle, d, kw, shape, design):
     """Every half-epoch starts from bit-identical factors (the GPU model is re-synchronised to the
     oracle's after each comparison), so differences are the kernels' own.  Truncated fp32 CG is
     sensitive to summation order (cond(A) ~ 1e3..1e4): the HIP result has to sit inside the oracle's
     OWN rounding envelope, measured against a float64 evaluation of the same recurrence:
-        err(hip, f64) <= max(5 * err(oracle, f64), 5e-5)   and   err(hip, oracle) <= 4 * max(...)."""
+        err(hip, f64) <= max(5 * err(oracle, f64), 5e-5)   and   err(hip, oracle) <= 4 * max(...)
+    (factor 10 instead of 5 for 128 < vdim <= 256)."""
     import ref_numpy as rn
     from buffalo_amd import synth
     if design == "scratch" and not (d == 128 and kw.get("block_size", 32) == 32):
         pytest.skip("identical to 'inreg' unless the in-register iALS++ solve applies")
     if shape == "tiny":
         csr = tiny_csr(U=320, I=280, density=0.06, seed=31, counts=True)   # every row shorter than a wave
+    elif shape == "heavy":
+        csr = tiny_csr(U=4300, I=12, density=0.97, seed=5, counts=True)    # item rows of ~4170 nnz
     else:
         csr = synth.generate(*synth.SHAPES["ml100k"], seed=7, vals="counts")  # row lengths 1..900: odd, > 64, > 128
     opt = als_opt(d=d, alpha=4.0, reg_u=0.2, reg_i=0.3, num_iters=2, **kw)
@@ -122,7 +131,10 @@ def test_half_epochs_match_oracle(oracle, d, kw, shape, design):
                 lg += obj.partial_update(a, b, mat.indptr, keys, vals, axis)
             # partial_update wrote the updated rows back into the caller's arrays (als.cu:403)
             e_or, e_hip, e_pair = H.relerr(Xo, truth), H.relerr(X[:, :d], truth_hip), H.relerr(X[:, :d], Xo)
-            env = max(5 * e_or, 5e-5)
+            # the explicit Gramian adds the rounding of an n-term fp32 sum per entry of M to what the matrix-free
+            # reference recurrence sees; CG amplifies it with the conditioning of the 32x32 blocks, which grows
+            # with d: the envelope is 5x the oracle's own error up to vdim 128 and 10x for the wide kernel
+            env = max((5 if _vdim(d) <= 128 else 10) * e_or, 5e-5)
             assert e_hip <= env, (it, axis, e_hip, e_or)
             gap = H.relerr(truth_hip, truth)     # what the two Gramians' roundings alone do to the exact recurrence
             assert e_pair <= 4 * env + 2 * gap, (it, axis, e_pair, e_or, gap)
