@@ -1012,7 +1012,8 @@ __device__ __forceinline__ void als_ialspp_inreg(const f32x16 (&acc)[T * (T + 1)
 // (row - start_x; heavy rows: slot_base + wk.slot, zeroed by the host, fp32 atomics) and als_solve_kernel
 // -- a 256-thread block per row -- rebuilds M = FF + G in LDS and runs als_dense_solve.
 // ------------------------------------------------------------------------------------------------
-template <int T, bool IALS, bool INREG>
+// BIG: the other factor matrix is 4 GiB or larger -- 64-bit gather offsets (a few % slower, 19 % in the wide kernel)
+template <int T, bool IALS, bool INREG, bool BIG>
 __global__ __launch_bounds__(256, 2) void als_gram_kernel(AlsParams p, const AlsWork* __restrict__ work, int n_items, float* __restrict__ scratch,
                                                           int slot_base) {
     static_assert(!INREG || IALS, "the in-register solve is the iALS++ recurrence");
@@ -1072,7 +1073,8 @@ __global__ __launch_bounds__(256, 2) void als_gram_kernel(AlsParams p, const Als
             const float v0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myv), 2 * pr));
             const float v1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myv), 2 * pr + 1));
             v = half ? v1 : v0;
-            const unsigned voff = static_cast<unsigned>(half ? c1 : c0) * row_bytes + static_cast<unsigned>(col) * 4u;   // host guarantees < 4 GiB
+            using off_t = typename std::conditional<BIG, size_t, unsigned>::type;   // 32-bit: one SGPR base + a VGPR offset
+            const off_t voff = static_cast<off_t>(static_cast<unsigned>(half ? c1 : c0)) * row_bytes + static_cast<unsigned>(col) * 4u;
             const float* q_ = reinterpret_cast<const float*>(qbase + voff);
 #pragma unroll
             for (int b = 0; b < T; ++b) q[b] = q_[b * 32];
@@ -1250,7 +1252,7 @@ struct AlsWideLds {          // carved from dynamic LDS: vdim | W*32 | 32 | 32 |
     float* red;              // [8] loss partials
 };
 
-template <int T, int WV>
+template <int T, int WV, bool BIG>
 __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork& wk, bool finalize, float* __restrict__ scratch, const AlsWideLds& L,
                                               int lane, int half, int col, double& nume_k, double& deno_k) {
     using C = AlsWide<T, WV>;
@@ -1301,7 +1303,8 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
             const float v0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myv), 2 * pr));
             const float v1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myv), 2 * pr + 1));
             v = half ? v1 : v0;
-            const unsigned voff = static_cast<unsigned>(half ? c1 : c0) * row_bytes + static_cast<unsigned>(col) * 4u;
+            using off_t = typename std::conditional<BIG, size_t, unsigned>::type;   // 32-bit: one SGPR base + a VGPR offset
+            const off_t voff = static_cast<off_t>(static_cast<unsigned>(half ? c1 : c0)) * row_bytes + static_cast<unsigned>(col) * 4u;
             const float* q_ = reinterpret_cast<const float*>(qbase + voff);
 #pragma unroll
             for (int b = 0; b < NB; ++b) q[b] = q_[b * 32];
@@ -1504,7 +1507,7 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
     __syncthreads();
 }
 
-template <int T>
+template <int T, bool BIG>
 __global__ __launch_bounds__(64 * ((T + 1) / 2), 2) void als_wide_kernel(AlsParams p, const AlsWork* __restrict__ work, int n_items,
                                                                          float* __restrict__ scratch, int finalize) {
     constexpr int W = (T + 1) / 2, VD = 32 * T;
@@ -1527,10 +1530,10 @@ __global__ __launch_bounds__(64 * ((T + 1) / 2), 2) void als_wide_kernel(AlsPara
         const int item = *s_item;
         if (item >= n_items) break;
         const AlsWork wk = work[item];
-        if (wv == 0) als_wide_item<T, 0>(p, wk, finalize != 0, scratch, L, lane, half, col, nume_k, deno_k);
-        else if (wv == 1) als_wide_item<T, 1>(p, wk, finalize != 0, scratch, L, lane, half, col, nume_k, deno_k);
-        else if (wv == 2) als_wide_item<T, 2>(p, wk, finalize != 0, scratch, L, lane, half, col, nume_k, deno_k);
-        else als_wide_item<T, (W > 3 ? 3 : 0)>(p, wk, finalize != 0, scratch, L, lane, half, col, nume_k, deno_k);
+        if (wv == 0) als_wide_item<T, 0, BIG>(p, wk, finalize != 0, scratch, L, lane, half, col, nume_k, deno_k);
+        else if (wv == 1) als_wide_item<T, 1, BIG>(p, wk, finalize != 0, scratch, L, lane, half, col, nume_k, deno_k);
+        else if (wv == 2) als_wide_item<T, 2, BIG>(p, wk, finalize != 0, scratch, L, lane, half, col, nume_k, deno_k);
+        else als_wide_item<T, (W > 3 ? 3 : 0), BIG>(p, wk, finalize != 0, scratch, L, lane, half, col, nume_k, deno_k);
     }
     if (p.compute_loss) {
         nume_k = wave_sum_f64(nume_k);
@@ -1805,11 +1808,10 @@ class AlsHandle : public HandleBase {
         BFH_HIP(hipMemsetAsync(ticket_.get(), 0, sizeof(int), stream));
         const int nrows = next_x - start_x;
         const int K = (vdim_ + 63) / 64;
-        // the Gramian kernels address the other factor with 32-bit byte offsets
-        const bool gram_path = vdim_ <= 128 && !force_v1_ && static_cast<uint64_t>(p.op_rows) * vdim_ * 4 < (1ull << 32);
+        const bool gram_path = vdim_ <= 128 && !force_v1_;
+        const bool big = static_cast<uint64_t>(p.op_rows) * vdim_ * 4 >= (1ull << 32);   // 64-bit gather offsets into the other factor
         // 128 < vdim <= 256: block-per-row kernel with the tiles spread over ceil(T/2) waves (als_wide_kernel)
-        const bool wide_path = !gram_path && !force_v1_ && vdim_ > 128 && vdim_ <= 256 && code_ == 8 && block_size_ == 32 && d_ == vdim_ &&
-                               static_cast<uint64_t>(p.op_rows) * vdim_ * 4 < (1ull << 32);
+        const bool wide_path = !gram_path && !force_v1_ && vdim_ > 128 && vdim_ <= 256 && code_ == 8 && block_size_ == 32 && d_ == vdim_;
         const WorkList* wl = nullptr;
         if (gram_path || wide_path) {
             wl = &work_list(axis, start_x, next_x, ip, beg);
@@ -1829,7 +1831,11 @@ class AlsHandle : public HandleBase {
             int blocks = (items + 3) / 4;                           // 4 independent waves per block, one work item each
             if (blocks > num_cus_ * 4) blocks = num_cus_ * 4;       // persistent: residency is set by the kernel's VGPR count
             if (items > 0 && inreg) {
-#define BFH_GK(TT) hipLaunchKernelGGL((als_gram_kernel<TT, true, true>), dim3(blocks), dim3(256), 0, stream, p, wl->work.get(), items, scratch_.get(), 0)
+#define BFH_GK(TT)                                                                                                                  \
+    do {                                                                                                                            \
+        if (big) hipLaunchKernelGGL((als_gram_kernel<TT, true, true, true>), dim3(blocks), dim3(256), 0, stream, p, wl->work.get(), items, scratch_.get(), 0); \
+        else hipLaunchKernelGGL((als_gram_kernel<TT, true, true, false>), dim3(blocks), dim3(256), 0, stream, p, wl->work.get(), items, scratch_.get(), 0);   \
+    } while (0)
                 if (T <= 1) BFH_GK(1);
                 else if (T <= 2) BFH_GK(2);
                 else if (T <= 3) BFH_GK(3);
@@ -1848,8 +1854,11 @@ class AlsHandle : public HandleBase {
                     BFH_HIP(hipMemsetAsync(gscratch_.get() + static_cast<size_t>(nrows) * per_row, 0, wl->n_heavy * per_row * sizeof(float), stream));
 #define BFH_GK(TT)                                                                                                                  \
     do {                                                                                                                            \
-        if (code_ == 8) hipLaunchKernelGGL((als_gram_kernel<TT, true, false>), dim3(blocks), dim3(256), 0, stream, p, wl->work.get(), items, gscratch_.get(), nrows); \
-        else hipLaunchKernelGGL((als_gram_kernel<TT, false, false>), dim3(blocks), dim3(256), 0, stream, p, wl->work.get(), items, gscratch_.get(), nrows);          \
+        if (big) {                                                                                                                  \
+            if (code_ == 8) hipLaunchKernelGGL((als_gram_kernel<TT, true, false, true>), dim3(blocks), dim3(256), 0, stream, p, wl->work.get(), items, gscratch_.get(), nrows); \
+            else hipLaunchKernelGGL((als_gram_kernel<TT, false, false, true>), dim3(blocks), dim3(256), 0, stream, p, wl->work.get(), items, gscratch_.get(), nrows);          \
+        } else if (code_ == 8) hipLaunchKernelGGL((als_gram_kernel<TT, true, false, false>), dim3(blocks), dim3(256), 0, stream, p, wl->work.get(), items, gscratch_.get(), nrows); \
+        else hipLaunchKernelGGL((als_gram_kernel<TT, false, false, false>), dim3(blocks), dim3(256), 0, stream, p, wl->work.get(), items, gscratch_.get(), nrows);          \
     } while (0)
                 if (T <= 1) BFH_GK(1);
                 else if (T <= 2) BFH_GK(2);
@@ -1868,8 +1877,10 @@ class AlsHandle : public HandleBase {
             const size_t lds = als_wide_lds_bytes(vdim_);
             int blocks = std::min(wl->n_work, num_cus_ * 2);
 #define BFH_WIDE(TT, ITEMS, N, FIN)                                                                                              \
-    hipLaunchKernelGGL(als_wide_kernel<TT>, dim3(std::max(1, std::min(N, num_cus_ * 2))), dim3(64 * ((TT + 1) / 2)), lds, stream, p, ITEMS, N, \
-                       scratch_.get(), FIN)
+    do {                                                                                                                         \
+        if (big) hipLaunchKernelGGL((als_wide_kernel<TT, true>), dim3(std::max(1, std::min(N, num_cus_ * 2))), dim3(64 * ((TT + 1) / 2)), lds, stream, p, ITEMS, N, scratch_.get(), FIN); \
+        else hipLaunchKernelGGL((als_wide_kernel<TT, false>), dim3(std::max(1, std::min(N, num_cus_ * 2))), dim3(64 * ((TT + 1) / 2)), lds, stream, p, ITEMS, N, scratch_.get(), FIN);   \
+    } while (0)
 #define BFH_WIDE_T(ITEMS, N, FIN)                  \
     do {                                           \
         if (T == 5) BFH_WIDE(5, ITEMS, N, FIN);    \

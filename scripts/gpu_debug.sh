@@ -1,5 +1,6 @@
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_als_gpu.py -m gpu -q --timeout 600 -p no:cacheprovider > gpurun_out/pytest_als.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_als.log
-grep -E "^E  +Assert|^E  +assert|FAILED|passed|failed" gpurun_out/pytest_als.log | cut -c1-300 | tail -30
-timeout 300 python scripts/bench_extra.py als 2>&1 | grep "^als" | cut -c1-200
+free -g | head -2
+( time timeout 900 python -m pytest tests/test_large_gpu.py -m gpu -q --timeout 800 -p no:cacheprovider -x ) > gpurun_out/pytest_large.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_large.log
+grep -E "^E  +|FAILED|passed|failed|rc=|real" gpurun_out/pytest_large.log | cut -c1-300 | tail -20
+timeout 300 python scripts/bench_extra.py als 2>&1 | grep "^als als_d128 \|^als als_d256" | cut -c1-200
