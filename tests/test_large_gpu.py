@@ -4,6 +4,7 @@
 * BPRMF with the item side frozen (update_i = update_j = False): a user's row then depends on its own triples
   only, and the shard offset keeps the sampler's counters global, so the oracle on the last users reproduces
   exactly what the full run did to them;
+* WARP (adagrad) with the item side frozen: the same argument for the gradient / velocity rows;
 * ALS (vdim 256, the wide kernel): a row update depends on the other side and FF only -- user rows beyond the mark
   vs the oracle on a sub-problem; item rows gather q rows from the 4.4 GB matrix (64-bit gather offsets).
 
@@ -14,7 +15,7 @@ import numpy as np
 import pytest
 
 import helpers as H
-from conftest import als_opt, bpr_opt
+from conftest import als_opt, bpr_opt, warp_opt
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("BFH_SKIP_LARGE") == "1", reason="BFH_SKIP_LARGE=1")]
 
@@ -72,6 +73,32 @@ def test_rows_beyond_4gib_match_the_oracle(oracle):
     o.update_parameters()
     assert H.relerr(Pg[u0:], Po) < 1e-5
     del obj, Pg, Qg
+
+    # ---------------- WARP, item side frozen: gradP / velocity rows beyond the mark ----------------
+    from buffalo_amd.backend import CyWARP
+    wopt = warp_opt(d=D, lr=0.05, min_lr=0.05, num_iters=1, update_i=False, update_j=False, random_seed=11, max_trials=20, threshold=0.5,
+                    optimizer="adagrad", accelerator=True)
+    Pw, Qw = P.copy(), Q.copy()
+    Pw[u0:] *= -1.0                                                     # some negative scores so that violators exist
+    Pw0 = Pw[u0:].copy()
+    warp = CyWARP()
+    assert warp.init(H.write_opt(wopt))
+    warp.initialize_model(Pw, Qw, np.zeros((I, 1), np.float32), csr.nnz, True)
+    warp.set_resident_csr(csr.indptr, csr.keys)
+    warp.add_jobs(0, U, csr.indptr, None)
+    warp.update_parameters()
+    Po, Qo = Pw0.copy(), Q.copy()
+    ow = oracle.OracleWARP()
+    assert ow.init(H.write_opt(dict(wopt, accelerator=False, num_workers=1)))
+    ow.initialize_model(Po, Qo, np.zeros((I, 1), np.float32), csr.nnz)
+    ow.set_cumulative_table(np.zeros(I, np.int64), I)
+    ow.set_modes(sampler="counter", pos_order="csr", inline=True)
+    ow.set_shard(u0 * DEG, 1)
+    ow.launch_workers()
+    ow.add_jobs(0, TAIL, sub.indptr, sub.keys)
+    ow.update_parameters()
+    assert not np.array_equal(Pw[u0:], Pw0) and H.relerr(Pw[u0:], Po) < 1e-4
+    del warp, Pw, Qw
 
     # ---------------- ALS vdim 256 (wide kernel) ----------------
     aopt = als_opt(d=D, alpha=4.0, reg_u=0.1, reg_i=0.1, compute_loss_on_training=False, accelerator=True)
