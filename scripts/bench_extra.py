@@ -136,6 +136,52 @@ if "bpr_pcie" in which:
                                            "note": "80 MB keys H2D (pageable numpy) + fill_rows + kernel + 85 MB D2H per epoch"}
     print("bpr_pcie", out["bpr_host_buffers_every_epoch"], flush=True)
 
+if "warp_c5" in which:
+    # BASELINE config #5's shape on ONE GPU: 10 M users x 1 M items, 1 B interactions, d=256 (the config shards users over 8)
+    U5, I5, deg, d = 10_000_000, 1_000_000, 100, 256
+    step = I5 // deg
+    t0 = time.perf_counter()
+    u = np.arange(U5, dtype=np.int64)
+    keys5 = np.ascontiguousarray((((u * 7919) % step)[:, None] + (np.arange(deg, dtype=np.int64) * step)[None, :]).astype(np.int32).reshape(-1))
+    indptr5 = (u + 1) * deg
+    del u
+    rng = np.random.default_rng(7)
+    base = (rng.normal(size=(65536, d)) / d).astype(np.float32)
+    P5 = np.ascontiguousarray(np.tile(base, (U5 // 65536 + 1, 1))[:U5])
+    Q5 = (rng.normal(size=(I5, d)) / d).astype(np.float32)
+    Qb5 = np.zeros((I5, 1), np.float32)
+    gen_s = time.perf_counter() - t0
+    opt = {"evaluation_on_learning": False, "compute_loss_on_training": False, "early_stopping_rounds": 0, "save_best": False,
+           "evaluation_period": 5, "save_period": 10, "random_seed": 7, "validation": {}, "accelerator": True, "num_workers": 8,
+           "hyper_threads": 256, "num_iters": 10, "d": d, "threshold": 1.0, "score_func": "dot", "max_trials": 500, "update_i": True,
+           "update_j": True, "reg_u": 0.0, "reg_i": 0.0, "reg_j": 0.0, "optimizer": "adagrad", "lr": 0.05, "min_lr": 0.0001,
+           "beta1": 0.9, "beta2": 0.999, "eps": 1e-10, "per_coordinate_normalize": False, "model_path": "", "data_opt": {}}
+    g = CyWARP()
+    assert g.init(write_opt(opt))
+    g.sync_every_epoch = False
+    t0 = time.perf_counter()
+    g.initialize_model(P5, Q5, Qb5, keys5.shape[0], True)
+    g.set_resident_csr(indptr5, keys5)
+    up_s = time.perf_counter() - t0
+    ep = []
+    for e in range(3):
+        g.reset_stats()
+        t0 = time.perf_counter()
+        g.add_jobs(0, U5, indptr5, None)
+        t1 = time.perf_counter()
+        g.update_parameters()
+        t2 = time.perf_counter()
+        st = g.stats()
+        ep.append({"epoch": e, "trial_kernel_ms": st["kernel_ms"], "optimizer_ms": st["optimizer_ms"], "wall_ms": (t2 - t0) * 1e3,
+                   "positives_per_s": keys5.shape[0] / (t1 - t0), "mean_scored_negatives_T": st["scored_negatives"] / keys5.shape[0],
+                   "accepted_frac": st["accepted"] / keys5.shape[0],
+                   "optimizer_GBps": (U5 + I5) * d * 4 * 6 / (st["optimizer_ms"] * 1e-3) / 1e9})
+        print("warp_c5", ep[-1], flush=True)
+    out["warp_10Mx1M_1B_d256_one_gpu"] = {"host_generation_s": gen_s, "upload_s": up_s, "epochs": ep,
+                                          "hbm_resident_GB": (3 * (U5 + I5) * d * 4 + keys5.nbytes * 2 + indptr5.nbytes) / 1e9}
+    print("warp_c5 resident", out["warp_10Mx1M_1B_d256_one_gpu"]["hbm_resident_GB"], "GB; gen", gen_s, "s; upload", up_s, "s", flush=True)
+    del g, P5, Q5, keys5, indptr5
+
 if "topk" in which:
     # the consumer right after training: top-100 of every user over all items (validation / ParALS.topk_recommendation)
     from buffalo_amd import parallel as par
