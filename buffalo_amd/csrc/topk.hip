@@ -114,12 +114,14 @@ struct SelectArgs {
     int32_t* out_keys;       // [.., k] (row q0 + b)
     float* out_scores;       // nullable (quickselect)
     int p2;                  // power of two >= kk: sort buffer entries
+    int cand_cap;            // entries of the candidate buffer behind the sort buffer (0: multi-pass path only)
 };
 
 __global__ __launch_bounds__(256) void topk_select_kernel(SelectArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long sel[];   // p2 entries
-    __shared__ int hist[256];
-    __shared__ int s_misc[8];   // 0: chosen bin, 1: remaining, 2: n_gt slots, 3: run_eq, 4..7: wave eq counts
+    extern __shared__ __attribute__((aligned(16))) unsigned long long sel[];   // p2 sort entries, then cand_cap candidates
+    __shared__ int hist[4096];
+    __shared__ int part[256];
+    __shared__ int s_misc[8];   // 0: chosen bin, 1: remaining, 2: n_gt slots, 3: run_eq, 4..7: wave eq counts / fast-path counters
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int b = blockIdx.x;
     const float* row = a.S + static_cast<size_t>(b) * a.ld_s;
@@ -133,104 +135,200 @@ __global__ __launch_bounds__(256) void topk_select_kernel(SelectArgs a) {
         key = desc_key(s);
         return true;
     };
-    uint32_t prefix = 0, mask = 0;
-    int remaining = a.kk, total = 0, eq_total = 0;
-    bool take_all = false;
-    for (int pass = 0; pass < 4 && !take_all; ++pass) {
-        const int shift = 24 - 8 * pass;
-        hist[tid] = 0;
+    auto pack = [](uint32_t key, int j) { return (static_cast<unsigned long long>(key) << 32) | (0xFFFFFFFFu - static_cast<uint32_t>(j)); };
+
+    // ---------------- fast path: two reads of the row ----------------
+    // 12-bit histogram of the key's top bits (sign, exponent, 3 mantissa bits), then ONE more pass that sends
+    // everything above the threshold bin to the output list and the bin's members (~1 % of the row) to an LDS
+    // candidate buffer, where the remaining 20 bits are resolved.  Falls through to the multi-pass path when the
+    // bin overflows the buffer or when ties straddle the k-th place (the reference's tie rule needs column order).
+    bool done = false;
+    int fast_kk_eff = 0;
+    if (a.cand_cap > 0) {
+        unsigned long long* cand = sel + a.p2;
+        // histogram `hist[0..nbins)` is filled; finds the bin where the running count reaches `want`
+        auto find_bin = [&](int nbins, int want) {   // -> s_misc[0] bin (-1: fewer than want in total), [1] remaining inside it, [2] total, [3] bin count
+            const int per = nbins / 256;
+            int ps = 0;
+            for (int q = 0; q < per; ++q) ps += hist[tid * per + q];
+            part[tid] = ps;
+            __syncthreads();
+            if (tid == 0) {
+                int tot = 0;
+                for (int t = 0; t < 256; ++t) tot += part[t];
+                int bin = -1, rem = want, cnt = 0;
+                if (tot >= want) {
+                    int cum = 0, t = 0;
+                    while (cum + part[t] < want) cum += part[t++];
+                    int q = t * per;
+                    while (cum + hist[q] < want) cum += hist[q++];
+                    bin = q;
+                    rem = want - cum;
+                    cnt = hist[q];
+                }
+                s_misc[0] = bin; s_misc[1] = rem; s_misc[2] = tot; s_misc[3] = cnt;
+            }
+            __syncthreads();
+        };
+        for (int i = tid; i < 4096; i += 256) hist[i] = 0;
+        for (int i = tid; i < a.p2; i += 256) sel[i] = ~0ull;
         __syncthreads();
         for (int j = tid; j < a.cols; j += 256) {
             uint32_t key;
-            if (key_of(j, key) && (key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1);
+            if (key_of(j, key)) atomicAdd(&hist[key >> 20], 1);
         }
         __syncthreads();
-        if (tid == 0) {
-            int cum = 0, bin = 255, rem = remaining;
-            int tot = 0;
-            for (int i = 0; i < 256; ++i) tot += hist[i];
-            if (pass == 0 && tot < remaining) {
-                bin = -1;   // fewer admissible candidates than slots: take them all
-            } else {
-                for (int i = 0; i < 256; ++i) {
-                    if (cum + hist[i] >= rem) { bin = i; break; }
-                    cum += hist[i];
-                }
-                rem -= cum;
-            }
-            s_misc[0] = bin;
-            s_misc[1] = rem;
-            s_misc[2] = tot;
-            s_misc[3] = bin >= 0 ? hist[bin] : 0;
-        }
+        find_bin(4096, a.kk);
+        const int bin1 = s_misc[0], rem1 = s_misc[1], total1 = s_misc[2];
         __syncthreads();
-        const int bin = s_misc[0];
-        if (pass == 0) total = s_misc[2];
-        if (bin < 0) { take_all = true; break; }
-        remaining = s_misc[1];
-        eq_total = s_misc[3];
-        prefix |= static_cast<uint32_t>(bin) << shift;
-        mask |= 255u << shift;
+        if (tid == 0) { s_misc[4] = 0; s_misc[5] = 0; }
         __syncthreads();
-    }
-    const int kk_eff = take_all ? total : a.kk;
-    // now: keys < prefix are in, `remaining` of the eq_total keys == prefix are in (the first ones by column)
-    for (int i = tid; i < a.p2; i += 256) sel[i] = ~0ull;
-    if (tid == 0) { s_misc[2] = 0; s_misc[3] = 0; }
-    __syncthreads();
-    const int n_gt = kk_eff - (take_all ? 0 : remaining);
-    // Boundary ties (more candidates equal to the k-th score than slots left): the reference's running list
-    // (_core.hpp:115-128) admits an equal-score candidate only while fewer than kk candidates >= that score
-    // have been seen, and every later better candidate then evicts the OLDEST of them.  Closed form: let F be
-    // the first kk candidates (by index) with score >= t and A the candidates == t inside F; the survivors are
-    // the `remaining` members of A with the HIGHEST indices.
-    const bool ordered = !take_all && remaining < eq_total;
-    auto pack = [](uint32_t key, int j) { return (static_cast<unsigned long long>(key) << 32) | (0xFFFFFFFFu - static_cast<uint32_t>(j)); };
-    if (kk_eff > 0) {
+        const bool all1 = bin1 < 0;
         for (int j = tid; j < a.cols; j += 256) {
-            uint32_t key = 0;
+            uint32_t key;
             if (!key_of(j, key)) continue;
-            if (take_all || key < prefix) sel[atomicAdd(&s_misc[2], 1)] = pack(key, j);
-            else if (!ordered && key == prefix) sel[n_gt + atomicAdd(&s_misc[3], 1)] = pack(key, j);   // all eq_total == remaining of them
+            const int top = static_cast<int>(key >> 20);
+            if (all1 || top < bin1) sel[atomicAdd(&s_misc[4], 1)] = pack(key, j);
+            else if (top == bin1) {
+                const int c = atomicAdd(&s_misc[5], 1);
+                if (c < a.cand_cap) cand[c] = pack(key, j);
+            }
         }
-    }
-    if (ordered) {
-        __shared__ int s_run[4];    // 0: candidates >= t so far, 1: candidates == t so far, 2: |A|, 3: done
-        __shared__ int s_wave[8];   // per-wave counts of the current 256-column step: [0..3] >= t, [4..7] == t
-        if (tid < 4) s_run[tid] = 0;
         __syncthreads();
-        for (int phase = 0; phase < 2; ++phase) {
-            // phase 0 finds |A| (the == t count when the kk-th candidate >= t arrives); phase 1 places the survivors
-            const int cnt_a = s_run[2];
+        const int n_cand = s_misc[5];
+        if (all1) {
+            done = true;
+            fast_kk_eff = total1;
+        } else if (n_cand <= a.cand_cap) {
+            for (int i = tid; i < 1024; i += 256) hist[i] = 0;
             __syncthreads();
-            if (tid < 2) s_run[tid] = 0;
+            for (int i = tid; i < n_cand; i += 256) atomicAdd(&hist[(static_cast<uint32_t>(cand[i] >> 32) >> 10) & 1023u], 1);
             __syncthreads();
-            for (int base = 0; base < a.cols; base += 256) {
-                const int j = base + tid;
-                uint32_t key = 0;
-                const bool ok = j < a.cols && key_of(j, key);
-                const bool ge = ok && key <= prefix, eq = ok && key == prefix;
-                const unsigned long long bge = __ballot(ge), beq = __ballot(eq);
-                const unsigned long long below = (1ull << lane) - 1ull;
-                if (lane == 0) { s_wave[wv] = __popcll(bge); s_wave[4 + wv] = __popcll(beq); }
-                __syncthreads();
-                int ge_rank = s_run[0] + __popcll(bge & below), eq_rank = s_run[1] + __popcll(beq & below);
-                for (int w = 0; w < wv; ++w) { ge_rank += s_wave[w]; eq_rank += s_wave[4 + w]; }
-                if (phase == 0) {
-                    if (ge && ge_rank == a.kk - 1) s_run[2] = eq_rank + (eq ? 1 : 0);
-                } else if (eq && eq_rank < cnt_a && eq_rank >= cnt_a - remaining) {
-                    sel[n_gt + (eq_rank - (cnt_a - remaining))] = pack(key, j);
-                }
-                __syncthreads();
-                if (tid == 0) {
-                    s_run[0] += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-                    s_run[1] += s_wave[4] + s_wave[5] + s_wave[6] + s_wave[7];
-                }
-                __syncthreads();
-                if (s_run[phase == 0 ? 0 : 1] >= (phase == 0 ? a.kk : cnt_a)) break;   // block-uniform
+            find_bin(1024, rem1);
+            const int bin2 = s_misc[0], rem2 = s_misc[1];
+            __syncthreads();
+            for (int i = tid; i < 1024; i += 256) hist[i] = 0;
+            __syncthreads();
+            for (int i = tid; i < n_cand; i += 256) {
+                const uint32_t k = static_cast<uint32_t>(cand[i] >> 32);
+                if (static_cast<int>((k >> 10) & 1023u) == bin2) atomicAdd(&hist[k & 1023u], 1);
             }
             __syncthreads();
+            find_bin(1024, rem2);
+            const int bin3 = s_misc[0], need_eq = s_misc[1], eq_cnt = s_misc[3];
+            __syncthreads();
+            if (need_eq == eq_cnt) {   // no tie straddles the k-th place: everything up to the threshold key is in
+                const uint32_t thr = (static_cast<uint32_t>(bin1) << 20) | (static_cast<uint32_t>(bin2) << 10) | static_cast<uint32_t>(bin3);
+                for (int i = tid; i < n_cand; i += 256)
+                    if (static_cast<uint32_t>(cand[i] >> 32) <= thr) sel[atomicAdd(&s_misc[4], 1)] = cand[i];
+                done = true;
+                fast_kk_eff = a.kk;
+            }
         }
+        __syncthreads();
+    }
+
+    int kk_eff = fast_kk_eff;
+    if (!done) {   // ---------------- multi-pass path (8 bits per pass over the row) ----------------
+        uint32_t prefix = 0, mask = 0;
+        int remaining = a.kk, total = 0, eq_total = 0;
+        bool take_all = false;
+        for (int pass = 0; pass < 4 && !take_all; ++pass) {
+            const int shift = 24 - 8 * pass;
+            hist[tid] = 0;
+            __syncthreads();
+            for (int j = tid; j < a.cols; j += 256) {
+                uint32_t key;
+                if (key_of(j, key) && (key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int cum = 0, bin = 255, rem = remaining;
+                int tot = 0;
+                for (int i = 0; i < 256; ++i) tot += hist[i];
+                if (pass == 0 && tot < remaining) {
+                    bin = -1;   // fewer admissible candidates than slots: take them all
+                } else {
+                    for (int i = 0; i < 256; ++i) {
+                        if (cum + hist[i] >= rem) { bin = i; break; }
+                        cum += hist[i];
+                    }
+                    rem -= cum;
+                }
+                s_misc[0] = bin;
+                s_misc[1] = rem;
+                s_misc[2] = tot;
+                s_misc[3] = bin >= 0 ? hist[bin] : 0;
+            }
+            __syncthreads();
+            const int bin = s_misc[0];
+            if (pass == 0) total = s_misc[2];
+            if (bin < 0) { take_all = true; break; }
+            remaining = s_misc[1];
+            eq_total = s_misc[3];
+            prefix |= static_cast<uint32_t>(bin) << shift;
+            mask |= 255u << shift;
+            __syncthreads();
+        }
+        kk_eff = take_all ? total : a.kk;
+        // now: keys < prefix are in, `remaining` of the eq_total keys == prefix are in (the first ones by column)
+        for (int i = tid; i < a.p2; i += 256) sel[i] = ~0ull;
+        if (tid == 0) { s_misc[2] = 0; s_misc[3] = 0; }
+        __syncthreads();
+        const int n_gt = kk_eff - (take_all ? 0 : remaining);
+        // Boundary ties (more candidates equal to the k-th score than slots left): the reference's running list
+        // (_core.hpp:115-128) admits an equal-score candidate only while fewer than kk candidates >= that score
+        // have been seen, and every later better candidate then evicts the OLDEST of them.  Closed form: let F be
+        // the first kk candidates (by index) with score >= t and A the candidates == t inside F; the survivors are
+        // the `remaining` members of A with the HIGHEST indices.
+        const bool ordered = !take_all && remaining < eq_total;
+        if (kk_eff > 0) {
+            for (int j = tid; j < a.cols; j += 256) {
+                uint32_t key = 0;
+                if (!key_of(j, key)) continue;
+                if (take_all || key < prefix) sel[atomicAdd(&s_misc[2], 1)] = pack(key, j);
+                else if (!ordered && key == prefix) sel[n_gt + atomicAdd(&s_misc[3], 1)] = pack(key, j);   // all eq_total == remaining of them
+            }
+        }
+        if (ordered) {
+            __shared__ int s_run[4];    // 0: candidates >= t so far, 1: candidates == t so far, 2: |A|, 3: done
+            __shared__ int s_wave[8];   // per-wave counts of the current 256-column step: [0..3] >= t, [4..7] == t
+            if (tid < 4) s_run[tid] = 0;
+            __syncthreads();
+            for (int phase = 0; phase < 2; ++phase) {
+                // phase 0 finds |A| (the == t count when the kk-th candidate >= t arrives); phase 1 places the survivors
+                const int cnt_a = s_run[2];
+                __syncthreads();
+                if (tid < 2) s_run[tid] = 0;
+                __syncthreads();
+                for (int base = 0; base < a.cols; base += 256) {
+                    const int j = base + tid;
+                    uint32_t key = 0;
+                    const bool ok = j < a.cols && key_of(j, key);
+                    const bool ge = ok && key <= prefix, eq = ok && key == prefix;
+                    const unsigned long long bge = __ballot(ge), beq = __ballot(eq);
+                    const unsigned long long below = (1ull << lane) - 1ull;
+                    if (lane == 0) { s_wave[wv] = __popcll(bge); s_wave[4 + wv] = __popcll(beq); }
+                    __syncthreads();
+                    int ge_rank = s_run[0] + __popcll(bge & below), eq_rank = s_run[1] + __popcll(beq & below);
+                    for (int w = 0; w < wv; ++w) { ge_rank += s_wave[w]; eq_rank += s_wave[4 + w]; }
+                    if (phase == 0) {
+                        if (ge && ge_rank == a.kk - 1) s_run[2] = eq_rank + (eq ? 1 : 0);
+                    } else if (eq && eq_rank < cnt_a && eq_rank >= cnt_a - remaining) {
+                        sel[n_gt + (eq_rank - (cnt_a - remaining))] = pack(key, j);
+                    }
+                    __syncthreads();
+                    if (tid == 0) {
+                        s_run[0] += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+                        s_run[1] += s_wave[4] + s_wave[5] + s_wave[6] + s_wave[7];
+                    }
+                    __syncthreads();
+                    if (s_run[phase == 0 ? 0 : 1] >= (phase == 0 ? a.kk : cnt_a)) break;   // block-uniform
+                }
+                __syncthreads();
+            }
+        }
+
     }
     __syncthreads();
     // bitonic sort, ascending composite = (score desc, column desc)
@@ -275,6 +373,11 @@ class TopkHandle : public HandleBase {
         }
     }
 
+    // candidate buffer of the select kernel's fast path (entries behind the sort buffer)
+    static int cand_capacity(int p2) {
+        const int room = (140 * 1024 - p2 * 8) / 8;
+        return room >= 1024 ? 1024 : 0;   // small on purpose: LDS per block decides how many rows a CU works on at once
+    }
     static int pow2_at_least(int n) {
         int p = 2;
         while (p < n) p <<= 1;
@@ -317,7 +420,8 @@ class TopkHandle : public HandleBase {
         const int d_pad = (d + 7) / 8 * 8;
         const int n_tiles = (q_rows + 31) / 32;
         const int p2 = pow2_at_least(kk);
-        const size_t lds = static_cast<size_t>(p2) * 8;
+        const int cand_cap = cand_capacity(p2);
+        const size_t lds = static_cast<size_t>(p2 + cand_cap) * 8;
         BFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(topk_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
         for (int q0 = 0; q0 < nq; q0 += batch) {
             const int nb = std::min(batch, nq - q0);
@@ -336,7 +440,7 @@ class TopkHandle : public HandleBase {
             a.S = S_.get(); a.ld_s = ld_s; a.cols = q_rows; a.Qb = dQb; a.pool = d_pool;
             a.self_idx = same ? d_idx_.get() : nullptr;
             a.q0 = q0; a.rule_flt_min = flt_min_rule_ ? 1 : 0; a.k = k; a.kk = kk;
-            a.out_keys = d_keys_.get(); a.out_scores = d_scores_.get(); a.p2 = p2;
+            a.out_keys = d_keys_.get(); a.out_scores = d_scores_.get(); a.p2 = p2; a.cand_cap = fast_select_ ? cand_cap : 0;
             const int slot2 = t_aux_.begin(stream);
             hipLaunchKernelGGL(topk_select_kernel, dim3(nb), dim3(256), lds, stream, a);
             BFH_HIP(hipGetLastError());
@@ -361,10 +465,20 @@ class TopkHandle : public HandleBase {
         ensure();
         const int d = p_cols, ld = (d + 7) / 8 * 8;
         for (int i = 0; i < nq; ++i) BFH_REQUIRE(indexes[i] >= 0 && indexes[i] < p_rows, "query index outside P");
-        std::vector<float> stage(static_cast<size_t>(nq) * ld, 0.f);
-        for (int i = 0; i < nq; ++i) std::memcpy(&stage[static_cast<size_t>(i) * ld], P + static_cast<size_t>(indexes[i]) * p_cols, sizeof(float) * d);
-        hP_.resize(std::max(hP_.size(), stage.size()));
-        BFH_HIP(hipMemcpyAsync(hP_.get(), stage.data(), stage.size() * 4, hipMemcpyHostToDevice, stream));
+        // query rows: when most of P is asked for and needs no padding, P goes up as it is and the kernel gathers by
+        // index; otherwise the rows are gathered (and zero-padded to ld) on the host first
+        const bool whole = ld == d && static_cast<int64_t>(nq) * 2 >= p_rows;
+        std::vector<float> stage;
+        if (whole) {
+            hP_.resize(std::max(hP_.size(), static_cast<size_t>(p_rows) * ld));
+            BFH_HIP(hipMemcpyAsync(hP_.get(), P, static_cast<size_t>(p_rows) * d * 4, hipMemcpyHostToDevice, stream));
+        } else {
+            stage.assign(static_cast<size_t>(nq) * ld, 0.f);
+            for (int i = 0; i < nq; ++i)
+                std::memcpy(&stage[static_cast<size_t>(i) * ld], P + static_cast<size_t>(indexes[i]) * p_cols, sizeof(float) * d);
+            hP_.resize(std::max(hP_.size(), stage.size()));
+            BFH_HIP(hipMemcpyAsync(hP_.get(), stage.data(), stage.size() * 4, hipMemcpyHostToDevice, stream));
+        }
         hQ_.resize(std::max(hQ_.size(), static_cast<size_t>(q_rows) * ld));
         if (ld == d) {
             BFH_HIP(hipMemcpyAsync(hQ_.get(), Q, static_cast<size_t>(q_rows) * d * 4, hipMemcpyHostToDevice, stream));
@@ -380,9 +494,9 @@ class TopkHandle : public HandleBase {
             dQb = hQb_.get();
         }
         BFH_HIP(hipStreamSynchronize(stream));   // `stage` is a local
-        stats.h2d_bytes += 4.0 * (stage.size() + static_cast<double>(q_rows) * d + (qb_rows ? q_rows : 0));
-        // queries were gathered: row b of hP_ is query b; the self-exclusion still needs the original ids
-        run_device(indexes, nq, hP_.get(), false, hQ_.get(), q_rows, d, ld, dQb, P == Q, out_keys, out_scores, pool, pool_size, k);
+        stats.h2d_bytes += 4.0 * ((whole ? static_cast<double>(p_rows) * d : static_cast<double>(stage.size())) + static_cast<double>(q_rows) * d + (qb_rows ? q_rows : 0));
+        // host-gathered: row b of hP_ is query b (the self-exclusion still needs the original ids, which run_device uploads)
+        run_device(indexes, nq, hP_.get(), whole, hQ_.get(), q_rows, d, ld, dQb, P == Q, out_keys, out_scores, pool, pool_size, k);
     }
 
     void quickselect(const float* scores, int rows, int cols, int32_t* result, int k) {
@@ -395,11 +509,12 @@ class TopkHandle : public HandleBase {
         BFH_HIP(hipMemcpyAsync(S_.get(), scores, n * 4, hipMemcpyHostToDevice, stream));
         d_keys_.resize(std::max(d_keys_.size(), static_cast<size_t>(rows) * k));
         const int p2 = pow2_at_least(k);
-        const size_t lds = static_cast<size_t>(p2) * 8;
+        const int cand_cap = cand_capacity(p2);
+        const size_t lds = static_cast<size_t>(p2 + cand_cap) * 8;
         BFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(topk_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
         SelectArgs a{};
         a.S = S_.get(); a.ld_s = cols; a.cols = cols; a.q0 = 0; a.rule_flt_min = 0; a.k = k; a.kk = k;
-        a.out_keys = d_keys_.get(); a.out_scores = nullptr; a.p2 = p2;
+        a.out_keys = d_keys_.get(); a.out_scores = nullptr; a.p2 = p2; a.cand_cap = fast_select_ ? cand_cap : 0;
         const int slot = t_aux_.begin(stream);
         hipLaunchKernelGGL(topk_select_kernel, dim3(rows), dim3(256), lds, stream, a);
         BFH_HIP(hipGetLastError());
@@ -413,12 +528,14 @@ class TopkHandle : public HandleBase {
 
     void set_mode(const std::string& name, int64_t v) {
         if (name == "flt_min_rule") flt_min_rule_ = v != 0;
+        else if (name == "fast_select") fast_select_ = v != 0;   // 0: multi-pass radix select only (debug / comparison)
         else if (name == "timing") timing = v != 0;
         else throw Error(BFH_ERR_INVALID, "unknown mode '" + name + "'");
     }
 
  private:
     int num_cus_ = 256;
+    bool fast_select_ = true;
     bool flt_min_rule_ = true;   // _core.hpp:26,115: the running list starts at FLT_MIN, so scores <= FLT_MIN are never admitted
     DevBuf<int32_t> d_idx_, d_keys_;
     DevBuf<uint32_t> d_pool_;
