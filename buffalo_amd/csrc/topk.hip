@@ -29,61 +29,102 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int TOPK_MAX_K = 16384;
 
 // ------------------------------------------------------------------------------------------------
+// Candidate matrix -> MFMA operand order, once per call (14 MB at ML-20M): Qp[((t*16 + v)*64 + lane)] (float4) =
+// Q[32 t + (lane&31)][kc + (lane>>5)*W/2 + 4v .. +3].  A wave's B-operand load in the score kernel is then ONE
+// contiguous KiB instead of 64 row-strided 16-byte pieces in 64 different cache lines -- with the strided form the
+// texture-address unit of the CU was as busy as the matrix cores.  Rows beyond q_rows and float4s beyond the chunk
+// are zero.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void topk_pack_kernel(const float* __restrict__ Q, int q_rows, int ld, int kc, int W, float4* __restrict__ Qp,
+                                                        int n_tiles) {
+    const int64_t idx = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;   // (t, v, lane)
+    if (idx >= static_cast<int64_t>(n_tiles) * 16 * 64) return;
+    const int lane = static_cast<int>(idx & 63), v = static_cast<int>((idx >> 6) & 15), t = static_cast<int>(idx >> 10);
+    const int j = t * 32 + (lane & 31);
+    float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j < q_rows && v < W / 8) out = *reinterpret_cast<const float4*>(Q + static_cast<int64_t>(j) * ld + kc + (lane >> 5) * (W / 2) + 4 * v);
+    Qp[idx] = out;
+}
+
+// ------------------------------------------------------------------------------------------------
 // S[b][j] (+)= sum_{c in [kc, kc+W)} A[row(b)][c] * Q[j][c]
 //   A row of query b: P + (qidx ? qidx[q0+b] : q0+b) * ld.  W = min(128, d_pad - kc), W % 8 == 0.
 // grid.x = item-tile groups, grid.y = query blocks of 128; block = 256 threads.
 // ------------------------------------------------------------------------------------------------
+// FULL: the K-chunk is a whole 128 columns (nv == 16): no per-float4 guards, straight-line MFMA stream
+template <bool FULL>
 __global__ __launch_bounds__(256, 3) void topk_scores_kernel(const float* __restrict__ P, const int32_t* __restrict__ qidx, int q0, int nq,
-                                                             const float* __restrict__ Q, int q_rows, int ld, int kc, int W, float* __restrict__ S,
+                                                             const float4* __restrict__ Qp, int q_rows, int ld, int kc, int W, float* __restrict__ S,
                                                              size_t ld_s, int tiles_per_block, int accumulate) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int half = lane >> 5, col = lane & 31;
-    const int b0 = (blockIdx.y * 4 + wv) * 32;   // first query (batch-local) of this wave
-    if (b0 >= nq) return;
+    const int b0q = (blockIdx.y * 4 + wv) * 32;   // first query (batch-local) of this wave
+    if (b0q >= nq) return;
     const int nv = W / 8;                        // float4s per lane and row
     const int koff = kc + half * (W / 2);
     // A operands: query row b0 + col, this half's columns
-    int bq = b0 + col;
+    int bq = b0q + col;
     if (bq >= nq) bq = nq - 1;                   // clamped rows compute garbage that is never stored
     const int64_t prow = qidx ? qidx[q0 + bq] : (q0 + bq);
     const float4* ap = reinterpret_cast<const float4*>(P + prow * ld + koff);
     float4 a[16];
 #pragma unroll
-    for (int v = 0; v < 16; ++v) a[v] = v < nv ? ap[v] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int v = 0; v < 16; ++v) a[v] = (FULL || v < nv) ? ap[v] : make_float4(0.f, 0.f, 0.f, 0.f);
 
     const int n_tiles = (q_rows + 31) / 32;
     const int t_begin = blockIdx.x * tiles_per_block;
     int t_end = t_begin + tiles_per_block;
     if (t_end > n_tiles) t_end = n_tiles;
-    for (int t = t_begin; t < t_end; ++t) {
-        int j = t * 32 + col;
-        const bool jok = j < q_rows;
-        if (!jok) j = q_rows - 1;
-        const float4* bp = reinterpret_cast<const float4*>(Q + static_cast<int64_t>(j) * ld + koff);
-        float4 bv[16];
+    // B operands of a tile in two halves of 8 float4s: the second half of tile t and the first half of tile t+1 are in
+    // flight while the first / second half's 32 MFMAs run (no wave waits for a whole tile's loads with an idle pipe)
+    auto tile_row = [&](int t) { return Qp + (static_cast<int64_t>(t) * 16 * 64 + lane); };   // float4 v of the tile at [v * 64]
+    float4 b0[8], b1[8];
+    if (t_begin < t_end) {
+        const float4* bp = tile_row(t_begin);
 #pragma unroll
-        for (int v = 0; v < 16; ++v)
-            if (v < nv) bv[v] = bp[v];
+        for (int v = 0; v < 8; ++v)
+            if (FULL || v < nv) b0[v] = bp[v * 64];
+    }
+    for (int t = t_begin; t < t_end; ++t) {
+        const bool jok = t * 32 + col < q_rows;
+        const float4* bp = tile_row(t);
+#pragma unroll
+        for (int v = 0; v < 8; ++v)
+            if (FULL || 8 + v < nv) b1[v] = bp[(8 + v) * 64];
         f32x16 acc;
-        float* Sl = S + static_cast<size_t>(b0 + 4 * half) * ld_s + t * 32 + col;   // C layout: row (e&3)+8(e>>2)+4half, col lane&31
+        float* Sl = S + static_cast<size_t>(b0q + 4 * half) * ld_s + t * 32 + col;   // C layout: row (e&3)+8(e>>2)+4half, col lane&31
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int r = (e & 3) + 8 * (e >> 2);
-            acc[e] = (accumulate && jok && b0 + 4 * half + r < nq) ? Sl[static_cast<size_t>(r) * ld_s] : 0.f;
+            acc[e] = (accumulate && jok && b0q + 4 * half + r < nq) ? Sl[static_cast<size_t>(r) * ld_s] : 0.f;
         }
 #pragma unroll
-        for (int v = 0; v < 16; ++v)
-            if (v < nv) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[v].x, bv[v].x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[v].y, bv[v].y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[v].z, bv[v].z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[v].w, bv[v].w, acc, 0, 0, 0);
+        for (int v = 0; v < 8; ++v)
+            if (FULL || v < nv) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[v].x, b0[v].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[v].y, b0[v].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[v].z, b0[v].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[v].w, b0[v].w, acc, 0, 0, 0);
+            }
+        if (t + 1 < t_end) {
+            const float4* bn = tile_row(t + 1);
+#pragma unroll
+            for (int v = 0; v < 8; ++v)
+                if (FULL || v < nv) b0[v] = bn[v * 64];
+        }
+#pragma unroll
+        for (int v = 0; v < 8; ++v)
+            if (FULL || 8 + v < nv) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[8 + v].x, b1[v].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[8 + v].y, b1[v].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[8 + v].z, b1[v].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[8 + v].w, b1[v].w, acc, 0, 0, 0);
             }
         if (jok) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int r = (e & 3) + 8 * (e >> 2);
-                if (b0 + 4 * half + r < nq) Sl[static_cast<size_t>(r) * ld_s] = acc[e];
+                if (b0q + 4 * half + r < nq) Sl[static_cast<size_t>(r) * ld_s] = acc[e];
             }
         }
     }
@@ -423,6 +464,19 @@ class TopkHandle : public HandleBase {
         const int cand_cap = cand_capacity(p2);
         const size_t lds = static_cast<size_t>(p2 + cand_cap) * 8;
         BFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(topk_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        {   // candidate matrix in operand order, one slab per K-chunk
+            const int n_chunks = (d_pad + 127) / 128;
+            const size_t per = static_cast<size_t>(n_tiles) * 16 * 64;
+            Qp_.resize(std::max(Qp_.size(), per * n_chunks));
+            const int slot = t_aux_.begin(stream);
+            for (int c = 0; c < n_chunks; ++c) {
+                const int W = std::min(128, d_pad - c * 128);
+                hipLaunchKernelGGL(topk_pack_kernel, dim3(static_cast<unsigned>((per + 255) / 256)), dim3(256), 0, stream, dQ, q_rows, ld, c * 128, W,
+                                   Qp_.get() + per * c, n_tiles);
+                BFH_HIP(hipGetLastError());
+            }
+            t_aux_.end(slot, stream);
+        }
         for (int q0 = 0; q0 < nq; q0 += batch) {
             const int nb = std::min(batch, nq - q0);
             const int qblocks = (nb + 127) / 128;
@@ -431,8 +485,14 @@ class TopkHandle : public HandleBase {
             const int slot = t_main_.begin(stream);
             for (int kc = 0; kc < d_pad; kc += 128) {
                 const int W = std::min(128, d_pad - kc);
-                hipLaunchKernelGGL(topk_scores_kernel, dim3((n_tiles + tpb - 1) / tpb, qblocks), dim3(256), 0, stream, dP,
-                                   gather ? d_idx_.get() : nullptr, q0, nb, dQ, q_rows, ld, kc, W, S_.get(), ld_s, tpb, kc > 0 ? 1 : 0);
+                if (W == 128)
+                    hipLaunchKernelGGL(topk_scores_kernel<true>, dim3((n_tiles + tpb - 1) / tpb, qblocks), dim3(256), 0, stream, dP,
+                                       gather ? d_idx_.get() : nullptr, q0, nb, Qp_.get() + static_cast<size_t>(kc / 128) * n_tiles * 16 * 64, q_rows, ld,
+                                       kc, W, S_.get(), ld_s, tpb, kc > 0 ? 1 : 0);
+                else
+                    hipLaunchKernelGGL(topk_scores_kernel<false>, dim3((n_tiles + tpb - 1) / tpb, qblocks), dim3(256), 0, stream, dP,
+                                       gather ? d_idx_.get() : nullptr, q0, nb, Qp_.get() + static_cast<size_t>(kc / 128) * n_tiles * 16 * 64, q_rows, ld,
+                                       kc, W, S_.get(), ld_s, tpb, kc > 0 ? 1 : 0);
                 BFH_HIP(hipGetLastError());
             }
             t_main_.end(slot, stream);
@@ -540,6 +600,7 @@ class TopkHandle : public HandleBase {
     DevBuf<int32_t> d_idx_, d_keys_;
     DevBuf<uint32_t> d_pool_;
     DevBuf<float> d_scores_, S_, hP_, hQ_, hQb_;
+    DevBuf<float4> Qp_;   // candidate matrix in MFMA operand order (topk_pack_kernel)
     EventTimer t_main_, t_aux_;
 };
 
