@@ -78,6 +78,17 @@ SIGNATURES = {
     "bfh_als_stream": (_vp, [_vp]),
     "bfh_als_get_stats": (_i32, [_vp, C.POINTER(Stats)]),
     "bfh_als_reset_stats": (_i32, [_vp]),
+    "bfh_cfr_create": (_vp, []),
+    "bfh_cfr_destroy": (None, [_vp]),
+    "bfh_cfr_set_device": (_i32, [_vp, _i32]),
+    "bfh_cfr_init": (_i32, [_vp, C.c_char_p]),
+    "bfh_cfr_set_embedding": (_i32, [_vp, _pf, _i32, C.c_char_p]),
+    "bfh_cfr_precompute": (_i32, [_vp, C.c_char_p]),
+    "bfh_cfr_partial_update_user": (_i32, [_vp, _i32, _i32, C.POINTER(_i64), _pi32, _pf, _pf64]),
+    "bfh_cfr_partial_update_item": (_i32, [_vp, _i32, _i32, C.POINTER(_i64), _pi32, _pf, C.POINTER(_i64), _pi32, _pf, _pf64]),
+    "bfh_cfr_partial_update_context": (_i32, [_vp, _i32, _i32, C.POINTER(_i64), _pi32, _pf, _pf64]),
+    "bfh_cfr_get_stats": (_i32, [_vp, C.POINTER(Stats)]),
+    "bfh_cfr_reset_stats": (_i32, [_vp]),
     "bfh_coo_to_csr": (_i32, [_pi32, _pi32, _pf, _i64, _i32, _i32, C.POINTER(_i64), _pi32, _pf, C.POINTER(Stats)]),
     "bfh_topk_create": (_vp, []),
     "bfh_topk_destroy": (None, [_vp]),

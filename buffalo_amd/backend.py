@@ -3,6 +3,7 @@ libbuffalo_hip.so through its C ABI.
 
 * ``CyBPR``  mirrors ``buffalo.algo.cuda._bpr.CyBPR``  (/root/reference/buffalo/algo/cuda/_bpr.pyx:27-80)
 * ``CyALS``  mirrors ``buffalo.algo.cuda._als.CyALS``  (/root/reference/buffalo/algo/cuda/_als.pyx:25-67)
+* ``CyCFR``  mirrors ``buffalo.algo._cfr.CyCFR``       (/root/reference/buffalo/algo/_cfr.pyx:25-71; CPU layout: [rows, d] unpadded)
 * ``CyWARP`` gives WARP the same surface as CyBPR, which is what the (unreachable) accelerator
   scaffold in /root/reference/buffalo/algo/warp.py:212-234 expects.
 
@@ -230,3 +231,40 @@ class CyALS(_Base):
 
     def synchronize(self, device_to_host):
         self._call("synchronize", int(bool(device_to_host)))
+
+
+class CyCFR(_Base):
+    """CoFactor row updates on the ALS Gramian / dense-solve kernels (csrc/cfr_impl.hpp)."""
+    _PFX = "bfh_cfr_"
+
+    def set_embedding(self, F, obj_type):
+        _arr(F, np.float32, 2, "F")
+        t = obj_type if isinstance(obj_type, bytes) else str(obj_type).encode("utf-8")
+        self._keep[t] = F
+        self._call("set_embedding", _ptr(F, C.c_float), F.shape[0], t)
+
+    def precompute(self, obj_type):
+        self._call("precompute", obj_type if isinstance(obj_type, bytes) else str(obj_type).encode("utf-8"))
+
+    def partial_update_user(self, start_x, next_x, indptrs, keys, vals):
+        _arr(indptrs, np.int64, 1, "indptrs"), _arr(keys, np.int32, 1, "keys"), _arr(vals, np.float32, 1, "vals")
+        loss = C.c_double(0.0)
+        self._call("partial_update_user", int(start_x), int(next_x), _ptr(indptrs, C.c_int64), _ptr(keys, C.c_int32), _ptr(vals, C.c_float),
+                   C.byref(loss))
+        return loss.value
+
+    def partial_update_item(self, start_x, next_x, indptrs_u, keys_u, vals_u, indptrs_c, keys_c, vals_c):
+        for a, dt, n in ((indptrs_u, np.int64, "indptrs_u"), (keys_u, np.int32, "keys_u"), (vals_u, np.float32, "vals_u"),
+                         (indptrs_c, np.int64, "indptrs_c"), (keys_c, np.int32, "keys_c"), (vals_c, np.float32, "vals_c")):
+            _arr(a, dt, 1, n)
+        loss = C.c_double(0.0)
+        self._call("partial_update_item", int(start_x), int(next_x), _ptr(indptrs_u, C.c_int64), _ptr(keys_u, C.c_int32), _ptr(vals_u, C.c_float),
+                   _ptr(indptrs_c, C.c_int64), _ptr(keys_c, C.c_int32), _ptr(vals_c, C.c_float), C.byref(loss))
+        return loss.value
+
+    def partial_update_context(self, start_x, next_x, indptrs, keys, vals):
+        _arr(indptrs, np.int64, 1, "indptrs"), _arr(keys, np.int32, 1, "keys"), _arr(vals, np.float32, 1, "vals")
+        loss = C.c_double(0.0)
+        self._call("partial_update_context", int(start_x), int(next_x), _ptr(indptrs, C.c_int64), _ptr(keys, C.c_int32), _ptr(vals, C.c_float),
+                   C.byref(loss))
+        return loss.value

@@ -4,8 +4,10 @@
 // (/root/reference/lib/algo.cc:39-82) behind CuALS's object surface
 // (/root/reference/include/buffalo/cuda/als/als.hpp:20-35).
 #include "als_kernels.hpp"
+#include "cfr_impl.hpp"
 
 using bfh::AlsHandle;
+using bfh::CfrHandle;
 using bfh::guarded;
 
 extern "C" {
@@ -73,6 +75,69 @@ int bfh_als_get_stats(void* h, bfh_stats* out) {
 }
 int bfh_als_reset_stats(void* h) {
     return guarded(h, [&] { static_cast<AlsHandle*>(h)->stats = bfh_stats{}; return BFH_OK; });
+}
+
+// ------------------------------------------------------------------------------------------------
+// CFR -- CCFR (/root/reference/lib/algo_impl/cfr/cfr.cc) behind CyCFR's surface (buffalo/algo/_cfr.pyx:25-71)
+// ------------------------------------------------------------------------------------------------
+void* bfh_cfr_create(void) {
+    try {
+        CfrHandle* h = new CfrHandle();
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) {
+            bfh::g_create_error = "no HIP device available (libbuffalo_hip has no CPU fallback)";
+            delete h;
+            return nullptr;
+        }
+        h->device = dev;
+        return h;
+    } catch (const std::exception& e) {
+        bfh::g_create_error = e.what();
+        return nullptr;
+    }
+}
+void bfh_cfr_destroy(void* h) { delete static_cast<CfrHandle*>(h); }
+int bfh_cfr_set_device(void* h, int device) {
+    return guarded(h, [&] { static_cast<CfrHandle*>(h)->device = device; BFH_HIP(hipSetDevice(device)); return BFH_OK; });
+}
+int bfh_cfr_init(void* h, const char* opt_json_path) {
+    int ok = 0;
+    int rc = guarded(h, [&] { ok = static_cast<CfrHandle*>(h)->init_cfr(opt_json_path) ? 1 : 0; return BFH_OK; });
+    return rc == BFH_OK ? ok : rc;
+}
+int bfh_cfr_set_embedding(void* h, float* data, int size, const char* obj_type) {
+    return guarded(h, [&] { static_cast<CfrHandle*>(h)->set_embedding(data, size, obj_type ? obj_type : ""); return BFH_OK; });
+}
+int bfh_cfr_precompute(void* h, const char* obj_type) {
+    return guarded(h, [&] { static_cast<CfrHandle*>(h)->precompute_cfr(obj_type ? obj_type : ""); return BFH_OK; });
+}
+int bfh_cfr_partial_update_user(void* h, int start_x, int next_x, const int64_t* indptr, const int32_t* keys, const float* vals, double* loss) {
+    return guarded(h, [&] {
+        const double v = static_cast<CfrHandle*>(h)->partial_update_user(start_x, next_x, indptr, keys, vals);
+        if (loss) *loss = v;
+        return BFH_OK;
+    });
+}
+int bfh_cfr_partial_update_item(void* h, int start_x, int next_x, const int64_t* indptr_u, const int32_t* keys_u, const float* vals_u,
+                                const int64_t* indptr_c, const int32_t* keys_c, const float* vals_c, double* loss) {
+    return guarded(h, [&] {
+        const double v = static_cast<CfrHandle*>(h)->partial_update_item(start_x, next_x, indptr_u, keys_u, vals_u, indptr_c, keys_c, vals_c);
+        if (loss) *loss = v;
+        return BFH_OK;
+    });
+}
+int bfh_cfr_partial_update_context(void* h, int start_x, int next_x, const int64_t* indptr, const int32_t* keys, const float* vals, double* loss) {
+    return guarded(h, [&] {
+        const double v = static_cast<CfrHandle*>(h)->partial_update_context(start_x, next_x, indptr, keys, vals);
+        if (loss) *loss = v;
+        return BFH_OK;
+    });
+}
+int bfh_cfr_get_stats(void* h, bfh_stats* out) {
+    return guarded(h, [&] { *out = static_cast<CfrHandle*>(h)->stats; return BFH_OK; });
+}
+int bfh_cfr_reset_stats(void* h) {
+    return guarded(h, [&] { static_cast<CfrHandle*>(h)->stats = bfh_stats{}; return BFH_OK; });
 }
 
 }  // extern "C"

@@ -42,6 +42,13 @@ struct AlsParams {
     int* ticket;
     int debug;             // profiling ablations: 1 skip dense solve, 4 skip M/FF staging
     int solver;            // 0 llt, 1 ldlt, 2 manual_cg, 8 ialspp
+    // generalisations used by CFR (cfr_impl.hpp); ALS sets ctx = accumulate = 0, out_scale = ff_scale = 1
+    int ctx;               // Gramian pass with weight 1 and coefficient (v - bias_self[row] - bias_other[key]) (cfr.cc:209-225, 283-289)
+    const float* bias_self;
+    const float* bias_other;
+    float out_scale;       // the pass's tiles / vector are multiplied by this before they reach the scratch slot (cfr.cc:130-131)
+    int accumulate;        // add into the row's (zeroed) slot instead of overwriting it: two passes build one system
+    float ff_scale;        // the solve kernel's M = ff_scale * FF + slot
 };
 
 template <int K>
@@ -1061,6 +1068,7 @@ __global__ __launch_bounds__(256, 2) void als_gram_kernel(AlsParams p, const Als
             if (kk < n) {
                 cc = p.keys[wk.kbeg + kk];
                 vvv = p.vals[wk.kbeg + kk];
+                if (!IALS && p.ctx) vvv -= p.bias_other[cc];
                 if (lossk) {   // constant and denominator of the loss, see als_gram_kernel
                     const double w = static_cast<double>(vvv * p.alpha);
                     deno_k += w;
@@ -1079,8 +1087,11 @@ __global__ __launch_bounds__(256, 2) void als_gram_kernel(AlsParams p, const Als
 #pragma unroll
             for (int b = 0; b < T; ++b) q[b] = q_[b * 32];
         };
+        const bool ctx = !IALS && p.ctx != 0;
+        const float bself = ctx ? p.bias_self[wk.row] : 0.f;
         auto consume = [&](const float (&q)[T], float v, float one) {
-            const float wgt = p.alpha * v;
+            const float wgt = ctx ? one : p.alpha * v;
+            const float cdense = ctx ? (v - bself) * one : one + wgt;
             int t = 0;
 #pragma unroll
             for (int a = 0; a < T; ++a) {
@@ -1088,7 +1099,7 @@ __global__ __launch_bounds__(256, 2) void als_gram_kernel(AlsParams p, const Als
 #pragma unroll
                 for (int b = a; b < T; ++b, ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, q[b], acc[t], 0, 0, 0);
                 // als.cc:184: float(1.0 + double(v*alpha)) == 1.0f + v*alpha (the exact sum rounded once either way)
-                gpart[a] += (IALS ? wgt : (one + wgt)) * q[a];
+                gpart[a] += (IALS ? wgt : cdense) * q[a];
                 if (IALS) g1part[a] += (lossk ? one : 0.f) * q[a];   // unconditional: keeps the loop body one basic block
             }
         };
@@ -1171,9 +1182,10 @@ __global__ __launch_bounds__(256, 2) void als_gram_kernel(AlsParams p, const Als
         }
         // upper-triangle tiles, g, g1 -> the row's scratch slot
         // (every element offset below is a compile-time constant off ONE lane base)
-        float* S = scratch + static_cast<size_t>(wk.slot >= 0 ? slot_base + wk.slot : wk.row - p.start_x) * als_slot_floats(VD);
+        float* S = scratch + static_cast<size_t>(wk.slot >= 0 && !p.accumulate ? slot_base + wk.slot : wk.row - p.start_x) * als_slot_floats(VD);
         float* Sl = S + half * 4 * VD + col;
-        const bool atomic = wk.slot >= 0;   // chunk of a heavy row: partials are summed (the slot was zeroed by the host)
+        const bool atomic = wk.slot >= 0 || p.accumulate;   // chunk of a heavy row / second pass: summed into the slot (zeroed by the host)
+        const float osc = p.out_scale;
         int t = 0;
 #pragma unroll
         for (int a = 0; a < T; ++a) {
@@ -1182,11 +1194,11 @@ __global__ __launch_bounds__(256, 2) void als_gram_kernel(AlsParams p, const Als
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     float* dst = Sl + (a * 32 + (e & 3) + 8 * (e >> 2)) * VD + b * 32;
-                    if (atomic) atomic_add_f32(dst, acc[t][e]);
-                    else *dst = acc[t][e];
+                    if (atomic) atomic_add_f32(dst, acc[t][e] * osc);
+                    else *dst = acc[t][e] * osc;
                 }
             }
-            const float gs = gpart[a] + __shfl_xor(gpart[a], 32, 64);   // the two halves hold the k-parities of the same element
+            const float gs = (gpart[a] + __shfl_xor(gpart[a], 32, 64)) * osc;   // the two halves hold the k-parities of the same element
             const float g1s = g1part[a] + __shfl_xor(g1part[a], 32, 64);
             if (half == 0) {
                 float* gdst = S + VD * VD + a * 32 + col;
@@ -1585,7 +1597,7 @@ __global__ __launch_bounds__(256) void als_solve_kernel(AlsParams p, const AlsHe
 #pragma unroll
                 for (int it = 0; it < 16; ++it) {
                     sv[it] = S[base + static_cast<size_t>(2 * it) * vdim];
-                    fv[it] = p.FF[base + static_cast<size_t>(2 * it) * vdim];
+                    fv[it] = p.ff_scale * p.FF[base + static_cast<size_t>(2 * it) * vdim];
                 }
 #pragma unroll
                 for (int it = 0; it < 16; ++it) {
@@ -1731,8 +1743,10 @@ class AlsHandle : public HandleBase {
     void precompute(int axis) {
         BFH_REQUIRE(model_, "precompute before initialize_model");
         BFH_REQUIRE(axis == 0 || axis == 1, "axis must be 0 or 1");
-        const float* F = axis == 0 ? Q_.get() : P_.get();
-        const int rows = axis == 0 ? Q_rows_ : P_rows_;
+        gramian_of(axis == 0 ? Q_.get() : P_.get(), axis == 0 ? Q_rows_ : P_rows_);
+    }
+    // FF = F^T F for a device matrix [rows, vdim]
+    void gramian_of(const float* F, int rows) {
         BFH_HIP(hipMemsetAsync(FF64_.get(), 0, FF64_.bytes(), stream));
         const int T = vdim_ / 32;
         constexpr int NT = 4;
@@ -1788,6 +1802,8 @@ class AlsHandle : public HandleBase {
         p.ticket = ticket_.get();
         p.debug = debug_;
         p.solver = static_cast<int>(code_);
+        p.out_scale = 1.0f;
+        p.ff_scale = 1.0f;
         if (A.resident) {
             p.keys = A.keys.get() + beg;
             p.vals = A.vals.get() + beg;

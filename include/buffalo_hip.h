@@ -233,6 +233,31 @@ int bfh_topk_reset_stats(void* h);
 int bfh_coo_to_csr(const int32_t* major, const int32_t* minor, const float* vals, int64_t nnz, int num_major,
                    int num_minor, int64_t* indptr, int32_t* out_minor, float* out_vals, bfh_stats* stats);
 
+/* ------------------------------------------------------------------------------------------------
+ * CFR / CoFactor   (CCFR: include/buffalo/algo_impl/cfr/cfr.hpp:19-45, lib/algo_impl/cfr/cfr.cc;
+ * SURVEY.md section 8(f) rank 4) -- the three row updates run on the ALS Gramian / dense-solve kernels.
+ * Arrays are the reference's CPU layout: C-contiguous float32 [rows, d] (NOT padded), biases [rows, 1];
+ * updated rows are written back into them before a call returns.  d <= 128; optimizers llt, ldlt, manual_cg.
+ * ---------------------------------------------------------------------------------------------- */
+void* bfh_cfr_create(void);                                                   /* CCFR::CCFR           cfr.cc:14  */
+void bfh_cfr_destroy(void* h);                                                /* CCFR::~CCFR          cfr.cc:18  */
+int bfh_cfr_set_device(void* h, int device);
+int bfh_cfr_init(void* h, const char* opt_json_path);                         /* CCFR::init           cfr.cc:29  */
+/* CCFR::set_embedding cfr.cc:70-82: obj_type in user | item | context | item_bias | context_bias */
+int bfh_cfr_set_embedding(void* h, float* data, int size, const char* obj_type);
+int bfh_cfr_precompute(void* h, const char* obj_type);                        /* CCFR::precompute     cfr.cc:85  */
+/* CCFR::partial_update_{user,item,context} cfr.cc:92-313: full END-offset indptr + the chunk's keys/vals; *loss
+ * receives the value the reference returns (0 unless the option "compute_loss" is set). */
+int bfh_cfr_partial_update_user(void* h, int start_x, int next_x, const int64_t* indptr, const int32_t* keys,
+                                const float* vals, double* loss);
+int bfh_cfr_partial_update_item(void* h, int start_x, int next_x, const int64_t* indptr_u, const int32_t* keys_u,
+                                const float* vals_u, const int64_t* indptr_c, const int32_t* keys_c, const float* vals_c,
+                                double* loss);
+int bfh_cfr_partial_update_context(void* h, int start_x, int next_x, const int64_t* indptr, const int32_t* keys,
+                                   const float* vals, double* loss);
+int bfh_cfr_get_stats(void* h, bfh_stats* out);
+int bfh_cfr_reset_stats(void* h);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1166,12 +1166,181 @@ class ALS {
     }
 };
 
+// ============================================================================
+// CCFR  (lib/algo_impl/cfr/cfr.cc) -- CoFactor: user-item ALS regularised by an item-context (SPPMI)
+// factorisation with biases.  SURVEY.md section 8(f) rank 4: "CFR calls the same _leastsquare".
+// Quirks kept: `cg_tolerance_` is read from the key "cg_tolerance_" (cfr.cc:38), which no option
+// object defines, so the manual CG never stops on its tolerance; `compute_loss` (not
+// compute_loss_on_training) switches the loss terms (:44); d >= 128 does NOT force iALS++ here.
+// ============================================================================
+class CFR : public ALS {
+ public:
+    float *U_ = nullptr, *I_ = nullptr, *C_ = nullptr, *Ib_ = nullptr, *Cb_ = nullptr;
+    int U_rows_ = 0, I_rows_ = 0, C_rows_ = 0;
+    float alpha_ = 0.f, l_ = 1.f, reg_u_ = 0.f, reg_i_ = 0.f, reg_c_ = 0.f;
+    bool compute_loss_ = false;
+
+    // cfr.cc:29-63
+    bool init_cfr() {
+        omp_set_num_threads(std::max(1, opt_.i("num_workers")));
+        D_ = opt_.i("d");
+        num_cg_max_iters_ = opt_.i("num_cg_max_iters");
+        alpha_ = (float)opt_.d("alpha");
+        l_ = (float)opt_.d("l");
+        cg_tolerance_ = (float)opt_.d("cg_tolerance_");   // sic: 0 unless someone sets that key
+        eps_ = (float)opt_.d("eps");
+        reg_u_ = (float)opt_.d("reg_u");
+        reg_i_ = (float)opt_.d("reg_i");
+        reg_c_ = (float)opt_.d("reg_c");
+        compute_loss_ = opt_.b("compute_loss");
+        const std::string optimizer = opt_.s("optimizer");
+        if (optimizer == "llt") optimizer_code_ = 0;
+        else if (optimizer == "ldlt") optimizer_code_ = 1;
+        else if (optimizer == "manual_cg") optimizer_code_ = 2;
+        else return false;   // eigen_* Krylov solvers are out of scope
+        use_ialspp_ = false;
+        FF_.assign((size_t)D_ * D_, 0.f);
+        return true;
+    }
+    // cfr.cc:70-82
+    void set_embedding(float* data, int size, const std::string& t) {
+        if (t == "user") { U_ = data; U_rows_ = size; }
+        else if (t == "item") { I_ = data; I_rows_ = size; }
+        else if (t == "context") { C_ = data; C_rows_ = size; }
+        else if (t == "item_bias") Ib_ = data;
+        else if (t == "context_bias") Cb_ = data;
+    }
+    // cfr.cc:85-90
+    void precompute_cfr(const std::string& t) {
+        if (t == "user") { Q_ = U_; Q_rows_ = U_rows_; precompute(0); }
+        else if (t == "item") { Q_ = I_; Q_rows_ = I_rows_; precompute(0); }
+    }
+    // A += sum_k w_k f_k f_k^T (row-major, symmetric), y += sum_k c_k f_k
+    void accumulate(std::vector<float>& A, std::vector<float>& y, const float* F, const int32_t* keys, const std::vector<float>& w,
+                    const std::vector<float>& c, size_t n) {
+        const int D = D_;
+        for (size_t k = 0; k < n; ++k) {
+            const float* f = F + (size_t)keys[k] * D;
+            for (int i = 0; i < D; ++i) {
+                const float wi = w[k] * f[i];
+                float* Ai = &A[(size_t)i * D];
+                for (int j = 0; j < D; ++j) Ai[j] += wi * f[j];
+                y[i] += c[k] * f[i];
+            }
+        }
+    }
+    // cfr.cc:92-146
+    double partial_update_user(int start_x, int next_x, const int64_t* indptr, const int32_t* keys, const float* vals) {
+        if (next_x == start_x) return 0.0;
+        const int D = D_;
+        const int64_t shifted = start_x == 0 ? 0 : indptr[start_x - 1];
+        double loss = 0.0;
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : loss)
+        for (int x = start_x; x < next_x; ++x) {
+            const size_t beg = x == 0 ? 0 : indptr[x - 1] - shifted, end = indptr[x] - shifted, n = end - beg;
+            if (n == 0) continue;
+            std::vector<float> A(FF_), y(D, 0.f), w(n), c(n);
+            for (size_t k = 0; k < n; ++k) { w[k] = vals[beg + k] * alpha_; c[k] = w[k] + 1.f; }
+            accumulate(A, y, I_, keys + beg, w, c, n);
+            for (auto& a : A) a *= l_;
+            for (auto& v : y) v *= l_;
+            for (int d = 0; d < D; ++d) A[(size_t)d * D + d] += reg_u_;
+            float* ux = U_ + (size_t)x * D;
+            leastsquare(ux, A, y);
+            if (compute_loss_) loss += dotf(ux, ux, D);
+        }
+        return reg_u_ * loss;
+    }
+    // cfr.cc:148-255
+    double partial_update_item(int start_x, int next_x, const int64_t* indptr_u, const int32_t* keys_u, const float* vals_u,
+                               const int64_t* indptr_c, const int32_t* keys_c, const float* vals_c) {
+        if (next_x == start_x) return 0.0;
+        const int D = D_;
+        const int64_t shifted_u = start_x == 0 ? 0 : indptr_u[start_x - 1];
+        const int64_t shifted_c = start_x == 0 ? 0 : indptr_c[start_x - 1];
+        double total = 0.0;
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : total)
+        for (int x = start_x; x < next_x; ++x) {
+            const size_t beg_u = x == 0 ? 0 : indptr_u[x - 1] - shifted_u, end_u = indptr_u[x] - shifted_u, nu = end_u - beg_u;
+            const size_t beg_c = x == 0 ? 0 : indptr_c[x - 1] - shifted_c, end_c = indptr_c[x] - shifted_c, nc = end_c - beg_c;
+            if (nu == 0 && nc == 0) continue;
+            float* ix = I_ + (size_t)x * D;
+            std::vector<float> A(FF_), y(D, 0.f), w(nu), c(nu);
+            float loss = 0.f;
+            if (compute_loss_) {   // (I_x FF) . I_x
+                for (int i = 0; i < D; ++i) {
+                    float t = 0.f;
+                    for (int j = 0; j < D; ++j) t += ix[j] * FF_[(size_t)j * D + i];
+                    loss += t * ix[i];
+                }
+            }
+            for (size_t k = 0; k < nu; ++k) {
+                w[k] = vals_u[beg_u + k] * alpha_;
+                if (compute_loss_) {
+                    const float dot = dotf(ix, U_ + (size_t)keys_u[beg_u + k] * D, D);
+                    loss += (-dot * dot + (1 + w[k]) * (dot - 1) * (dot - 1));
+                }
+                c[k] = w[k] + 1.f;
+            }
+            if (compute_loss_) total += loss * l_;
+            accumulate(A, y, U_, keys_u + beg_u, w, c, nu);
+            for (auto& a : A) a *= l_;
+            for (auto& v : y) v *= l_;
+            std::vector<float> w1(nc, 1.f), cc(nc);
+            loss = 0.f;
+            for (size_t k = 0; k < nc; ++k) {
+                const int cidx = keys_c[beg_c + k];
+                const float v = vals_c[beg_c + k];
+                cc[k] = v - Ib_[x] - Cb_[cidx];
+                if (compute_loss_) {
+                    const float err = v - dotf(ix, C_ + (size_t)cidx * D, D) - Ib_[x] - Cb_[cidx];
+                    loss += err * err;
+                }
+            }
+            if (compute_loss_) total += loss + reg_i_ * dotf(ix, ix, D);
+            accumulate(A, y, C_, keys_c + beg_c, w1, cc, nc);
+            for (int d = 0; d < D; ++d) A[(size_t)d * D + d] += reg_i_;
+            leastsquare(ix, A, y);
+            float b = 0.f;   // bias from the UPDATED row (cfr.cc:244-250)
+            for (size_t k = 0; k < nc; ++k) {
+                const int cidx = keys_c[beg_c + k];
+                b += (vals_c[beg_c + k] - dotf(ix, C_ + (size_t)cidx * D, D) - Cb_[cidx]);
+            }
+            Ib_[x] = b / ((float)nc + 1e-10f);
+        }
+        return total;
+    }
+    // cfr.cc:257-313
+    double partial_update_context(int start_x, int next_x, const int64_t* indptr, const int32_t* keys, const float* vals) {
+        if (next_x == start_x) return 0.0;
+        const int D = D_;
+        const int64_t shifted = start_x == 0 ? 0 : indptr[start_x - 1];
+        double loss = 0.0;
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : loss)
+        for (int x = start_x; x < next_x; ++x) {
+            const size_t beg = x == 0 ? 0 : indptr[x - 1] - shifted, end = indptr[x] - shifted, n = end - beg;
+            if (n == 0) continue;
+            float* cx = C_ + (size_t)x * D;
+            std::vector<float> A((size_t)D * D, 0.f), y(D, 0.f), w(n, 1.f), c(n);
+            for (size_t k = 0; k < n; ++k) c[k] = vals[beg + k] - Cb_[x] - Ib_[keys[beg + k]];
+            accumulate(A, y, I_, keys + beg, w, c, n);
+            for (int d = 0; d < D; ++d) A[(size_t)d * D + d] += reg_c_;
+            if (compute_loss_) loss += dotf(cx, cx, D);   // the row BEFORE the update (cfr.cc:297-298)
+            leastsquare(cx, A, y);
+            float b = 0.f;
+            for (size_t k = 0; k < n; ++k) b += (vals[beg + k] - dotf(cx, I_ + (size_t)keys[beg + k] * D, D) - Ib_[keys[beg + k]]);
+            Cb_[x] = b / ((float)n + 1e-10f);
+        }
+        return reg_c_ * loss;
+    }
+};
+
 struct Handle {
-    int kind;  // 0 bpr, 1 warp, 2 als
+    int kind;  // 0 bpr, 1 warp, 2 als, 3 cfr
     SGD* sgd = nullptr;
-    ALS* als = nullptr;
+    ALS* als = nullptr;   // kind 3: a CFR
     std::vector<int32_t> trace;
-    Opt* opt() { return kind == 2 ? &als->opt_ : &sgd->opt_; }
+    Opt* opt() { return kind >= 2 ? &als->opt_ : &sgd->opt_; }
 };
 
 }  // namespace
@@ -1190,7 +1359,9 @@ struct Handle {
 //   (strict, :124) -- since FLT_MIN is the smallest POSITIVE normal float, non-positive scores are
 //   never admitted -- and is placed in front of the first slot whose val is not greater than it
 //   (lower_bound with `val > that`, :53), i.e. BEFORE earlier candidates of equal score.
-//   Net effect: the kept set is the first k by (score desc, j asc), listed by (score desc, j desc).
+//   Net effect: listed by (score desc, j desc); at the boundary a tie is admitted only while fewer than
+//   k candidates >= that score have been seen, and later better candidates evict the OLDEST tie
+//   (closed form: tests/topk_cases.py:spec_dot_topn).
 //   Slots correct_k..k-1 are written as (-1, 0.0) (:134-137).
 // orc_quickselect ~ parallel::quickselect (_core.hpp:69-87): std::nth_element over column indices
 //   with `scores[l] > scores[r]`, then std::sort of the first k when `sorted`.
@@ -1261,7 +1432,8 @@ void* orc_create(int kind) {
     h->kind = kind;
     if (kind == 0) h->sgd = new BPR();
     else if (kind == 1) h->sgd = new WARP();
-    else h->als = new ALS();
+    else if (kind == 2) h->als = new ALS();
+    else h->als = new CFR();
     return h;
 }
 void orc_destroy(void* hp) {
@@ -1275,6 +1447,7 @@ void orc_opt_str(void* hp, const char* k, const char* v) { ((Handle*)hp)->opt()-
 void orc_opt_bool(void* hp, const char* k, int v) { ((Handle*)hp)->opt()->boo[k] = v != 0; }
 int orc_init(void* hp) {
     Handle* h = (Handle*)hp;
+    if (h->kind == 3) return (int)static_cast<CFR*>(h->als)->init_cfr();
     return h->kind == 2 ? (int)h->als->init() : (int)h->sgd->init();
 }
 void orc_set_modes(void* hp, int sampler, int pos_order, int inline_mode) {
@@ -1368,6 +1541,18 @@ void orc_quickselect(const float* scores, int rows, int cols, int32_t* result, i
 }
 // _sort_and_compressed_binarization (buffalo/data/fileio.hpp:263-420) on 0-based in-memory records: stable sort by
 // (major, minor) (:328-339), END-offset indptr (:359-379), minor ids and values in sorted order (:389-410).
+void orc_cfr_set_embedding(void* hp, float* data, int size, const char* type) { static_cast<CFR*>(((Handle*)hp)->als)->set_embedding(data, size, type); }
+void orc_cfr_precompute(void* hp, const char* type) { static_cast<CFR*>(((Handle*)hp)->als)->precompute_cfr(type); }
+double orc_cfr_partial_update_user(void* hp, int s, int n, const int64_t* indptr, const int32_t* keys, const float* vals) {
+    return static_cast<CFR*>(((Handle*)hp)->als)->partial_update_user(s, n, indptr, keys, vals);
+}
+double orc_cfr_partial_update_item(void* hp, int s, int n, const int64_t* ipu, const int32_t* ku, const float* vu, const int64_t* ipc, const int32_t* kc,
+                                   const float* vc) {
+    return static_cast<CFR*>(((Handle*)hp)->als)->partial_update_item(s, n, ipu, ku, vu, ipc, kc, vc);
+}
+double orc_cfr_partial_update_context(void* hp, int s, int n, const int64_t* indptr, const int32_t* keys, const float* vals) {
+    return static_cast<CFR*>(((Handle*)hp)->als)->partial_update_context(s, n, indptr, keys, vals);
+}
 void orc_coo_to_csr(const int32_t* major, const int32_t* minor, const float* vals, int64_t nnz, int num_major, int64_t* indptr,
                     int32_t* out_minor, float* out_vals) {
     std::vector<int64_t> order(nnz);

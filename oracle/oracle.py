@@ -77,6 +77,11 @@ def lib():
         "orc_dot_topn": (None, [pi32, i32, pf, i32, i32, pf, i32, i32, pf, i32, pi32, pf, pi32, i32, i32, i32]),
         "orc_quickselect": (None, [pf, i32, i32, pi32, i32, i32]),
         "orc_coo_to_csr": (None, [pi32, pi32, pf, i64, i32, pi64, pi32, pf]),
+        "orc_cfr_set_embedding": (None, [vp, pf, i32, C.c_char_p]),
+        "orc_cfr_precompute": (None, [vp, C.c_char_p]),
+        "orc_cfr_partial_update_user": (f64, [vp, i32, i32, pi64, pi32, pf]),
+        "orc_cfr_partial_update_item": (f64, [vp, i32, i32, pi64, pi32, pf, pi64, pi32, pf]),
+        "orc_cfr_partial_update_context": (f64, [vp, i32, i32, pi64, pi32, pf]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -250,6 +255,35 @@ class OracleALS(_Base):
         lib().orc_als_partial_update(self._h, int(start_x), int(next_x), _p(indptr, C.c_int64),
                                      _p(keys, C.c_int32), _p(vals, C.c_float), int(axis), out)
         return out[0], out[1]
+
+
+class OracleCFR(_Base):
+    """~ buffalo.algo._cfr.CyCFR (/root/reference/buffalo/algo/_cfr.pyx:25-71)."""
+    KIND = 3
+
+    def set_embedding(self, F, obj_type):
+        _chk(F, np.float32, 2)
+        t = obj_type.decode() if isinstance(obj_type, bytes) else obj_type
+        self._keep[t] = F
+        lib().orc_cfr_set_embedding(self._h, _p(F, C.c_float), F.shape[0], t.encode())
+
+    def precompute(self, obj_type):
+        t = obj_type.decode() if isinstance(obj_type, bytes) else obj_type
+        lib().orc_cfr_precompute(self._h, t.encode())
+
+    def partial_update_user(self, start_x, next_x, indptrs, keys, vals):
+        _chk(indptrs, np.int64, 1), _chk(keys, np.int32, 1), _chk(vals, np.float32, 1)
+        return lib().orc_cfr_partial_update_user(self._h, int(start_x), int(next_x), _p(indptrs, C.c_int64), _p(keys, C.c_int32), _p(vals, C.c_float))
+
+    def partial_update_item(self, start_x, next_x, indptrs_u, keys_u, vals_u, indptrs_c, keys_c, vals_c):
+        for a, dt in ((indptrs_u, np.int64), (keys_u, np.int32), (vals_u, np.float32), (indptrs_c, np.int64), (keys_c, np.int32), (vals_c, np.float32)):
+            _chk(a, dt, 1)
+        return lib().orc_cfr_partial_update_item(self._h, int(start_x), int(next_x), _p(indptrs_u, C.c_int64), _p(keys_u, C.c_int32),
+                                                 _p(vals_u, C.c_float), _p(indptrs_c, C.c_int64), _p(keys_c, C.c_int32), _p(vals_c, C.c_float))
+
+    def partial_update_context(self, start_x, next_x, indptrs, keys, vals):
+        _chk(indptrs, np.int64, 1), _chk(keys, np.int32, 1), _chk(vals, np.float32, 1)
+        return lib().orc_cfr_partial_update_context(self._h, int(start_x), int(next_x), _p(indptrs, C.c_int64), _p(keys, C.c_int32), _p(vals, C.c_float))
 
 
 def philox4x32_10(ctr, key):

@@ -396,3 +396,70 @@ def test_coo_to_csr_matches_scipy_and_is_stable(oracle):
     M.sort_indices()
     assert np.array_equal(np.unique(np.stack([np.repeat(np.arange(R + 3), np.diff(np.concatenate([[0], g["indptr"]]))), g["key"]]), axis=1),
                           np.stack([np.repeat(np.arange(R + 3), np.diff(M.indptr)), M.indices]))
+
+
+# ------------------------------------------------------------------------------------------------
+# CCFR restatement against a float64 evaluation of the normal equations of
+# cfr.cc:92-313 written directly from the paper's objective (user / item / context rows, biases, losses)
+# ------------------------------------------------------------------------------------------------
+def test_cfr_rows_biases_and_losses_match_numpy(oracle, opt_file):
+    Uu, Ii, d = 14, 9, 6
+    csr = tiny_csr(U=Uu, I=Ii, density=0.4, seed=1, counts=True)
+    t = csr.transpose()
+    ctx = tiny_csr(U=Ii, I=Ii, density=0.35, seed=2, counts=True)
+    alpha, l, ru, ri, rc = 3.0, 0.6, 0.1, 0.2, 0.3
+    opt = {"d": d, "num_workers": 2, "num_cg_max_iters": 3, "alpha": alpha, "l": l, "eps": 1e-10, "reg_u": ru, "reg_i": ri, "reg_c": rc,
+           "compute_loss": True, "optimizer": "llt", "cg_tolerance": 1e-10}
+    rng = np.random.default_rng(0)
+    f = lambda r, c: rng.normal(scale=0.3, size=(r, c)).astype(np.float32)     # noqa: E731
+    U, I, Cx, Ib, Cb = f(Uu, d), f(Ii, d), f(Ii, d), f(Ii, 1), f(Ii, 1)
+    o = oracle.OracleCFR()
+    assert o.init(opt_file(opt))
+    for F, n in ((U, "user"), (I, "item"), (Cx, "context"), (Ib, "item_bias"), (Cb, "context_bias")):
+        o.set_embedding(F, n)
+    f64 = lambda a: a.astype(np.float64)     # noqa: E731
+    # ---- users (cfr.cc:92-146)
+    I0 = f64(I)
+    FF = I0.T @ I0
+    want_U = f64(U).copy()
+    for x in range(Uu):
+        k, v = csr.row(x)
+        Fs = I0[k]
+        A = (FF + Fs.T @ (Fs * (alpha * v)[:, None])) * l + ru * np.eye(d)
+        want_U[x] = np.linalg.solve(A, ((1 + alpha * v) @ Fs) * l)
+    o.precompute("item")
+    loss_u = o.partial_update_user(0, Uu, csr.indptr, csr.keys, csr.vals)
+    np.testing.assert_allclose(U, want_U, rtol=2e-4, atol=2e-5)
+    assert abs(loss_u - ru * (f64(U) ** 2).sum()) < 1e-4 * max(1.0, loss_u)       # the UPDATED rows
+    # ---- items (cfr.cc:148-255)
+    U0, C0, Ib0, Cb0, Iold = f64(U), f64(Cx), f64(Ib).ravel(), f64(Cb).ravel(), f64(I).copy()
+    FFu = U0.T @ U0
+    want_I, want_Ib, want_loss = Iold.copy(), Ib0.copy(), 0.0
+    for x in range(Ii):
+        ku, vu = t.row(x)
+        kc, vc = ctx.row(x)
+        Fu, Fc = U0[ku], C0[kc]
+        dots = Fu @ Iold[x]
+        want_loss += l * (Iold[x] @ FFu @ Iold[x] + (-dots ** 2 + (1 + alpha * vu) * (dots - 1) ** 2).sum())
+        want_loss += ((vc - Fc @ Iold[x] - Ib0[x] - Cb0[kc]) ** 2).sum() + ri * Iold[x] @ Iold[x]
+        A = (FFu + Fu.T @ (Fu * (alpha * vu)[:, None])) * l + Fc.T @ Fc + ri * np.eye(d)
+        y = ((1 + alpha * vu) @ Fu) * l + (vc - Ib0[x] - Cb0[kc]) @ Fc
+        want_I[x] = np.linalg.solve(A, y)
+        want_Ib[x] = (vc - Fc @ want_I[x] - Cb0[kc]).sum() / (len(kc) + 1e-10)
+    o.precompute("user")
+    loss_i = o.partial_update_item(0, Ii, t.indptr, t.keys, t.vals, ctx.indptr, ctx.keys, ctx.vals)
+    np.testing.assert_allclose(I, want_I, rtol=5e-4, atol=5e-5)
+    np.testing.assert_allclose(Ib.ravel(), want_Ib, rtol=5e-4, atol=5e-5)
+    assert abs(loss_i - want_loss) < 2e-4 * max(1.0, abs(want_loss))
+    # ---- contexts (cfr.cc:257-313)
+    I1, Ib1, Cold = f64(I), f64(Ib).ravel(), f64(Cx).copy()
+    want_C, want_Cb = Cold.copy(), Cb0.copy()
+    for x in range(Ii):
+        k, v = ctx.row(x)
+        Fs = I1[k]
+        want_C[x] = np.linalg.solve(Fs.T @ Fs + rc * np.eye(d), (v - Cb0[x] - Ib1[k]) @ Fs)
+        want_Cb[x] = (v - Fs @ want_C[x] - Ib1[k]).sum() / (len(k) + 1e-10)
+    loss_c = o.partial_update_context(0, Ii, ctx.indptr, ctx.keys, ctx.vals)
+    np.testing.assert_allclose(Cx, want_C, rtol=5e-4, atol=5e-5)
+    np.testing.assert_allclose(Cb.ravel(), want_Cb, rtol=5e-4, atol=5e-5)
+    assert abs(loss_c - rc * (Cold ** 2).sum()) < 1e-4 * max(1.0, loss_c)          # the rows BEFORE the update
