@@ -78,6 +78,16 @@ SIGNATURES = {
     "bfh_als_stream": (_vp, [_vp]),
     "bfh_als_get_stats": (_i32, [_vp, C.POINTER(Stats)]),
     "bfh_als_reset_stats": (_i32, [_vp]),
+    "bfh_eals_create": (_vp, []),
+    "bfh_eals_destroy": (None, [_vp]),
+    "bfh_eals_set_device": (_i32, [_vp, _i32]),
+    "bfh_eals_init": (_i32, [_vp, C.c_char_p]),
+    "bfh_eals_initialize_model": (_i32, [_vp, _pf, _pf, _pf, _i32, _i32]),
+    "bfh_eals_precompute_cache": (_i32, [_vp, _i32, C.POINTER(_i64), _pi32, _i32]),
+    "bfh_eals_update": (_i32, [_vp, C.POINTER(_i64), _pi32, _pf, _i32]),
+    "bfh_eals_estimate_loss": (_i32, [_vp, _i32, C.POINTER(_i64), _pi32, _pf, _i32, _pf, _pf]),
+    "bfh_eals_get_stats": (_i32, [_vp, C.POINTER(Stats)]),
+    "bfh_eals_reset_stats": (_i32, [_vp]),
     "bfh_cfr_create": (_vp, []),
     "bfh_cfr_destroy": (None, [_vp]),
     "bfh_cfr_set_device": (_i32, [_vp, _i32]),

@@ -268,3 +268,28 @@ class CyCFR(_Base):
         self._call("partial_update_context", int(start_x), int(next_x), _ptr(indptrs, C.c_int64), _ptr(keys, C.c_int32), _ptr(vals, C.c_float),
                    C.byref(loss))
         return loss.value
+
+
+class CyEALS(_Base):
+    """Element-wise ALS (csrc/eals_impl.hpp); mirrors buffalo.algo._eals.CyEALS (/root/reference/buffalo/algo/_eals.pyx:23-67)."""
+    _PFX = "bfh_eals_"
+
+    def initialize_model(self, P, Q, Cw):
+        _arr(P, np.float32, 2, "P"), _arr(Q, np.float32, 2, "Q"), _arr(Cw, np.float32, 1, "C")
+        self._keep.update(P=P, Q=Q, C=Cw)
+        self._call("initialize_model", _ptr(P, C.c_float), _ptr(Q, C.c_float), _ptr(Cw, C.c_float), P.shape[0], Q.shape[0])
+
+    def precompute_cache(self, nnz, indptr, keys, axis):
+        _arr(indptr, np.int64, 1, "indptr"), _arr(keys, np.int32, 1, "keys")
+        self._call("precompute_cache", int(nnz), _ptr(indptr, C.c_int64), _ptr(keys, C.c_int32), int(axis))
+
+    def update(self, indptr, keys, vals, axis):
+        _arr(indptr, np.int64, 1, "indptr"), _arr(keys, np.int32, 1, "keys"), _arr(vals, np.float32, 1, "vals")
+        return bool(self._call("update", _ptr(indptr, C.c_int64), _ptr(keys, C.c_int32), _ptr(vals, C.c_float), int(axis)))
+
+    def estimate_loss(self, nnz, indptr, keys, vals, axis):
+        _arr(indptr, np.int64, 1, "indptr"), _arr(keys, np.int32, 1, "keys"), _arr(vals, np.float32, 1, "vals")
+        rmse, loss = C.c_float(0.0), C.c_float(0.0)
+        self._call("estimate_loss", int(nnz), _ptr(indptr, C.c_int64), _ptr(keys, C.c_int32), _ptr(vals, C.c_float), int(axis),
+                   C.byref(rmse), C.byref(loss))
+        return rmse.value, loss.value

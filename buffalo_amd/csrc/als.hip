@@ -5,9 +5,11 @@
 // (/root/reference/include/buffalo/cuda/als/als.hpp:20-35).
 #include "als_kernels.hpp"
 #include "cfr_impl.hpp"
+#include "eals_impl.hpp"
 
 using bfh::AlsHandle;
 using bfh::CfrHandle;
+using bfh::EalsHandle;
 using bfh::guarded;
 
 extern "C" {
@@ -138,6 +140,61 @@ int bfh_cfr_get_stats(void* h, bfh_stats* out) {
 }
 int bfh_cfr_reset_stats(void* h) {
     return guarded(h, [&] { static_cast<CfrHandle*>(h)->stats = bfh_stats{}; return BFH_OK; });
+}
+
+// ------------------------------------------------------------------------------------------------
+// eALS -- CEALS (/root/reference/lib/algo_impl/eals/eals.cc) behind CyEALS's surface (buffalo/algo/_eals.pyx:23-67)
+// ------------------------------------------------------------------------------------------------
+void* bfh_eals_create(void) {
+    try {
+        EalsHandle* h = new EalsHandle();
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) {
+            bfh::g_create_error = "no HIP device available (libbuffalo_hip has no CPU fallback)";
+            delete h;
+            return nullptr;
+        }
+        h->device = dev;
+        return h;
+    } catch (const std::exception& e) {
+        bfh::g_create_error = e.what();
+        return nullptr;
+    }
+}
+void bfh_eals_destroy(void* h) { delete static_cast<EalsHandle*>(h); }
+int bfh_eals_set_device(void* h, int device) {
+    return guarded(h, [&] { static_cast<EalsHandle*>(h)->device = device; BFH_HIP(hipSetDevice(device)); return BFH_OK; });
+}
+int bfh_eals_init(void* h, const char* opt_json_path) {
+    int ok = 0;
+    int rc = guarded(h, [&] { ok = static_cast<EalsHandle*>(h)->init_eals(opt_json_path) ? 1 : 0; return BFH_OK; });
+    return rc == BFH_OK ? ok : rc;
+}
+int bfh_eals_initialize_model(void* h, float* P, float* Q, float* C, int P_rows, int Q_rows) {
+    return guarded(h, [&] { static_cast<EalsHandle*>(h)->initialize_model_eals(P, Q, C, P_rows, Q_rows); return BFH_OK; });
+}
+int bfh_eals_precompute_cache(void* h, int nnz, const int64_t* indptr, const int32_t* keys, int axis) {
+    return guarded(h, [&] { static_cast<EalsHandle*>(h)->precompute_cache(nnz, indptr, keys, axis); return BFH_OK; });
+}
+int bfh_eals_update(void* h, const int64_t* indptr, const int32_t* keys, const float* vals, int axis) {
+    int ok = 0;
+    int rc = guarded(h, [&] { ok = static_cast<EalsHandle*>(h)->update(indptr, keys, vals, axis) ? 1 : 0; return BFH_OK; });
+    return rc == BFH_OK ? ok : rc;
+}
+int bfh_eals_estimate_loss(void* h, int nnz, const int64_t* indptr, const int32_t* keys, const float* vals, int axis, float* rmse, float* loss) {
+    return guarded(h, [&] {
+        float a = 0.f, b = 0.f;
+        static_cast<EalsHandle*>(h)->estimate_loss(nnz, indptr, keys, vals, axis, &a, &b);
+        if (rmse) *rmse = a;
+        if (loss) *loss = b;
+        return BFH_OK;
+    });
+}
+int bfh_eals_get_stats(void* h, bfh_stats* out) {
+    return guarded(h, [&] { *out = static_cast<EalsHandle*>(h)->stats; return BFH_OK; });
+}
+int bfh_eals_reset_stats(void* h) {
+    return guarded(h, [&] { static_cast<EalsHandle*>(h)->stats = bfh_stats{}; return BFH_OK; });
 }
 
 }  // extern "C"

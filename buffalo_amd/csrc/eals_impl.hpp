@@ -1,0 +1,392 @@
+// eALS (element-wise ALS, He et al. SIGIR'16) on gfx950 -- handle + kernels.
+//
+// Reference semantics: CEALS (/root/reference/lib/algo_impl/eals/eals.cc:33-281) behind CyEALS's surface
+// (/root/reference/buffalo/algo/_eals.pyx:23-67); SURVEY.md section 8(f) rank 4.  Coordinate descent over the
+// latent dimensions of every row, driven by a cache of the predictions vhat of the observed entries that
+// is kept in BOTH orientations and linked by index maps (eals.cc:49-100).
+//
+// Device formulation: one wave per row.  The row's entries sit one per lane (up to 4 per lane in registers:
+// key, value, vhat, weight; longer rows stream them from HBM each step); for every dimension d the lanes form
+// the numerator / denominator terms of eals.cc:196-213 against the gathered column element Y[key][d], three
+// wave reductions finish the step (the p.S[:,d] product rides on the numerator), the new coordinate is
+// broadcast through LDS and folded back into vhat.  The mirrored cache of the other orientation is written once
+// per row at the end instead of twice per (entry, dimension): nobody reads it before the other half-epoch and
+// both copies receive the same +-pq sequence, so the stored values are identical.
+// Arrays are the reference's CPU layout ([rows, d], unpadded); the device copies are padded to vdim so the
+// MFMA Gramian kernel of the ALS path serves S^p = P^T P and S^q = sum_i C_i q_i q_i^T.
+#pragma once
+#include <algorithm>
+
+#include "als_kernels.hpp"
+
+namespace bfh {
+
+struct EalsParams {
+    float* X;               // side being updated [rows, vdim]
+    const float* Y;         // other side
+    const float* Cw;        // item weights c_i [items]
+    const float* S;         // [vdim, vdim]: axis 0 -> sum_i C_i q q^T, axis 1 -> P^T P
+    const int64_t* indptr;  // END offsets of this orientation
+    const int32_t* keys;
+    const float* vals;
+    float* own;             // vhat cache of this orientation
+    float* other;           // vhat cache of the other orientation
+    const int64_t* map;     // own position -> other position
+    int rows, d, vdim, axis;
+    float alpha, reg;
+    int* ticket;
+};
+
+constexpr int EALS_REG = 4;   // entries per lane kept in registers (rows up to 256 entries)
+
+__global__ __launch_bounds__(256) void eals_update_kernel(EalsParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float* xs = lds + wv * p.vdim;
+    const int D = p.d, vdim = p.vdim;
+    while (true) {
+        int x = 0;
+        if (lane == 0) x = atomicAdd(p.ticket, 1);
+        x = __builtin_amdgcn_readfirstlane(x);
+        if (x >= p.rows) break;
+        const int64_t beg = x == 0 ? 0 : p.indptr[x - 1], end = p.indptr[x];
+        const int64_t n = end - beg;
+        float* xrow = p.X + static_cast<size_t>(x) * vdim;
+        wave_lds_sync();
+        for (int e = lane; e < vdim; e += 64) xs[e] = xrow[e];
+        wave_lds_sync();
+        const float cx = p.axis == 1 ? p.Cw[x] : 0.f;
+        const bool inreg = n <= 64 * EALS_REG;
+        int rk[EALS_REG];
+        float rv[EALS_REG], rh[EALS_REG], rc[EALS_REG];
+        if (inreg) {
+#pragma unroll
+            for (int s = 0; s < EALS_REG; ++s) {
+                const int64_t ind = beg + s * 64 + lane;
+                const bool ok = ind < end;
+                rk[s] = ok ? p.keys[ind] : 0;
+                rv[s] = ok ? p.vals[ind] : 0.f;
+                rh[s] = ok ? p.own[ind] : 0.f;
+                rc[s] = p.axis == 0 ? (ok ? p.Cw[rk[s]] : 0.f) : cx;
+            }
+        }
+        for (int d = 0; d < D; ++d) {
+            const float xd = xs[d];
+            float num = 0.f, den = 0.f;
+            float yds[EALS_REG];
+            if (inreg) {
+#pragma unroll
+                for (int s = 0; s < EALS_REG; ++s) {
+                    const bool ok = beg + s * 64 + lane < end;
+                    const float yd = ok ? p.Y[static_cast<size_t>(rk[s]) * vdim + d] : 0.f;
+                    yds[s] = yd;
+                    const float pq = xd * yd;
+                    const float vf = rh[s] - pq;
+                    const float w = 1.f + p.alpha * rv[s];
+                    const float wmc = w - rc[s];
+                    if (ok) {
+                        num += (w * rv[s] - wmc * vf) * yd;
+                        den += wmc * yd * yd;
+                    }
+                    rh[s] = vf;
+                }
+            } else {
+                for (int64_t ind = beg + lane; ind < end; ind += 64) {
+                    const int y = p.keys[ind];
+                    const float v = p.vals[ind];
+                    const float yd = p.Y[static_cast<size_t>(y) * vdim + d];
+                    const float pq = xd * yd;
+                    const float vf = p.own[ind] - pq;
+                    const float w = 1.f + p.alpha * v;
+                    const float wmc = w - (p.axis == 0 ? p.Cw[y] : cx);
+                    num += (w * v - wmc * vf) * yd;
+                    den += wmc * yd * yd;
+                    p.own[ind] = vf;
+                }
+            }
+            float dot = 0.f;   // x . S[:, d] (S symmetric)
+            for (int e = lane; e < D; e += 64) dot += xs[e] * p.S[static_cast<size_t>(d) * vdim + e];
+            num = wave_sum(num);
+            den = wave_sum(den);
+            dot = wave_sum(dot);
+            const float sdd = p.S[static_cast<size_t>(d) * vdim + d];
+            if (p.axis == 0) {   // eals.cc:214-215
+                num += -dot + xd * sdd;
+                den += sdd + p.reg;
+            } else {             // eals.cc:261-262
+                num += -cx * (dot - xd * sdd);
+                den += cx * sdd + p.reg;
+            }
+            const float xn = num / den;
+            wave_lds_sync();
+            if (lane == 0) xs[d] = xn;
+            wave_lds_sync();
+            if (inreg) {
+#pragma unroll
+                for (int s = 0; s < EALS_REG; ++s) rh[s] += xn * yds[s];
+            } else {
+                for (int64_t ind = beg + lane; ind < end; ind += 64)
+                    p.own[ind] += xn * p.Y[static_cast<size_t>(p.keys[ind]) * vdim + d];
+            }
+        }
+        for (int e = lane; e < D; e += 64) xrow[e] = xs[e];
+        if (inreg) {
+#pragma unroll
+            for (int s = 0; s < EALS_REG; ++s) {
+                const int64_t ind = beg + s * 64 + lane;
+                if (ind < end) {
+                    p.own[ind] = rh[s];
+                    p.other[p.map[ind]] = rh[s];
+                }
+            }
+        } else {
+            for (int64_t ind = beg + lane; ind < end; ind += 64) p.other[p.map[ind]] = p.own[ind];
+        }
+    }
+}
+
+// vhat[ind] = X[row(ind)] . Y[key(ind)]   (eals.cc:72-78); one wave per row
+__global__ __launch_bounds__(256) void eals_cache_kernel(const float* __restrict__ X, const float* __restrict__ Y, int vdim, int rows,
+                                                         const int64_t* __restrict__ indptr, const int32_t* __restrict__ keys, float* __restrict__ vhat) {
+    const int lane = threadIdx.x & 63;
+    const int x = static_cast<int>((static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6);
+    if (x >= rows) return;
+    const int64_t beg = x == 0 ? 0 : indptr[x - 1], end = indptr[x];
+    const float* xr = X + static_cast<size_t>(x) * vdim;
+    for (int64_t ind = beg; ind < end; ++ind) {
+        const float* yr = Y + static_cast<size_t>(keys[ind]) * vdim;
+        float part = 0.f;
+        for (int e = lane; e < vdim; e += 64) part += xr[e] * yr[e];
+        part = wave_sum(part);
+        if (lane == 0) vhat[ind] = part;
+    }
+}
+
+// out[r][e] = sqrt(w[r]) * F[r][e]
+__global__ __launch_bounds__(256) void eals_scale_rows_kernel(const float* __restrict__ F, const float* __restrict__ w, int rows, int vdim, float* __restrict__ out) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (i < static_cast<int64_t>(rows) * vdim) out[i] = sqrtf(w[i / vdim]) * F[i];
+}
+
+// eals.cc:134-150: per-entry loss terms; out[0] += feedbacks, out[1] += squared error
+__global__ __launch_bounds__(256) void eals_loss_kernel(const int64_t* __restrict__ indptr, const int32_t* __restrict__ keys, const float* __restrict__ vals,
+                                                        const float* __restrict__ vhat, const float* __restrict__ Cw, int rows, int axis, float alpha,
+                                                        double* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int x = static_cast<int>((static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6);
+    if (x >= rows) return;
+    const int64_t beg = x == 0 ? 0 : indptr[x - 1], end = indptr[x];
+    double fb = 0.0, se = 0.0;
+    for (int64_t ind = beg + lane; ind < end; ind += 64) {
+        const float v = vals[ind], vh = vhat[ind], err = v - vh;
+        fb += static_cast<double>((1.f + alpha * v) * err * err) - static_cast<double>(Cw[axis == 0 ? keys[ind] : x] * vh * vh);
+        se += static_cast<double>(err * err);
+    }
+    fb = wave_sum_f64(fb);
+    se = wave_sum_f64(se);
+    if (lane == 0 && end > beg) {
+        atomicAdd(out, fb);
+        atomicAdd(out + 1, se);
+    }
+}
+
+// out += sum F^2 over [rows, vdim] (pad columns are zero)
+__global__ __launch_bounds__(256) void eals_sqsum_kernel(const float* __restrict__ F, int64_t n, double* __restrict__ out) {
+    double part = 0.0;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * 256)
+        part += static_cast<double>(F[i]) * static_cast<double>(F[i]);
+    part = wave_sum_f64(part);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, part);
+}
+
+class EalsHandle : public AlsHandle {
+ public:
+    bool init_eals(const char* opt_path) {   // eals.cc:19-31
+        std::string err;
+        if (!opt_.load(opt_path ? opt_path : "", &err)) {
+            last_error = err;
+            return false;
+        }
+        BFH_HIP(hipSetDevice(device));
+        if (!stream) BFH_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        hipDeviceProp_t prop;
+        BFH_HIP(hipGetDeviceProperties(&prop, device));
+        num_cus_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        d_ = opt_.integer("d");
+        BFH_REQUIRE(d_ > 0, "option d must be positive");
+        vdim_ = vdim_of(d_);
+        BFH_REQUIRE(vdim_ <= 1024, "d > 1024 is not supported by the gfx950 kernels yet");
+        alpha_ = static_cast<float>(opt_.num("alpha"));
+        reg_u_ = static_cast<float>(opt_.num("reg_u"));
+        reg_i_ = static_cast<float>(opt_.num("reg_i"));
+        FF_.resize(static_cast<size_t>(vdim_) * vdim_, true, stream);
+        FF64_.resize(static_cast<size_t>(vdim_) * vdim_, true, stream);
+        S2_.resize(static_cast<size_t>(vdim_) * vdim_, true, stream);
+        loss_.resize(4, true, stream);
+        ticket_.resize(1, true, stream);
+        inited_ = true;
+        BFH_HIP(hipStreamSynchronize(stream));
+        return true;
+    }
+    // eals.cc:33-47
+    void initialize_model_eals(float* P, float* Q, float* Cw, int P_rows, int Q_rows) {
+        BFH_REQUIRE(inited_, "initialize_model called before init");
+        BFH_REQUIRE(P && Q && Cw && P_rows > 0 && Q_rows > 0, "initialize_model: null arrays or empty shapes");
+        hostP_ = P; hostQ_ = Q; hostC_ = Cw; P_rows_ = P_rows; Q_rows_ = Q_rows;
+        P_.resize(static_cast<size_t>(P_rows) * vdim_, true, stream);
+        Q_.resize(static_cast<size_t>(Q_rows) * vdim_, true, stream);
+        Cw_.resize(Q_rows);
+        push_factors();
+        BFH_HIP(hipMemcpyAsync(Cw_.get(), Cw, sizeof(float) * Q_rows, hipMemcpyHostToDevice, stream));
+        BFH_HIP(hipStreamSynchronize(stream));
+        cached_[0] = cached_[1] = false;
+        model_ = true;
+    }
+    void push_factors() {
+        BFH_HIP(hipMemcpy2DAsync(P_.get(), static_cast<size_t>(vdim_) * 4, hostP_, static_cast<size_t>(d_) * 4, static_cast<size_t>(d_) * 4, P_rows_,
+                                 hipMemcpyHostToDevice, stream));
+        BFH_HIP(hipMemcpy2DAsync(Q_.get(), static_cast<size_t>(vdim_) * 4, hostQ_, static_cast<size_t>(d_) * 4, static_cast<size_t>(d_) * 4, Q_rows_,
+                                 hipMemcpyHostToDevice, stream));
+        stats.h2d_bytes += 4.0 * d_ * (static_cast<double>(P_rows_) + Q_rows_);
+    }
+    void pull_factor(int axis) {
+        float* host = axis == 0 ? hostP_ : hostQ_;
+        const float* dev = axis == 0 ? P_.get() : Q_.get();
+        const int rows = axis == 0 ? P_rows_ : Q_rows_;
+        BFH_HIP(hipMemcpy2DAsync(host, static_cast<size_t>(d_) * 4, dev, static_cast<size_t>(vdim_) * 4, static_cast<size_t>(d_) * 4, rows,
+                                 hipMemcpyDeviceToHost, stream));
+        stats.d2h_bytes += 4.0 * d_ * rows;
+    }
+    struct Side {
+        DevBuf<int64_t> indptr, map;
+        DevBuf<int32_t> keys;
+        DevBuf<float> vals, vhat;
+        int64_t nnz = 0;
+    };
+    // eals.cc:49-100: the orientation's structure stays resident; vhat from the current factors; the index map by a host sort
+    void precompute_cache(int nnz, const int64_t* indptr, const int32_t* keys, int axis) {
+        BFH_REQUIRE(model_, "precompute_cache before initialize_model");
+        BFH_REQUIRE(axis == 0 || axis == 1, "axis must be 0 or 1");
+        if (cached_[axis]) return;   // eals.cc:54-56
+        const int rows = axis == 0 ? P_rows_ : Q_rows_;
+        BFH_REQUIRE(indptr && keys && nnz >= 0 && (rows == 0 || indptr[rows - 1] == nnz), "precompute_cache: indptr does not end at nnz");
+        Side& s = side_[axis];
+        s.nnz = nnz;
+        s.indptr.resize(rows);
+        s.keys.resize(std::max(nnz, 1));
+        s.vals.resize(std::max(nnz, 1));
+        s.vhat.resize(std::max(nnz, 1));
+        s.map.resize(std::max(nnz, 1));
+        BFH_HIP(hipMemcpyAsync(s.indptr.get(), indptr, sizeof(int64_t) * rows, hipMemcpyHostToDevice, stream));
+        if (nnz) BFH_HIP(hipMemcpyAsync(s.keys.get(), keys, sizeof(int32_t) * nnz, hipMemcpyHostToDevice, stream));
+        // rank of every entry in (other id, own id) order = its position in the other orientation (eals.cc:81-99)
+        std::vector<std::pair<uint64_t, int64_t>> coord(nnz);
+        {
+            int64_t prev = 0;
+            for (int x = 0; x < rows; ++x) {
+                for (int64_t ind = prev; ind < indptr[x]; ++ind)
+                    coord[ind] = {(static_cast<uint64_t>(static_cast<uint32_t>(keys[ind])) << 32) | static_cast<uint32_t>(x), ind};
+                prev = indptr[x];
+            }
+        }
+        std::sort(coord.begin(), coord.end());
+        std::vector<int64_t> map(nnz);
+        for (int64_t r = 0; r < nnz; ++r) map[coord[r].second] = r;
+        if (nnz) BFH_HIP(hipMemcpyAsync(s.map.get(), map.data(), sizeof(int64_t) * nnz, hipMemcpyHostToDevice, stream));
+        const int slot = t_aux_.begin(stream);
+        hipLaunchKernelGGL(eals_cache_kernel, dim3(static_cast<unsigned>((rows + 3) / 4)), dim3(256), 0, stream, axis == 0 ? P_.get() : Q_.get(),
+                           axis == 0 ? Q_.get() : P_.get(), vdim_, rows, s.indptr.get(), s.keys.get(), s.vhat.get());
+        BFH_HIP(hipGetLastError());
+        t_aux_.end(slot, stream);
+        BFH_HIP(hipStreamSynchronize(stream));   // map is a local
+        stats.h2d_bytes += 8.0 * rows + 12.0 * nnz;
+        stats.aux_ms += t_aux_.drain();
+        cached_[axis] = true;
+    }
+    // S for the update of `axis`: axis 0 -> sum_i C_i q q^T (eals.cc:179-191), axis 1 -> P^T P (:234-235); lands in FF_
+    void gram_for(int axis) {
+        if (axis == 0) {
+            CQ_.resize(static_cast<size_t>(Q_rows_) * vdim_);
+            const int64_t n = static_cast<int64_t>(Q_rows_) * vdim_;
+            hipLaunchKernelGGL(eals_scale_rows_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, stream, Q_.get(), Cw_.get(), Q_rows_, vdim_,
+                               CQ_.get());
+            BFH_HIP(hipGetLastError());
+            gramian_of(CQ_.get(), Q_rows_);
+        } else {
+            gramian_of(P_.get(), P_rows_);
+        }
+    }
+    // eals.cc:102-115: false until both caches exist
+    bool update(const int64_t* indptr, const int32_t* keys, const float* vals, int axis) {
+        BFH_REQUIRE(model_, "update before initialize_model");
+        BFH_REQUIRE(axis == 0 || axis == 1, "axis must be 0 or 1");
+        if (!(cached_[0] && cached_[1])) return false;
+        (void)indptr; (void)keys;   // the structure was bound by precompute_cache
+        Side& s = side_[axis];
+        if (s.nnz) BFH_HIP(hipMemcpyAsync(s.vals.get(), vals, sizeof(float) * s.nnz, hipMemcpyHostToDevice, stream));
+        stats.h2d_bytes += 4.0 * s.nnz;
+        gram_for(axis);
+        EalsParams p{};
+        p.X = axis == 0 ? P_.get() : Q_.get();
+        p.Y = axis == 0 ? Q_.get() : P_.get();
+        p.Cw = Cw_.get(); p.S = FF_.get();
+        p.indptr = s.indptr.get(); p.keys = s.keys.get(); p.vals = s.vals.get();
+        p.own = s.vhat.get(); p.other = side_[1 - axis].vhat.get(); p.map = s.map.get();
+        p.rows = axis == 0 ? P_rows_ : Q_rows_;
+        p.d = d_; p.vdim = vdim_; p.axis = axis; p.alpha = alpha_; p.reg = axis == 0 ? reg_u_ : reg_i_;
+        p.ticket = ticket_.get();
+        BFH_HIP(hipMemsetAsync(ticket_.get(), 0, sizeof(int), stream));
+        int blocks = (p.rows + 3) / 4;
+        if (blocks > num_cus_ * 8) blocks = num_cus_ * 8;
+        const int slot = t_main_.begin(stream);
+        hipLaunchKernelGGL(eals_update_kernel, dim3(std::max(blocks, 1)), dim3(256), static_cast<size_t>(4) * vdim_ * sizeof(float), stream, p);
+        BFH_HIP(hipGetLastError());
+        t_main_.end(slot, stream);
+        pull_factor(axis);
+        BFH_HIP(hipStreamSynchronize(stream));
+        stats.kernel_ms += t_main_.drain();
+        stats.samples += s.nnz;
+        stats.launches += 1;
+        return true;
+    }
+    // eals.cc:117-174 -> (rmse, loss); accumulated in double (the reference sums tens of millions of floats in a float)
+    void estimate_loss(int nnz, const int64_t* indptr, const int32_t* keys, const float* vals, int axis, float* rmse, float* loss) {
+        (void)indptr; (void)keys;
+        *rmse = 0.f;
+        *loss = 0.f;
+        if (!(cached_[0] && cached_[1])) return;
+        Side& s = side_[axis];
+        BFH_REQUIRE(nnz == s.nnz, "estimate_loss: nnz differs from the cached structure");
+        if (s.nnz) BFH_HIP(hipMemcpyAsync(s.vals.get(), vals, sizeof(float) * s.nnz, hipMemcpyHostToDevice, stream));
+        BFH_HIP(hipMemsetAsync(loss_.get(), 0, 4 * sizeof(double), stream));
+        const int rows = axis == 0 ? P_rows_ : Q_rows_;
+        hipLaunchKernelGGL(eals_loss_kernel, dim3(static_cast<unsigned>((rows + 3) / 4)), dim3(256), 0, stream, s.indptr.get(), s.keys.get(), s.vals.get(),
+                           s.vhat.get(), Cw_.get(), rows, axis, alpha_, loss_.get());
+        hipLaunchKernelGGL(eals_sqsum_kernel, dim3(num_cus_ * 4), dim3(256), 0, stream, P_.get(), static_cast<int64_t>(P_rows_) * vdim_, loss_.get() + 2);
+        hipLaunchKernelGGL(eals_sqsum_kernel, dim3(num_cus_ * 4), dim3(256), 0, stream, Q_.get(), static_cast<int64_t>(Q_rows_) * vdim_, loss_.get() + 3);
+        BFH_HIP(hipGetLastError());
+        // <S^p, S^q> over the full symmetric matrices (misc/blas.hpp:49-63 mirrors the computed triangle)
+        const size_t nn = static_cast<size_t>(vdim_) * vdim_;
+        gram_for(1);
+        BFH_HIP(hipMemcpyAsync(S2_.get(), FF_.get(), nn * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        gram_for(0);
+        std::vector<float> sp(nn), sq(nn);
+        double acc[4];
+        BFH_HIP(hipMemcpyAsync(sp.data(), S2_.get(), nn * sizeof(float), hipMemcpyDeviceToHost, stream));
+        BFH_HIP(hipMemcpyAsync(sq.data(), FF_.get(), nn * sizeof(float), hipMemcpyDeviceToHost, stream));
+        BFH_HIP(hipMemcpyAsync(acc, loss_.get(), 4 * sizeof(double), hipMemcpyDeviceToHost, stream));
+        BFH_HIP(hipStreamSynchronize(stream));
+        double ip = 0.0;
+        for (size_t k = 0; k < nn; ++k) ip += static_cast<double>(sp[k]) * static_cast<double>(sq[k]);
+        const double reg = static_cast<double>(reg_u_) * acc[2] + static_cast<double>(reg_i_) * acc[3];
+        *rmse = static_cast<float>(std::sqrt(acc[1] / std::max(nnz, 1)));
+        *loss = static_cast<float>(acc[0] + ip + reg);
+    }
+
+    float* hostC_ = nullptr;
+    bool cached_[2] = {false, false};
+    Side side_[2];
+    DevBuf<float> Cw_, CQ_, S2_;
+};
+
+}  // namespace bfh

@@ -258,6 +258,27 @@ int bfh_cfr_partial_update_context(void* h, int start_x, int next_x, const int64
 int bfh_cfr_get_stats(void* h, bfh_stats* out);
 int bfh_cfr_reset_stats(void* h);
 
+/* ------------------------------------------------------------------------------------------------
+ * eALS   (CEALS: include/buffalo/algo_impl/eals/eals.hpp:20-84, lib/algo_impl/eals/eals.cc)
+ * Element-wise ALS with a prediction cache in both orientations.  Whole-matrix calls: indptr are END offsets
+ * of the full matrix, P [P_rows, d] / Q [Q_rows, d] unpadded, C [Q_rows] the item weights c_i.  The structure
+ * handed to precompute_cache stays bound; update / estimate_loss take the same arrays again (only vals are read).
+ * ---------------------------------------------------------------------------------------------- */
+void* bfh_eals_create(void);                                                       /* CEALS::CEALS            eals.cc:6   */
+void bfh_eals_destroy(void* h);
+int bfh_eals_set_device(void* h, int device);
+int bfh_eals_init(void* h, const char* opt_json_path);                             /* CEALS::init             eals.cc:19  */
+int bfh_eals_initialize_model(void* h, float* P, float* Q, float* C, int P_rows, int Q_rows);   /* eals.cc:33 */
+/* CEALS::precompute_cache eals.cc:49-100: vhat of every observed entry + the index map to the other orientation */
+int bfh_eals_precompute_cache(void* h, int nnz, const int64_t* indptr, const int32_t* keys, int axis);
+/* CEALS::update eals.cc:102-115 -> 1, or 0 while a cache is missing; the updated side is copied back into P / Q */
+int bfh_eals_update(void* h, const int64_t* indptr, const int32_t* keys, const float* vals, int axis);
+/* CEALS::estimate_loss eals.cc:117-174 -> (rmse, loss); both 0 while a cache is missing */
+int bfh_eals_estimate_loss(void* h, int nnz, const int64_t* indptr, const int32_t* keys, const float* vals, int axis,
+                           float* rmse, float* loss);
+int bfh_eals_get_stats(void* h, bfh_stats* out);
+int bfh_eals_reset_stats(void* h);
+
 #ifdef __cplusplus
 }
 #endif

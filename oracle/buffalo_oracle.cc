@@ -1335,12 +1335,150 @@ class CFR : public ALS {
     }
 };
 
+// ============================================================================
+// CEALS  (lib/algo_impl/eals/eals.cc) -- element-wise ALS (He et al., SIGIR'16): coordinate descent over the
+// latent dimensions of every row with a cache of the predictions vhat for the observed entries, kept in both
+// orientations (vhat_u in user-major, vhat_i in item-major order) and linked by index maps.
+// Whole-matrix calls (no chunking): indptr are END offsets of the full matrix.
+// ============================================================================
+class EALS {
+ public:
+    Opt opt_;
+    float *P_ = nullptr, *Q_ = nullptr, *C_ = nullptr;
+    int P_rows_ = 0, Q_rows_ = 0;
+    bool cached_[2] = {false, false};
+    std::vector<float> vhat_[2];       // [0] user-major, [1] item-major
+    std::vector<int64_t> map_[2];      // [0] u2i: position in the item-major order of user-major entry ind; [1] i2u
+    bool init() { omp_set_num_threads(std::max(1, opt_.i("num_workers"))); return true; }   // eals.cc:19-26
+    void initialize_model(float* P, float* Q, float* C, int P_rows, int Q_rows) {           // eals.cc:33-47
+        P_ = P; Q_ = Q; C_ = C; P_rows_ = P_rows; Q_rows_ = Q_rows;
+        cached_[0] = cached_[1] = false;
+    }
+    // eals.cc:49-100
+    void precompute_cache(int nnz, const int64_t* indptr, const int32_t* keys, int axis) {
+        if (cached_[axis]) return;
+        const float* X = axis == 0 ? P_ : Q_;
+        const float* Y = axis == 0 ? Q_ : P_;
+        const int rows = axis == 0 ? P_rows_ : Q_rows_, D = opt_.i("d");
+        vhat_[axis].assign(nnz, 0.f);
+        std::vector<std::pair<std::pair<int32_t, int32_t>, int64_t>> coord(nnz);   // ((other id, own id), position)
+#pragma omp parallel for schedule(dynamic, 8)
+        for (int x = 0; x < rows; ++x) {
+            const int64_t beg = x == 0 ? 0 : indptr[x - 1], end = indptr[x];
+            for (int64_t ind = beg; ind < end; ++ind) {
+                const int32_t y = keys[ind];
+                float acc = 0.f;   // std::inner_product: sequential
+                for (int c = 0; c < D; ++c) acc += X[(size_t)x * D + c] * Y[(size_t)y * D + c];
+                vhat_[axis][ind] = acc;
+                coord[ind] = {{y, x}, ind};
+            }
+        }
+        std::sort(coord.begin(), coord.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+        map_[axis].assign(nnz, 0);
+        for (int64_t r = 0; r < nnz; ++r) map_[axis][coord[r].second] = r;
+        cached_[axis] = true;
+    }
+    // S[d][e] = sum_rows w_r F[r][d] F[r][e]  (blas::syrk + fill_left_elems: the full symmetric matrix)
+    std::vector<float> gram(const float* F, int rows, const float* w) const {
+        const int D = opt_.i("d");
+        std::vector<float> S((size_t)D * D, 0.f);
+        for (int r = 0; r < rows; ++r) {
+            const float wr = w ? w[r] : 1.f;   // (sqrt(C) q)(sqrt(C) q)^T = C q q^T
+            const float* f = F + (size_t)r * D;
+            for (int a = 0; a < D; ++a) {
+                const float fa = wr * f[a];
+                for (int b = 0; b < D; ++b) S[(size_t)a * D + b] += fa * f[b];
+            }
+        }
+        return S;
+    }
+    // eals.cc:102-115, 176-281
+    bool update(const int64_t* indptr, const int32_t* keys, const float* vals, int axis) {
+        if (!(cached_[0] && cached_[1])) return false;
+        const int D = opt_.i("d");
+        const float alpha = (float)opt_.d("alpha");
+        const float reg = (float)opt_.d(axis == 0 ? "reg_u" : "reg_i");
+        float* X = axis == 0 ? P_ : Q_;
+        const float* Y = axis == 0 ? Q_ : P_;
+        const int rows = axis == 0 ? P_rows_ : Q_rows_;
+        const std::vector<float> S = axis == 0 ? gram(Q_, Q_rows_, C_) : gram(P_, P_rows_, nullptr);
+        std::vector<float>& own = vhat_[axis];
+        std::vector<float>& other = vhat_[1 - axis];
+        const std::vector<int64_t>& map = map_[axis];
+#pragma omp parallel for schedule(dynamic, 8)
+        for (int x = 0; x < rows; ++x) {
+            float* xp = X + (size_t)x * D;
+            const int64_t beg = x == 0 ? 0 : indptr[x - 1], end = indptr[x];
+            for (int d = 0; d < D; ++d) {
+                float numerator = 0.f, denominator = 0.f;
+                for (int64_t ind = beg; ind < end; ++ind) {
+                    const int32_t y = keys[ind];
+                    const float v = vals[ind];
+                    const float yd = Y[(size_t)y * D + d];
+                    const float pq = xp[d] * yd;
+                    const float vf = own[ind] - pq;
+                    const float w = 1.f + alpha * v;
+                    const float wmc = w - C_[axis == 0 ? y : x];
+                    numerator += (w * v - wmc * vf) * yd;
+                    denominator += wmc * yd * yd;
+                    own[ind] -= pq;
+                    other[map[ind]] -= pq;
+                }
+                float dot = 0.f;
+                for (int c = 0; c < D; ++c) dot += xp[c] * S[(size_t)d * D + c];
+                if (axis == 0) {
+                    numerator += -dot + xp[d] * S[(size_t)d * D + d];
+                    denominator += S[(size_t)d * D + d] + reg;
+                } else {
+                    numerator += -C_[x] * (dot - xp[d] * S[(size_t)d * D + d]);
+                    denominator += C_[x] * S[(size_t)d * D + d] + reg;
+                }
+                xp[d] = numerator / denominator;
+                for (int64_t ind = beg; ind < end; ++ind) {
+                    const float pq = xp[d] * Y[(size_t)keys[ind] * D + d];
+                    own[ind] += pq;
+                    other[map[ind]] += pq;
+                }
+            }
+        }
+        return true;
+    }
+    // eals.cc:117-174: float accumulators, as the reference
+    std::pair<float, float> estimate_loss(int nnz, const int64_t* indptr, const int32_t* keys, const float* vals, int axis) {
+        if (!(cached_[0] && cached_[1])) return {0.f, 0.f};
+        const int D = opt_.i("d");
+        const float alpha = (float)opt_.d("alpha");
+        float feedbacks = 0.f, squared_error = 0.f;
+        const int rows = axis == 0 ? P_rows_ : Q_rows_;
+        for (int x = 0; x < rows; ++x) {
+            const int64_t beg = x == 0 ? 0 : indptr[x - 1], end = indptr[x];
+            for (int64_t ind = beg; ind < end; ++ind) {
+                const float v = vals[ind], vh = vhat_[axis][ind], err = v - vh;
+                feedbacks += (1.f + alpha * v) * err * err;
+                feedbacks -= C_[axis == 0 ? keys[ind] : x] * vh * vh;
+                squared_error += err * err;
+            }
+        }
+        float rp = 0.f, rq = 0.f;
+        for (size_t k = 0; k < (size_t)P_rows_ * D; ++k) rp += P_[k] * P_[k];
+        for (size_t k = 0; k < (size_t)Q_rows_ * D; ++k) rq += Q_[k] * Q_[k];
+        const float reg = (float)opt_.d("reg_u") * rp + (float)opt_.d("reg_i") * rq;
+        const std::vector<float> Sp = gram(P_, P_rows_, nullptr), Sq = gram(Q_, Q_rows_, C_);
+        // <Sp, Sq> over the full symmetric D x D matrices (blas::syrk mirrors the triangle it computed, misc/blas.hpp:49-63,80)
+        float ip = 0.f;
+        for (size_t k = 0; k < (size_t)D * D; ++k) ip += Sp[k] * Sq[k];
+        feedbacks += ip;
+        return {std::sqrt(squared_error / (float)nnz), feedbacks + reg};
+    }
+};
+
 struct Handle {
     int kind;  // 0 bpr, 1 warp, 2 als, 3 cfr
     SGD* sgd = nullptr;
     ALS* als = nullptr;   // kind 3: a CFR
+    EALS* eals = nullptr; // kind 4
     std::vector<int32_t> trace;
-    Opt* opt() { return kind >= 2 ? &als->opt_ : &sgd->opt_; }
+    Opt* opt() { return kind == 4 ? &eals->opt_ : (kind >= 2 ? &als->opt_ : &sgd->opt_); }
 };
 
 }  // namespace
@@ -1433,7 +1571,8 @@ void* orc_create(int kind) {
     if (kind == 0) h->sgd = new BPR();
     else if (kind == 1) h->sgd = new WARP();
     else if (kind == 2) h->als = new ALS();
-    else h->als = new CFR();
+    else if (kind == 3) h->als = new CFR();
+    else h->eals = new EALS();
     return h;
 }
 void orc_destroy(void* hp) {
@@ -1447,6 +1586,7 @@ void orc_opt_str(void* hp, const char* k, const char* v) { ((Handle*)hp)->opt()-
 void orc_opt_bool(void* hp, const char* k, int v) { ((Handle*)hp)->opt()->boo[k] = v != 0; }
 int orc_init(void* hp) {
     Handle* h = (Handle*)hp;
+    if (h->kind == 4) return (int)h->eals->init();
     if (h->kind == 3) return (int)static_cast<CFR*>(h->als)->init_cfr();
     return h->kind == 2 ? (int)h->als->init() : (int)h->sgd->init();
 }
@@ -1541,6 +1681,19 @@ void orc_quickselect(const float* scores, int rows, int cols, int32_t* result, i
 }
 // _sort_and_compressed_binarization (buffalo/data/fileio.hpp:263-420) on 0-based in-memory records: stable sort by
 // (major, minor) (:328-339), END-offset indptr (:359-379), minor ids and values in sorted order (:389-410).
+void orc_eals_initialize_model(void* hp, float* P, float* Q, float* Cw, int P_rows, int Q_rows) { ((Handle*)hp)->eals->initialize_model(P, Q, Cw, P_rows, Q_rows); }
+void orc_eals_precompute_cache(void* hp, int nnz, const int64_t* indptr, const int32_t* keys, int axis) { ((Handle*)hp)->eals->precompute_cache(nnz, indptr, keys, axis); }
+int orc_eals_update(void* hp, const int64_t* indptr, const int32_t* keys, const float* vals, int axis) { return ((Handle*)hp)->eals->update(indptr, keys, vals, axis) ? 1 : 0; }
+void orc_eals_estimate_loss(void* hp, int nnz, const int64_t* indptr, const int32_t* keys, const float* vals, int axis, float* out2) {
+    auto r = ((Handle*)hp)->eals->estimate_loss(nnz, indptr, keys, vals, axis);
+    out2[0] = r.first;
+    out2[1] = r.second;
+}
+void orc_eals_caches(void* hp, int axis, float* vhat, int64_t* map) {
+    EALS* e = ((Handle*)hp)->eals;
+    std::copy(e->vhat_[axis].begin(), e->vhat_[axis].end(), vhat);
+    std::copy(e->map_[axis].begin(), e->map_[axis].end(), map);
+}
 void orc_cfr_set_embedding(void* hp, float* data, int size, const char* type) { static_cast<CFR*>(((Handle*)hp)->als)->set_embedding(data, size, type); }
 void orc_cfr_precompute(void* hp, const char* type) { static_cast<CFR*>(((Handle*)hp)->als)->precompute_cfr(type); }
 double orc_cfr_partial_update_user(void* hp, int s, int n, const int64_t* indptr, const int32_t* keys, const float* vals) {

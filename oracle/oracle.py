@@ -77,6 +77,11 @@ def lib():
         "orc_dot_topn": (None, [pi32, i32, pf, i32, i32, pf, i32, i32, pf, i32, pi32, pf, pi32, i32, i32, i32]),
         "orc_quickselect": (None, [pf, i32, i32, pi32, i32, i32]),
         "orc_coo_to_csr": (None, [pi32, pi32, pf, i64, i32, pi64, pi32, pf]),
+        "orc_eals_initialize_model": (None, [vp, pf, pf, pf, i32, i32]),
+        "orc_eals_precompute_cache": (None, [vp, i32, pi64, pi32, i32]),
+        "orc_eals_update": (i32, [vp, pi64, pi32, pf, i32]),
+        "orc_eals_estimate_loss": (None, [vp, i32, pi64, pi32, pf, i32, pf]),
+        "orc_eals_caches": (None, [vp, i32, pf, pi64]),
         "orc_cfr_set_embedding": (None, [vp, pf, i32, C.c_char_p]),
         "orc_cfr_precompute": (None, [vp, C.c_char_p]),
         "orc_cfr_partial_update_user": (f64, [vp, i32, i32, pi64, pi32, pf]),
@@ -284,6 +289,34 @@ class OracleCFR(_Base):
     def partial_update_context(self, start_x, next_x, indptrs, keys, vals):
         _chk(indptrs, np.int64, 1), _chk(keys, np.int32, 1), _chk(vals, np.float32, 1)
         return lib().orc_cfr_partial_update_context(self._h, int(start_x), int(next_x), _p(indptrs, C.c_int64), _p(keys, C.c_int32), _p(vals, C.c_float))
+
+
+class OracleEALS(_Base):
+    """~ buffalo.algo._eals.CyEALS (/root/reference/buffalo/algo/_eals.pyx:23-67)."""
+    KIND = 4
+
+    def initialize_model(self, P, Q, Cw):
+        _chk(P, np.float32, 2), _chk(Q, np.float32, 2), _chk(Cw, np.float32, 1)
+        self._keep.update(P=P, Q=Q, C=Cw)
+        lib().orc_eals_initialize_model(self._h, _p(P, C.c_float), _p(Q, C.c_float), _p(Cw, C.c_float), P.shape[0], Q.shape[0])
+
+    def precompute_cache(self, nnz, indptr, keys, axis):
+        _chk(indptr, np.int64, 1), _chk(keys, np.int32, 1)
+        lib().orc_eals_precompute_cache(self._h, int(nnz), _p(indptr, C.c_int64), _p(keys, C.c_int32), int(axis))
+
+    def update(self, indptr, keys, vals, axis):
+        _chk(indptr, np.int64, 1), _chk(keys, np.int32, 1), _chk(vals, np.float32, 1)
+        return bool(lib().orc_eals_update(self._h, _p(indptr, C.c_int64), _p(keys, C.c_int32), _p(vals, C.c_float), int(axis)))
+
+    def estimate_loss(self, nnz, indptr, keys, vals, axis):
+        out = (C.c_float * 2)()
+        lib().orc_eals_estimate_loss(self._h, int(nnz), _p(indptr, C.c_int64), _p(keys, C.c_int32), _p(vals, C.c_float), int(axis), out)
+        return float(out[0]), float(out[1])
+
+    def caches(self, axis, nnz):
+        vhat, mp = np.empty(nnz, np.float32), np.empty(nnz, np.int64)
+        lib().orc_eals_caches(self._h, int(axis), _p(vhat, C.c_float), _p(mp, C.c_int64))
+        return vhat, mp
 
 
 def philox4x32_10(ctr, key):

@@ -136,6 +136,39 @@ if "bpr_pcie" in which:
                                            "note": "80 MB keys H2D (pageable numpy) + fill_rows + kernel + 85 MB D2H per epoch"}
     print("bpr_pcie", out["bpr_host_buffers_every_epoch"], flush=True)
 
+if "eals" in which:
+    from buffalo_amd.backend import CyEALS
+    rng = np.random.default_rng(7)
+    vals = (1 + rng.poisson(1.0, size=nnz)).astype(np.float32)
+    c2 = synth.CSR(U, I, csr.indptr, csr.keys, vals)
+    t = c2.transpose()
+    pop = np.bincount(csr.keys, minlength=I).astype(np.float64) ** 0.5
+    Cw = (1.0 * pop / pop.sum()).astype(np.float32)
+    for d in (32, 128):
+        P = rng.normal(scale=0.1, size=(U, d)).astype(np.float32)
+        Q = rng.normal(scale=0.1, size=(I, d)).astype(np.float32)
+        g = CyEALS()
+        assert g.init(write_opt({"d": d, "num_workers": 8, "alpha": 8.0, "reg_u": 0.1, "reg_i": 0.1, "num_iters": 3}))
+        g.initialize_model(P, Q, Cw)
+        t0 = time.perf_counter()
+        g.precompute_cache(nnz, c2.indptr, c2.keys, 0)
+        g.precompute_cache(nnz, t.indptr, t.keys, 1)
+        cache_s = time.perf_counter() - t0
+        l0 = g.estimate_loss(nnz, c2.indptr, c2.keys, c2.vals, 0)
+        g.update(c2.indptr, c2.keys, c2.vals, 0), g.update(t.indptr, t.keys, t.vals, 1)
+        g.reset_stats()
+        t0 = time.perf_counter()
+        n = 2
+        for _ in range(n):
+            g.update(c2.indptr, c2.keys, c2.vals, 0)
+            g.update(t.indptr, t.keys, t.vals, 1)
+        dt = (time.perf_counter() - t0) / n
+        st = g.stats()
+        l1 = g.estimate_loss(nnz, c2.indptr, c2.keys, c2.vals, 0)
+        out["eals_d%d" % d] = {"epoch_ms": dt * 1e3, "kernel_ms_per_epoch": st["kernel_ms"] / n, "precompute_cache_s_incl_host_sort": cache_s,
+                               "interactions_per_s": 2 * nnz / dt, "loss_before": l0[1], "loss_after_3_epochs": l1[1]}
+        print("eals", d, out["eals_d%d" % d], flush=True)
+
 if "warp_c5" in which:
     # BASELINE config #5's shape on ONE GPU: 10 M users x 1 M items, 1 B interactions, d=256 (the config shards users over 8)
     U5, I5, deg, d = 10_000_000, 1_000_000, 100, 256

@@ -463,3 +463,52 @@ def test_cfr_rows_biases_and_losses_match_numpy(oracle, opt_file):
     np.testing.assert_allclose(Cx, want_C, rtol=5e-4, atol=5e-5)
     np.testing.assert_allclose(Cb.ravel(), want_Cb, rtol=5e-4, atol=5e-5)
     assert abs(loss_c - rc * (Cold ** 2).sum()) < 1e-4 * max(1.0, loss_c)          # the rows BEFORE the update
+
+
+def test_eals_descends_the_float64_objective_and_keeps_its_cache(oracle, opt_file):
+    """CEALS restatement: every half-epoch is an exact coordinate minimisation of
+        sum_obs (1 + alpha v)(v - p.q)^2 + sum_unobs c_i (p.q)^2 + reg_u |P|^2 + reg_i |Q|^2
+    (eals.cc:122-125), so the loss `estimate_loss` derives from the prediction cache must equal that objective
+    recomputed from P, Q in float64, never increase, and the index maps must link the two orientations."""
+    csr = tiny_csr(U=25, I=18, density=0.3, seed=1, counts=True)
+    t = csr.transpose()
+    d, alpha, ru, ri = 6, 2.0, 0.1, 0.2
+    rng = np.random.default_rng(0)
+    P = rng.normal(scale=0.3, size=(25, d)).astype(np.float32)
+    Q = rng.normal(scale=0.3, size=(18, d)).astype(np.float32)
+    pop = np.bincount(csr.keys, minlength=18).astype(np.float64) ** 0.5
+    Cw = (0.5 * pop / pop.sum()).astype(np.float32)
+    o = oracle.OracleEALS()
+    assert o.init(opt_file({"d": d, "num_workers": 2, "alpha": alpha, "reg_u": ru, "reg_i": ri}))
+    o.initialize_model(P, Q, Cw)
+    assert not o.update(csr.indptr, csr.keys, csr.vals, 0)                 # eals.cc:106-114: no cache, no update
+    assert o.estimate_loss(csr.nnz, csr.indptr, csr.keys, csr.vals, 0) == (0.0, 0.0)
+    o.precompute_cache(csr.nnz, csr.indptr, csr.keys, 0)
+    o.precompute_cache(csr.nnz, t.indptr, t.keys, 1)
+    rows = np.repeat(np.arange(25), np.diff(np.concatenate([[0], csr.indptr])))
+    trows = np.repeat(np.arange(18), np.diff(np.concatenate([[0], t.indptr])))
+    pos = {(int(u), int(i)): r for r, (i, u) in enumerate(zip(trows, t.keys))}
+    _, u2i = o.caches(0, csr.nnz)
+    assert all(pos[(int(rows[k]), int(csr.keys[k]))] == u2i[k] for k in range(csr.nnz))
+
+    def objective():
+        P64, Q64 = P.astype(np.float64), Q.astype(np.float64)
+        S = P64 @ Q64.T
+        W = np.tile(Cw.astype(np.float64), (25, 1))
+        R = np.zeros_like(S)
+        R[rows, csr.keys] = csr.vals
+        W[rows, csr.keys] = 1 + alpha * csr.vals
+        return (W * (R - S) ** 2).sum() + ru * (P64 ** 2).sum() + ri * (Q64 ** 2).sum()
+    prev = objective()
+    assert abs(o.estimate_loss(csr.nnz, csr.indptr, csr.keys, csr.vals, 0)[1] - prev) < 1e-4 * prev
+    for _ in range(4):
+        for axis, m in ((0, csr), (1, t)):
+            assert o.update(m.indptr, m.keys, m.vals, axis)
+            cur = objective()
+            assert cur <= prev * (1 + 1e-6)
+            prev = cur
+    rmse, loss = o.estimate_loss(csr.nnz, t.indptr, t.keys, t.vals, 1)
+    assert abs(loss - prev) < 1e-4 * prev
+    vh, _ = o.caches(0, csr.nnz)
+    assert np.abs(vh - (P[rows] * Q[csr.keys]).sum(1)).max() < 1e-5
+    assert abs(rmse - np.sqrt(((csr.vals - vh) ** 2).mean())) < 1e-5
