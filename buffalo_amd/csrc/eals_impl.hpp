@@ -35,6 +35,8 @@ struct EalsParams {
     int rows, d, vdim, axis;
     float alpha, reg;
     int* ticket;
+    const int32_t* row_list;   // rows this launch works on (light or heavy rows of the orientation)
+    int n_list;
 };
 
 constexpr int EALS_REG = 4;   // entries per lane kept in registers (rows up to 256 entries)
@@ -45,10 +47,11 @@ __global__ __launch_bounds__(256) void eals_update_kernel(EalsParams p) {
     float* xs = lds + wv * p.vdim;
     const int D = p.d, vdim = p.vdim;
     while (true) {
-        int x = 0;
-        if (lane == 0) x = atomicAdd(p.ticket, 1);
-        x = __builtin_amdgcn_readfirstlane(x);
-        if (x >= p.rows) break;
+        int item = 0;
+        if (lane == 0) item = atomicAdd(p.ticket, 1);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= p.n_list) break;
+        const int x = p.row_list[item];
         const int64_t beg = x == 0 ? 0 : p.indptr[x - 1], end = p.indptr[x];
         const int64_t n = end - beg;
         float* xrow = p.X + static_cast<size_t>(x) * vdim;
@@ -142,6 +145,68 @@ __global__ __launch_bounds__(256) void eals_update_kernel(EalsParams p) {
         } else {
             for (int64_t ind = beg + lane; ind < end; ind += 64) p.other[p.map[ind]] = p.own[ind];
         }
+    }
+}
+
+// Rows above EALS_HEAVY entries: one 1024-thread block per row.  The per-dimension sums are formed by all 16 waves
+// (entries strided over the block, vhat streamed from HBM), combined through LDS, and every thread derives the new
+// coordinate redundantly -- three barriers per dimension instead of a 131 K-entry row crawling through one wave.
+constexpr int EALS_HEAVY = 1024;
+
+__global__ __launch_bounds__(1024) void eals_update_heavy_kernel(EalsParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* xs = lds;                 // [vdim]
+    float* red = lds + p.vdim;       // [3][16]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int D = p.d, vdim = p.vdim;
+    for (int item = blockIdx.x; item < p.n_list; item += gridDim.x) {
+        const int x = p.row_list[item];
+        const int64_t beg = x == 0 ? 0 : p.indptr[x - 1], end = p.indptr[x];
+        float* xrow = p.X + static_cast<size_t>(x) * vdim;
+        __syncthreads();
+        for (int e = tid; e < vdim; e += 1024) xs[e] = xrow[e];
+        __syncthreads();
+        const float cx = p.axis == 1 ? p.Cw[x] : 0.f;
+        for (int d = 0; d < D; ++d) {
+            const float xd = xs[d];
+            float num = 0.f, den = 0.f;
+            for (int64_t ind = beg + tid; ind < end; ind += 1024) {
+                const int y = p.keys[ind];
+                const float v = p.vals[ind];
+                const float yd = p.Y[static_cast<size_t>(y) * vdim + d];
+                const float pq = xd * yd;
+                const float vf = p.own[ind] - pq;
+                const float w = 1.f + p.alpha * v;
+                const float wmc = w - (p.axis == 0 ? p.Cw[y] : cx);
+                num += (w * v - wmc * vf) * yd;
+                den += wmc * yd * yd;
+                p.own[ind] = vf;
+            }
+            float dot = tid < D ? xs[tid] * p.S[static_cast<size_t>(d) * vdim + tid] : 0.f;   // D <= 1024
+            num = wave_sum(num);
+            den = wave_sum(den);
+            dot = wave_sum(dot);
+            if (lane == 0) { red[wv] = num; red[16 + wv] = den; red[32 + wv] = dot; }
+            __syncthreads();
+            float tn = 0.f, td = 0.f, tt = 0.f;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) { tn += red[w]; td += red[16 + w]; tt += red[32 + w]; }
+            const float sdd = p.S[static_cast<size_t>(d) * vdim + d];
+            if (p.axis == 0) {
+                tn += -tt + xd * sdd;
+                td += sdd + p.reg;
+            } else {
+                tn += -cx * (tt - xd * sdd);
+                td += cx * sdd + p.reg;
+            }
+            const float xn = tn / td;
+            __syncthreads();
+            if (tid == 0) xs[d] = xn;
+            for (int64_t ind = beg + tid; ind < end; ind += 1024) p.own[ind] += xn * p.Y[static_cast<size_t>(p.keys[ind]) * vdim + d];
+            __syncthreads();
+        }
+        for (int e = tid; e < D; e += 1024) xrow[e] = xs[e];
+        for (int64_t ind = beg + tid; ind < end; ind += 1024) p.other[p.map[ind]] = p.own[ind];
     }
 }
 
@@ -261,6 +326,8 @@ class EalsHandle : public AlsHandle {
         DevBuf<int64_t> indptr, map;
         DevBuf<int32_t> keys;
         DevBuf<float> vals, vhat;
+        DevBuf<int32_t> light, heavy;   // row ids with <= / > EALS_HEAVY entries (empty rows are light: the regulariser still moves them)
+        int n_light = 0, n_heavy = 0;
         int64_t nnz = 0;
     };
     // eals.cc:49-100: the orientation's structure stays resident; vhat from the current factors; the index map by a host sort
@@ -288,6 +355,24 @@ class EalsHandle : public AlsHandle {
                     coord[ind] = {(static_cast<uint64_t>(static_cast<uint32_t>(keys[ind])) << 32) | static_cast<uint32_t>(x), ind};
                 prev = indptr[x];
             }
+        }
+        {
+            std::vector<int32_t> li, hv;
+            int64_t prev = 0;
+            for (int x = 0; x < rows; ++x) {
+                (indptr[x] - prev > EALS_HEAVY ? hv : li).push_back(x);
+                prev = indptr[x];
+            }
+            std::stable_sort(hv.begin(), hv.end(), [&](int a, int b) {   // longest first
+                return indptr[a] - (a ? indptr[a - 1] : 0) > indptr[b] - (b ? indptr[b - 1] : 0);
+            });
+            s.n_light = static_cast<int>(li.size());
+            s.n_heavy = static_cast<int>(hv.size());
+            s.light.resize(std::max<size_t>(1, li.size()));
+            s.heavy.resize(std::max<size_t>(1, hv.size()));
+            if (!li.empty()) BFH_HIP(hipMemcpyAsync(s.light.get(), li.data(), li.size() * 4, hipMemcpyHostToDevice, stream));
+            if (!hv.empty()) BFH_HIP(hipMemcpyAsync(s.heavy.get(), hv.data(), hv.size() * 4, hipMemcpyHostToDevice, stream));
+            BFH_HIP(hipStreamSynchronize(stream));   // li / hv are locals
         }
         std::sort(coord.begin(), coord.end());
         std::vector<int64_t> map(nnz);
@@ -336,11 +421,23 @@ class EalsHandle : public AlsHandle {
         p.d = d_; p.vdim = vdim_; p.axis = axis; p.alpha = alpha_; p.reg = axis == 0 ? reg_u_ : reg_i_;
         p.ticket = ticket_.get();
         BFH_HIP(hipMemsetAsync(ticket_.get(), 0, sizeof(int), stream));
-        int blocks = (p.rows + 3) / 4;
-        if (blocks > num_cus_ * 8) blocks = num_cus_ * 8;
         const int slot = t_main_.begin(stream);
-        hipLaunchKernelGGL(eals_update_kernel, dim3(std::max(blocks, 1)), dim3(256), static_cast<size_t>(4) * vdim_ * sizeof(float), stream, p);
-        BFH_HIP(hipGetLastError());
+        if (s.n_heavy) {   // the long rows first, one block each
+            EalsParams ph = p;
+            ph.row_list = s.heavy.get();
+            ph.n_list = s.n_heavy;
+            hipLaunchKernelGGL(eals_update_heavy_kernel, dim3(std::min(s.n_heavy, num_cus_ * 2)), dim3(1024), (static_cast<size_t>(vdim_) + 48) * sizeof(float),
+                               stream, ph);
+            BFH_HIP(hipGetLastError());
+        }
+        if (s.n_light) {
+            p.row_list = s.light.get();
+            p.n_list = s.n_light;
+            int blocks = (s.n_light + 3) / 4;
+            if (blocks > num_cus_ * 8) blocks = num_cus_ * 8;
+            hipLaunchKernelGGL(eals_update_kernel, dim3(blocks), dim3(256), static_cast<size_t>(4) * vdim_ * sizeof(float), stream, p);
+            BFH_HIP(hipGetLastError());
+        }
         t_main_.end(slot, stream);
         pull_factor(axis);
         BFH_HIP(hipStreamSynchronize(stream));

@@ -28,8 +28,10 @@ def _problem(shape, d, seed=0):
     elif shape == "empty_rows":
         from buffalo_amd.synth import CSR
         csr = CSR(6, 5, [2, 2, 3, 3, 5, 6], [0, 3, 1, 0, 4, 2], np.array([1, 2, 1, 3, 1, 2], np.float32))
-    else:   # rows beyond 256 entries take the streaming path, item rows of ~540 and user rows of ~54
+    elif shape == "long":   # rows beyond 256 entries take the streaming path: item rows of ~540, user rows of ~54
         csr = tiny_csr(U=600, I=60, density=0.9, seed=2, counts=True)
+    else:   # "heavy": item rows of ~2300 entries run on the block-per-row kernel (> 1024 entries)
+        csr = tiny_csr(U=2500, I=24, density=0.92, seed=4, counts=True)
     rng = np.random.default_rng(seed)
     P = rng.normal(scale=0.3, size=(csr.num_users, d)).astype(np.float32)
     Q = rng.normal(scale=0.3, size=(csr.num_items, d)).astype(np.float32)
@@ -56,7 +58,7 @@ def _pair(oracle, opt, csr, P, Q, Cw):
     return o, g, t, Po, Qo
 
 
-@pytest.mark.parametrize("d,shape", [(20, "tiny"), (128, "tiny"), (20, "empty_rows"), (40, "long")])
+@pytest.mark.parametrize("d,shape", [(20, "tiny"), (128, "tiny"), (20, "empty_rows"), (40, "long"), (24, "heavy")])
 def test_half_epochs_match_oracle(oracle, d, shape):
     csr, P, Q, Cw = _problem(shape, d)
     opt = _opt(d)
