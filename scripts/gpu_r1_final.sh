@@ -11,7 +11,7 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bpr 
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o bpr -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o bpr -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_write.log 2>&1
 cd $R
-timeout 900 python scripts/bench_extra.py als warp bpr_adagrad bpr_pcie topk > $O/bench_extra.log 2>&1; cp gpurun_out/bench_extra.json $O/bench_extra.json
+timeout 900 python scripts/bench_extra.py als warp bpr_adagrad bpr_pcie topk eals warp_c5 > $O/bench_extra.log 2>&1; cp gpurun_out/bench_extra.json $O/bench_extra.json
 cd /tmp
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_extra -o extra -- python $R/scripts/bench_extra.py als topk > $O/prof_extra.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_als -o als -- python $R/scripts/bench_extra.py als > $O/pmc_als.log 2>&1
