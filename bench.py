@@ -237,11 +237,18 @@ def main():
                                    % (args.shape, U, I, nnz, "" if args.scaling == "strong" or world == 1 else " per GPU", D),
                        "parallelism": "1 GPU" if world == 1 else "dp%d: users sharded, Q replicated, %d RCCL delta all-reduce/epoch"
                                       % (world, args.minibatches),
-                       "hogwild": {"0": "write-through (sc1) racy stores on item rows", "1": "fp32 atomics on item rows"}[hog]},
+                       "hogwild": {"0": "write-through (sc1) racy stores on item rows", "1": "fp32 atomics on item rows",
+                                   "2": "per-XCD item-factor replicas (plain stores through the XCD's L2, merged by the delta rule "
+                                        "%.1f times per epoch); popular rows stay chip-wide on fp32 atomics"
+                                        % (st["merges"] / max(steps, 1))}[hog]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "bpr_update_kernel", "kernel_ms": kernel_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes},
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "launches_per_step": st["launches"] / max(steps, 1),
+                         # the same bytes over ALL device time of a step (update launches + replica broadcast / merge kernels)
+                         "frac_incl_merge_kernels": (bytes_per_update * st["samples"] / max((st["kernel_ms"] + st["aux_ms"]) * 1e-3, 1e-12)
+                                                     / 1e9 / HBM_PEAK_GBS)},
             "epoch_ms": elapsed / steps * 1e3,
         }
         if world == 1 and not args.no_cpu_baseline:

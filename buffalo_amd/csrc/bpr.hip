@@ -29,6 +29,8 @@
 //     400-item planted test), so atomics are the default.
 #include "sgd_base.hpp"
 
+#include <algorithm>
+
 namespace bfh {
 
 struct BprConsts {
@@ -43,7 +45,21 @@ struct BprConsts {
     const int32_t* inj_p;
     const int32_t* inj_n;
     int64_t total;  // number of (position, slot) items
+    int64_t work_begin, work_end;  // work items [begin, end) of this launch (a segment of the call)
+    // policy 2: one private copy of the item factors per XCD (see xcd_* kernels below)
+    float* rep_Q;
+    float* rep_Qb;
+    int64_t rep_stride, rep_bstride;
+    const uint8_t* hot;   // [Q_rows] 1 = row stays in the chip-wide matrix and is updated with atomics
 };
+
+// The XCD this wave runs on (0..7), from the hardware register: the address of a wave's item-factor
+// replica depends on it, so it must be the truth, not a guess from blockIdx.
+__device__ __forceinline__ int xcc_id() {
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(x));
+    return static_cast<int>(x & 7u);
+}
 
 // CBPRMF::build_exp_table bpr.cc:57-63 + lookup bpr.cc:124-131 (Q-2: integer 1000/6/2 == 83)
 __device__ __forceinline__ float bpr_logit(float x, const float* __restrict__ table) {
@@ -168,7 +184,24 @@ __global__ __launch_bounds__(256) void bpr_update_kernel(SgdParams p, BprConsts 
     const int64_t wave0 = static_cast<int64_t>(blockIdx.x) * wpb + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t nwaves = static_cast<int64_t>(gridDim.x) * wpb;
     const int vdim = p.vdim;
-    const int64_t n_work = (c.total + c.chunk - 1) / c.chunk;
+    // item factors this wave works on: the chip-wide matrix, or (policy 2) the replica owned by
+    // the wave's XCD -- only waves of that XCD ever touch it, so its L2 is the point of coherence
+    // and plain stores are visible to every other wave that can read the row
+    float* Qbase = p.Q;
+    float* Qbbase = p.Qb;
+    bool rep = false;
+    if constexpr (V4 && SGD) {
+        if (c.atomic == 2) {
+            const int x = xcc_id();
+            Qbase = c.rep_Q + static_cast<size_t>(x) * c.rep_stride;
+            Qbbase = c.rep_Qb + static_cast<size_t>(x) * c.rep_bstride;
+            rep = true;
+        }
+    }
+
+    // policy 2 keeps the popular ("hot") rows in the chip-wide matrix: (pol bit set) <=> atomics on p.Q
+    auto q_of = [&](int item, bool hot) -> float* { return (hot ? p.Q : Qbase) + static_cast<size_t>(item) * vdim; };
+    auto qb_of = [&](int item, bool hot) -> float* { return (hot ? p.Qb : Qbbase) + item; };
 
     int cur_u = -1;
     bool cur_excl = true;
@@ -194,7 +227,7 @@ __global__ __launch_bounds__(256) void bpr_update_kernel(SgdParams p, BprConsts 
         cur_u = -1;
     };
 
-    for (int64_t w = wave0; w < n_work; w += nwaves) {
+    for (int64_t w = c.work_begin + wave0; w < c.work_end; w += nwaves) {
         const int64_t t_beg = w * c.chunk;
         const int64_t t_end = (t_beg + c.chunk < c.total) ? t_beg + c.chunk : c.total;
         for (int64_t t0 = t_beg; t0 < t_end; t0 += 64) {
@@ -219,7 +252,8 @@ __global__ __launch_bounds__(256) void bpr_update_kernel(SgdParams p, BprConsts 
                     // does this wave own the user's whole run?  (then P[u] needs no atomics)
                     my_excl = c.sequential || (ubeg * c.num_neg >= t_beg && uend * c.num_neg <= t_end);
                 }
-                if (c.sequential || c.atomic == 0) my_pol = 0;   // sequential: one wave, plain stores are exact
+                if (c.sequential || c.atomic != 1) my_pol = 0;   // sequential: one wave, plain stores are exact
+                if (rep && c.hot) my_pol = (c.hot[my_pos] ? 1 : 0) | (c.hot[my_neg] ? 2 : 0);
             }
             const int n_here = static_cast<int>((t_end - t0) < 64 ? (t_end - t0) : 64);
 
@@ -228,9 +262,11 @@ __global__ __launch_bounds__(256) void bpr_update_kernel(SgdParams p, BprConsts 
             int pos = __builtin_amdgcn_readlane(my_pos, 0);
             int neg = __builtin_amdgcn_readlane(my_neg, 0);
             if (PIPE) {
-                row_load<K, V4, true>(qi, p.Q + static_cast<size_t>(pos) * vdim, lane, vdim);
-                row_load<K, V4, true>(qj, p.Q + static_cast<size_t>(neg) * vdim, lane, vdim);
-                if (c.use_bias) { bi = V4 ? coh_load(p.Qb + pos) : p.Qb[pos]; bj = V4 ? coh_load(p.Qb + neg) : p.Qb[neg]; }
+                const int pol0 = __builtin_amdgcn_readlane(my_pol, 0);
+                const bool h_i = rep && (pol0 & 1), h_j = rep && (pol0 & 2);
+                row_load<K, V4, true>(qi, q_of(pos, h_i), lane, vdim);
+                row_load<K, V4, true>(qj, q_of(neg, h_j), lane, vdim);
+                if (c.use_bias) { bi = V4 ? coh_load(qb_of(pos, h_i)) : Qbbase[pos]; bj = V4 ? coh_load(qb_of(neg, h_j)) : Qbbase[neg]; }
             }
             for (int j = 0; j < n_here; ++j) {
                 const int u = __builtin_amdgcn_readlane(my_u, j);
@@ -239,24 +275,30 @@ __global__ __launch_bounds__(256) void bpr_update_kernel(SgdParams p, BprConsts 
                 const bool at_i = (pol & 1) != 0, at_j = (pol & 2) != 0;
                 pos = __builtin_amdgcn_readlane(my_pos, j);
                 neg = __builtin_amdgcn_readlane(my_neg, j);
-                float* Qi = p.Q + static_cast<size_t>(pos) * vdim;
-                float* Qj = p.Q + static_cast<size_t>(neg) * vdim;
+                float* Qi = q_of(pos, rep && at_i);
+                float* Qj = q_of(neg, rep && at_j);
+                float* Bi = qb_of(pos, rep && at_i);
+                float* Bj = qb_of(neg, rep && at_j);
                 int pos_n = 0, neg_n = 0;
+                bool hn_i = false, hn_j = false;
                 if (PIPE) {
                     if (j + 1 < n_here) {
                         pos_n = __builtin_amdgcn_readlane(my_pos, j + 1);
                         neg_n = __builtin_amdgcn_readlane(my_neg, j + 1);
-                        row_load<K, V4, true>(qi_n, p.Q + static_cast<size_t>(pos_n) * vdim, lane, vdim);
-                        row_load<K, V4, true>(qj_n, p.Q + static_cast<size_t>(neg_n) * vdim, lane, vdim);
+                        const int pol_n = __builtin_amdgcn_readlane(my_pol, j + 1);
+                        hn_i = rep && (pol_n & 1);
+                        hn_j = rep && (pol_n & 2);
+                        row_load<K, V4, true>(qi_n, q_of(pos_n, hn_i), lane, vdim);
+                        row_load<K, V4, true>(qj_n, q_of(neg_n, hn_j), lane, vdim);
                         if (c.use_bias) {
-                            bi_n = V4 ? coh_load(p.Qb + pos_n) : p.Qb[pos_n];
-                            bj_n = V4 ? coh_load(p.Qb + neg_n) : p.Qb[neg_n];
+                            bi_n = V4 ? coh_load(qb_of(pos_n, hn_i)) : Qbbase[pos_n];
+                            bj_n = V4 ? coh_load(qb_of(neg_n, hn_j)) : Qbbase[neg_n];
                         }
                     }
                 } else {
                     row_load<K, V4, true>(qi, Qi, lane, vdim);
                     row_load<K, V4, true>(qj, Qj, lane, vdim);
-                    if (c.use_bias) { bi = V4 ? coh_load(p.Qb + pos) : p.Qb[pos]; bj = V4 ? coh_load(p.Qb + neg) : p.Qb[neg]; }
+                    if (c.use_bias) { bi = V4 ? coh_load(Bi) : Qbbase[pos]; bj = V4 ? coh_load(Bj) : Qbbase[neg]; }
                 }
                 if (u != cur_u) {
                     flush_user();
@@ -298,10 +340,12 @@ __global__ __launch_bounds__(256) void bpr_update_kernel(SgdParams p, BprConsts 
                     }
                     if (c.update_i) {
                         if (at_i) row_atomic_add<K, V4>(di, Qi, lane, vdim);
+                        else if (rep) row_store<K, V4, false>(qi, Qi, lane, vdim);
                         else row_store<K, V4, true>(qi, Qi, lane, vdim);
                     }
                     if (c.update_j) {
                         if (at_j) row_atomic_add<K, V4>(dj, Qj, lane, vdim);
+                        else if (rep) row_store<K, V4, false>(qj, Qj, lane, vdim);
                         else row_store<K, V4, true>(qj, Qj, lane, vdim);
                     }
                     if (c.use_bias && lane == 0) {
@@ -309,14 +353,14 @@ __global__ __launch_bounds__(256) void bpr_update_kernel(SgdParams p, BprConsts 
                         if (same) bj = bi + dbi;
                         const float dbj = c.lr * (-logit - c.reg_b * bj);
                         if (c.update_i) {
-                            if (at_i) atomic_add_f32(p.Qb + pos, dbi);
-                            else if (V4) coh_store(p.Qb + pos, bi + dbi);
-                            else p.Qb[pos] = bi + dbi;
+                            if (at_i) atomic_add_f32(Bi, dbi);
+                            else if (V4 && !rep) coh_store(Bi, bi + dbi);
+                            else *Bi = bi + dbi;
                         }
                         if (c.update_j) {
-                            if (at_j) atomic_add_f32(p.Qb + neg, dbj);
-                            else if (V4) coh_store(p.Qb + neg, bj + dbj);
-                            else p.Qb[neg] = bj + dbj;
+                            if (at_j) atomic_add_f32(Bj, dbj);
+                            else if (V4 && !rep) coh_store(Bj, bj + dbj);
+                            else *Bj = bj + dbj;
                         }
                     }
                 } else {
@@ -351,11 +395,11 @@ __global__ __launch_bounds__(256) void bpr_update_kernel(SgdParams p, BprConsts 
                         qi = qi_n; qj = qj_n; bi = bi_n; bj = bj_n;
                         if (SGD && (!at_i || !at_j) && (pos_n == pos || pos_n == neg || neg_n == pos || neg_n == neg)) {
                             // plain-store rows: the prefetch raced with this wave's own stores -> reload
-                            row_load<K, V4, true>(qi, p.Q + static_cast<size_t>(pos_n) * vdim, lane, vdim);
-                            row_load<K, V4, true>(qj, p.Q + static_cast<size_t>(neg_n) * vdim, lane, vdim);
+                            row_load<K, V4, true>(qi, q_of(pos_n, hn_i), lane, vdim);
+                            row_load<K, V4, true>(qj, q_of(neg_n, hn_j), lane, vdim);
                             if (c.use_bias) {
-                                bi = V4 ? coh_load(p.Qb + pos_n) : p.Qb[pos_n];
-                                bj = V4 ? coh_load(p.Qb + neg_n) : p.Qb[neg_n];
+                                bi = V4 ? coh_load(qb_of(pos_n, hn_i)) : Qbbase[pos_n];
+                                bj = V4 ? coh_load(qb_of(neg_n, hn_j)) : Qbbase[neg_n];
                             }
                         }
                     }
@@ -392,6 +436,82 @@ __global__ void bpr_loss_kernel(const float* __restrict__ P, const float* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
+// Policy 2: per-XCD replicas of the item factors.
+//
+// The 8 XCDs' L2s are not coherent with each other, and the only chip-wide coherent update of a
+// shared row -- an fp32 atomic per dword, executed one dword per clock per channel -- caps the
+// update kernel at half the HBM roofline.  Inside ONE XCD the L2 is the point of coherence: plain
+// stores are visible to every wave of that XCD (item rows are loaded with sc1, i.e. past the CU's
+// L1).  So every XCD trains on its own copy of Q/Qb with the CPU reference's literal Hogwild
+// read-modify-write (bpr.cc:157-172), and the copies are reconciled every `xcd_sync_updates`
+// updates with the rule buffalo_amd/dist.py applies between GPUs: Q <- S + sum_x (Q_x - S), where
+// S is the state at the previous reconciliation.  A launch boundary writes the L2s back, so the
+// merge kernel sees every replica's final state.  An update is therefore never lost between XCDs
+// (it arrives at the next merge); within an XCD two waves racing on one row behave like two CPU
+// threads racing on it.
+// ------------------------------------------------------------------------------------------------
+constexpr int kXcdReplicas = 8;
+
+template <typename T>
+__global__ __launch_bounds__(256) void xcd_broadcast_kernel(const T* __restrict__ S, T* __restrict__ rep, int64_t n, int64_t stride) {
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const T v = S[i];
+#pragma unroll
+        for (int x = 0; x < kXcdReplicas; ++x) rep[x * stride + i] = v;
+    }
+}
+
+__device__ __forceinline__ float4 f4_sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4_fma(float sc, float4 a, float4 b) { return make_float4(sc * a.x + b.x, sc * a.y + b.y, sc * a.z + b.z, sc * a.w + b.w); }
+__device__ __forceinline__ float f4_sub(float a, float b) { return a - b; }
+__device__ __forceinline__ float f4_add(float a, float b) { return a + b; }
+__device__ __forceinline__ float f4_fma(float sc, float a, float b) { return sc * a + b; }
+
+// S <- S + scale * sum_x (rep_x - S); the replicas are refreshed unless this was the last segment.
+// Hot rows live in S itself (updated there with atomics) and are skipped; `row_len` = elements per row.
+template <typename T>
+__global__ __launch_bounds__(256) void xcd_merge_kernel(T* __restrict__ S, T* __restrict__ rep, int64_t n, int64_t stride, float scale,
+                                                         int write_replicas, const uint8_t* __restrict__ hot, int row_len) {
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        if (hot && hot[i / row_len]) continue;
+        const T s0 = S[i];
+        T r[kXcdReplicas];
+#pragma unroll
+        for (int x = 0; x < kXcdReplicas; ++x) r[x] = rep[x * stride + i];
+        T acc = f4_sub(r[0], s0);
+#pragma unroll
+        for (int x = 1; x < kXcdReplicas; ++x) acc = f4_add(acc, f4_sub(r[x], s0));
+        const T out = f4_fma(scale, acc, s0);
+        S[i] = out;
+        if (write_replicas) {
+#pragma unroll
+            for (int x = 0; x < kXcdReplicas; ++x) rep[x * stride + i] = out;
+        }
+    }
+}
+
+// How often is every item row updated?  One int atomic per index (once per resident CSR).
+__global__ void item_count_kernel(const int32_t* __restrict__ idx, int64_t n, int* __restrict__ cnt) {
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+        atomicAdd(cnt + idx[i], 1);
+}
+
+// A row is hot when the expected number of OTHER waves of the same XCD holding it between their load
+// and their store -- updates_i / updates_total * (item rows in flight per XCD) -- reaches tau: those
+// rows would lose that fraction of their updates to racing plain stores (a CPU Hogwild thread pool
+// sits at a few percent on the head items).  updates_i = positives_i * pos_mult + triples * P(neg = i).
+__global__ void xcd_hot_kernel(const int* __restrict__ cnt, const int64_t* __restrict__ cum, int64_t cum_total, int rows, double pos_mult,
+                               double triples, double neg_uniform, double inflight, double tau, uint8_t* __restrict__ hot) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    double pneg = neg_uniform;
+    if (cum) pneg = static_cast<double>(cum[i] - (i ? cum[i - 1] : 0)) / static_cast<double>(cum_total);
+    const double upd = cnt[i] * pos_mult + triples * pneg;
+    hot[i] = (upd * inflight >= tau * 2.0 * triples) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 class BprHandle : public SgdHandle {
  public:
     BprHandle() : SgdHandle(0) {}
@@ -423,6 +543,12 @@ class BprHandle : public SgdHandle {
         c.exp_table = exp_table_.get();
         c.loss_out = scratch_.get();
         c.chunk = chunk_;
+        if (xcd_replicas()) {
+            if (!chunk_set_) c.chunk = 64;   // short work items: a segment ends when its slowest wave does
+            c.atomic = 2;
+        } else if (c.atomic == 2) {
+            c.atomic = 1;                    // adam/adagrad accumulate exact sums: atomics
+        }
         return c;
     }
 
@@ -436,9 +562,103 @@ class BprHandle : public SgdHandle {
         else hipLaunchKernelGGL((bpr_update_kernel<K, false, false, INJECT, V4>), grid, block, 0, stream, p, c);
     }
 
+    bool xcd_replicas() const { return hogwild_atomic_ == 2 && optimizer_ == "sgd" && !sequential_; }
+
+    // stream-ordered helpers of policy 2
+    void xcd_broadcast() {
+        const int64_t nq4 = static_cast<int64_t>(Q_rows_) * vdim_ / 4;
+        hipLaunchKernelGGL((xcd_broadcast_kernel<float4>), dim3(static_cast<unsigned>(std::min<int64_t>((nq4 + 255) / 256, 8192))), dim3(256), 0, stream,
+                           reinterpret_cast<const float4*>(Q_.get()), reinterpret_cast<float4*>(repQ_.get()), nq4, nq4);
+        hipLaunchKernelGGL((xcd_broadcast_kernel<float>), dim3((Q_rows_ + 255) / 256), dim3(256), 0, stream,
+                           static_cast<const float*>(Qb_.get()), repQb_.get(), static_cast<int64_t>(Q_rows_), rep_bstride());
+        BFH_HIP(hipGetLastError());
+    }
+    void xcd_merge(bool write_replicas, const uint8_t* hot) {
+        const int64_t nq4 = static_cast<int64_t>(Q_rows_) * vdim_ / 4;
+        const float scale = xcd_merge_mean_ ? 1.0f / kXcdReplicas : 1.0f;
+        hipLaunchKernelGGL((xcd_merge_kernel<float4>), dim3(static_cast<unsigned>(std::min<int64_t>((nq4 + 255) / 256, 8192))), dim3(256), 0, stream,
+                           reinterpret_cast<float4*>(Q_.get()), reinterpret_cast<float4*>(repQ_.get()), nq4, nq4, scale, write_replicas ? 1 : 0,
+                           hot, vdim_ / 4);
+        hipLaunchKernelGGL((xcd_merge_kernel<float>), dim3((Q_rows_ + 255) / 256), dim3(256), 0, stream, Qb_.get(), repQb_.get(),
+                           static_cast<int64_t>(Q_rows_), rep_bstride(), scale, write_replicas ? 1 : 0, hot, 1);
+        BFH_HIP(hipGetLastError());
+    }
+    // hot-row flags for this call (policy 2); returns null when the split is disabled
     template <bool INJECT>
-    void launch(const SgdParams& p, const BprConsts& c) {
+    const uint8_t* xcd_hot_rows(const SgdParams& p, const BprConsts& c, int64_t seg_work) {
+        if (xcd_hot_tau_ <= 0) return nullptr;
+        itemcnt_.resize(static_cast<size_t>(Q_rows_));
+        hot_.resize(static_cast<size_t>(Q_rows_));
+        double pos_mult = num_neg_, triples = static_cast<double>(c.total), neg_uniform = uniform_ ? 1.0 / Q_rows_ : 0.0;
+        const int64_t* cum = (!INJECT && !uniform_) ? p.cum_table : nullptr;
+        auto count = [&](const int32_t* idx, int64_t n) {
+            hipLaunchKernelGGL(item_count_kernel, dim3(static_cast<unsigned>(std::min<int64_t>((n + 255) / 256, 4096))), dim3(256), 0, stream, idx, n,
+                               itemcnt_.get());
+        };
+        if (INJECT) {
+            BFH_HIP(hipMemsetAsync(itemcnt_.get(), 0, itemcnt_.bytes(), stream));
+            count(c.inj_p, c.total);
+            count(c.inj_n, c.total);
+            pos_mult = 1.0;
+            neg_uniform = 0.0;
+            itemcnt_gen_ = -1;
+        } else if (resident_) {
+            if (itemcnt_gen_ != csr_generation_) {   // popularity of the whole resident matrix, counted once
+                BFH_HIP(hipMemsetAsync(itemcnt_.get(), 0, itemcnt_.bytes(), stream));
+                count(keys_.get(), resident_nnz_);
+                itemcnt_gen_ = csr_generation_;
+            }
+            triples = static_cast<double>(resident_nnz_) * num_neg_;
+        } else {
+            BFH_HIP(hipMemsetAsync(itemcnt_.get(), 0, itemcnt_.bytes(), stream));
+            count(p.keys, p.chunk_nnz);
+            itemcnt_gen_ = -1;
+        }
+        const int wpc = waves_per_cu_ > 0 ? waves_per_cu_ : 32;
+        const double waves = static_cast<double>(std::min<int64_t>(static_cast<int64_t>(num_cus_) * wpc, seg_work));
+        const double inflight = 2.0 * waves / kXcdReplicas;     // a wave holds the two item rows of its next triple
+        hipLaunchKernelGGL(xcd_hot_kernel, dim3((Q_rows_ + 255) / 256), dim3(256), 0, stream, itemcnt_.get(), cum, cum_total_, Q_rows_, pos_mult,
+                           triples, neg_uniform, inflight, xcd_hot_tau_ * 1e-3, hot_.get());
+        BFH_HIP(hipGetLastError());
+        return hot_.get();
+    }
+    int64_t rep_bstride() const { return (static_cast<int64_t>(Q_rows_) + 63) / 64 * 64; }
+
+    template <bool INJECT>
+    void launch(const SgdParams& p, const BprConsts& c_in) {
+        BprConsts c = c_in;
         const int64_t n_work = (c.total + c.chunk - 1) / c.chunk;
+        const bool reps = c.atomic == 2;
+        int64_t seg_work = n_work;          // work items per launch
+        if (reps) {
+            repQ_.resize(static_cast<size_t>(kXcdReplicas) * Q_rows_ * vdim_);
+            repQb_.resize(static_cast<size_t>(kXcdReplicas) * rep_bstride());
+            c.rep_Q = repQ_.get();
+            c.rep_Qb = repQb_.get();
+            c.rep_stride = static_cast<int64_t>(Q_rows_) * vdim_;
+            c.rep_bstride = rep_bstride();
+            seg_work = std::max<int64_t>(1, xcd_sync_updates_ / c.chunk);
+            const int slot = t_aux_.begin(stream);
+            c.hot = xcd_hot_rows<INJECT>(p, c, std::min(seg_work, n_work));
+            xcd_broadcast();
+            t_aux_.end(slot, stream);
+        }
+        for (int64_t w0 = 0; w0 < n_work; w0 += seg_work) {
+            c.work_begin = w0;
+            c.work_end = std::min(n_work, w0 + seg_work);
+            launch_segment<INJECT>(p, c);
+            if (reps) {
+                const int slot = t_aux_.begin(stream);
+                xcd_merge(c.work_end < n_work, c.hot);
+                t_aux_.end(slot, stream);
+                stats.merges += 1;
+            }
+        }
+    }
+
+    template <bool INJECT>
+    void launch_segment(const SgdParams& p, const BprConsts& c) {
+        const int64_t n_work = c.work_end - c.work_begin;
         dim3 block(256), grid(1);
         if (sequential_) {
             block = dim3(64);
@@ -450,7 +670,7 @@ class BprHandle : public SgdHandle {
         }
         // write-through Hogwild (policies 0 / 2) moves item rows as float4 with sc1; the atomic and
         // the deterministic sequential paths keep the dword-per-lane layout
-        const bool v4 = optimizer_ == "sgd" && !sequential_ && hogwild_atomic_ != 1;
+        const bool v4 = optimizer_ == "sgd" && !sequential_ && c.atomic != 1;
         const int slot = t_main_.begin(stream);
         if (v4) {
             const int KV = (vdim_ + 255) / 256;
@@ -535,6 +755,10 @@ class BprHandle : public SgdHandle {
     int num_neg_ = 1;
     bool verify_neg_ = true, uniform_ = true;
     DevBuf<float> exp_table_;
+    DevBuf<float> repQ_, repQb_;   // policy 2: [8][Q_rows][vdim], [8][ceil64(Q_rows)]
+    DevBuf<int> itemcnt_;          // policy 2: updates per item row (popularity)
+    DevBuf<uint8_t> hot_;
+    int64_t itemcnt_gen_ = -1;
     DevBuf<int32_t> inj_;
 };
 

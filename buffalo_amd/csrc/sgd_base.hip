@@ -283,6 +283,7 @@ void SgdHandle::set_resident_csr(const int64_t* indptr, const int32_t* keys, int
     stats.h2d_bytes += static_cast<double>(P_rows_ * sizeof(int64_t) + nnz * sizeof(int32_t));
     launch_fill_rows(indptr_.get(), 0, P_rows_, 0, nnz, rows_.get(), stream);
     resident_ = true;
+    csr_generation_ += 1;
     resident_nnz_ = nnz;
     placeholder_set_ = true;
     sync_stream();
@@ -436,10 +437,17 @@ void SgdHandle::update_parameters() {
 
 void SgdHandle::set_mode(const std::string& name, int64_t v) {
     if (name == "sequential") sequential_ = static_cast<int>(v);
-    else if (name == "hogwild_atomic") { BFH_REQUIRE(v == 0 || v == 1, "hogwild_atomic must be 0 (write-through stores) or 1 (fp32 atomics)"); hogwild_atomic_ = static_cast<int>(v); }
+    else if (name == "hogwild_atomic") {
+        BFH_REQUIRE(v == 0 || v == 1 || (v == 2 && kind_ == 0),
+                    "hogwild_atomic must be 0 (write-through stores), 1 (fp32 atomics) or, for BPRMF, 2 (per-XCD replicas)");
+        hogwild_atomic_ = static_cast<int>(v);
+    }
+    else if (name == "xcd_sync_updates") { BFH_REQUIRE(v >= 1, "xcd_sync_updates must be positive"); xcd_sync_updates_ = v; }
+    else if (name == "xcd_merge_mean") xcd_merge_mean_ = v != 0;
+    else if (name == "xcd_hot_tau") { BFH_REQUIRE(v >= 0, "xcd_hot_tau is a permille value >= 0"); xcd_hot_tau_ = static_cast<int>(v); }
     else if (name == "prefetch") prefetch_ = static_cast<int>(v);
     else if (name == "waves_per_cu") waves_per_cu_ = static_cast<int>(v);
-    else if (name == "chunk") { BFH_REQUIRE(v >= 64 && v % 64 == 0, "chunk must be a positive multiple of 64"); chunk_ = static_cast<int>(v); }
+    else if (name == "chunk") { BFH_REQUIRE(v >= 64 && v % 64 == 0, "chunk must be a positive multiple of 64"); chunk_ = static_cast<int>(v); chunk_set_ = true; }
     else if (name == "timing") timing = v != 0;
     else if (name == "epoch") epoch_ = static_cast<uint32_t>(v);
     else throw Error(BFH_ERR_INVALID, "unknown mode '" + name + "'");

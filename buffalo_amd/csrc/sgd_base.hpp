@@ -73,6 +73,13 @@ class SgdHandle : public HandleBase {
 
     // knobs
     int sequential_ = 0, hogwild_atomic_ = 1, prefetch_ = 1, waves_per_cu_ = 0, chunk_ = 256;
+    // policy 2 (BPRMF sgd): updates between two merges of the per-XCD item-factor replicas, and
+    // whether the merge sums (0) or averages (1) the replicas' deltas
+    int64_t xcd_sync_updates_ = int64_t(1) << 21;
+    int xcd_merge_mean_ = 0;
+    int xcd_hot_tau_ = 100;        // permille: tolerated collision probability of a replica row (0 = no hot rows)
+    int64_t csr_generation_ = 0;   // bumped by set_resident_csr
+    bool chunk_set_ = false;
 
     float *hostP_ = nullptr, *hostQ_ = nullptr, *hostQb_ = nullptr;
     DevBuf<float> P_, Q_, Qb_, gradP_, gradQ_, gradQb_, momP_, momQ_, momQb_, velP_, velQ_, velQb_;

@@ -132,7 +132,7 @@ def generate(num_users, num_items, nnz, seed=7, zipf_s=1.0, vals="ones", sigma=1
     return CSR(U, I, indptr, c, v)
 
 
-def planted(num_users, num_items, d_true=8, density=0.05, seed=7, noise=0.5):
+def planted(num_users, num_items, d_true=8, density=0.05, seed=7, noise=0.5, popularity=0.0):
     """Small matrix with planted low-rank structure for the NDCG/MAP threshold tests that mirror
     /root/reference/tests/algo/base.py:83-97.  Returns (train CSR, held-out (user,item) pairs)."""
     rng = np.random.default_rng(seed)
@@ -140,6 +140,8 @@ def planted(num_users, num_items, d_true=8, density=0.05, seed=7, noise=0.5):
     A = rng.normal(size=(U, d_true))
     B = rng.normal(size=(I, d_true))
     S = A @ B.T + noise * rng.normal(size=(U, I))
+    if popularity:   # a per-item offset skews the item popularity (head items end up in most users' rows)
+        S += popularity * rng.normal(size=(1, I))
     k = max(2, int(density * I))
     top = np.argpartition(-S, k, axis=1)[:, :k]
     rows = np.repeat(np.arange(U), k)

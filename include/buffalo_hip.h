@@ -58,6 +58,7 @@ typedef struct {
     double optimizer_ms;      /* HIP-event time of the epoch-end optimizer kernels                */
     double aux_ms;            /* everything else the backend launched (precompute, loss, ...)     */
     double h2d_bytes, d2h_bytes;
+    int64_t merges;           /* BPRMF policy 2: reconciliations of the per-XCD item-factor replicas */
 } bfh_stats;
 
 const char* bfh_version(void);
@@ -151,7 +152,9 @@ int bfh_als_synchronize(void* h, int device_to_host);
 /* Named integer knobs.  Common: "sequential" (1 = one wave walks the chunk in CSR order: the
  * deterministic parity mode), "hogwild_atomic" (1 = fp32 atomic adds on shared item rows [default], 0 = racy
  * device-coherent write-through stores like CPU Hogwild), "prefetch" (software pipelining depth 0/1), "waves_per_cu",
- * "chunk" (nnz positions per wave work item), "als_writeback" (0 = defer), "timing" (1 = record
+ * "chunk" (nnz positions per wave work item), "xcd_sync_updates" / "xcd_merge_mean" (BPRMF "hogwild_atomic" = 2: every XCD
+ * trains a private replica of the item factors with plain stores through its own L2; the replicas are reconciled every
+ * xcd_sync_updates updates by Q <- S + sum_x (Q_x - S), or the mean of the deltas), "als_writeback" (0 = defer), "timing" (1 = record
  * HIP events around every launch).  Unknown names fail with BFH_ERR_INVALID. */
 int bfh_bpr_set_mode(void* h, const char* name, int64_t value);
 int bfh_warp_set_mode(void* h, const char* name, int64_t value);

@@ -106,7 +106,9 @@ def test_triples_parallel_disjoint_rows(oracle):
     pos, neg = np.ascontiguousarray(items[:U]), np.ascontiguousarray(items[U:2 * U])
     opt = bpr_opt(d=d, lr=0.1, min_lr=0.1)
     outs = []
-    for mode in (dict(sequential=1), dict(hogwild_atomic=1, chunk=64), dict(hogwild_atomic=0, chunk=64, prefetch=0)):
+    for mode in (dict(sequential=1), dict(hogwild_atomic=1, chunk=64), dict(hogwild_atomic=0, chunk=64, prefetch=0),
+                 dict(hogwild_atomic=2, xcd_hot_tau=0), dict(hogwild_atomic=2, xcd_hot_tau=0, xcd_sync_updates=64),
+                 dict(hogwild_atomic=2, xcd_hot_tau=1), dict(hogwild_atomic=2, xcd_hot_tau=100, xcd_merge_mean=0, chunk=128)):
         rng2 = np.random.default_rng(1)
         P = rng2.normal(scale=0.3, size=(U, vdim)).astype(np.float32)
         Q = rng2.normal(scale=0.3, size=(I, vdim)).astype(np.float32)
@@ -146,7 +148,7 @@ def test_compute_loss_matches_oracle(oracle):
     assert abs(got - want) < 1e-5 * max(1.0, abs(want))
 
 
-@pytest.mark.parametrize("atomic", [1, 0])
+@pytest.mark.parametrize("atomic", [1, 0, 2])
 def test_hogwild_statistical_parity(oracle, atomic):
     """Throughput mode vs the threaded reference path: same ranking quality on planted low-rank data
     (mirrors the ndcg threshold test, tests/algo/test_bpr.py:38-47).  With fp32 atomics no update is
@@ -169,25 +171,40 @@ def test_hogwild_statistical_parity(oracle, atomic):
     base = H.ndcg_at_k(P0, Q0, csr, vali, Qb=Qb0)
     assert np.isfinite(P).all() and np.isfinite(Q).all()
     assert n_ref > 3 * max(base, 0.01)
-    if atomic:
+    print("hogwild_atomic=%d ndcg %.4f (reference path %.4f, untrained %.4f)" % (atomic, n_hip, n_ref, base))
+    if atomic:   # 1: atomics everywhere; 2: per-XCD replicas + atomics on the rows the popularity rule marks hot
         assert n_hip > 3 * max(base, 0.01)
         assert abs(n_hip - n_ref) < 0.25 * n_ref, (n_hip, n_ref)
     else:
         assert n_hip > base, (n_hip, base)
 
 
-def test_full_size_properties():
-    """BASELINE config #2 shape (138,493 x 27,278, 20,000,263 nnz, d=128): size-independent checks."""
+_FULL = {}
+
+
+def _full_size_csr():
+    from buffalo_amd import synth
+    if "csr" not in _FULL:
+        import bench   # same generator call, cached under /tmp for the other full-size runs on this box
+        _FULL["csr"] = bench.load_matrix("ml20m", 7)
+    return _FULL["csr"]
+
+
+@pytest.mark.parametrize("policy", [1, 2])
+def test_full_size_properties(policy):
+    """BASELINE config #2 shape (138,493 x 27,278, 20,000,263 nnz, d=128): size-independent checks, for the
+    atomic policy and for the per-XCD replica policy (several merges per epoch, hot rows on atomics)."""
     from buffalo_amd import synth
     from buffalo_amd.backend import CyBPR
     U, I, nnz = synth.SHAPES["ml20m"]
-    csr = synth.generate(U, I, nnz, seed=7)
+    csr = _full_size_csr()
     d = vdim = 128
     opt = bpr_opt(d=d, lr=0.0, min_lr=0.0, num_iters=2, random_seed=7, compute_loss_on_training=True)
     P, Q, Qb = synth.init_factors(U, I, d, seed=7)
     P0, Q0, Qb0 = P.copy(), Q.copy(), Qb.copy()
     obj = CyBPR()
     assert obj.init(H.write_opt(dict(opt, accelerator=True)))
+    obj.set_mode("hogwild_atomic", policy)
     obj.initialize_model(P, Q, Qb, nnz, True)
     obj.set_cumulative_table(np.zeros(I, np.int64), I)
     obj.set_resident_csr(csr.indptr, csr.keys)
@@ -195,6 +212,7 @@ def test_full_size_properties():
     loss0, n = obj.add_jobs(0, U, csr.indptr, None)
     obj.update_parameters()
     assert n == nnz and obj.stats()["samples"] == nnz
+    assert (obj.stats()["merges"] >= 2) == (policy == 2)
     np.testing.assert_array_equal(P, P0)
     np.testing.assert_array_equal(Q, Q0)
     np.testing.assert_array_equal(Qb, Qb0)
@@ -204,6 +222,7 @@ def test_full_size_properties():
     obj2 = CyBPR()
     opt2 = dict(opt, lr=0.05, min_lr=0.05, accelerator=True)
     assert obj2.init(H.write_opt(opt2))
+    obj2.set_mode("hogwild_atomic", policy)
     obj2.initialize_model(P, Q, Qb, nnz, True)
     obj2.set_cumulative_table(np.zeros(I, np.int64), I)
     obj2.set_resident_csr(csr.indptr, csr.keys)
