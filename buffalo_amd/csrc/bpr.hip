@@ -51,6 +51,7 @@ struct BprConsts {
     float* rep_Qb;
     int64_t rep_stride, rep_bstride;
     const uint8_t* hot;   // [Q_rows] 1 = row stays in the chip-wide matrix and is updated with atomics
+    int fresh;            // re-read replica rows right before storing them
 };
 
 // The XCD this wave runs on (0..7), from the hardware register: the address of a wave's item-factor
@@ -98,6 +99,16 @@ __device__ __forceinline__ void load_row(Row<K>& r, const float* __restrict__ ba
     for (int k = 0; k < K; ++k) {
         const int e = k * 64 + lane;
         r.v[k] = (e < vdim) ? base[e] : 0.0f;
+    }
+}
+// same map, every dword loaded past the CU's L1 (global_load_dword sc1): what another CU of this
+// XCD stored is in the L2, not in this CU's L1
+template <int K>
+__device__ __forceinline__ void load_row_coh(Row<K>& r, const float* base, int lane, int vdim) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int e = k * 64 + lane;
+        r.v[k] = (e < vdim) ? __hip_atomic_load(base + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
     }
 }
 template <int K>
@@ -190,7 +201,7 @@ __global__ __launch_bounds__(256) void bpr_update_kernel(SgdParams p, BprConsts 
     float* Qbase = p.Q;
     float* Qbbase = p.Qb;
     bool rep = false;
-    if constexpr (V4 && SGD) {
+    if constexpr (SGD) {
         if (c.atomic == 2) {
             const int x = xcc_id();
             Qbase = c.rep_Q + static_cast<size_t>(x) * c.rep_stride;
@@ -202,6 +213,13 @@ __global__ __launch_bounds__(256) void bpr_update_kernel(SgdParams p, BprConsts 
     // policy 2 keeps the popular ("hot") rows in the chip-wide matrix: (pol bit set) <=> atomics on p.Q
     auto q_of = [&](int item, bool hot) -> float* { return (hot ? p.Q : Qbase) + static_cast<size_t>(item) * vdim; };
     auto qb_of = [&](int item, bool hot) -> float* { return (hot ? p.Qb : Qbbase) + item; };
+    // item rows and biases are read past the L1 whenever another CU may have plain-stored them
+    auto qload = [&](Row<K>& r, const float* base) {
+        if constexpr (V4) row_load<K, true, true>(r, base, lane, vdim);
+        else if (rep) load_row_coh<K>(r, base, lane, vdim);
+        else load_row<K>(r, base, lane, vdim);
+    };
+    auto bload = [&](const float* ptr) -> float { return (V4 || rep) ? coh_load(ptr) : *ptr; };
 
     int cur_u = -1;
     bool cur_excl = true;
@@ -264,9 +282,9 @@ __global__ __launch_bounds__(256) void bpr_update_kernel(SgdParams p, BprConsts 
             if (PIPE) {
                 const int pol0 = __builtin_amdgcn_readlane(my_pol, 0);
                 const bool h_i = rep && (pol0 & 1), h_j = rep && (pol0 & 2);
-                row_load<K, V4, true>(qi, q_of(pos, h_i), lane, vdim);
-                row_load<K, V4, true>(qj, q_of(neg, h_j), lane, vdim);
-                if (c.use_bias) { bi = V4 ? coh_load(qb_of(pos, h_i)) : Qbbase[pos]; bj = V4 ? coh_load(qb_of(neg, h_j)) : Qbbase[neg]; }
+                qload(qi, q_of(pos, h_i));
+                qload(qj, q_of(neg, h_j));
+                if (c.use_bias) { bi = bload(qb_of(pos, h_i)); bj = bload(qb_of(neg, h_j)); }
             }
             for (int j = 0; j < n_here; ++j) {
                 const int u = __builtin_amdgcn_readlane(my_u, j);
@@ -288,17 +306,17 @@ __global__ __launch_bounds__(256) void bpr_update_kernel(SgdParams p, BprConsts 
                         const int pol_n = __builtin_amdgcn_readlane(my_pol, j + 1);
                         hn_i = rep && (pol_n & 1);
                         hn_j = rep && (pol_n & 2);
-                        row_load<K, V4, true>(qi_n, q_of(pos_n, hn_i), lane, vdim);
-                        row_load<K, V4, true>(qj_n, q_of(neg_n, hn_j), lane, vdim);
+                        qload(qi_n, q_of(pos_n, hn_i));
+                        qload(qj_n, q_of(neg_n, hn_j));
                         if (c.use_bias) {
-                            bi_n = V4 ? coh_load(qb_of(pos_n, hn_i)) : Qbbase[pos_n];
-                            bj_n = V4 ? coh_load(qb_of(neg_n, hn_j)) : Qbbase[neg_n];
+                            bi_n = bload(qb_of(pos_n, hn_i));
+                            bj_n = bload(qb_of(neg_n, hn_j));
                         }
                     }
                 } else {
-                    row_load<K, V4, true>(qi, Qi, lane, vdim);
-                    row_load<K, V4, true>(qj, Qj, lane, vdim);
-                    if (c.use_bias) { bi = V4 ? coh_load(Bi) : Qbbase[pos]; bj = V4 ? coh_load(Bj) : Qbbase[neg]; }
+                    qload(qi, Qi);
+                    qload(qj, Qj);
+                    if (c.use_bias) { bi = bload(Bi); bj = bload(Bj); }
                 }
                 if (u != cur_u) {
                     flush_user();
@@ -338,13 +356,30 @@ __global__ __launch_bounds__(256) void bpr_update_kernel(SgdParams p, BprConsts 
                         if (same) qi.v[k] = qj.v[k];
                         pu.v[k] += c.lr * (logit * (qi.v[k] - qj.v[k]) - c.reg_u * pu.v[k]);
                     }
+                    // replica rows: optionally re-read the row right before the store, so that the window in
+                    // which another wave's update of the same row can be overwritten is one L2 round trip
+                    // instead of the prefetch distance (the step itself was computed from the prefetched row)
+                    const bool fr_i = rep && c.fresh && c.update_i && !at_i, fr_j = rep && c.fresh && c.update_j && !at_j && !same;
+                    Row<K> fi, fj;
+                    if (fr_i) qload(fi, Qi);
+                    if (fr_j) qload(fj, Qj);
                     if (c.update_i) {
                         if (at_i) row_atomic_add<K, V4>(di, Qi, lane, vdim);
+                        else if (fr_i) {
+#pragma unroll
+                            for (int k = 0; k < K; ++k) fi.v[k] += di.v[k];
+                            row_store<K, V4, false>(fi, Qi, lane, vdim);
+                        }
                         else if (rep) row_store<K, V4, false>(qi, Qi, lane, vdim);
                         else row_store<K, V4, true>(qi, Qi, lane, vdim);
                     }
                     if (c.update_j) {
                         if (at_j) row_atomic_add<K, V4>(dj, Qj, lane, vdim);
+                        else if (fr_j) {
+#pragma unroll
+                            for (int k = 0; k < K; ++k) fj.v[k] += dj.v[k];
+                            row_store<K, V4, false>(fj, Qj, lane, vdim);
+                        }
                         else if (rep) row_store<K, V4, false>(qj, Qj, lane, vdim);
                         else row_store<K, V4, true>(qj, Qj, lane, vdim);
                     }
@@ -395,11 +430,11 @@ __global__ __launch_bounds__(256) void bpr_update_kernel(SgdParams p, BprConsts 
                         qi = qi_n; qj = qj_n; bi = bi_n; bj = bj_n;
                         if (SGD && (!at_i || !at_j) && (pos_n == pos || pos_n == neg || neg_n == pos || neg_n == neg)) {
                             // plain-store rows: the prefetch raced with this wave's own stores -> reload
-                            row_load<K, V4, true>(qi, q_of(pos_n, hn_i), lane, vdim);
-                            row_load<K, V4, true>(qj, q_of(neg_n, hn_j), lane, vdim);
+                            qload(qi, q_of(pos_n, hn_i));
+                            qload(qj, q_of(neg_n, hn_j));
                             if (c.use_bias) {
-                                bi = V4 ? coh_load(qb_of(pos_n, hn_i)) : Qbbase[pos_n];
-                                bj = V4 ? coh_load(qb_of(neg_n, hn_j)) : Qbbase[neg_n];
+                                bi = bload(qb_of(pos_n, hn_i));
+                                bj = bload(qb_of(neg_n, hn_j));
                             }
                         }
                     }
@@ -546,20 +581,53 @@ class BprHandle : public SgdHandle {
         if (xcd_replicas()) {
             if (!chunk_set_) c.chunk = 64;   // short work items: a segment ends when its slowest wave does
             c.atomic = 2;
+            c.fresh = xcd_fresh_;
         } else if (c.atomic == 2) {
             c.atomic = 1;                    // adam/adagrad accumulate exact sums: atomics
         }
         return c;
     }
 
+    using KernelFn = void (*)(SgdParams, BprConsts);
+
     template <int K, bool INJECT, bool V4>
-    void launch_k(const SgdParams& p, const BprConsts& c, dim3 grid, dim3 block) {
+    KernelFn pick_k() const {
         const bool sgd = optimizer_ == "sgd";
         const bool pipe = prefetch_ != 0 && !sequential_;
-        if (sgd && pipe) hipLaunchKernelGGL((bpr_update_kernel<K, true, true, INJECT, V4>), grid, block, 0, stream, p, c);
-        else if (sgd) hipLaunchKernelGGL((bpr_update_kernel<K, true, false, INJECT, V4>), grid, block, 0, stream, p, c);
-        else if (pipe) hipLaunchKernelGGL((bpr_update_kernel<K, false, true, INJECT, V4>), grid, block, 0, stream, p, c);
-        else hipLaunchKernelGGL((bpr_update_kernel<K, false, false, INJECT, V4>), grid, block, 0, stream, p, c);
+        if (sgd && pipe) return bpr_update_kernel<K, true, true, INJECT, V4>;
+        if (sgd) return bpr_update_kernel<K, true, false, INJECT, V4>;
+        if (pipe) return bpr_update_kernel<K, false, true, INJECT, V4>;
+        return bpr_update_kernel<K, false, false, INJECT, V4>;
+    }
+    // the instantiation for this handle's vdim / optimizer / policy
+    template <bool INJECT>
+    KernelFn pick(const BprConsts& c) const {
+        // write-through Hogwild (policy 0; policy 2 on request) moves item rows as float4 with sc1; the
+        // atomic, the replica and the deterministic sequential paths keep the dword-per-lane layout
+        const bool v4 = optimizer_ == "sgd" && !sequential_ && (c.atomic == 0 || (c.atomic == 2 && xcd_v4_));
+        if (v4) {
+            const int KV = (vdim_ + 255) / 256;
+            if (KV <= 1) return pick_k<4, INJECT, true>();
+            if (KV <= 2) return pick_k<8, INJECT, true>();
+            return pick_k<16, INJECT, true>();
+        }
+        const int K = (vdim_ + 63) / 64;
+        if (K <= 1) return pick_k<1, INJECT, false>();
+        if (K <= 2) return pick_k<2, INJECT, false>();
+        if (K <= 4) return pick_k<4, INJECT, false>();
+        if (K <= 8) return pick_k<8, INJECT, false>();
+        return pick_k<16, INJECT, false>();
+    }
+    // waves of `fn` the chip keeps resident at once (256-thread blocks); "waves_per_cu" overrides
+    int64_t resident_waves(KernelFn fn) {
+        if (waves_per_cu_ > 0) return static_cast<int64_t>(num_cus_) * waves_per_cu_;
+        auto it = occupancy_.find(reinterpret_cast<const void*>(fn));
+        if (it == occupancy_.end()) {
+            int blocks = 0;
+            BFH_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, reinterpret_cast<const void*>(fn), 256, 0));
+            it = occupancy_.emplace(reinterpret_cast<const void*>(fn), std::max(1, std::min(blocks, 8))).first;
+        }
+        return static_cast<int64_t>(num_cus_) * it->second * 4;
     }
 
     bool xcd_replicas() const { return hogwild_atomic_ == 2 && optimizer_ == "sgd" && !sequential_; }
@@ -614,8 +682,7 @@ class BprHandle : public SgdHandle {
             count(p.keys, p.chunk_nnz);
             itemcnt_gen_ = -1;
         }
-        const int wpc = waves_per_cu_ > 0 ? waves_per_cu_ : 32;
-        const double waves = static_cast<double>(std::min<int64_t>(static_cast<int64_t>(num_cus_) * wpc, seg_work));
+        const double waves = static_cast<double>(std::min<int64_t>(resident_waves(pick<INJECT>(c)), seg_work));
         const double inflight = 2.0 * waves / kXcdReplicas;     // a wave holds the two item rows of its next triple
         hipLaunchKernelGGL(xcd_hot_kernel, dim3((Q_rows_ + 255) / 256), dim3(256), 0, stream, itemcnt_.get(), cum, cum_total_, Q_rows_, pos_mult,
                            triples, neg_uniform, inflight, xcd_hot_tau_ * 1e-3, hot_.get());
@@ -637,7 +704,9 @@ class BprHandle : public SgdHandle {
             c.rep_Qb = repQb_.get();
             c.rep_stride = static_cast<int64_t>(Q_rows_) * vdim_;
             c.rep_bstride = rep_bstride();
-            seg_work = std::max<int64_t>(1, xcd_sync_updates_ / c.chunk);
+            // a segment is a whole number of work items per resident wave: it ends when its slowest wave does
+            const int64_t waves = resident_waves(pick<INJECT>(c));
+            seg_work = std::max<int64_t>(1, (xcd_sync_updates_ / c.chunk + waves / 2) / waves) * waves;
             const int slot = t_aux_.begin(stream);
             c.hot = xcd_hot_rows<INJECT>(p, c, std::min(seg_work, n_work));
             xcd_broadcast();
@@ -659,32 +728,17 @@ class BprHandle : public SgdHandle {
     template <bool INJECT>
     void launch_segment(const SgdParams& p, const BprConsts& c) {
         const int64_t n_work = c.work_end - c.work_begin;
+        const KernelFn fn = pick<INJECT>(c);
         dim3 block(256), grid(1);
         if (sequential_) {
             block = dim3(64);
         } else {
-            const int wpc = waves_per_cu_ > 0 ? waves_per_cu_ : 32;
-            int64_t waves = static_cast<int64_t>(num_cus_) * wpc;
+            int64_t waves = resident_waves(fn);
             if (waves > n_work) waves = n_work;
             grid = dim3(static_cast<unsigned>((waves + 3) / 4));
         }
-        // write-through Hogwild (policies 0 / 2) moves item rows as float4 with sc1; the atomic and
-        // the deterministic sequential paths keep the dword-per-lane layout
-        const bool v4 = optimizer_ == "sgd" && !sequential_ && c.atomic != 1;
         const int slot = t_main_.begin(stream);
-        if (v4) {
-            const int KV = (vdim_ + 255) / 256;
-            if (KV <= 1) launch_k<4, INJECT, true>(p, c, grid, block);
-            else if (KV <= 2) launch_k<8, INJECT, true>(p, c, grid, block);
-            else launch_k<16, INJECT, true>(p, c, grid, block);
-        } else {
-            const int K = (vdim_ + 63) / 64;
-            if (K <= 1) launch_k<1, INJECT, false>(p, c, grid, block);
-            else if (K <= 2) launch_k<2, INJECT, false>(p, c, grid, block);
-            else if (K <= 4) launch_k<4, INJECT, false>(p, c, grid, block);
-            else if (K <= 8) launch_k<8, INJECT, false>(p, c, grid, block);
-            else launch_k<16, INJECT, false>(p, c, grid, block);
-        }
+        hipLaunchKernelGGL(fn, grid, block, 0, stream, p, c);
         BFH_HIP(hipGetLastError());
         t_main_.end(slot, stream);
         stats.launches += 1;
@@ -759,6 +813,7 @@ class BprHandle : public SgdHandle {
     DevBuf<int> itemcnt_;          // policy 2: updates per item row (popularity)
     DevBuf<uint8_t> hot_;
     int64_t itemcnt_gen_ = -1;
+    std::map<const void*, int> occupancy_;   // kernel -> resident 256-thread blocks per CU
     DevBuf<int32_t> inj_;
 };
 

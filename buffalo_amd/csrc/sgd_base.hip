@@ -444,6 +444,8 @@ void SgdHandle::set_mode(const std::string& name, int64_t v) {
     }
     else if (name == "xcd_sync_updates") { BFH_REQUIRE(v >= 1, "xcd_sync_updates must be positive"); xcd_sync_updates_ = v; }
     else if (name == "xcd_merge_mean") xcd_merge_mean_ = v != 0;
+    else if (name == "xcd_fresh") xcd_fresh_ = v != 0;
+    else if (name == "xcd_v4") xcd_v4_ = v != 0;
     else if (name == "xcd_hot_tau") { BFH_REQUIRE(v >= 0, "xcd_hot_tau is a permille value >= 0"); xcd_hot_tau_ = static_cast<int>(v); }
     else if (name == "prefetch") prefetch_ = static_cast<int>(v);
     else if (name == "waves_per_cu") waves_per_cu_ = static_cast<int>(v);

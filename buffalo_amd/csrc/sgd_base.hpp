@@ -77,6 +77,7 @@ class SgdHandle : public HandleBase {
     // whether the merge sums (0) or averages (1) the replicas' deltas
     int64_t xcd_sync_updates_ = int64_t(1) << 21;
     int xcd_merge_mean_ = 0;
+    int xcd_fresh_ = 0, xcd_v4_ = 0;  // re-read before store; float4-per-lane rows (hot-row atomics then cost 4x the line operations)
     int xcd_hot_tau_ = 100;        // permille: tolerated collision probability of a replica row (0 = no hot rows)
     int64_t csr_generation_ = 0;   // bumped by set_resident_csr
     bool chunk_set_ = false;

@@ -108,7 +108,9 @@ def test_triples_parallel_disjoint_rows(oracle):
     outs = []
     for mode in (dict(sequential=1), dict(hogwild_atomic=1, chunk=64), dict(hogwild_atomic=0, chunk=64, prefetch=0),
                  dict(hogwild_atomic=2, xcd_hot_tau=0), dict(hogwild_atomic=2, xcd_hot_tau=0, xcd_sync_updates=64),
-                 dict(hogwild_atomic=2, xcd_hot_tau=1), dict(hogwild_atomic=2, xcd_hot_tau=100, xcd_merge_mean=0, chunk=128)):
+                 dict(hogwild_atomic=2, xcd_hot_tau=1), dict(hogwild_atomic=2, xcd_hot_tau=100, xcd_merge_mean=0, chunk=128),
+                 dict(hogwild_atomic=2, xcd_hot_tau=0, xcd_fresh=1), dict(hogwild_atomic=2, xcd_hot_tau=0, xcd_v4=1),
+                 dict(hogwild_atomic=2, xcd_hot_tau=1, xcd_v4=1, xcd_fresh=1)):
         rng2 = np.random.default_rng(1)
         P = rng2.normal(scale=0.3, size=(U, vdim)).astype(np.float32)
         Q = rng2.normal(scale=0.3, size=(I, vdim)).astype(np.float32)
