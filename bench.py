@@ -240,7 +240,10 @@ def main():
                        "hogwild": {"0": "write-through (sc1) racy stores on item rows", "1": "fp32 atomics on item rows",
                                    "2": "per-XCD item-factor replicas (plain stores through the XCD's L2, merged by the delta rule "
                                         "%.1f times per epoch); popular rows stay chip-wide on fp32 atomics"
-                                        % (st["merges"] / max(steps, 1))}[hog]},
+                                        % (st["merges"] / max(steps, 1)),
+                                   "3": "item-major walk: users owned by XCDs (plain stores through the owner's L2), the positive "
+                                        "item row in registers with bounded-staleness atomic flushes, negatives in per-XCD replicas "
+                                        "merged by the delta rule %.1f times per epoch" % (st["merges"] / max(steps, 1))}[hog]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "bpr_update_kernel", "kernel_ms": kernel_ms,

@@ -488,11 +488,10 @@ __global__ void bpr_loss_kernel(const float* __restrict__ P, const float* __rest
 constexpr int kXcdReplicas = 8;
 
 template <typename T>
-__global__ __launch_bounds__(256) void xcd_broadcast_kernel(const T* __restrict__ S, T* __restrict__ rep, int64_t n, int64_t stride) {
+__global__ __launch_bounds__(256) void xcd_broadcast_kernel(const T* __restrict__ S, T* __restrict__ rep, int64_t n, int64_t stride, int copies) {
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
         const T v = S[i];
-#pragma unroll
-        for (int x = 0; x < kXcdReplicas; ++x) rep[x * stride + i] = v;
+        for (int x = 0; x < copies; ++x) rep[x * stride + i] = v;
     }
 }
 
@@ -503,25 +502,29 @@ __device__ __forceinline__ float f4_sub(float a, float b) { return a - b; }
 __device__ __forceinline__ float f4_add(float a, float b) { return a + b; }
 __device__ __forceinline__ float f4_fma(float sc, float a, float b) { return sc * a + b; }
 
-// S <- S + scale * sum_x (rep_x - S); the replicas are refreshed unless this was the last segment.
+// S <- S + scale * sum_x (rep_x - base); the replicas are refreshed unless this was the last segment.
 // Hot rows live in S itself (updated there with atomics) and are skipped; `row_len` = elements per row.
+// `base` is what the replicas started the segment from: S itself (policy 2, null), or a ninth copy when S
+// also receives atomic steps during the segment (policy 3: the register-resident rows are flushed into S).
 template <typename T>
 __global__ __launch_bounds__(256) void xcd_merge_kernel(T* __restrict__ S, T* __restrict__ rep, int64_t n, int64_t stride, float scale,
-                                                         int write_replicas, const uint8_t* __restrict__ hot, int row_len) {
+                                                         int write_replicas, const uint8_t* __restrict__ hot, int row_len, T* __restrict__ base) {
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
         if (hot && hot[i / row_len]) continue;
-        const T s0 = S[i];
+        const T s_now = S[i];
+        const T s0 = base ? base[i] : s_now;
         T r[kXcdReplicas];
 #pragma unroll
         for (int x = 0; x < kXcdReplicas; ++x) r[x] = rep[x * stride + i];
         T acc = f4_sub(r[0], s0);
 #pragma unroll
         for (int x = 1; x < kXcdReplicas; ++x) acc = f4_add(acc, f4_sub(r[x], s0));
-        const T out = f4_fma(scale, acc, s0);
+        const T out = f4_fma(scale, acc, s_now);
         S[i] = out;
         if (write_replicas) {
 #pragma unroll
             for (int x = 0; x < kXcdReplicas; ++x) rep[x * stride + i] = out;
+            if (base) base[i] = out;
         }
     }
 }
@@ -544,6 +547,17 @@ __global__ void xcd_hot_kernel(const int* __restrict__ cnt, const int64_t* __res
     if (cum) pneg = static_cast<double>(cum[i] - (i ? cum[i - 1] : 0)) / static_cast<double>(cum_total);
     const double upd = cnt[i] * pos_mult + triples * pneg;
     hot[i] = (upd * inflight >= tau * 2.0 * triples) ? 1 : 0;
+}
+
+}  // namespace bfh
+
+#include "bpr_item_major.hpp"
+
+namespace bfh {
+
+static int64_t gcd64(int64_t a, int64_t b) {
+    while (b) { const int64_t t = a % b; a = b; b = t; }
+    return a;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -581,8 +595,11 @@ class BprHandle : public SgdHandle {
         if (xcd_replicas()) {
             if (!chunk_set_) c.chunk = 64;   // short work items: a segment ends when its slowest wave does
             c.atomic = 2;
-            c.fresh = xcd_fresh_;
-        } else if (c.atomic == 2) {
+            c.fresh = xcd_fresh_ > 0;
+        } else if (item_major()) {
+            c.atomic = 3;
+            c.fresh = xcd_fresh_ != 0;       // default (-1): on
+        } else if (c.atomic >= 2) {
             c.atomic = 1;                    // adam/adagrad accumulate exact sums: atomics
         }
         return c;
@@ -631,24 +648,207 @@ class BprHandle : public SgdHandle {
     }
 
     bool xcd_replicas() const { return hogwild_atomic_ == 2 && optimizer_ == "sgd" && !sequential_; }
+    bool item_major() const { return hogwild_atomic_ == 3 && optimizer_ == "sgd" && !sequential_; }
 
-    // stream-ordered helpers of policy 2
-    void xcd_broadcast() {
-        const int64_t nq4 = static_cast<int64_t>(Q_rows_) * vdim_ / 4;
-        hipLaunchKernelGGL((xcd_broadcast_kernel<float4>), dim3(static_cast<unsigned>(std::min<int64_t>((nq4 + 255) / 256, 8192))), dim3(256), 0, stream,
-                           reinterpret_cast<const float4*>(Q_.get()), reinterpret_cast<float4*>(repQ_.get()), nq4, nq4);
-        hipLaunchKernelGGL((xcd_broadcast_kernel<float>), dim3((Q_rows_ + 255) / 256), dim3(256), 0, stream,
-                           static_cast<const float*>(Qb_.get()), repQb_.get(), static_cast<int64_t>(Q_rows_), rep_bstride());
+    // ---------------------------------------------------------------------------------------------
+    // policy 3 (bpr_item_major.hpp)
+    // ---------------------------------------------------------------------------------------------
+    void im_probe() {   // which XCC ids do workgroups of this device report?
+        if (im_nq_ > 0) return;
+        DevBuf<int> seen;
+        seen.resize(16, true, stream);
+        hipLaunchKernelGGL(xcd_probe_kernel, dim3(4096), dim3(64), 0, stream, seen.get());
+        BFH_HIP(hipGetLastError());
+        int host[16];
+        BFH_HIP(hipMemcpyAsync(host, seen.get(), sizeof(host), hipMemcpyDeviceToHost, stream));
+        sync_stream();
+        int n = 0;
+        for (int i = 0; i < 16; ++i) im_xcd_queue_[i] = host[i] ? n++ : -1;
+        BFH_REQUIRE(n >= 1 && n <= kImMaxQueues, "hogwild_atomic=3: unexpected number of XCDs reported by HW_REG_XCC_ID");
+        im_nq_ = n;
+    }
+
+    template <int K>
+    void im_launch_k(const SgdParams& p, const BprConsts& c, const ImQueues& q, int64_t waves) {
+        const dim3 grid(static_cast<unsigned>((waves + 3) / 4)), block(256);
+        if (prefetch_) hipLaunchKernelGGL((bpr_item_major_kernel<K, true>), grid, block, 0, stream, p, c, q);
+        else hipLaunchKernelGGL((bpr_item_major_kernel<K, false>), grid, block, 0, stream, p, c, q);
         BFH_HIP(hipGetLastError());
     }
-    void xcd_merge(bool write_replicas, const uint8_t* hot) {
+    void im_launch(const SgdParams& p, const BprConsts& c, const ImQueues& q, int64_t waves) {
+        const int KV = (vdim_ + 255) / 256;
+        if (KV <= 1) im_launch_k<4>(p, c, q, waves);
+        else if (KV <= 2) im_launch_k<8>(p, c, q, waves);
+        else im_launch_k<16>(p, c, q, waves);
+    }
+    int64_t im_resident_waves() {
+        if (waves_per_cu_ > 0) return static_cast<int64_t>(num_cus_) * waves_per_cu_;
+        const int KV = (vdim_ + 255) / 256;
+        const void* fn = KV <= 1 ? reinterpret_cast<const void*>(bpr_item_major_kernel<4, true>)
+                                 : (KV <= 2 ? reinterpret_cast<const void*>(bpr_item_major_kernel<8, true>)
+                                            : reinterpret_cast<const void*>(bpr_item_major_kernel<16, true>));
+        auto it = occupancy_.find(fn);
+        if (it == occupancy_.end()) {
+            int blocks = 0;
+            BFH_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, fn, 256, 0));
+            it = occupancy_.emplace(fn, std::max(1, std::min(blocks, 8))).first;
+        }
+        return static_cast<int64_t>(num_cus_) * it->second * 4;
+    }
+
+    // one call of the item-major path over the staged chunk [start_x, next_x)
+    void launch_item_major(const SgdParams& p, BprConsts c, int start_x, int next_x) {
+        im_probe();
+        const int64_t n = p.chunk_nnz;
+        BFH_REQUIRE(n < (int64_t(1) << 31), "hogwild_atomic=3: chunk of 2^31 or more interactions");
+        BFH_REQUIRE(static_cast<int64_t>(im_nq_) * Q_rows_ < (int64_t(1) << 32), "hogwild_atomic=3: too many items for the 32-bit sort key");
+        const int nq = im_nq_;
+        int slot = t_aux_.begin(stream);
+        // ---- entries grouped by (owner queue of the user, item); cached for a resident matrix ----
+        const bool cached = resident_ && im_gen_ == csr_generation_ && im_start_ == start_x && im_next_ == next_x && im_n_ == n;
+        if (!cached) {
+            im_key_a_.resize(static_cast<size_t>(n)); im_key_b_.resize(static_cast<size_t>(n));
+            im_pos_a_.resize(static_cast<size_t>(n)); im_pos_b_.resize(static_cast<size_t>(n));
+            im_qbeg_dev_.resize(kImMaxQueues + 1);
+            hipLaunchKernelGGL(im_keys_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, stream, p.rows, p.keys, n, nq,
+                               static_cast<uint32_t>(Q_rows_), im_key_a_.get(), im_pos_a_.get());
+            BFH_HIP(hipGetLastError());
+            int bits = 1;
+            while ((int64_t(1) << bits) < static_cast<int64_t>(nq) * Q_rows_) ++bits;
+            device_sort_pairs_u32(im_key_a_.get(), im_key_b_.get(), im_pos_a_.get(), im_pos_b_.get(), n, bits, im_tmp_, stream);
+            hipLaunchKernelGGL(im_bounds_kernel, dim3(1), dim3(64), 0, stream, im_key_b_.get(), n, nq, static_cast<uint32_t>(Q_rows_), im_qbeg_dev_.get());
+            BFH_HIP(hipGetLastError());
+            BFH_HIP(hipMemcpyAsync(im_qbeg_, im_qbeg_dev_.get(), (nq + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+            sync_stream();
+            im_gen_ = resident_ ? csr_generation_ : -1;
+            im_start_ = start_x; im_next_ = next_x; im_n_ = n;
+        }
+        // ---- per-row policy flags ----
+        const int64_t waves = im_resident_waves();
+        const double triples = static_cast<double>(c.total);
+        itemcnt_.resize(static_cast<size_t>(Q_rows_));
+        hot_.resize(static_cast<size_t>(Q_rows_));
+        im_flush_.resize(static_cast<size_t>(Q_rows_));
+        im_hot_user_.resize(static_cast<size_t>(P_rows_));
+        double cnt_triples = triples;   // what the item counts are normalised by
+        if (resident_) {
+            if (itemcnt_gen_ != csr_generation_) {
+                BFH_HIP(hipMemsetAsync(itemcnt_.get(), 0, itemcnt_.bytes(), stream));
+                hipLaunchKernelGGL(item_count_kernel, dim3(static_cast<unsigned>(std::min<int64_t>((resident_nnz_ + 255) / 256, 4096))), dim3(256), 0,
+                                   stream, keys_.get(), resident_nnz_, itemcnt_.get());
+                itemcnt_gen_ = csr_generation_;
+            }
+            cnt_triples = static_cast<double>(resident_nnz_) * num_neg_;
+        } else {
+            BFH_HIP(hipMemsetAsync(itemcnt_.get(), 0, itemcnt_.bytes(), stream));
+            hipLaunchKernelGGL(item_count_kernel, dim3(static_cast<unsigned>(std::min<int64_t>((n + 255) / 256, 4096))), dim3(256), 0, stream, p.keys, n,
+                               itemcnt_.get());
+            itemcnt_gen_ = -1;
+        }
+        const double queue_waves = static_cast<double>(waves) / nq;
+        // rows a queue's waves hold between the load and the store of one update: the current and the prefetched
+        // triple's, or -- when the row is re-read right before the store -- one L2 round trip out of a triple's time
+        const double inflight = (c.fresh ? 0.5 : 2.0) * queue_waves;
+        const double tau = xcd_hot_tau_ * 1e-3;
+        hipLaunchKernelGGL(im_item_flags_kernel, dim3((Q_rows_ + 255) / 256), dim3(256), 0, stream, itemcnt_.get(),
+                           uniform_ ? nullptr : p.cum_table, cum_total_, Q_rows_, static_cast<double>(num_neg_), cnt_triples,
+                           uniform_ ? 1.0 / Q_rows_ : 0.0, inflight, tau, static_cast<double>(waves), static_cast<double>(im_max_stale_), hot_.get(),
+                           im_flush_.get());
+        BFH_HIP(hipMemsetAsync(im_hot_user_.get(), 0, im_hot_user_.bytes(), stream));
+        hipLaunchKernelGGL(im_user_flags_kernel, dim3((next_x - start_x + 255) / 256), dim3(256), 0, stream, p.indptr, start_x, next_x - start_x,
+                           static_cast<double>(num_neg_), triples / nq, inflight, tau, im_hot_user_.get());
+        BFH_HIP(hipGetLastError());
+        // ---- replicas of the item factors (+ the copy they started from) ----
+        xcd_alloc(true);
+        c.rep_Q = repQ_.get();
+        c.rep_Qb = repQb_.get();
+        c.rep_stride = static_cast<int64_t>(Q_rows_) * vdim_;
+        c.rep_bstride = rep_bstride();
+        c.hot = hot_.get();
+        xcd_broadcast(true);
+        // ---- queues, slice order, segments ----
+        ImQueues q{};
+        q.ent_key = im_key_b_.get();
+        q.ent_pos = im_pos_b_.get();
+        q.nq = nq;
+        for (int i = 0; i < 16; ++i) q.xcd_queue[i] = im_xcd_queue_[i];
+        q.hot_user = im_hot_user_.get();
+        q.flush_every = im_flush_.get();
+        q.done = reinterpret_cast<unsigned long long*>(scratch_.get() + 1);
+        BFH_HIP(hipMemsetAsync(scratch_.get() + 1, 0, sizeof(double), stream));
+        for (int x = 0; x < nq; ++x) {
+            q.q_beg[x] = im_qbeg_[x];
+            q.q_triples[x] = (im_qbeg_[x + 1] - im_qbeg_[x]) * num_neg_;
+            q.q_slices[x] = (q.q_triples[x] + 63) / 64;
+            int64_t st = static_cast<int64_t>(static_cast<double>(q.q_slices[x]) * 0.6180339887498949) | 1;   // golden-ratio order
+            while (q.q_slices[x] > 1 && gcd64(st, q.q_slices[x]) != 1) st += 2;
+            q.q_stride[x] = q.q_slices[x] > 1 ? st % q.q_slices[x] : 1;
+            if (q.q_stride[x] == 0) q.q_stride[x] = 1;
+        }
+        const int64_t segments = std::max<int64_t>(1, (c.total + xcd_sync_updates_ / 2) / xcd_sync_updates_);
+        im_tickets_.resize(static_cast<size_t>(segments) * kImMaxQueues);
+        BFH_HIP(hipMemsetAsync(im_tickets_.get(), 0, im_tickets_.bytes(), stream));
+        t_aux_.end(slot, stream);
+        for (int64_t sgm = 0; sgm < segments; ++sgm) {
+            int64_t seg_slices = 0;
+            for (int x = 0; x < nq; ++x) {
+                q.t_beg[x] = q.q_slices[x] * sgm / segments;
+                q.t_end[x] = q.q_slices[x] * (sgm + 1) / segments;
+                seg_slices += q.t_end[x] - q.t_beg[x];
+            }
+            q.tickets = im_tickets_.get() + sgm * kImMaxQueues;
+            const int64_t grid_waves = std::max<int64_t>(4, std::min(waves, seg_slices));
+            slot = t_main_.begin(stream);
+            q.drain = 0;
+            if (!im_drain_only_) im_launch(p, c, q, grid_waves);
+            q.drain = 1;
+            im_launch(p, c, q, grid_waves);
+            t_main_.end(slot, stream);
+            stats.launches += 1;
+            slot = t_aux_.begin(stream);
+            xcd_merge(sgm + 1 < segments, c.hot, true);
+            t_aux_.end(slot, stream);
+            stats.merges += 1;
+        }
+        im_expect_done_ = c.total;
+    }
+    // after the stream was synchronised: every triple must have been processed exactly once
+    void im_check_done() {
+        if (im_expect_done_ < 0) return;
+        unsigned long long done = 0;
+        BFH_HIP(hipMemcpy(&done, scratch_.get() + 1, sizeof(done), hipMemcpyDeviceToHost));
+        const int64_t want = im_expect_done_;
+        im_expect_done_ = -1;
+        if (static_cast<int64_t>(done) != want)
+            throw Error(BFH_ERR_HIP, "hogwild_atomic=3: " + std::to_string(done) + " of " + std::to_string(want) + " updates were processed");
+    }
+
+    // stream-ordered helpers of policy 2
+    // `with_base`: a ninth copy keeps what the replicas started from (policy 3)
+    void xcd_alloc(bool with_base) {
+        const size_t copies = kXcdReplicas + (with_base ? 1 : 0);
+        if (repQ_.size() < copies * Q_rows_ * vdim_) repQ_.resize(copies * Q_rows_ * vdim_);
+        if (repQb_.size() < copies * rep_bstride()) repQb_.resize(copies * rep_bstride());
+    }
+    void xcd_broadcast(bool with_base) {
+        const int64_t nq4 = static_cast<int64_t>(Q_rows_) * vdim_ / 4;
+        const int copies = kXcdReplicas + (with_base ? 1 : 0);
+        hipLaunchKernelGGL((xcd_broadcast_kernel<float4>), dim3(static_cast<unsigned>(std::min<int64_t>((nq4 + 255) / 256, 8192))), dim3(256), 0, stream,
+                           reinterpret_cast<const float4*>(Q_.get()), reinterpret_cast<float4*>(repQ_.get()), nq4, nq4, copies);
+        hipLaunchKernelGGL((xcd_broadcast_kernel<float>), dim3((Q_rows_ + 255) / 256), dim3(256), 0, stream,
+                           static_cast<const float*>(Qb_.get()), repQb_.get(), static_cast<int64_t>(Q_rows_), rep_bstride(), copies);
+        BFH_HIP(hipGetLastError());
+    }
+    void xcd_merge(bool write_replicas, const uint8_t* hot, bool with_base) {
         const int64_t nq4 = static_cast<int64_t>(Q_rows_) * vdim_ / 4;
         const float scale = xcd_merge_mean_ ? 1.0f / kXcdReplicas : 1.0f;
+        float4* base4 = with_base ? reinterpret_cast<float4*>(repQ_.get()) + kXcdReplicas * nq4 : nullptr;
+        float* baseb = with_base ? repQb_.get() + kXcdReplicas * rep_bstride() : nullptr;
         hipLaunchKernelGGL((xcd_merge_kernel<float4>), dim3(static_cast<unsigned>(std::min<int64_t>((nq4 + 255) / 256, 8192))), dim3(256), 0, stream,
                            reinterpret_cast<float4*>(Q_.get()), reinterpret_cast<float4*>(repQ_.get()), nq4, nq4, scale, write_replicas ? 1 : 0,
-                           hot, vdim_ / 4);
+                           hot, vdim_ / 4, base4);
         hipLaunchKernelGGL((xcd_merge_kernel<float>), dim3((Q_rows_ + 255) / 256), dim3(256), 0, stream, Qb_.get(), repQb_.get(),
-                           static_cast<int64_t>(Q_rows_), rep_bstride(), scale, write_replicas ? 1 : 0, hot, 1);
+                           static_cast<int64_t>(Q_rows_), rep_bstride(), scale, write_replicas ? 1 : 0, hot, 1, baseb);
         BFH_HIP(hipGetLastError());
     }
     // hot-row flags for this call (policy 2); returns null when the split is disabled
@@ -698,8 +898,7 @@ class BprHandle : public SgdHandle {
         const bool reps = c.atomic == 2;
         int64_t seg_work = n_work;          // work items per launch
         if (reps) {
-            repQ_.resize(static_cast<size_t>(kXcdReplicas) * Q_rows_ * vdim_);
-            repQb_.resize(static_cast<size_t>(kXcdReplicas) * rep_bstride());
+            xcd_alloc(false);
             c.rep_Q = repQ_.get();
             c.rep_Qb = repQb_.get();
             c.rep_stride = static_cast<int64_t>(Q_rows_) * vdim_;
@@ -709,7 +908,7 @@ class BprHandle : public SgdHandle {
             seg_work = std::max<int64_t>(1, (xcd_sync_updates_ / c.chunk + waves / 2) / waves) * waves;
             const int slot = t_aux_.begin(stream);
             c.hot = xcd_hot_rows<INJECT>(p, c, std::min(seg_work, n_work));
-            xcd_broadcast();
+            xcd_broadcast(false);
             t_aux_.end(slot, stream);
         }
         for (int64_t w0 = 0; w0 < n_work; w0 += seg_work) {
@@ -718,7 +917,7 @@ class BprHandle : public SgdHandle {
             launch_segment<INJECT>(p, c);
             if (reps) {
                 const int slot = t_aux_.begin(stream);
-                xcd_merge(c.work_end < n_work, c.hot);
+                xcd_merge(c.work_end < n_work, c.hot, false);
                 t_aux_.end(slot, stream);
                 stats.merges += 1;
             }
@@ -755,9 +954,11 @@ class BprHandle : public SgdHandle {
         BprConsts c = consts(current_lr());
         c.total = n * num_neg_;
         if (compute_loss_) BFH_HIP(hipMemsetAsync(scratch_.get(), 0, sizeof(double), stream));
-        launch<false>(p, c);
+        if (c.atomic == 3) launch_item_major(p, c, start_x, next_x);
+        else launch<false>(p, c);
         if (compute_loss_) BFH_HIP(hipMemcpyAsync(loss_sum, scratch_.get(), sizeof(double), hipMemcpyDeviceToHost, stream));
         sync_stream();
+        im_check_done();
         harvest_timers();
         stats.samples += c.total;
         advance_progress(start_x, next_x, indptr);
@@ -776,6 +977,7 @@ class BprHandle : public SgdHandle {
         p.cntP = cntP_.get(); p.cntQ = cntQ_.get();
         p.P_rows = P_rows_; p.Q_rows = Q_rows_; p.d = d_; p.vdim = vdim_;
         BprConsts c = consts(lr);
+        if (c.atomic == 3) c.atomic = 1;   // injected triples have no CSR to regroup: atomics
         c.compute_loss = 0;
         c.num_neg = 1;
         c.total = n;
@@ -814,6 +1016,17 @@ class BprHandle : public SgdHandle {
     DevBuf<uint8_t> hot_;
     int64_t itemcnt_gen_ = -1;
     std::map<const void*, int> occupancy_;   // kernel -> resident 256-thread blocks per CU
+    // policy 3
+    int im_nq_ = 0, im_xcd_queue_[16];
+    DevBuf<uint32_t> im_key_a_, im_key_b_;
+    DevBuf<int32_t> im_pos_a_, im_pos_b_;
+    DevBuf<char> im_tmp_;
+    DevBuf<int64_t> im_qbeg_dev_;
+    DevBuf<uint8_t> im_flush_, im_hot_user_;
+    DevBuf<int> im_tickets_;
+    int64_t im_qbeg_[kImMaxQueues + 1] = {0};
+    int64_t im_gen_ = -1, im_n_ = -1, im_expect_done_ = -1;
+    int im_start_ = -1, im_next_ = -1;
     DevBuf<int32_t> inj_;
 };
 

@@ -1,0 +1,331 @@
+// BPRMF policy 3: the Hogwild SGD epoch walked ITEM-major, users owned by XCDs.
+// (included by bpr.hip after the row helpers; same reference semantics: CBPRMF::worker,
+// /root/reference/lib/algo_impl/bpr/bpr.cc:72-188)
+//
+// Why a second formulation.  The user-major kernel keeps P[u] in registers and pays for BOTH item
+// rows of every triple in shared memory.  The positive item follows the popularity law: the 300
+// most popular rows of the ML-20M-shaped matrix take a third of all positive updates, a single row
+// 130 K per epoch.  Chip-wide fp32 atomics on such rows serialise (measured ~1.1 ns per row update
+// on the head, 24 ns back to back on one row), XCD-private replicas of them diverge (thousands of
+// independent updates summed at every merge) and racy stores lose most of the colliding updates
+// (profiles/r01_xcd_study_pass*.json).  Walking the same triples grouped by their POSITIVE item
+// turns the hot row into the register-resident one:
+//
+//   * entries (nnz positions) are split into one queue per XCD by `user % n_xcd` and sorted by item
+//     inside a queue; a wave only pulls work from the queue of the XCD it runs on (HW_REG_XCC_ID),
+//     so a user row is only ever touched through ONE L2: plain loads (sc1: past the L1) and plain
+//     stores of P[u] are coherent without atomics;
+//   * Q[i] of the slice's item lives in registers; its accumulated step goes to the chip-wide matrix
+//     with one atomic row add every `flush_every[i]` triples (1 for the hottest rows .. 64), after
+//     which the row is re-read -- the number of updates of a row that are in flight unseen by the
+//     other waves stays below `im_max_stale` whatever the row's popularity;
+//   * Q[j] (uniformly drawn negatives: no popular rows unless the catalogue is tiny) uses the per-XCD
+//     replicas of policy 2: plain read-modify-write through the XCD's L2, reconciled by the delta
+//     rule at segment boundaries; rows the collision rule marks hot -- and heavy users' P rows -- are
+//     updated with atomics on the chip-wide copy instead;
+//   * slices are handed out through a per-queue ticket in a golden-ratio order, so the waves that run
+//     at the same time work on different items.
+//
+// A launch is followed by a `drain` launch in which any wave may take any ticket that is left (a
+// queue whose XCD received no workgroups, e.g. a tiny grid) and performs every update with atomics
+// on the chip-wide copies: completeness never depends on where the hardware places a workgroup.
+#pragma once
+
+namespace bfh {
+
+constexpr int kImMaxQueues = 8;
+
+struct ImQueues {
+    const uint32_t* ent_key;   // [n] queue * Q_rows + item, sorted
+    const int32_t* ent_pos;    // [n] chunk-local nnz position of the entry
+    int nq;                    // number of queues (= XCDs seen by the probe)
+    int drain;                 // 1: any wave takes any ticket, every update is an atomic on the chip-wide copy
+    int xcd_queue[16];         // HW_REG_XCC_ID -> queue (-1: not seen by the probe)
+    int64_t q_beg[kImMaxQueues];      // first entry of a queue
+    int64_t q_triples[kImMaxQueues];  // (entries of the queue) * num_neg
+    int64_t q_slices[kImMaxQueues];   // ceil(q_triples / 64)
+    int64_t q_stride[kImMaxQueues];   // slice = (ticket * stride) % q_slices, gcd(stride, q_slices) == 1
+    int64_t t_beg[kImMaxQueues], t_end[kImMaxQueues];   // ticket range of this launch
+    int* tickets;              // [nq] tickets handed out so far in this launch's range
+    unsigned long long* done;  // triples processed (checked by the host)
+    const uint8_t* hot_user;   // [P_rows] 1: P[u] is updated with atomics
+    const uint8_t* flush_every;  // [Q_rows] triples between two flushes of the register-resident item row (1..64)
+};
+
+__device__ __forceinline__ int xcc_id_raw() {
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(x));
+    return static_cast<int>(x & 15u);
+}
+
+__global__ void xcd_probe_kernel(int* seen) {
+    if (threadIdx.x == 0) atomicOr(seen + xcc_id_raw(), 1);
+}
+
+// sort key of every entry: (owner queue of the user) * Q_rows + item
+__global__ __launch_bounds__(256) void im_keys_kernel(const int32_t* __restrict__ rows, const int32_t* __restrict__ keys, int64_t n, int nq,
+                                                      uint32_t q_rows, uint32_t* __restrict__ kout, int32_t* __restrict__ vout) {
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (t >= n) return;
+    kout[t] = static_cast<uint32_t>(rows[t] % nq) * q_rows + static_cast<uint32_t>(keys[t]);
+    vout[t] = static_cast<int32_t>(t);
+}
+
+__global__ void im_bounds_kernel(const uint32_t* __restrict__ sorted, int64_t n, int nq, uint32_t q_rows, int64_t* __restrict__ q_beg) {
+    const int x = threadIdx.x;
+    if (x > nq) return;
+    q_beg[x] = x == nq ? n : lower_bound_dev<uint32_t>(sorted, n, static_cast<uint32_t>(x) * q_rows);
+}
+
+// per-row policy flags.  `inflight` = item (or user) rows a queue's waves hold between load and store.
+//   hot_item[i]    : P(negative == i) * inflight >= tau            -> atomics on the chip-wide row
+//   flush_every[i] : max_stale / (waves working on item i at once) clamped to [1, 64]
+//   hot_user[u]    : (share of the queue's triples with user u) * inflight >= tau
+__global__ void im_item_flags_kernel(const int* __restrict__ cnt, const int64_t* __restrict__ cum, int64_t cum_total, int rows, double pos_triples,
+                                     double total_triples, double neg_uniform, double inflight, double tau, double waves, double max_stale,
+                                     uint8_t* __restrict__ hot_item, uint8_t* __restrict__ flush_every) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    double pneg = neg_uniform;
+    if (cum) pneg = static_cast<double>(cum[i] - (i ? cum[i - 1] : 0)) / static_cast<double>(cum_total);
+    hot_item[i] = (tau > 0.0 && pneg * inflight >= tau) ? 1 : 0;
+    const double conc = cnt[i] * pos_triples / total_triples * waves;   // waves inside item i's entries at any time
+    double f = conc > 0.0 ? max_stale / conc : 64.0;
+    f = f < 1.0 ? 1.0 : (f > 64.0 ? 64.0 : f);
+    flush_every[i] = static_cast<uint8_t>(f);
+}
+
+__global__ void im_user_flags_kernel(const int64_t* __restrict__ indptr, int first_row, int rows, double num_neg, double queue_triples,
+                                     double inflight, double tau, uint8_t* __restrict__ hot_user) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= rows) return;
+    const int g = first_row + u;
+    const double deg = static_cast<double>(indptr[g] - (g ? indptr[g - 1] : 0));
+    hot_user[g] = (tau > 0.0 && deg * num_neg / queue_triples * inflight >= tau) ? 1 : 0;
+}
+
+// float4-per-lane registers -> dword-per-lane order (element k*64 + lane), so that one atomic
+// instruction covers whole 128-B lines: the atomic units charge per line touched, and a strided
+// float4 row would touch every line of the row four times.
+template <int K>
+__device__ __forceinline__ void row_atomic_add_full_lines(const Row<K>& r, float* __restrict__ base, int lane, int vdim) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (k * 64 < vdim) {
+            const int src = ((k & 3) * 16 + (lane >> 2)) * 4;   // byte address of the source lane
+            const int kv = (k >> 2) * 4;
+            const int c0 = __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, r.v[kv + 0]));
+            const int c1 = __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, r.v[kv + 1]));
+            const int c2 = __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, r.v[kv + 2]));
+            const int c3 = __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, r.v[kv + 3]));
+            const int sel = lane & 3;
+            const int v = sel == 0 ? c0 : (sel == 1 ? c1 : (sel == 2 ? c2 : c3));
+            const int e = k * 64 + lane;
+            if (e < vdim) atomic_add_f32(base + e, __builtin_bit_cast(float, v));
+        }
+    }
+}
+
+template <int K, bool PIPE>
+__global__ __launch_bounds__(256) void bpr_item_major_kernel(SgdParams p, BprConsts c, ImQueues q) {
+    const int lane = threadIdx.x & 63;
+    const int vdim = p.vdim;
+    const int my_queue = q.xcd_queue[xcc_id_raw()];
+    const bool drain = q.drain != 0;
+    float* const Qrep = drain ? p.Q : c.rep_Q + static_cast<size_t>(my_queue < 0 ? 0 : my_queue) * c.rep_stride;
+    float* const Qbrep = drain ? p.Qb : c.rep_Qb + static_cast<size_t>(my_queue < 0 ? 0 : my_queue) * c.rep_bstride;
+    auto rload = [&](Row<K>& r, const float* base) { row_load<K, true, true>(r, base, lane, vdim); };
+    auto rstore = [&](const Row<K>& r, float* base) { row_store<K, true, false>(r, base, lane, vdim); };
+
+    int cur_i = -1, since_flush = 0, flush_n = 64;
+    Row<K> qi, dqi;       // the slice's item row and its step since the last flush
+    float bi = 0.f, dbi_acc = 0.f;
+    double loss = 0.0;
+    unsigned long long processed = 0;
+
+    auto flush_item = [&](bool reload) {
+        if (cur_i < 0) return;
+        float* Qi = p.Q + static_cast<size_t>(cur_i) * vdim;
+        if (c.update_i) {
+            row_atomic_add_full_lines<K>(dqi, Qi, lane, vdim);
+            if (c.use_bias && lane == 0) atomic_add_f32(p.Qb + cur_i, dbi_acc);
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) dqi.v[k] = 0.f;
+        dbi_acc = 0.f;
+        since_flush = 0;
+        if (reload) {
+            // the atomics were acknowledged by the memory side before the row is read again
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            rload(qi, Qi);
+            if (c.use_bias) bi = coh_load(p.Qb + cur_i);
+        }
+    };
+
+    for (int qq = 0; qq < q.nq; ++qq) {
+        if (!drain && qq != my_queue) continue;
+        const int64_t n_tickets = q.t_end[qq] - q.t_beg[qq];
+        if (n_tickets <= 0) continue;
+        for (;;) {
+            int64_t tk = 0;
+            if (lane == 0) {
+                // drain: look before taking a ticket (thousands of waves find nothing left)
+                const int seen = drain ? __hip_atomic_load(q.tickets + qq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+                tk = seen >= n_tickets ? n_tickets : static_cast<int64_t>(atomicAdd(q.tickets + qq, 1));
+            }
+            tk = __builtin_amdgcn_readfirstlane(static_cast<int>(tk));
+            if (tk >= n_tickets) break;
+            const int64_t slice = static_cast<int64_t>((static_cast<unsigned long long>(q.t_beg[qq] + tk) * static_cast<unsigned long long>(q.q_stride[qq])) %
+                                                       static_cast<unsigned long long>(q.q_slices[qq]));
+            const int64_t t0 = slice * 64;
+            const int n_here = static_cast<int>((q.q_triples[qq] - t0) < 64 ? (q.q_triples[qq] - t0) : 64);
+            // ---------------- lane-parallel: entry -> (item, user), sample the negative ----------------
+            int my_u = 0, my_item = 0, my_neg = 0, my_pol = 0;   // bit0: P[u] atomic, bit1: Q[neg] atomic on the chip-wide row
+            if (lane < n_here) {
+                const int64_t t = t0 + lane;
+                const int64_t e = q.q_beg[qq] + t / c.num_neg;
+                const uint32_t slot = static_cast<uint32_t>(t % c.num_neg);
+                my_item = static_cast<int>(q.ent_key[e] - static_cast<uint32_t>(qq) * static_cast<uint32_t>(p.Q_rows));
+                const int64_t pos_idx = q.ent_pos[e];
+                my_u = p.rows[pos_idx];
+                const int64_t ubeg = (my_u == 0 ? 0 : p.indptr[my_u - 1]) - p.shift;
+                const int64_t uend = p.indptr[my_u] - p.shift;
+                my_neg = bpr_sample_negative(p, c, static_cast<uint64_t>(p.nnz_offset + p.shift + pos_idx), slot, ubeg, uend);
+                my_pol = drain ? 3 : ((q.hot_user[my_u] ? 1 : 0) | (c.hot[my_neg] ? 2 : 0));
+            }
+            auto pu_ptr = [&](int u) -> float* { return p.P + static_cast<size_t>(u) * vdim; };
+            auto qj_ptr = [&](int j, bool hot) -> float* { return (hot ? p.Q : Qrep) + static_cast<size_t>(j) * vdim; };
+            auto bj_ptr = [&](int j, bool hot) -> float* { return (hot ? p.Qb : Qbrep) + j; };
+
+            Row<K> pu, qj, pu_n, qj_n;
+            float bj = 0.f, bj_n = 0.f;
+            {
+                const int u0 = __builtin_amdgcn_readlane(my_u, 0), j0 = __builtin_amdgcn_readlane(my_neg, 0);
+                const int pol0 = __builtin_amdgcn_readlane(my_pol, 0);
+                rload(pu, pu_ptr(u0));
+                rload(qj, qj_ptr(j0, (pol0 & 2) != 0));
+                if (c.use_bias) bj = coh_load(bj_ptr(j0, (pol0 & 2) != 0));
+            }
+            for (int j = 0; j < n_here; ++j) {
+                const int item = __builtin_amdgcn_readlane(my_item, j);
+                const int u = __builtin_amdgcn_readlane(my_u, j);
+                const int neg = __builtin_amdgcn_readlane(my_neg, j);
+                const int pol = __builtin_amdgcn_readlane(my_pol, j);
+                const bool at_u = (pol & 1) != 0, at_j = (pol & 2) != 0;
+                int u_n = -1, neg_n = -1, pol_n = 0;
+                if (j + 1 < n_here) {
+                    u_n = __builtin_amdgcn_readlane(my_u, j + 1);
+                    neg_n = __builtin_amdgcn_readlane(my_neg, j + 1);
+                    pol_n = __builtin_amdgcn_readlane(my_pol, j + 1);
+                    if (PIPE) {
+                        rload(pu_n, pu_ptr(u_n));
+                        rload(qj_n, qj_ptr(neg_n, (pol_n & 2) != 0));
+                        if (c.use_bias) bj_n = coh_load(bj_ptr(neg_n, (pol_n & 2) != 0));
+                    }
+                }
+                if (item != cur_i) {
+                    flush_item(false);
+                    cur_i = item;
+                    flush_n = drain ? 1 : q.flush_every[item];
+                    rload(qi, p.Q + static_cast<size_t>(item) * vdim);
+                    if (c.use_bias) bi = coh_load(p.Qb + item);
+                }
+                // ---------------- score + sigmoid table (bpr.cc:119-131) ----------------
+                float part = 0.f;
+#pragma unroll
+                for (int k = 0; k < K; ++k) part += pu.v[k] * (qi.v[k] - qj.v[k]);
+                float x = wave_sum(part);
+                if (c.use_bias) x += (bi - bj);
+                const float logit = bpr_logit(x, c.exp_table);
+                if (c.compute_loss) loss += static_cast<double>(log1pf(__expf(-fminf(fmaxf(x, -6.f), 6.f))));
+                // ---------------- bpr.cc:157-171 (Q-1: the user step sees the updated item rows) ----------------
+                const bool same = item == neg;   // verify_neg == false only: the one row takes both steps in turn
+                Row<K> dj, dpu;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const float idv = logit * pu.v[k];
+                    const float di = c.update_i ? c.lr * (idv - c.reg_i * qi.v[k]) : 0.f;
+                    qi.v[k] += di;
+                    dqi.v[k] += di;
+                    if (same) qj.v[k] = qi.v[k];
+                    dj.v[k] = c.update_j ? c.lr * (-idv - c.reg_j * qj.v[k]) : 0.f;
+                    qj.v[k] += dj.v[k];
+                    if (same) { qi.v[k] = qj.v[k]; dqi.v[k] += dj.v[k]; }
+                    dpu.v[k] = c.lr * (logit * (qi.v[k] - qj.v[k]) - c.reg_u * pu.v[k]);
+                    pu.v[k] += dpu.v[k];
+                }
+                float dbj = 0.f;
+                if (c.use_bias) {
+                    const float dbi = c.update_i ? c.lr * (logit - c.reg_b * bi) : 0.f;
+                    bi += dbi;
+                    dbi_acc += dbi;
+                    if (same) bj = bi;
+                    dbj = c.update_j ? c.lr * (-logit - c.reg_b * bj) : 0.f;
+                    bj += dbj;
+                    if (same) { bi = bj; dbi_acc += dbj; }
+                }
+                // ---------------- write the two per-triple rows back ----------------
+                float* Pu = pu_ptr(u);
+                float* Qj = qj_ptr(neg, at_j);
+                const bool fr_u = c.fresh && !at_u, fr_j = c.fresh && !at_j && !same && c.update_j;
+                Row<K> fu, fj;
+                if (fr_u) rload(fu, Pu);
+                if (fr_j) rload(fj, Qj);
+                if (at_u) {
+                    row_atomic_add_full_lines<K>(dpu, Pu, lane, vdim);
+                } else if (fr_u) {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) fu.v[k] += dpu.v[k];
+                    rstore(fu, Pu);
+                } else {
+                    rstore(pu, Pu);
+                }
+                if (c.update_j && !same) {
+                    if (at_j) {
+                        row_atomic_add_full_lines<K>(dj, Qj, lane, vdim);
+                    } else if (fr_j) {
+#pragma unroll
+                        for (int k = 0; k < K; ++k) fj.v[k] += dj.v[k];
+                        rstore(fj, Qj);
+                    } else {
+                        rstore(qj, Qj);
+                    }
+                    if (c.use_bias && lane == 0) {
+                        float* Bj = bj_ptr(neg, at_j);
+                        if (at_j) atomic_add_f32(Bj, dbj);
+                        else *Bj = bj;
+                    }
+                }
+                processed += 1;
+                since_flush += 1;
+                const bool item_goes_on = j + 1 < n_here && __builtin_amdgcn_readlane(my_item, j + 1) == item;
+                if (since_flush >= flush_n && item_goes_on) flush_item(true);
+                // ---------------- next triple's rows ----------------
+                if (j + 1 < n_here) {
+                    if (u_n == u) {
+                        // consecutive slots of one entry (num_negative_samples > 1): carry the row instead of re-reading it
+                    } else if (PIPE) {
+                        pu = pu_n;
+                    } else {
+                        rload(pu, pu_ptr(u_n));
+                    }
+                    if (neg_n == neg && ((pol_n & 2) != 0) == at_j) {
+                        // same negative twice in a row: carry
+                    } else if (PIPE) {
+                        qj = qj_n;
+                        bj = bj_n;
+                    } else {
+                        rload(qj, qj_ptr(neg_n, (pol_n & 2) != 0));
+                        if (c.use_bias) bj = coh_load(bj_ptr(neg_n, (pol_n & 2) != 0));
+                    }
+                }
+            }
+            flush_item(false);
+            cur_i = -1;
+        }
+    }
+    if (lane == 0 && processed) atomicAdd(q.done, processed);
+    if (c.compute_loss && lane == 0 && loss != 0.0) atomicAdd(c.loss_out, loss);
+}
+
+}  // namespace bfh

@@ -44,6 +44,15 @@ static int bits_for(int64_t range) {   // bits needed for ids in [0, range)
     return b;
 }
 
+void device_sort_pairs_u32(const uint32_t* keys_in, uint32_t* keys_out, const int32_t* vals_in, int32_t* vals_out, int64_t n, int bits,
+                           DevBuf<char>& tmp, hipStream_t s) {
+    size_t bytes = 0;
+    BFH_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, keys_in, keys_out, vals_in, vals_out, n, 0, bits, s));
+    if (tmp.size() < bytes) tmp.resize(bytes ? bytes : 1);
+    bytes = tmp.size();
+    BFH_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.get(), bytes, keys_in, keys_out, vals_in, vals_out, n, 0, bits, s));
+}
+
 static void coo_to_csr(const int32_t* major, const int32_t* minor, const float* vals, int64_t nnz, int num_major, int num_minor, int64_t* indptr,
                        int32_t* out_minor, float* out_vals, bfh_stats* stats) {
     BFH_REQUIRE(nnz >= 0 && num_major > 0 && num_minor > 0, "coo_to_csr: empty shape");

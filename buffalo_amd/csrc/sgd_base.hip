@@ -438,13 +438,15 @@ void SgdHandle::update_parameters() {
 void SgdHandle::set_mode(const std::string& name, int64_t v) {
     if (name == "sequential") sequential_ = static_cast<int>(v);
     else if (name == "hogwild_atomic") {
-        BFH_REQUIRE(v == 0 || v == 1 || (v == 2 && kind_ == 0),
-                    "hogwild_atomic must be 0 (write-through stores), 1 (fp32 atomics) or, for BPRMF, 2 (per-XCD replicas)");
+        BFH_REQUIRE(v == 0 || v == 1 || ((v == 2 || v == 3) && kind_ == 0),
+                    "hogwild_atomic must be 0 (write-through stores), 1 (fp32 atomics) or, for BPRMF, 2 (per-XCD replicas) / 3 (item-major)");
         hogwild_atomic_ = static_cast<int>(v);
     }
     else if (name == "xcd_sync_updates") { BFH_REQUIRE(v >= 1, "xcd_sync_updates must be positive"); xcd_sync_updates_ = v; }
     else if (name == "xcd_merge_mean") xcd_merge_mean_ = v != 0;
-    else if (name == "xcd_fresh") xcd_fresh_ = v != 0;
+    else if (name == "xcd_fresh") xcd_fresh_ = v != 0 ? 1 : 0;
+    else if (name == "im_drain_only") im_drain_only_ = v != 0;
+    else if (name == "im_max_stale") { BFH_REQUIRE(v >= 1, "im_max_stale must be positive"); im_max_stale_ = static_cast<int>(v); }
     else if (name == "xcd_v4") xcd_v4_ = v != 0;
     else if (name == "xcd_hot_tau") { BFH_REQUIRE(v >= 0, "xcd_hot_tau is a permille value >= 0"); xcd_hot_tau_ = static_cast<int>(v); }
     else if (name == "prefetch") prefetch_ = static_cast<int>(v);

@@ -77,7 +77,9 @@ class SgdHandle : public HandleBase {
     // whether the merge sums (0) or averages (1) the replicas' deltas
     int64_t xcd_sync_updates_ = int64_t(1) << 21;
     int xcd_merge_mean_ = 0;
-    int xcd_fresh_ = 0, xcd_v4_ = 0;  // re-read before store; float4-per-lane rows (hot-row atomics then cost 4x the line operations)
+    int im_drain_only_ = 0;        // test hook: skip the owner-XCD launch, the atomic drain launch does everything
+    int im_max_stale_ = 64;        // policy 3: updates of one item row that may be in flight unseen by the other waves
+    int xcd_fresh_ = -1, xcd_v4_ = 0;  // re-read before store; float4-per-lane rows (hot-row atomics then cost 4x the line operations)
     int xcd_hot_tau_ = 100;        // permille: tolerated collision probability of a replica row (0 = no hot rows)
     int64_t csr_generation_ = 0;   // bumped by set_resident_csr
     bool chunk_set_ = false;

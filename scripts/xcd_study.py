@@ -46,16 +46,16 @@ def timing():
     csr = load_matrix("ml20m", 7)
     U, I, nnz = csr.num_users, csr.num_items, csr.nnz
     res = out.setdefault("timing", {})
-    cfgs = [dict(hogwild_atomic=1), dict(hogwild_atomic=2, xcd_hot_tau=0), dict(hogwild_atomic=2, xcd_hot_tau=0, xcd_v4=1),
-            dict(hogwild_atomic=2, xcd_hot_tau=0, xcd_fresh=1)]
-    for tau in (100, 250, 500):
-        for fresh in (0, 1):
-            cfgs.append(dict(hogwild_atomic=2, xcd_hot_tau=tau, xcd_fresh=fresh))
-    for sync in (1 << 20, 1 << 22, 1 << 23):
-        cfgs.append(dict(hogwild_atomic=2, xcd_hot_tau=250, xcd_fresh=1, xcd_sync_updates=sync))
-    cfgs.append(dict(hogwild_atomic=2, xcd_hot_tau=250, xcd_fresh=1, chunk=128))
-    cfgs.append(dict(hogwild_atomic=2, xcd_hot_tau=250, xcd_fresh=1, waves_per_cu=16))
-    cfgs.append(dict(hogwild_atomic=2, xcd_hot_tau=250, xcd_fresh=1, prefetch=0))
+    cfgs = [dict(hogwild_atomic=1), dict(hogwild_atomic=2, xcd_hot_tau=0, xcd_v4=1), dict(hogwild_atomic=3), dict(hogwild_atomic=3, xcd_fresh=0),
+            dict(hogwild_atomic=3, prefetch=0), dict(hogwild_atomic=3, xcd_fresh=0, prefetch=0)]
+    for sync in (1 << 22, 1 << 23, 1 << 25):
+        cfgs.append(dict(hogwild_atomic=3, xcd_sync_updates=sync))
+    for stale in (16, 256):
+        cfgs.append(dict(hogwild_atomic=3, im_max_stale=stale))
+    for tau in (0, 30, 300):
+        cfgs.append(dict(hogwild_atomic=3, xcd_hot_tau=tau))
+    for wpc in (12, 16, 32):
+        cfgs.append(dict(hogwild_atomic=3, waves_per_cu=wpc))
     steps, warm = 6, 2
     for modes in cfgs:
         name = ",".join("%s=%s" % kv for kv in modes.items())
@@ -98,8 +98,8 @@ def planted():
                                     "norms": [float(np.linalg.norm(Po)), float(np.linalg.norm(Qo))]}
     print("planted cpu", res["cpu_oracle_64_threads"], flush=True)
     save()
-    for modes in (dict(hogwild_atomic=1), dict(hogwild_atomic=2, xcd_hot_tau=250, xcd_fresh=1), dict(hogwild_atomic=2, xcd_hot_tau=500, xcd_fresh=1),
-                  dict(hogwild_atomic=2, xcd_hot_tau=250), dict(hogwild_atomic=2, xcd_hot_tau=0, xcd_fresh=1)):
+    for modes in (dict(hogwild_atomic=1), dict(hogwild_atomic=3), dict(hogwild_atomic=3, xcd_fresh=0), dict(hogwild_atomic=3, im_max_stale=256),
+                  dict(hogwild_atomic=3, xcd_hot_tau=0), dict(hogwild_atomic=3, xcd_sync_updates=1 << 25)):
         name = ",".join("%s=%s" % kv for kv in modes.items())
         if modes.get("sequential") and csr.nnz > 3_000_000:
             continue
@@ -121,12 +121,9 @@ def ml20m():
     ep = np.array([csr.row(int(u))[0][0] for u in eu], dtype=np.int32)
     en = rng.integers(0, I, 4000).astype(np.int32)
     res = out.setdefault("ml20m", {"epochs": epochs, "lr": lr, "cpu_reference": "profiles/r01_bpr_policy_quality_study.json"})
-    grid = [dict(hogwild_atomic=1)]
-    for tau in (100, 250, 500):
-        for fresh in (0, 1):
-            grid.append(dict(hogwild_atomic=2, xcd_hot_tau=tau, xcd_fresh=fresh))
-    grid.append(dict(hogwild_atomic=2, xcd_hot_tau=250, xcd_fresh=1, xcd_sync_updates=1 << 23))
-    grid.append(dict(hogwild_atomic=2, xcd_hot_tau=1000, xcd_fresh=1))
+    grid = [dict(hogwild_atomic=1), dict(hogwild_atomic=3), dict(hogwild_atomic=3, xcd_fresh=0), dict(hogwild_atomic=3, im_max_stale=256),
+            dict(hogwild_atomic=3, im_max_stale=16), dict(hogwild_atomic=3, xcd_sync_updates=1 << 23), dict(hogwild_atomic=3, xcd_hot_tau=300),
+            dict(hogwild_atomic=3, xcd_hot_tau=0)]
     for modes in grid:
         name = ",".join("%s=%s" % kv for kv in modes.items())
         P, Q, Qb = synth.init_factors(U, I, 128, seed=7)

@@ -128,6 +128,61 @@ def test_triples_parallel_disjoint_rows(oracle):
             assert H.relerr(x, y) < 2e-6
 
 
+@pytest.mark.parametrize("d,kw,modes", [
+    (128, {}, {}),
+    (40, {}, dict(xcd_fresh=0)),
+    (128, {}, dict(xcd_hot_tau=1)),                      # every user / negative row "hot": the atomic paths
+    (64, {}, dict(im_drain_only=1)),                     # the any-XCD drain launch does all the work
+    (300, dict(num_negative_samples=2), dict(prefetch=0)),
+    (128, dict(num_negative_samples=2, use_bias=False), dict(im_max_stale=1)),
+    (96, dict(update_j=False), dict(xcd_sync_updates=1024)),
+    (32, dict(update_i=False), {}),
+])
+def test_item_major_conflict_free(oracle, d, kw, modes):
+    """hogwild_atomic=3 (item-major walk, users owned by XCDs, Q[i] in registers, Q[j] in per-XCD replicas):
+    on a matrix where every user has one positive and the positives are distinct items, a triple whose
+    three rows no other triple touches has one possible result -- the sequential oracle's (same counter
+    sampler), whatever the schedule, the queue a wave serves or the path (plain / atomic / drain) a row takes."""
+    from buffalo_amd import synth
+    from buffalo_amd.backend import CyBPR
+    U, I = 3000, 60000
+    rng = np.random.default_rng(5)
+    keys = rng.permutation(I)[:U].astype(np.int32)
+    csr = synth.CSR(U, I, np.arange(1, U + 1, dtype=np.int64), keys, np.ones(U, np.float32))
+    opt = bpr_opt(d=d, lr=0.05, min_lr=0.05, num_iters=1, random_seed=11, **kw)
+    vdim = _vdim(d)
+    P, Q, Qb = _factors(csr, d, vdim, bias=opt["use_bias"])
+    P0, Q0 = P.copy(), Q.copy()
+    Po, Qo, Qbo = P[:, :d].copy(), Q[:, :d].copy(), Qb.copy()
+    o = H.run_oracle_sgd(oracle.OracleBPRMF, opt, csr, Po, Qo, Qbo, epochs=1, modes=DET, trace=True)
+    tr = o.get_trace()
+    nn = opt["num_negative_samples"]
+    assert len(tr) == U * nn
+    obj = H.run_hip_sgd(CyBPR, opt, csr, P, Q, Qb, epochs=1, modes=dict(hogwild_atomic=3, **modes), resident=True)
+    st = obj.stats()
+    assert st["samples"] == U * nn and st["merges"] >= 1
+    # rows touched by exactly one entry
+    touch = np.zeros(I, np.int64)
+    np.add.at(touch, keys, 1)                       # each entry's positive once
+    np.add.at(touch, tr[:, 2], 1)                   # every drawn negative
+    ent_neg_clean = (touch[tr[:, 2]] == 1).reshape(U, nn).all(axis=1)
+    clean = (touch[keys] == 1) & ent_neg_clean
+    assert clean.sum() > U // 2
+    cu = np.flatnonzero(clean)
+    ci = keys[cu]
+    cj = tr[:, 2].reshape(U, nn)[cu].reshape(-1)
+    assert H.relerr(P[cu][:, :d], Po[cu]) < 1e-5, H.relerr(P[cu][:, :d], Po[cu])
+    assert H.relerr(Q[ci][:, :d], Qo[ci]) < 1e-5, H.relerr(Q[ci][:, :d], Qo[ci])
+    assert H.relerr(Q[cj][:, :d], Qo[cj]) < 1e-5, H.relerr(Q[cj][:, :d], Qo[cj])
+    if opt["use_bias"]:
+        assert H.relerr(Qb[ci], Qbo[ci]) < 1e-5 and H.relerr(Qb[cj], Qbo[cj]) < 1e-5
+    # something was learned, nothing else moved, pad columns stay zero
+    assert not np.array_equal(P[cu], P0[cu])
+    untouched = np.flatnonzero(touch == 0)
+    np.testing.assert_array_equal(Q[untouched], Q0[untouched])
+    assert np.isfinite(P).all() and np.isfinite(Q).all() and np.all(P[:, d:] == 0) and np.all(Q[:, d:] == 0)
+
+
 def test_compute_loss_matches_oracle(oracle):
     from buffalo_amd.backend import CyBPR
     csr = tiny_csr(U=30, I=40, seed=2)
@@ -150,7 +205,7 @@ def test_compute_loss_matches_oracle(oracle):
     assert abs(got - want) < 1e-5 * max(1.0, abs(want))
 
 
-@pytest.mark.parametrize("atomic", [1, 0, 2])
+@pytest.mark.parametrize("atomic", [1, 0, 2, 3])
 def test_hogwild_statistical_parity(oracle, atomic):
     """Throughput mode vs the threaded reference path: same ranking quality on planted low-rank data
     (mirrors the ndcg threshold test, tests/algo/test_bpr.py:38-47).  With fp32 atomics no update is
@@ -174,7 +229,8 @@ def test_hogwild_statistical_parity(oracle, atomic):
     assert np.isfinite(P).all() and np.isfinite(Q).all()
     assert n_ref > 3 * max(base, 0.01)
     print("hogwild_atomic=%d ndcg %.4f (reference path %.4f, untrained %.4f)" % (atomic, n_hip, n_ref, base))
-    if atomic:   # 1: atomics everywhere; 2: per-XCD replicas + atomics on the rows the popularity rule marks hot
+    # 1: atomics everywhere; 2: per-XCD replicas + atomics on the rows the popularity rule marks hot; 3: item-major
+    if atomic:
         assert n_hip > 3 * max(base, 0.01)
         assert abs(n_hip - n_ref) < 0.25 * n_ref, (n_hip, n_ref)
     else:
@@ -192,7 +248,7 @@ def _full_size_csr():
     return _FULL["csr"]
 
 
-@pytest.mark.parametrize("policy", [1, 2])
+@pytest.mark.parametrize("policy", [1, 2, 3])
 def test_full_size_properties(policy):
     """BASELINE config #2 shape (138,493 x 27,278, 20,000,263 nnz, d=128): size-independent checks, for the
     atomic policy and for the per-XCD replica policy (several merges per epoch, hot rows on atomics)."""
@@ -214,7 +270,7 @@ def test_full_size_properties(policy):
     loss0, n = obj.add_jobs(0, U, csr.indptr, None)
     obj.update_parameters()
     assert n == nnz and obj.stats()["samples"] == nnz
-    assert (obj.stats()["merges"] >= 2) == (policy == 2)
+    assert (obj.stats()["merges"] >= 2) == (policy >= 2)
     np.testing.assert_array_equal(P, P0)
     np.testing.assert_array_equal(Q, Q0)
     np.testing.assert_array_equal(Qb, Qb0)
