@@ -127,7 +127,7 @@ __device__ __forceinline__ void row_atomic_add_full_lines(const Row<K>& r, float
 }
 
 template <int K, bool PIPE>
-__global__ __launch_bounds__(256) void bpr_item_major_kernel(SgdParams p, BprConsts c, ImQueues q) {
+__global__ __launch_bounds__(256, K <= 4 ? 5 : 1) void bpr_item_major_kernel(SgdParams p, BprConsts c, ImQueues q) {
     const int lane = threadIdx.x & 63;
     const int vdim = p.vdim;
     const int my_queue = q.xcd_queue[xcc_id_raw()];
@@ -138,11 +138,17 @@ __global__ __launch_bounds__(256) void bpr_item_major_kernel(SgdParams p, BprCon
     auto rstore = [&](const Row<K>& r, float* base) { row_store<K, true, false>(r, base, lane, vdim); };
 
     int cur_i = -1, since_flush = 0, flush_n = 64;
-    Row<K> qi, dqi;       // the slice's item row and its step since the last flush
-    float bi = 0.f, dbi_acc = 0.f;
+    Row<K> qi, dqi, qi_re;   // the slice's item row, its step since the last flush, the row as re-read after a flush
+    float bi = 0.f, dbi_acc = 0.f, bi_re = 0.f;
+    bool re_pending = false;
+#pragma unroll
+    for (int k = 0; k < K; ++k) { qi.v[k] = 0.f; dqi.v[k] = 0.f; qi_re.v[k] = 0.f; }
     double loss = 0.0;
     unsigned long long processed = 0;
 
+    // push the accumulated step of the register-resident row to the chip-wide matrix.  `reload`: the row is
+    // read back behind the atomics (same wave, same addresses: the memory pipeline keeps them in order) without
+    // waiting for either -- the next triple runs on the local copy and folds the re-read row in when it arrives.
     auto flush_item = [&](bool reload) {
         if (cur_i < 0) return;
         float* Qi = p.Q + static_cast<size_t>(cur_i) * vdim;
@@ -154,11 +160,11 @@ __global__ __launch_bounds__(256) void bpr_item_major_kernel(SgdParams p, BprCon
         for (int k = 0; k < K; ++k) dqi.v[k] = 0.f;
         dbi_acc = 0.f;
         since_flush = 0;
+        re_pending = false;
         if (reload) {
-            // the atomics were acknowledged by the memory side before the row is read again
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            rload(qi, Qi);
-            if (c.use_bias) bi = coh_load(p.Qb + cur_i);
+            rload(qi_re, Qi);
+            if (c.use_bias) bi_re = coh_load(p.Qb + cur_i);
+            re_pending = true;
         }
     };
 
@@ -180,7 +186,7 @@ __global__ __launch_bounds__(256) void bpr_item_major_kernel(SgdParams p, BprCon
             const int64_t t0 = slice * 64;
             const int n_here = static_cast<int>((q.q_triples[qq] - t0) < 64 ? (q.q_triples[qq] - t0) : 64);
             // ---------------- lane-parallel: entry -> (item, user), sample the negative ----------------
-            int my_u = 0, my_item = 0, my_neg = 0, my_pol = 0;   // bit0: P[u] atomic, bit1: Q[neg] atomic on the chip-wide row
+            int my_u = -1, my_item = -1, my_neg = -1, my_pol = 0;   // bit0: P[u] atomic, bit1: Q[neg] atomic on the chip-wide row
             if (lane < n_here) {
                 const int64_t t = t0 + lane;
                 const int64_t e = q.q_beg[qq] + t / c.num_neg;
@@ -197,32 +203,48 @@ __global__ __launch_bounds__(256) void bpr_item_major_kernel(SgdParams p, BprCon
             auto qj_ptr = [&](int j, bool hot) -> float* { return (hot ? p.Q : Qrep) + static_cast<size_t>(j) * vdim; };
             auto bj_ptr = [&](int j, bool hot) -> float* { return (hot ? p.Qb : Qbrep) + j; };
 
-            Row<K> pu, qj, pu_n, qj_n;
-            float bj = 0.f, bj_n = 0.f;
-            {
-                const int u0 = __builtin_amdgcn_readlane(my_u, 0), j0 = __builtin_amdgcn_readlane(my_neg, 0);
-                const int pol0 = __builtin_amdgcn_readlane(my_pol, 0);
-                rload(pu, pu_ptr(u0));
-                rload(qj, qj_ptr(j0, (pol0 & 2) != 0));
-                if (c.use_bias) bj = coh_load(bj_ptr(j0, (pol0 & 2) != 0));
-            }
-            for (int j = 0; j < n_here; ++j) {
+            // the two per-triple rows are fetched two triples ahead into the slots A (even triples) and B (odd):
+            // a wave keeps four rows in flight, which is what random 512-B rows need to cover the HBM latency
+            struct Slot { Row<K> pu, qj; float bj; };
+            Slot A, B;
+            auto fetch = [&](Slot& s, int j) {
+                if (j < n_here) {
+                    const int u = __builtin_amdgcn_readlane(my_u, j), ng = __builtin_amdgcn_readlane(my_neg, j);
+                    const bool hj = (__builtin_amdgcn_readlane(my_pol, j) & 2) != 0;
+                    rload(s.pu, pu_ptr(u));
+                    rload(s.qj, qj_ptr(ng, hj));
+                    s.bj = c.use_bias ? coh_load(bj_ptr(ng, hj)) : 0.f;
+                }
+            };
+            Row<K> pu, qj;
+            float bj = 0.f;
+            int prev_u = -1, prev_neg = -1, prev2_u = -1, prev2_neg = -1;
+            bool prev_hj = false;
+
+            auto step = [&](Slot& s, int j) {
                 const int item = __builtin_amdgcn_readlane(my_item, j);
                 const int u = __builtin_amdgcn_readlane(my_u, j);
                 const int neg = __builtin_amdgcn_readlane(my_neg, j);
                 const int pol = __builtin_amdgcn_readlane(my_pol, j);
                 const bool at_u = (pol & 1) != 0, at_j = (pol & 2) != 0;
-                int u_n = -1, neg_n = -1, pol_n = 0;
-                if (j + 1 < n_here) {
-                    u_n = __builtin_amdgcn_readlane(my_u, j + 1);
-                    neg_n = __builtin_amdgcn_readlane(my_neg, j + 1);
-                    pol_n = __builtin_amdgcn_readlane(my_pol, j + 1);
-                    if (PIPE) {
-                        rload(pu_n, pu_ptr(u_n));
-                        rload(qj_n, qj_ptr(neg_n, (pol_n & 2) != 0));
-                        if (c.use_bias) bj_n = coh_load(bj_ptr(neg_n, (pol_n & 2) != 0));
-                    }
+                // take the prefetched rows -- unless this wave itself changed the row after the prefetch was issued
+                if (u == prev_u) {
+                    // consecutive slots of one entry (num_negative_samples > 1): carry the updated row
+                } else if (u == prev2_u) {
+                    rload(pu, pu_ptr(u));
+                } else {
+                    pu = s.pu;
                 }
+                if (neg == prev_neg && at_j == prev_hj) {
+                    // the same negative twice in a row: carry
+                } else if (neg == prev2_neg) {
+                    rload(qj, qj_ptr(neg, at_j));
+                    if (c.use_bias) bj = coh_load(bj_ptr(neg, at_j));
+                } else {
+                    qj = s.qj;
+                    bj = s.bj;
+                }
+                if (PIPE) fetch(s, j + 2);
                 if (item != cur_i) {
                     flush_item(false);
                     cur_i = item;
@@ -298,27 +320,25 @@ __global__ __launch_bounds__(256) void bpr_item_major_kernel(SgdParams p, BprCon
                 }
                 processed += 1;
                 since_flush += 1;
+                // a row re-read behind the previous flush has arrived by now: it carries the other waves' steps
+                if (re_pending) {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) qi.v[k] = qi_re.v[k] + dqi.v[k];
+                    if (c.use_bias) bi = bi_re + dbi_acc;
+                    re_pending = false;
+                }
                 const bool item_goes_on = j + 1 < n_here && __builtin_amdgcn_readlane(my_item, j + 1) == item;
                 if (since_flush >= flush_n && item_goes_on) flush_item(true);
-                // ---------------- next triple's rows ----------------
-                if (j + 1 < n_here) {
-                    if (u_n == u) {
-                        // consecutive slots of one entry (num_negative_samples > 1): carry the row instead of re-reading it
-                    } else if (PIPE) {
-                        pu = pu_n;
-                    } else {
-                        rload(pu, pu_ptr(u_n));
-                    }
-                    if (neg_n == neg && ((pol_n & 2) != 0) == at_j) {
-                        // same negative twice in a row: carry
-                    } else if (PIPE) {
-                        qj = qj_n;
-                        bj = bj_n;
-                    } else {
-                        rload(qj, qj_ptr(neg_n, (pol_n & 2) != 0));
-                        if (c.use_bias) bj = coh_load(bj_ptr(neg_n, (pol_n & 2) != 0));
-                    }
-                }
+                prev2_u = prev_u; prev2_neg = prev_neg;
+                prev_u = u; prev_neg = neg; prev_hj = at_j;
+                if (!PIPE) fetch(s, j + 2);
+            };
+
+            fetch(A, 0);
+            fetch(B, 1);
+            for (int j = 0; j < n_here; j += 2) {
+                step(A, j);
+                if (j + 1 < n_here) step(B, j + 1);
             }
             flush_item(false);
             cur_i = -1;

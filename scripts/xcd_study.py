@@ -46,16 +46,15 @@ def timing():
     csr = load_matrix("ml20m", 7)
     U, I, nnz = csr.num_users, csr.num_items, csr.nnz
     res = out.setdefault("timing", {})
-    cfgs = [dict(hogwild_atomic=1), dict(hogwild_atomic=2, xcd_hot_tau=0, xcd_v4=1), dict(hogwild_atomic=3), dict(hogwild_atomic=3, xcd_fresh=0),
-            dict(hogwild_atomic=3, prefetch=0), dict(hogwild_atomic=3, xcd_fresh=0, prefetch=0)]
-    for sync in (1 << 22, 1 << 23, 1 << 25):
+    cfgs = [dict(hogwild_atomic=1), dict(hogwild_atomic=3), dict(hogwild_atomic=3, xcd_fresh=0), dict(hogwild_atomic=3, prefetch=0)]
+    for sync in (1 << 22, 1 << 23):
         cfgs.append(dict(hogwild_atomic=3, xcd_sync_updates=sync))
-    for stale in (16, 256):
+    for stale in (16, 128, 256):
         cfgs.append(dict(hogwild_atomic=3, im_max_stale=stale))
-    for tau in (0, 30, 300):
-        cfgs.append(dict(hogwild_atomic=3, xcd_hot_tau=tau))
-    for wpc in (12, 16, 32):
+    for wpc in (12, 16, 24):
         cfgs.append(dict(hogwild_atomic=3, waves_per_cu=wpc))
+    cfgs.append(dict(hogwild_atomic=3, xcd_hot_tau=0))
+    cfgs.append(dict(hogwild_atomic=3, xcd_sync_updates=1 << 22, im_max_stale=128))
     steps, warm = 6, 2
     for modes in cfgs:
         name = ",".join("%s=%s" % kv for kv in modes.items())
