@@ -750,10 +750,16 @@ class BprHandle : public SgdHandle {
         // triple's, or -- when the row is re-read right before the store -- one L2 round trip out of a triple's time
         const double inflight = (c.fresh ? 0.5 : 2.0) * queue_waves;
         const double tau = xcd_hot_tau_ * 1e-3;
+        // the staleness budgets are stated for lr = 0.05 and scale with 1 / lr: what matters is how far a row moves
+        const int64_t segments = std::max<int64_t>(1, (c.total + xcd_sync_updates_ / 2) / xcd_sync_updates_);
+        const double lr_scale = c.lr > 0.f ? 0.05 / static_cast<double>(c.lr) : 1e9;
+        const double max_stale = std::min(1e9, static_cast<double>(im_max_stale_) * lr_scale);
+        // positive steps of a row between two merges, in units of lr: counts (of `cnt_triples` triples) -> this call's share
+        const double lr_steps_per_count = static_cast<double>(num_neg_) * (triples / cnt_triples) / static_cast<double>(segments) * c.lr;
         hipLaunchKernelGGL(im_item_flags_kernel, dim3((Q_rows_ + 255) / 256), dim3(256), 0, stream, itemcnt_.get(),
                            uniform_ ? nullptr : p.cum_table, cum_total_, Q_rows_, static_cast<double>(num_neg_), cnt_triples,
-                           uniform_ ? 1.0 / Q_rows_ : 0.0, inflight, tau, static_cast<double>(waves), static_cast<double>(im_max_stale_), hot_.get(),
-                           im_flush_.get());
+                           uniform_ ? 1.0 / Q_rows_ : 0.0, inflight, tau, static_cast<double>(waves), max_stale, lr_steps_per_count,
+                           im_drift_budget_milli_ * 1e-3, hot_.get(), im_flush_.get());
         BFH_HIP(hipMemsetAsync(im_hot_user_.get(), 0, im_hot_user_.bytes(), stream));
         hipLaunchKernelGGL(im_user_flags_kernel, dim3((next_x - start_x + 255) / 256), dim3(256), 0, stream, p.indptr, start_x, next_x - start_x,
                            static_cast<double>(num_neg_), triples / nq, inflight, tau, im_hot_user_.get());
@@ -785,7 +791,6 @@ class BprHandle : public SgdHandle {
             q.q_stride[x] = q.q_slices[x] > 1 ? st % q.q_slices[x] : 1;
             if (q.q_stride[x] == 0) q.q_stride[x] = 1;
         }
-        const int64_t segments = std::max<int64_t>(1, (c.total + xcd_sync_updates_ / 2) / xcd_sync_updates_);
         im_tickets_.resize(static_cast<size_t>(segments) * kImMaxQueues);
         BFH_HIP(hipMemsetAsync(im_tickets_.get(), 0, im_tickets_.bytes(), stream));
         t_aux_.end(slot, stream);

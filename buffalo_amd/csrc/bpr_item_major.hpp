@@ -78,17 +78,25 @@ __global__ void im_bounds_kernel(const uint32_t* __restrict__ sorted, int64_t n,
 }
 
 // per-row policy flags.  `inflight` = item (or user) rows a queue's waves hold between load and store.
-//   hot_item[i]    : P(negative == i) * inflight >= tau            -> atomics on the chip-wide row
+//   hot_item[i]    : the NEGATIVE updates of row i go to the chip-wide row with atomics (and read it) when
+//                    (a) P(negative == i) * inflight >= tau: racing plain stores would lose that share of them, or
+//                    (b) the row's positive steps between two merges, weighted by the learning rate, reach
+//                        `drift_budget`: a replica does not see the flushes of the register-resident copies until the
+//                        next merge, and a negative step computed against a row that has since moved by O(1) closes
+//                        the feedback loop one merge late (measured: a popular catalogue head diverges at lr 0.05);
 //   flush_every[i] : max_stale / (waves working on item i at once) clamped to [1, 64]
 //   hot_user[u]    : (share of the queue's triples with user u) * inflight >= tau
 __global__ void im_item_flags_kernel(const int* __restrict__ cnt, const int64_t* __restrict__ cum, int64_t cum_total, int rows, double pos_triples,
                                      double total_triples, double neg_uniform, double inflight, double tau, double waves, double max_stale,
-                                     uint8_t* __restrict__ hot_item, uint8_t* __restrict__ flush_every) {
+                                     double lr_steps_per_count, double drift_budget, uint8_t* __restrict__ hot_item,
+                                     uint8_t* __restrict__ flush_every) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows) return;
     double pneg = neg_uniform;
     if (cum) pneg = static_cast<double>(cum[i] - (i ? cum[i - 1] : 0)) / static_cast<double>(cum_total);
-    hot_item[i] = (tau > 0.0 && pneg * inflight >= tau) ? 1 : 0;
+    const bool collide = tau > 0.0 && pneg * inflight >= tau;
+    const bool drift = drift_budget > 0.0 && cnt[i] * lr_steps_per_count >= drift_budget;
+    hot_item[i] = (collide || drift) ? 1 : 0;
     const double conc = cnt[i] * pos_triples / total_triples * waves;   // waves inside item i's entries at any time
     double f = conc > 0.0 ? max_stale / conc : 64.0;
     f = f < 1.0 ? 1.0 : (f > 64.0 ? 64.0 : f);
