@@ -684,9 +684,15 @@ class BprHandle : public SgdHandle {
     int64_t im_resident_waves() {
         if (waves_per_cu_ > 0) return static_cast<int64_t>(num_cus_) * waves_per_cu_;
         const int KV = (vdim_ + 255) / 256;
-        const void* fn = KV <= 1 ? reinterpret_cast<const void*>(bpr_item_major_kernel<4, true>)
-                                 : (KV <= 2 ? reinterpret_cast<const void*>(bpr_item_major_kernel<8, true>)
-                                            : reinterpret_cast<const void*>(bpr_item_major_kernel<16, true>));
+        const void* fn = nullptr;
+        if (prefetch_)
+            fn = KV <= 1 ? reinterpret_cast<const void*>(bpr_item_major_kernel<4, true>)
+                         : (KV <= 2 ? reinterpret_cast<const void*>(bpr_item_major_kernel<8, true>)
+                                    : reinterpret_cast<const void*>(bpr_item_major_kernel<16, true>));
+        else
+            fn = KV <= 1 ? reinterpret_cast<const void*>(bpr_item_major_kernel<4, false>)
+                         : (KV <= 2 ? reinterpret_cast<const void*>(bpr_item_major_kernel<8, false>)
+                                    : reinterpret_cast<const void*>(bpr_item_major_kernel<16, false>));
         auto it = occupancy_.find(fn);
         if (it == occupancy_.end()) {
             int blocks = 0;
@@ -748,7 +754,7 @@ class BprHandle : public SgdHandle {
         const double queue_waves = static_cast<double>(waves) / nq;
         // rows a queue's waves hold between the load and the store of one update: the current and the prefetched
         // triple's, or -- when the row is re-read right before the store -- one L2 round trip out of a triple's time
-        const double inflight = (c.fresh ? 0.5 : 2.0) * queue_waves;
+        const double inflight = (!prefetch_ ? 0.25 : (c.fresh ? 0.5 : 2.0)) * queue_waves;
         const double tau = xcd_hot_tau_ * 1e-3;
         // the staleness budgets are stated for lr = 0.05 and scale with 1 / lr: what matters is how far a row moves
         const int64_t segments = std::max<int64_t>(1, (c.total + xcd_sync_updates_ / 2) / xcd_sync_updates_);

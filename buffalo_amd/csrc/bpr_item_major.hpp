@@ -135,7 +135,7 @@ __device__ __forceinline__ void row_atomic_add_full_lines(const Row<K>& r, float
 }
 
 template <int K, bool PIPE>
-__global__ __launch_bounds__(256, K <= 4 ? 5 : 1) void bpr_item_major_kernel(SgdParams p, BprConsts c, ImQueues q) {
+__global__ __launch_bounds__(256, K <= 4 ? (PIPE ? 5 : 6) : 1) void bpr_item_major_kernel(SgdParams p, BprConsts c, ImQueues q) {
     const int lane = threadIdx.x & 63;
     const int vdim = p.vdim;
     const int my_queue = q.xcd_queue[xcc_id_raw()];
@@ -235,17 +235,19 @@ __global__ __launch_bounds__(256, K <= 4 ? 5 : 1) void bpr_item_major_kernel(Sgd
                 const int neg = __builtin_amdgcn_readlane(my_neg, j);
                 const int pol = __builtin_amdgcn_readlane(my_pol, j);
                 const bool at_u = (pol & 1) != 0, at_j = (pol & 2) != 0;
-                // take the prefetched rows -- unless this wave itself changed the row after the prefetch was issued
+                // take the prefetched rows -- unless this wave itself changed the row after the prefetch was issued.
+                // !PIPE: no prefetch at all, the rows are read here and written back a few hundred cycles later (the
+                // narrowest window another wave's update of the same row can fall into; latency is covered by occupancy)
                 if (u == prev_u) {
                     // consecutive slots of one entry (num_negative_samples > 1): carry the updated row
-                } else if (u == prev2_u) {
+                } else if (!PIPE || u == prev2_u) {
                     rload(pu, pu_ptr(u));
                 } else {
                     pu = s.pu;
                 }
                 if (neg == prev_neg && at_j == prev_hj) {
                     // the same negative twice in a row: carry
-                } else if (neg == prev2_neg) {
+                } else if (!PIPE || neg == prev2_neg) {
                     rload(qj, qj_ptr(neg, at_j));
                     if (c.use_bias) bj = coh_load(bj_ptr(neg, at_j));
                 } else {
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(256, K <= 4 ? 5 : 1) void bpr_item_major_kernel(Sgd
                 // ---------------- write the two per-triple rows back ----------------
                 float* Pu = pu_ptr(u);
                 float* Qj = qj_ptr(neg, at_j);
-                const bool fr_u = c.fresh && !at_u, fr_j = c.fresh && !at_j && !same && c.update_j;
+                const bool fr_u = PIPE && c.fresh && !at_u, fr_j = PIPE && c.fresh && !at_j && !same && c.update_j;
                 Row<K> fu, fj;
                 if (fr_u) rload(fu, Pu);
                 if (fr_j) rload(fj, Qj);
@@ -339,11 +341,12 @@ __global__ __launch_bounds__(256, K <= 4 ? 5 : 1) void bpr_item_major_kernel(Sgd
                 if (since_flush >= flush_n && item_goes_on) flush_item(true);
                 prev2_u = prev_u; prev2_neg = prev_neg;
                 prev_u = u; prev_neg = neg; prev_hj = at_j;
-                if (!PIPE) fetch(s, j + 2);
             };
 
-            fetch(A, 0);
-            fetch(B, 1);
+            if (PIPE) {
+                fetch(A, 0);
+                fetch(B, 1);
+            }
             for (int j = 0; j < n_here; j += 2) {
                 step(A, j);
                 if (j + 1 < n_here) step(B, j + 1);

@@ -46,13 +46,9 @@ def timing():
     csr = load_matrix("ml20m", 7)
     U, I, nnz = csr.num_users, csr.num_items, csr.nnz
     res = out.setdefault("timing", {})
-    cfgs = [dict(hogwild_atomic=1), dict(hogwild_atomic=3), dict(hogwild_atomic=3, im_drift_budget=0)]
-    for sync in (1 << 22, 1 << 23, 1 << 25):
-        cfgs.append(dict(hogwild_atomic=3, xcd_sync_updates=sync))
-    for wpc in (16, 20):
-        cfgs.append(dict(hogwild_atomic=3, waves_per_cu=wpc, xcd_sync_updates=1 << 23))
-    cfgs.append(dict(hogwild_atomic=3, xcd_sync_updates=1 << 23, xcd_fresh=0))
-    cfgs.append(dict(hogwild_atomic=3, xcd_sync_updates=1 << 23, xcd_hot_tau=0))
+    S8 = dict(hogwild_atomic=3, xcd_sync_updates=1 << 23)
+    cfgs = [S8, dict(S8, prefetch=0), dict(S8, prefetch=0, waves_per_cu=24), dict(S8, prefetch=0, waves_per_cu=20), dict(S8, prefetch=0, waves_per_cu=32),
+            dict(S8, prefetch=0, xcd_hot_tau=0), dict(hogwild_atomic=3, prefetch=0), dict(S8, prefetch=0, chunk=128)]
     steps, warm = 6, 2
     for modes in cfgs:
         name = ",".join("%s=%s" % kv for kv in modes.items())
@@ -117,9 +113,7 @@ def ml20m():
     ep = np.array([csr.row(int(u))[0][0] for u in eu], dtype=np.int32)
     en = rng.integers(0, I, 4000).astype(np.int32)
     res = out.setdefault("ml20m", {"epochs": epochs, "lr": lr, "cpu_reference": "profiles/r01_bpr_policy_quality_study.json"})
-    grid = [dict(hogwild_atomic=1), dict(hogwild_atomic=3), dict(hogwild_atomic=3, xcd_sync_updates=1 << 22), dict(hogwild_atomic=3, xcd_sync_updates=1 << 23),
-            dict(hogwild_atomic=3, im_drift_budget=300), dict(hogwild_atomic=3, im_drift_budget=3000), dict(hogwild_atomic=3, im_drift_budget=300, im_max_stale=16),
-            dict(hogwild_atomic=3, xcd_fresh=0)]
+    grid = [dict(hogwild_atomic=3, xcd_sync_updates=1 << 23, prefetch=0), dict(hogwild_atomic=3, prefetch=0)]
     for modes in grid:
         name = ",".join("%s=%s" % kv for kv in modes.items())
         P, Q, Qb = synth.init_factors(U, I, 128, seed=7)
