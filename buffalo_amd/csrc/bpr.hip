@@ -563,7 +563,7 @@ static int64_t gcd64(int64_t a, int64_t b) {
 // ------------------------------------------------------------------------------------------------
 class BprHandle : public SgdHandle {
  public:
-    BprHandle() : SgdHandle(0) {}
+    BprHandle() : SgdHandle(0) { hogwild_atomic_ = 3; }   // sgd default: the item-major walk (bpr_item_major.hpp)
     void parse_specific() override {
         num_neg_ = opt_.integer("num_negative_samples");
         BFH_REQUIRE(num_neg_ >= 1 && num_neg_ <= 255, "num_negative_samples must be in [1,255]");
@@ -649,6 +649,9 @@ class BprHandle : public SgdHandle {
 
     bool xcd_replicas() const { return hogwild_atomic_ == 2 && optimizer_ == "sgd" && !sequential_; }
     bool item_major() const { return hogwild_atomic_ == 3 && optimizer_ == "sgd" && !sequential_; }
+    // item-major default: no prefetch, rows are read where they are used (narrowest race window, least traffic,
+    // 7 waves per SIMD cover the latency); "prefetch" = 1 selects the two-triples-ahead slots
+    bool im_prefetch() const { return prefetch_ > 0; }
 
     // ---------------------------------------------------------------------------------------------
     // policy 3 (bpr_item_major.hpp)
@@ -669,30 +672,31 @@ class BprHandle : public SgdHandle {
     }
 
     template <int K>
-    void im_launch_k(const SgdParams& p, const BprConsts& c, const ImQueues& q, int64_t waves) {
+    void im_launch_k(const SgdParams& p, const BprConsts& c, const ImQueues& q, int64_t waves, bool drain) {
         const dim3 grid(static_cast<unsigned>((waves + 3) / 4)), block(256);
-        if (prefetch_) hipLaunchKernelGGL((bpr_item_major_kernel<K, true>), grid, block, 0, stream, p, c, q);
-        else hipLaunchKernelGGL((bpr_item_major_kernel<K, false>), grid, block, 0, stream, p, c, q);
+        if (drain) hipLaunchKernelGGL((bpr_item_major_kernel<K, false, true>), grid, block, 0, stream, p, c, q);
+        else if (im_prefetch()) hipLaunchKernelGGL((bpr_item_major_kernel<K, true, false>), grid, block, 0, stream, p, c, q);
+        else hipLaunchKernelGGL((bpr_item_major_kernel<K, false, false>), grid, block, 0, stream, p, c, q);
         BFH_HIP(hipGetLastError());
     }
-    void im_launch(const SgdParams& p, const BprConsts& c, const ImQueues& q, int64_t waves) {
+    void im_launch(const SgdParams& p, const BprConsts& c, const ImQueues& q, int64_t waves, bool drain) {
         const int KV = (vdim_ + 255) / 256;
-        if (KV <= 1) im_launch_k<4>(p, c, q, waves);
-        else if (KV <= 2) im_launch_k<8>(p, c, q, waves);
-        else im_launch_k<16>(p, c, q, waves);
+        if (KV <= 1) im_launch_k<4>(p, c, q, waves, drain);
+        else if (KV <= 2) im_launch_k<8>(p, c, q, waves, drain);
+        else im_launch_k<16>(p, c, q, waves, drain);
     }
     int64_t im_resident_waves() {
         if (waves_per_cu_ > 0) return static_cast<int64_t>(num_cus_) * waves_per_cu_;
         const int KV = (vdim_ + 255) / 256;
         const void* fn = nullptr;
-        if (prefetch_)
-            fn = KV <= 1 ? reinterpret_cast<const void*>(bpr_item_major_kernel<4, true>)
-                         : (KV <= 2 ? reinterpret_cast<const void*>(bpr_item_major_kernel<8, true>)
-                                    : reinterpret_cast<const void*>(bpr_item_major_kernel<16, true>));
+        if (im_prefetch())
+            fn = KV <= 1 ? reinterpret_cast<const void*>(bpr_item_major_kernel<4, true, false>)
+                         : (KV <= 2 ? reinterpret_cast<const void*>(bpr_item_major_kernel<8, true, false>)
+                                    : reinterpret_cast<const void*>(bpr_item_major_kernel<16, true, false>));
         else
-            fn = KV <= 1 ? reinterpret_cast<const void*>(bpr_item_major_kernel<4, false>)
-                         : (KV <= 2 ? reinterpret_cast<const void*>(bpr_item_major_kernel<8, false>)
-                                    : reinterpret_cast<const void*>(bpr_item_major_kernel<16, false>));
+            fn = KV <= 1 ? reinterpret_cast<const void*>(bpr_item_major_kernel<4, false, false>)
+                         : (KV <= 2 ? reinterpret_cast<const void*>(bpr_item_major_kernel<8, false, false>)
+                                    : reinterpret_cast<const void*>(bpr_item_major_kernel<16, false, false>));
         auto it = occupancy_.find(fn);
         if (it == occupancy_.end()) {
             int blocks = 0;
@@ -707,27 +711,29 @@ class BprHandle : public SgdHandle {
         im_probe();
         const int64_t n = p.chunk_nnz;
         BFH_REQUIRE(n < (int64_t(1) << 31), "hogwild_atomic=3: chunk of 2^31 or more interactions");
-        BFH_REQUIRE(static_cast<int64_t>(im_nq_) * Q_rows_ < (int64_t(1) << 32), "hogwild_atomic=3: too many items for the 32-bit sort key");
+        const int64_t blocks = std::max(1, im_blocks_);
+        BFH_REQUIRE(static_cast<int64_t>(im_nq_) * blocks * Q_rows_ < (int64_t(1) << 32), "hogwild_atomic=3: too many items for the 32-bit sort key");
         const int nq = im_nq_;
         int slot = t_aux_.begin(stream);
         // ---- entries grouped by (owner queue of the user, item); cached for a resident matrix ----
-        const bool cached = resident_ && im_gen_ == csr_generation_ && im_start_ == start_x && im_next_ == next_x && im_n_ == n;
+        const bool cached = resident_ && im_gen_ == csr_generation_ && im_start_ == start_x && im_next_ == next_x && im_n_ == n && im_built_blocks_ == blocks;
         if (!cached) {
             im_key_a_.resize(static_cast<size_t>(n)); im_key_b_.resize(static_cast<size_t>(n));
             im_pos_a_.resize(static_cast<size_t>(n)); im_pos_b_.resize(static_cast<size_t>(n));
             im_qbeg_dev_.resize(kImMaxQueues + 1);
             hipLaunchKernelGGL(im_keys_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, stream, p.rows, p.keys, n, nq,
-                               static_cast<uint32_t>(Q_rows_), im_key_a_.get(), im_pos_a_.get());
+                               static_cast<uint32_t>(blocks), static_cast<uint32_t>(Q_rows_), im_key_a_.get(), im_pos_a_.get());
             BFH_HIP(hipGetLastError());
             int bits = 1;
-            while ((int64_t(1) << bits) < static_cast<int64_t>(nq) * Q_rows_) ++bits;
+            while ((int64_t(1) << bits) < static_cast<int64_t>(nq) * blocks * Q_rows_) ++bits;
             device_sort_pairs_u32(im_key_a_.get(), im_key_b_.get(), im_pos_a_.get(), im_pos_b_.get(), n, bits, im_tmp_, stream);
-            hipLaunchKernelGGL(im_bounds_kernel, dim3(1), dim3(64), 0, stream, im_key_b_.get(), n, nq, static_cast<uint32_t>(Q_rows_), im_qbeg_dev_.get());
+            hipLaunchKernelGGL(im_bounds_kernel, dim3(1), dim3(64), 0, stream, im_key_b_.get(), n, nq, static_cast<uint32_t>(blocks * Q_rows_),
+                               im_qbeg_dev_.get());
             BFH_HIP(hipGetLastError());
             BFH_HIP(hipMemcpyAsync(im_qbeg_, im_qbeg_dev_.get(), (nq + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
             sync_stream();
             im_gen_ = resident_ ? csr_generation_ : -1;
-            im_start_ = start_x; im_next_ = next_x; im_n_ = n;
+            im_start_ = start_x; im_next_ = next_x; im_n_ = n; im_built_blocks_ = blocks;
         }
         // ---- per-row policy flags ----
         const int64_t waves = im_resident_waves();
@@ -754,10 +760,11 @@ class BprHandle : public SgdHandle {
         const double queue_waves = static_cast<double>(waves) / nq;
         // rows a queue's waves hold between the load and the store of one update: the current and the prefetched
         // triple's, or -- when the row is re-read right before the store -- one L2 round trip out of a triple's time
-        const double inflight = (!prefetch_ ? 0.25 : (c.fresh ? 0.5 : 2.0)) * queue_waves;
+        const double inflight = (!im_prefetch() ? 0.25 : (c.fresh ? 0.5 : 2.0)) * queue_waves;
         const double tau = xcd_hot_tau_ * 1e-3;
         // the staleness budgets are stated for lr = 0.05 and scale with 1 / lr: what matters is how far a row moves
-        const int64_t segments = std::max<int64_t>(1, (c.total + xcd_sync_updates_ / 2) / xcd_sync_updates_);
+        const int64_t sync_updates = xcd_sync_updates_ > 0 ? xcd_sync_updates_ : int64_t(1) << 23;
+        const int64_t segments = std::max<int64_t>(1, (c.total + sync_updates / 2) / sync_updates);
         const double lr_scale = c.lr > 0.f ? 0.05 / static_cast<double>(c.lr) : 1e9;
         const double max_stale = std::min(1e9, static_cast<double>(im_max_stale_) * lr_scale);
         // positive steps of a row between two merges, in units of lr: counts (of `cnt_triples` triples) -> this call's share
@@ -810,13 +817,11 @@ class BprHandle : public SgdHandle {
             q.tickets = im_tickets_.get() + sgm * kImMaxQueues;
             const int64_t grid_waves = std::max<int64_t>(4, std::min(waves, seg_slices));
             slot = t_main_.begin(stream);
-            q.drain = 0;
-            if (!im_drain_only_) im_launch(p, c, q, grid_waves);
-            q.drain = 1;
-            im_launch(p, c, q, grid_waves);
+            if (!im_drain_only_) im_launch(p, c, q, grid_waves, false);
             t_main_.end(slot, stream);
             stats.launches += 1;
             slot = t_aux_.begin(stream);
+            im_launch(p, c, q, grid_waves, true);
             xcd_merge(sgm + 1 < segments, c.hot, true);
             t_aux_.end(slot, stream);
             stats.merges += 1;
@@ -916,7 +921,8 @@ class BprHandle : public SgdHandle {
             c.rep_bstride = rep_bstride();
             // a segment is a whole number of work items per resident wave: it ends when its slowest wave does
             const int64_t waves = resident_waves(pick<INJECT>(c));
-            seg_work = std::max<int64_t>(1, (xcd_sync_updates_ / c.chunk + waves / 2) / waves) * waves;
+            const int64_t sync_updates = xcd_sync_updates_ > 0 ? xcd_sync_updates_ : int64_t(1) << 21;
+            seg_work = std::max<int64_t>(1, (sync_updates / c.chunk + waves / 2) / waves) * waves;
             const int slot = t_aux_.begin(stream);
             c.hot = xcd_hot_rows<INJECT>(p, c, std::min(seg_work, n_work));
             xcd_broadcast(false);
@@ -1036,7 +1042,7 @@ class BprHandle : public SgdHandle {
     DevBuf<uint8_t> im_flush_, im_hot_user_;
     DevBuf<int> im_tickets_;
     int64_t im_qbeg_[kImMaxQueues + 1] = {0};
-    int64_t im_gen_ = -1, im_n_ = -1, im_expect_done_ = -1;
+    int64_t im_gen_ = -1, im_n_ = -1, im_expect_done_ = -1, im_built_blocks_ = -1;
     int im_start_ = -1, im_next_ = -1;
     DevBuf<int32_t> inj_;
 };

@@ -39,7 +39,6 @@ struct ImQueues {
     const uint32_t* ent_key;   // [n] queue * Q_rows + item, sorted
     const int32_t* ent_pos;    // [n] chunk-local nnz position of the entry
     int nq;                    // number of queues (= XCDs seen by the probe)
-    int drain;                 // 1: any wave takes any ticket, every update is an atomic on the chip-wide copy
     int xcd_queue[16];         // HW_REG_XCC_ID -> queue (-1: not seen by the probe)
     int64_t q_beg[kImMaxQueues];      // first entry of a queue
     int64_t q_triples[kImMaxQueues];  // (entries of the queue) * num_neg
@@ -62,19 +61,21 @@ __global__ void xcd_probe_kernel(int* seen) {
     if (threadIdx.x == 0) atomicOr(seen + xcc_id_raw(), 1);
 }
 
-// sort key of every entry: (owner queue of the user) * Q_rows + item
+// sort key of every entry: ((owner queue of the user) * blocks + block) * Q_rows + item.  `blocks` > 1 cuts an
+// item's entries inside a queue into that many runs (by a hash of the nnz position), visited at different times.
 __global__ __launch_bounds__(256) void im_keys_kernel(const int32_t* __restrict__ rows, const int32_t* __restrict__ keys, int64_t n, int nq,
-                                                      uint32_t q_rows, uint32_t* __restrict__ kout, int32_t* __restrict__ vout) {
+                                                      uint32_t blocks, uint32_t q_rows, uint32_t* __restrict__ kout, int32_t* __restrict__ vout) {
     const int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
     if (t >= n) return;
-    kout[t] = static_cast<uint32_t>(rows[t] % nq) * q_rows + static_cast<uint32_t>(keys[t]);
+    const uint32_t blk = blocks > 1 ? ((static_cast<uint32_t>(t) * 2654435761u) >> 16) % blocks : 0u;
+    kout[t] = (static_cast<uint32_t>(rows[t] % nq) * blocks + blk) * q_rows + static_cast<uint32_t>(keys[t]);
     vout[t] = static_cast<int32_t>(t);
 }
 
-__global__ void im_bounds_kernel(const uint32_t* __restrict__ sorted, int64_t n, int nq, uint32_t q_rows, int64_t* __restrict__ q_beg) {
+__global__ void im_bounds_kernel(const uint32_t* __restrict__ sorted, int64_t n, int nq, uint32_t queue_span, int64_t* __restrict__ q_beg) {
     const int x = threadIdx.x;
     if (x > nq) return;
-    q_beg[x] = x == nq ? n : lower_bound_dev<uint32_t>(sorted, n, static_cast<uint32_t>(x) * q_rows);
+    q_beg[x] = x == nq ? n : lower_bound_dev<uint32_t>(sorted, n, static_cast<uint32_t>(x) * queue_span);
 }
 
 // per-row policy flags.  `inflight` = item (or user) rows a queue's waves hold between load and store.
@@ -134,12 +135,13 @@ __device__ __forceinline__ void row_atomic_add_full_lines(const Row<K>& r, float
     }
 }
 
-template <int K, bool PIPE>
+// DRAIN: the clean-up launch (any wave takes any ticket that is left, every update an atomic on the chip-wide copies)
+template <int K, bool PIPE, bool DRAIN>
 __global__ __launch_bounds__(256, K <= 4 ? (PIPE ? 5 : 6) : 1) void bpr_item_major_kernel(SgdParams p, BprConsts c, ImQueues q) {
     const int lane = threadIdx.x & 63;
     const int vdim = p.vdim;
     const int my_queue = q.xcd_queue[xcc_id_raw()];
-    const bool drain = q.drain != 0;
+    constexpr bool drain = DRAIN;
     float* const Qrep = drain ? p.Q : c.rep_Q + static_cast<size_t>(my_queue < 0 ? 0 : my_queue) * c.rep_stride;
     float* const Qbrep = drain ? p.Qb : c.rep_Qb + static_cast<size_t>(my_queue < 0 ? 0 : my_queue) * c.rep_bstride;
     auto rload = [&](Row<K>& r, const float* base) { row_load<K, true, true>(r, base, lane, vdim); };
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(256, K <= 4 ? (PIPE ? 5 : 6) : 1) void bpr_item_maj
                 const int64_t t = t0 + lane;
                 const int64_t e = q.q_beg[qq] + t / c.num_neg;
                 const uint32_t slot = static_cast<uint32_t>(t % c.num_neg);
-                my_item = static_cast<int>(q.ent_key[e] - static_cast<uint32_t>(qq) * static_cast<uint32_t>(p.Q_rows));
+                my_item = static_cast<int>(q.ent_key[e] % static_cast<uint32_t>(p.Q_rows));
                 const int64_t pos_idx = q.ent_pos[e];
                 my_u = p.rows[pos_idx];
                 const int64_t ubeg = (my_u == 0 ? 0 : p.indptr[my_u - 1]) - p.shift;

@@ -72,13 +72,14 @@ class SgdHandle : public HandleBase {
     int num_shards_ = 1;
 
     // knobs
-    int sequential_ = 0, hogwild_atomic_ = 1, prefetch_ = 1, waves_per_cu_ = 0, chunk_ = 256;
+    int sequential_ = 0, hogwild_atomic_ = 1, prefetch_ = -1, waves_per_cu_ = 0, chunk_ = 256;  // prefetch -1: the kernel's default
     // policy 2 (BPRMF sgd): updates between two merges of the per-XCD item-factor replicas, and
     // whether the merge sums (0) or averages (1) the replicas' deltas
-    int64_t xcd_sync_updates_ = int64_t(1) << 21;
+    int64_t xcd_sync_updates_ = -1;   // default: 2^21 (policy 2), 2^23 (policy 3)
     int xcd_merge_mean_ = 0;
     int im_drain_only_ = 0;        // test hook: skip the owner-XCD launch, the atomic drain launch does everything
     int im_drift_budget_milli_ = 1000;  // policy 3: lr-weighted positive steps of a row per merge interval above which its negatives go chip-wide
+    int im_blocks_ = 1;            // policy 3: runs an item's entries are cut into inside a queue
     int im_max_stale_ = 64;        // policy 3: updates of one item row that may be in flight unseen by the other waves
     int xcd_fresh_ = -1, xcd_v4_ = 0;  // re-read before store; float4-per-lane rows (hot-row atomics then cost 4x the line operations)
     int xcd_hot_tau_ = 100;        // permille: tolerated collision probability of a replica row (0 = no hot rows)

@@ -46,12 +46,11 @@ def timing():
     csr = load_matrix("ml20m", 7)
     U, I, nnz = csr.num_users, csr.num_items, csr.nnz
     res = out.setdefault("timing", {})
-    S8 = dict(hogwild_atomic=3, xcd_sync_updates=1 << 23)
-    cfgs = [S8, dict(S8, prefetch=0), dict(S8, prefetch=0, waves_per_cu=24), dict(S8, prefetch=0, waves_per_cu=20), dict(S8, prefetch=0, waves_per_cu=32),
-            dict(S8, prefetch=0, xcd_hot_tau=0), dict(hogwild_atomic=3, prefetch=0), dict(S8, prefetch=0, chunk=128)]
+    cfgs = [dict(hogwild_atomic=1), dict(), dict(im_blocks=4), dict(im_blocks=8), dict(im_blocks=16), dict(prefetch=1), dict(xcd_hot_tau=0),
+            dict(im_drift_budget=0)]
     steps, warm = 6, 2
     for modes in cfgs:
-        name = ",".join("%s=%s" % kv for kv in modes.items())
+        name = ",".join("%s=%s" % kv for kv in modes.items()) or "default(hogwild_atomic=3)"
         P, Q, Qb = synth.init_factors(U, I, 128, seed=7)
         obj = make(bpr_options(steps + warm), modes, P, Q, Qb, csr)
         for _ in range(warm):
@@ -107,31 +106,58 @@ def planted():
 def ml20m():
     csr = load_matrix("ml20m", 7)
     U, I, nnz = csr.num_users, csr.num_items, csr.nnz
-    epochs, lr = 4, 0.05
+    epochs = 4
     rng = np.random.default_rng(0)
     eu = rng.integers(0, U, 4000).astype(np.int32)
     ep = np.array([csr.row(int(u))[0][0] for u in eu], dtype=np.int32)
     en = rng.integers(0, I, 4000).astype(np.int32)
-    res = out.setdefault("ml20m", {"epochs": epochs, "lr": lr, "cpu_reference": "profiles/r01_bpr_policy_quality_study.json"})
-    grid = [dict(hogwild_atomic=3, xcd_sync_updates=1 << 23, prefetch=0), dict(hogwild_atomic=3, prefetch=0)]
-    for modes in grid:
-        name = ",".join("%s=%s" % kv for kv in modes.items())
-        P, Q, Qb = synth.init_factors(U, I, 128, seed=7)
-        obj = make(bpr_options(epochs, lr=lr, min_lr=lr, compute_loss_on_training=True), modes, P, Q, Qb, csr)
-        tr, ev = [], [obj.compute_loss(eu, ep, en)]
-        for _ in range(epochs):
-            loss, n = obj.add_jobs(0, U, csr.indptr, None)
-            obj.update_parameters()
-            tr.append(loss / n)
-            ev.append(obj.compute_loss(eu, ep, en))
-        obj.synchronize(True)
-        cnt = np.bincount(csr.keys, minlength=I)
-        head = np.argsort(-cnt)[:200]
-        res[name] = {"train_loss": tr, "eval_loss": ev, "P_norm": float(np.linalg.norm(P)), "Q_norm": float(np.linalg.norm(Q)),
-                     "Q_head200_norm": float(np.linalg.norm(Q[head])), "Qb_norm": float(np.linalg.norm(Qb))}
-        print("ml20m", name, json.dumps(res[name]), flush=True)
-        del obj
-        save()
+    cnt = np.bincount(csr.keys, minlength=I)
+    head = np.argsort(-cnt)[:200]
+    for lr in (0.05, 0.002):
+        res = out.setdefault("ml20m_lr%g" % lr, {"epochs": epochs, "lr": lr})
+        for modes in (dict(hogwild_atomic=1), dict(), dict(im_blocks=4), dict(im_blocks=8), dict(im_blocks=16), dict(prefetch=1)):
+            name = ",".join("%s=%s" % kv for kv in modes.items()) or "default(hogwild_atomic=3)"
+            P, Q, Qb = synth.init_factors(U, I, 128, seed=7)
+            obj = make(bpr_options(epochs, lr=lr, min_lr=lr, compute_loss_on_training=True), modes, P, Q, Qb, csr)
+            tr, ev = [], [obj.compute_loss(eu, ep, en)]
+            for _ in range(epochs):
+                loss, n = obj.add_jobs(0, U, csr.indptr, None)
+                obj.update_parameters()
+                tr.append(loss / n)
+                ev.append(obj.compute_loss(eu, ep, en))
+            obj.synchronize(True)
+            res[name] = {"train_loss": tr, "eval_loss": ev, "P_norm": float(np.linalg.norm(P)), "Q_norm": float(np.linalg.norm(Q)),
+                         "Q_head200_norm": float(np.linalg.norm(Q[head])), "Qb_norm": float(np.linalg.norm(Qb))}
+            print("ml20m lr=%g" % lr, name, json.dumps(res[name]), flush=True)
+            del obj
+            save()
+        if os.environ.get("WITH_CPU", "0") == "1" and lr == 0.002:
+            from oracle import oracle as orc
+            orc.build()
+            P, Q, Qb = synth.init_factors(U, I, 128, seed=7)
+            o = orc.OracleBPRMF()
+            assert o.init(write_opt(bpr_options(epochs, lr=lr, min_lr=lr, accelerator=False, num_workers=64)))
+            o.initialize_model(P, Q, Qb, nnz)
+            o.set_cumulative_table(np.zeros(I, np.int64), I)
+            o.launch_workers()
+            ev = [o.compute_loss(eu, ep, en)]
+            for e in range(epochs):
+                o.add_jobs(0, U, csr.indptr, csr.keys)
+                prev = -1
+                while True:
+                    o.wait_until_done()
+                    cur = o.stats()["samples"]
+                    if cur == prev and cur >= (e + 1) * nnz:
+                        break
+                    prev = cur
+                    time.sleep(0.05)
+                o.update_parameters()
+                ev.append(o.compute_loss(eu, ep, en))
+            o.join()
+            res["cpu_oracle_64_threads"] = {"eval_loss": ev, "P_norm": float(np.linalg.norm(P)), "Q_norm": float(np.linalg.norm(Q)),
+                                            "Q_head200_norm": float(np.linalg.norm(Q[head])), "Qb_norm": float(np.linalg.norm(Qb))}
+            print("ml20m lr=%g cpu" % lr, json.dumps(res["cpu_oracle_64_threads"]), flush=True)
+            save()
 
 
 if __name__ == "__main__":
