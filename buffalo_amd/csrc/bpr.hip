@@ -794,6 +794,12 @@ class BprHandle : public SgdHandle {
         q.hot_user = im_hot_user_.get();
         q.flush_every = im_flush_.get();
         q.done = reinterpret_cast<unsigned long long*>(scratch_.get() + 1);
+        if (im_presample_) {
+            im_neg_.resize(static_cast<size_t>(c.total));
+            hipLaunchKernelGGL(bpr_presample_kernel, dim3(static_cast<unsigned>((c.total + 255) / 256)), dim3(256), 0, stream, p, c, im_neg_.get());
+            BFH_HIP(hipGetLastError());
+            q.neg_pre = im_neg_.get();
+        }
         BFH_HIP(hipMemsetAsync(scratch_.get() + 1, 0, sizeof(double), stream));
         for (int x = 0; x < nq; ++x) {
             q.q_beg[x] = im_qbeg_[x];
@@ -1041,6 +1047,7 @@ class BprHandle : public SgdHandle {
     DevBuf<int64_t> im_qbeg_dev_;
     DevBuf<uint8_t> im_flush_, im_hot_user_;
     DevBuf<int> im_tickets_;
+    DevBuf<int32_t> im_neg_;
     int64_t im_qbeg_[kImMaxQueues + 1] = {0};
     int64_t im_gen_ = -1, im_n_ = -1, im_expect_done_ = -1, im_built_blocks_ = -1;
     int im_start_ = -1, im_next_ = -1;

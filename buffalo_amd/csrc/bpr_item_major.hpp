@@ -49,6 +49,7 @@ struct ImQueues {
     unsigned long long* done;  // triples processed (checked by the host)
     const uint8_t* hot_user;   // [P_rows] 1: P[u] is updated with atomics
     const uint8_t* flush_every;  // [Q_rows] triples between two flushes of the register-resident item row (1..64)
+    const int32_t* neg_pre;    // [chunk nnz * num_neg] negatives drawn by bpr_presample_kernel, or null: draw in the walk
 };
 
 __device__ __forceinline__ int xcc_id_raw() {
@@ -116,6 +117,21 @@ __global__ void im_user_flags_kernel(const int64_t* __restrict__ indptr, int fir
 // float4-per-lane registers -> dword-per-lane order (element k*64 + lane), so that one atomic
 // instruction covers whole 128-B lines: the atomic units charge per line touched, and a strided
 // float4 row would touch every line of the row four times.
+// The negatives of a whole call, drawn in CSR order before the item-major walk: neighbouring threads share a
+// user, so the rejection test's binary search runs in cached key runs -- inside the item-major kernel every lane
+// of a slice has a different user and the same search costs ~6 GB of scattered sector reads per ML-20M epoch.
+// Same draw as bpr_update_kernel: a pure function of (seed, global nnz position, slot, epoch, attempt).
+__global__ __launch_bounds__(256) void bpr_presample_kernel(SgdParams p, BprConsts c, int32_t* __restrict__ neg_out) {
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (t >= c.total) return;
+    const int64_t pos_idx = t / c.num_neg;
+    const uint32_t slot = static_cast<uint32_t>(t % c.num_neg);
+    const int u = p.rows[pos_idx];
+    const int64_t ubeg = (u == 0 ? 0 : p.indptr[u - 1]) - p.shift;
+    const int64_t uend = p.indptr[u] - p.shift;
+    neg_out[t] = bpr_sample_negative(p, c, static_cast<uint64_t>(p.nnz_offset + p.shift + pos_idx), slot, ubeg, uend);
+}
+
 template <int K>
 __device__ __forceinline__ void row_atomic_add_full_lines(const Row<K>& r, float* __restrict__ base, int lane, int vdim) {
 #pragma unroll
@@ -204,9 +220,13 @@ __global__ __launch_bounds__(256, K <= 4 ? (PIPE ? 5 : 6) : 1) void bpr_item_maj
                 my_item = static_cast<int>(q.ent_key[e] % static_cast<uint32_t>(p.Q_rows));
                 const int64_t pos_idx = q.ent_pos[e];
                 my_u = p.rows[pos_idx];
-                const int64_t ubeg = (my_u == 0 ? 0 : p.indptr[my_u - 1]) - p.shift;
-                const int64_t uend = p.indptr[my_u] - p.shift;
-                my_neg = bpr_sample_negative(p, c, static_cast<uint64_t>(p.nnz_offset + p.shift + pos_idx), slot, ubeg, uend);
+                if (q.neg_pre) {
+                    my_neg = q.neg_pre[pos_idx * c.num_neg + slot];
+                } else {
+                    const int64_t ubeg = (my_u == 0 ? 0 : p.indptr[my_u - 1]) - p.shift;
+                    const int64_t uend = p.indptr[my_u] - p.shift;
+                    my_neg = bpr_sample_negative(p, c, static_cast<uint64_t>(p.nnz_offset + p.shift + pos_idx), slot, ubeg, uend);
+                }
                 my_pol = drain ? 3 : ((q.hot_user[my_u] ? 1 : 0) | (c.hot[my_neg] ? 2 : 0));
             }
             auto pu_ptr = [&](int u) -> float* { return p.P + static_cast<size_t>(u) * vdim; };

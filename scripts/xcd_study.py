@@ -46,8 +46,7 @@ def timing():
     csr = load_matrix("ml20m", 7)
     U, I, nnz = csr.num_users, csr.num_items, csr.nnz
     res = out.setdefault("timing", {})
-    cfgs = [dict(hogwild_atomic=1), dict(), dict(im_blocks=4), dict(im_blocks=8), dict(im_blocks=16), dict(prefetch=1), dict(xcd_hot_tau=0),
-            dict(im_drift_budget=0)]
+    cfgs = [dict(), dict(im_presample=0), dict(im_blocks=1), dict(im_blocks=4), dict(xcd_sync_updates=1 << 25)]
     steps, warm = 6, 2
     for modes in cfgs:
         name = ",".join("%s=%s" % kv for kv in modes.items()) or "default(hogwild_atomic=3)"

@@ -130,10 +130,11 @@ def test_triples_parallel_disjoint_rows(oracle):
 
 @pytest.mark.parametrize("d,kw,modes", [
     (128, {}, {}),
-    (40, {}, dict(xcd_fresh=0)),
+    (40, {}, dict(im_presample=0, im_blocks=1)),            # negatives drawn inside the walk, one run per item and queue
     (128, {}, dict(xcd_hot_tau=1)),                      # every user / negative row "hot": the atomic paths
     (64, {}, dict(im_drain_only=1)),                     # the any-XCD drain launch does all the work
-    (300, dict(num_negative_samples=2), dict(prefetch=0)),
+    (300, dict(num_negative_samples=2), dict(prefetch=1)),  # two-triples-ahead prefetch slots + re-read before store
+    (200, dict(num_negative_samples=3), dict(prefetch=1, xcd_fresh=0, im_presample=0)),
     (128, dict(num_negative_samples=2, use_bias=False), dict(im_max_stale=1)),
     (96, dict(update_j=False), dict(xcd_sync_updates=1024)),
     (32, dict(update_i=False), {}),

@@ -53,6 +53,7 @@ def test_rows_beyond_4gib_match_the_oracle(oracle):
     Pg, Qg = P.copy(), Q.copy()
     obj = CyBPR()
     assert obj.init(H.write_opt(opt))
+    obj.set_mode("hogwild_atomic", 1)      # user-major walk: a user's triples are applied in CSR order, like the oracle's
     obj.initialize_model(Pg, Qg, Qb, csr.nnz, True)
     obj.set_cumulative_table(np.zeros(I, np.int64), I)
     obj.set_resident_csr(csr.indptr, csr.keys)
@@ -72,6 +73,21 @@ def test_rows_beyond_4gib_match_the_oracle(oracle):
     o.add_jobs(0, TAIL, sub.indptr, sub.keys)
     o.update_parameters()
     assert H.relerr(Pg[u0:], Po) < 1e-5
+    del obj, Pg, Qg
+    # the default item-major walk applies a user's 8 steps in item order at different times: same rows, same
+    # addresses, a different (legal Hogwild) order -- the rows beyond the mark agree to the order of lr^2
+    Pg, Qg = P.copy(), Q.copy()
+    obj = CyBPR()
+    assert obj.init(H.write_opt(opt))
+    obj.initialize_model(Pg, Qg, Qb, csr.nnz, True)
+    obj.set_cumulative_table(np.zeros(I, np.int64), I)
+    obj.set_resident_csr(csr.indptr, csr.keys)
+    obj.add_jobs(0, U, csr.indptr, None)
+    obj.update_parameters()
+    assert obj.stats()["merges"] >= 1 and np.array_equal(Qg, Q)
+    moved = np.abs(Pg[::100003] - P[::100003]).max(axis=1)
+    assert np.all(moved > 0) and np.isfinite(Pg[-TAIL:]).all()
+    assert H.relerr(Pg[u0:], Po) < 5e-3, H.relerr(Pg[u0:], Po)
     del obj, Pg, Qg
 
     # ---------------- WARP, item side frozen: gradP / velocity rows beyond the mark ----------------
