@@ -1,0 +1,37 @@
+"""rocprofv3 --pmc passes of bench.py -> profiles/pmc_latest.json (per launch of the dominant BPR kernel).
+usage: python scripts/pmc_summary.py <dir with pmc_fetch/ pmc_write/ [pmc_tcc/]> <out.json>"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+root, out_path = sys.argv[1], sys.argv[2]
+per = collections.defaultdict(lambda: collections.defaultdict(list))
+meta = {}
+for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if "bpr_item_major_kernel" not in k and "bpr_update_kernel" not in k:
+            continue
+        per[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        meta[k] = {"vgpr": r.get("VGPR_Count"), "sgpr": r.get("SGPR_Count"), "grid": r.get("Grid_Size"), "wg": r.get("Workgroup_Size")}
+# the dominant kernel = the one with the largest total FETCH_SIZE (the drain instantiation finds nothing to do)
+dom = max(per, key=lambda k: sum(per[k].get("FETCH_SIZE", [0.0])))
+c = {n: sum(v) / len(v) for n, v in per[dom].items()}
+out = {
+    "command": "rocprofv3 --kernel-trace --pmc <COUNTER> --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline",
+    "kernel": dom, "launches_seen": {n: len(v) for n, v in per[dom].items()}, "counters_per_launch": c, **meta[dom],
+    "fetch_bytes_raw": c.get("FETCH_SIZE", 0.0) * 1024, "fetch_bytes_corrected_x2": c.get("FETCH_SIZE", 0.0) * 2048,
+    "write_bytes": c.get("WRITE_SIZE", 0.0) * 1024,
+    "hbm_bytes_per_launch": c.get("FETCH_SIZE", 0.0) * 2048 + c.get("WRITE_SIZE", 0.0) * 1024,
+    "notes": "FETCH_SIZE/WRITE_SIZE are in KiB; separate --pmc passes. FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B "
+             "requests at 64 B; calibrated there on 16 B/lane streams, which is what this kernel's float4 row loads are). Memory-side counters "
+             "include Infinity-Cache hits. Other kernels of the step (drain instantiation, replica broadcast / merge, pre-sampling) are listed "
+             "under 'others'.",
+    "others": {k[:90]: {n: sum(v) / len(v) for n, v in d.items()} for k, d in per.items() if k != dom},
+}
+if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
+    out["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+json.dump(out, open(out_path, "w"), indent=1)
+print(json.dumps({k: out[k] for k in ("kernel", "hbm_bytes_per_launch", "fetch_bytes_corrected_x2", "write_bytes")}))
