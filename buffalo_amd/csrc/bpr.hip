@@ -801,10 +801,11 @@ class BprHandle : public SgdHandle {
             q.neg_pre = im_neg_.get();
         }
         BFH_HIP(hipMemsetAsync(scratch_.get() + 1, 0, sizeof(double), stream));
+        q.slice_len = num_neg_ <= 64 ? (64 / num_neg_) * num_neg_ : 64;
         for (int x = 0; x < nq; ++x) {
             q.q_beg[x] = im_qbeg_[x];
             q.q_triples[x] = (im_qbeg_[x + 1] - im_qbeg_[x]) * num_neg_;
-            q.q_slices[x] = (q.q_triples[x] + 63) / 64;
+            q.q_slices[x] = (q.q_triples[x] + q.slice_len - 1) / q.slice_len;
             int64_t st = static_cast<int64_t>(static_cast<double>(q.q_slices[x]) * 0.6180339887498949) | 1;   // golden-ratio order
             while (q.q_slices[x] > 1 && gcd64(st, q.q_slices[x]) != 1) st += 2;
             q.q_stride[x] = q.q_slices[x] > 1 ? st % q.q_slices[x] : 1;

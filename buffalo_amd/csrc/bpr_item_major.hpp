@@ -42,7 +42,9 @@ struct ImQueues {
     int xcd_queue[16];         // HW_REG_XCC_ID -> queue (-1: not seen by the probe)
     int64_t q_beg[kImMaxQueues];      // first entry of a queue
     int64_t q_triples[kImMaxQueues];  // (entries of the queue) * num_neg
-    int64_t q_slices[kImMaxQueues];   // ceil(q_triples / 64)
+    int slice_len;                    // triples per slice: the largest multiple of num_neg <= 64, so that the slots of one
+                                      // entry (which share the user row) are never split between two waves
+    int64_t q_slices[kImMaxQueues];   // ceil(q_triples / slice_len)
     int64_t q_stride[kImMaxQueues];   // slice = (ticket * stride) % q_slices, gcd(stride, q_slices) == 1
     int64_t t_beg[kImMaxQueues], t_end[kImMaxQueues];   // ticket range of this launch
     int* tickets;              // [nq] tickets handed out so far in this launch's range
@@ -209,8 +211,8 @@ __global__ __launch_bounds__(256, K <= 4 ? (PIPE ? 5 : 6) : 1) void bpr_item_maj
             if (tk >= n_tickets) break;
             const int64_t slice = static_cast<int64_t>((static_cast<unsigned long long>(q.t_beg[qq] + tk) * static_cast<unsigned long long>(q.q_stride[qq])) %
                                                        static_cast<unsigned long long>(q.q_slices[qq]));
-            const int64_t t0 = slice * 64;
-            const int n_here = static_cast<int>((q.q_triples[qq] - t0) < 64 ? (q.q_triples[qq] - t0) : 64);
+            const int64_t t0 = slice * q.slice_len;
+            const int n_here = static_cast<int>((q.q_triples[qq] - t0) < q.slice_len ? (q.q_triples[qq] - t0) : q.slice_len);
             // ---------------- lane-parallel: entry -> (item, user), sample the negative ----------------
             int my_u = -1, my_item = -1, my_neg = -1, my_pol = 0;   // bit0: P[u] atomic, bit1: Q[neg] atomic on the chip-wide row
             if (lane < n_here) {

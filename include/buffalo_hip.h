@@ -149,13 +149,28 @@ int bfh_als_set_resident_csr(void* h, int axis, const int64_t* indptr, const int
 /* With resident CSR the per-call write-back of updated rows (als.cu:403) can be deferred. */
 int bfh_als_synchronize(void* h, int device_to_host);
 
-/* Named integer knobs.  Common: "sequential" (1 = one wave walks the chunk in CSR order: the
- * deterministic parity mode), "hogwild_atomic" (1 = fp32 atomic adds on shared item rows [default], 0 = racy
- * device-coherent write-through stores like CPU Hogwild), "prefetch" (software pipelining depth 0/1), "waves_per_cu",
- * "chunk" (nnz positions per wave work item), "xcd_sync_updates" / "xcd_merge_mean" (BPRMF "hogwild_atomic" = 2: every XCD
- * trains a private replica of the item factors with plain stores through its own L2; the replicas are reconciled every
- * xcd_sync_updates updates by Q <- S + sum_x (Q_x - S), or the mean of the deltas), "als_writeback" (0 = defer), "timing" (1 = record
- * HIP events around every launch).  Unknown names fail with BFH_ERR_INVALID. */
+/* Named integer knobs.  Unknown names fail with BFH_ERR_INVALID.
+ *   "sequential"      1 = one wave walks the chunk in CSR order: the deterministic parity mode.
+ *   "hogwild_atomic"  how the SGD (Hogwild) kernels keep the shared factor rows coherent across the 8 XCDs:
+ *                       3  BPRMF sgd default: item-major walk (csrc/bpr_item_major.hpp) -- users owned by XCDs (plain
+ *                          stores through the owner's L2), the positive item row in registers with bounded-staleness
+ *                          atomic flushes, negatives in per-XCD replicas merged by the delta rule;
+ *                       1  fp32 atomic adds on the shared item rows, user-major walk (WARP; BPRMF adam/adagrad
+ *                          accumulation always uses this);
+ *                       2  BPRMF: user-major walk on per-XCD replicas of the item factors, popular rows on atomics;
+ *                       0  racy device-coherent write-through stores (CPU Hogwild literally; loses colliding updates).
+ *   "xcd_sync_updates" updates between two merges of the per-XCD replicas (default 2^23 for 3, 2^21 for 2);
+ *   "xcd_merge_mean"   1 = average instead of sum the replicas' deltas;  "xcd_hot_tau" (permille) tolerated collision
+ *                      probability of a plainly stored row, above it the row is updated with atomics;
+ *   "im_max_stale"     (3) updates of one item row in flight unseen by the other waves, stated at lr 0.05 (scales 1/lr);
+ *   "im_drift_budget"  (3, permille) lr-weighted positive steps of a row per merge interval above which its negative
+ *                      updates also go to the chip-wide copy;  "im_blocks" runs an item's entries are cut into per queue;
+ *   "im_presample"     (3) 1 = draw the call's negatives in CSR order before the walk;  "xcd_fresh" re-read a row right
+ *                      before storing it (prefetching variants);  "im_drain_only" test hook;
+ *   "prefetch"         software prefetch of the per-triple rows (user-major: 0/1, default 1; item-major: default 0 = rows
+ *                      are read where they are used, 1 = two triples ahead);
+ *   "waves_per_cu", "chunk" (nnz positions per wave work item), "als_writeback" (0 = defer), "timing" (1 = record HIP
+ *   events around every launch), "epoch". */
 int bfh_bpr_set_mode(void* h, const char* name, int64_t value);
 int bfh_warp_set_mode(void* h, const char* name, int64_t value);
 int bfh_als_set_mode(void* h, const char* name, int64_t value);
