@@ -138,6 +138,7 @@ def test_triples_parallel_disjoint_rows(oracle):
     (128, dict(num_negative_samples=2, use_bias=False), dict(im_max_stale=1)),
     (96, dict(update_j=False), dict(xcd_sync_updates=1024)),
     (32, dict(update_i=False), {}),
+    (64, {}, dict(n_chunks=3)),                          # the reference's call pattern: keys sent chunk by chunk, nothing resident
 ])
 def test_item_major_conflict_free(oracle, d, kw, modes):
     """hogwild_atomic=3 (item-major walk, users owned by XCDs, Q[i] in registers, Q[j] in per-XCD replicas):
@@ -159,7 +160,9 @@ def test_item_major_conflict_free(oracle, d, kw, modes):
     tr = o.get_trace()
     nn = opt["num_negative_samples"]
     assert len(tr) == U * nn
-    obj = H.run_hip_sgd(CyBPR, opt, csr, P, Q, Qb, epochs=1, modes=dict(hogwild_atomic=3, **modes), resident=True)
+    modes = dict(modes)
+    n_chunks = modes.pop("n_chunks", 1)
+    obj = H.run_hip_sgd(CyBPR, opt, csr, P, Q, Qb, epochs=1, n_chunks=n_chunks, modes=dict(hogwild_atomic=3, **modes), resident=n_chunks == 1)
     st = obj.stats()
     assert st["samples"] == U * nn and st["merges"] >= 1
     # rows touched by exactly one entry
