@@ -446,7 +446,7 @@ void SgdHandle::set_mode(const std::string& name, int64_t v) {
     else if (name == "xcd_merge_mean") xcd_merge_mean_ = v != 0;
     else if (name == "xcd_fresh") xcd_fresh_ = v != 0 ? 1 : 0;
     else if (name == "im_drift_budget") { BFH_REQUIRE(v >= 0, "im_drift_budget is a permille value >= 0"); im_drift_budget_milli_ = static_cast<int>(v); }
-    else if (name == "im_blocks") { BFH_REQUIRE(v >= 1 && v <= 64, "im_blocks must be in [1,64]"); im_blocks_ = static_cast<int>(v); }
+    else if (name == "im_blocks") { BFH_REQUIRE(v >= 0 && v <= 64, "im_blocks must be in [0,64] (0 = choose from the learning rate)"); im_blocks_ = static_cast<int>(v); }
     else if (name == "im_presample") im_presample_ = v != 0;
     else if (name == "im_drain_only") im_drain_only_ = v != 0;
     else if (name == "im_max_stale") { BFH_REQUIRE(v >= 1, "im_max_stale must be positive"); im_max_stale_ = static_cast<int>(v); }

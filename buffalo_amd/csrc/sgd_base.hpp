@@ -80,7 +80,7 @@ class SgdHandle : public HandleBase {
     int im_drain_only_ = 0;        // test hook: skip the owner-XCD launch, the atomic drain launch does everything
     int im_drift_budget_milli_ = 1000;  // policy 3: lr-weighted positive steps of a row per merge interval above which its negatives go chip-wide
     int im_presample_ = 1;         // policy 3: draw the call's negatives in CSR order before the walk
-    int im_blocks_ = 8;            // policy 3: runs an item's entries are cut into inside a queue
+    int im_blocks_ = 0;            // policy 3: runs an item's entries are cut into inside a queue (0 = from the learning rate)
     int im_max_stale_ = 64;        // policy 3: updates of one item row that may be in flight unseen by the other waves
     int xcd_fresh_ = -1, xcd_v4_ = 0;  // re-read before store; float4-per-lane rows (hot-row atomics then cost 4x the line operations)
     int xcd_hot_tau_ = 100;        // permille: tolerated collision probability of a replica row (0 = no hot rows)

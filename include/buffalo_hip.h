@@ -164,7 +164,7 @@ int bfh_als_synchronize(void* h, int device_to_host);
  *                      probability of a plainly stored row, above it the row is updated with atomics;
  *   "im_max_stale"     (3) updates of one item row in flight unseen by the other waves, stated at lr 0.05 (scales 1/lr);
  *   "im_drift_budget"  (3, permille) lr-weighted positive steps of a row per merge interval above which its negative
- *                      updates also go to the chip-wide copy;  "im_blocks" runs an item's entries are cut into per queue;
+ *                      updates also go to the chip-wide copy;  "im_blocks" runs an item's entries are cut into per queue (0 = ceil(160 lr));
  *   "im_presample"     (3) 1 = draw the call's negatives in CSR order before the walk;  "xcd_fresh" re-read a row right
  *                      before storing it (prefetching variants);  "im_drain_only" test hook;
  *   "prefetch"         software prefetch of the per-triple rows (user-major: 0/1, default 1; item-major: default 0 = rows

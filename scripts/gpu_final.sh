@@ -15,6 +15,7 @@ python scripts/pmc_summary.py $O $O/pmc_latest.json
 for f in $(find $O/prof_bpr -name "*kernel_stats.csv"); do cut -c1-200 $f | head -8; done
 find $O -name "*kernel_trace.csv" -size +4M -delete
 timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log; tail -2 $O/smoke.log
+timeout 200 python scripts/bench_extra.py bpr_pcie bpr_adagrad > $O/bench_extra_bpr.log 2>&1; grep -E "^bpr" $O/bench_extra_bpr.log | cut -c1-300
 if [ -n "$FULL_TESTS" ]; then
   timeout 900 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -4 $O/pytest.log
 fi
