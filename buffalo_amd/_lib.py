@@ -63,6 +63,7 @@ SIGNATURES = {
     "bfh_last_error": (C.c_char_p, [_vp]),
     "bfh_device_count": (_i32, []),
     "bfh_bpr_update_triples": (_i32, [_vp, _i64, _pi32, _pi32, _pi32, _f64]),
+    "bfh_bpr_item_major_plan": (_i32, [_i32, _pi64, _i32, _i64, C.POINTER(C.c_int), _pi64, _pi64, _pi64]),
     "bfh_als_create": (_vp, []),
     "bfh_als_destroy": (None, [_vp]),
     "bfh_als_init": (_i32, [_vp, C.c_char_p]),

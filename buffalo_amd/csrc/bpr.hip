@@ -555,11 +555,6 @@ __global__ void xcd_hot_kernel(const int* __restrict__ cnt, const int64_t* __res
 
 namespace bfh {
 
-static int64_t gcd64(int64_t a, int64_t b) {
-    while (b) { const int64_t t = a % b; a = b; b = t; }
-    return a;
-}
-
 // ------------------------------------------------------------------------------------------------
 class BprHandle : public SgdHandle {
  public:
@@ -767,7 +762,10 @@ class BprHandle : public SgdHandle {
         const double tau = xcd_hot_tau_ * 1e-3;
         // the staleness budgets are stated for lr = 0.05 and scale with 1 / lr: what matters is how far a row moves
         const int64_t sync_updates = xcd_sync_updates_ > 0 ? xcd_sync_updates_ : int64_t(1) << 23;
-        const int64_t segments = std::max<int64_t>(1, (c.total + sync_updates / 2) / sync_updates);
+        int64_t q_entries[kImMaxQueues] = {0};
+        for (int x = 0; x < nq; ++x) q_entries[x] = im_qbeg_[x + 1] - im_qbeg_[x];
+        const ImPlan plan = im_make_plan(nq, q_entries, num_neg_, sync_updates);
+        const int64_t segments = plan.segments;
         const double lr_scale = c.lr > 0.f ? 0.05 / static_cast<double>(c.lr) : 1e9;
         const double max_stale = std::min(1e9, static_cast<double>(im_max_stale_) * lr_scale);
         // positive steps of a row between two merges, in units of lr: counts (of `cnt_triples` triples) -> this call's share
@@ -804,15 +802,12 @@ class BprHandle : public SgdHandle {
             q.neg_pre = im_neg_.get();
         }
         BFH_HIP(hipMemsetAsync(scratch_.get() + 1, 0, sizeof(double), stream));
-        q.slice_len = num_neg_ <= 64 ? (64 / num_neg_) * num_neg_ : 64;
+        q.slice_len = plan.slice_len;
         for (int x = 0; x < nq; ++x) {
             q.q_beg[x] = im_qbeg_[x];
-            q.q_triples[x] = (im_qbeg_[x + 1] - im_qbeg_[x]) * num_neg_;
-            q.q_slices[x] = (q.q_triples[x] + q.slice_len - 1) / q.slice_len;
-            int64_t st = static_cast<int64_t>(static_cast<double>(q.q_slices[x]) * 0.6180339887498949) | 1;   // golden-ratio order
-            while (q.q_slices[x] > 1 && gcd64(st, q.q_slices[x]) != 1) st += 2;
-            q.q_stride[x] = q.q_slices[x] > 1 ? st % q.q_slices[x] : 1;
-            if (q.q_stride[x] == 0) q.q_stride[x] = 1;
+            q.q_triples[x] = plan.q_triples[x];
+            q.q_slices[x] = plan.q_slices[x];
+            q.q_stride[x] = plan.q_stride[x];
         }
         im_tickets_.resize(static_cast<size_t>(segments) * kImMaxQueues);
         BFH_HIP(hipMemsetAsync(im_tickets_.get(), 0, im_tickets_.bytes(), stream));
@@ -820,8 +815,7 @@ class BprHandle : public SgdHandle {
         for (int64_t sgm = 0; sgm < segments; ++sgm) {
             int64_t seg_slices = 0;
             for (int x = 0; x < nq; ++x) {
-                q.t_beg[x] = q.q_slices[x] * sgm / segments;
-                q.t_end[x] = q.q_slices[x] * (sgm + 1) / segments;
+                im_segment_tickets(plan, x, sgm, &q.t_beg[x], &q.t_end[x]);
                 seg_slices += q.t_end[x] - q.t_beg[x];
             }
             q.tickets = im_tickets_.get() + sgm * kImMaxQueues;
@@ -1139,6 +1133,20 @@ int bfh_bpr_device_buffer(void* h, const char* name, void** dptr, size_t* bytes)
     return guarded(h, [&] { static_cast<BprHandle*>(h)->device_buffer(name ? name : "", dptr, bytes); return BFH_OK; });
 }
 void* bfh_bpr_stream(void* h) { return h ? static_cast<void*>(static_cast<BprHandle*>(h)->stream) : nullptr; }
+int bfh_bpr_item_major_plan(int num_queues, const int64_t* queue_entries, int num_negative_samples, int64_t sync_updates, int* slice_len,
+                            int64_t* segments, int64_t* queue_slices, int64_t* queue_stride) {
+    if (num_queues < 1 || num_queues > bfh::kImMaxQueues || !queue_entries || num_negative_samples < 1 || !slice_len || !segments ||
+        !queue_slices || !queue_stride)
+        return BFH_ERR_INVALID;
+    const bfh::ImPlan pl = bfh::im_make_plan(num_queues, queue_entries, num_negative_samples, sync_updates);
+    *slice_len = pl.slice_len;
+    *segments = pl.segments;
+    for (int x = 0; x < num_queues; ++x) {
+        queue_slices[x] = pl.q_slices[x];
+        queue_stride[x] = pl.q_stride[x];
+    }
+    return BFH_OK;
+}
 int bfh_bpr_get_stats(void* h, bfh_stats* out) {
     return guarded(h, [&] { *out = static_cast<BprHandle*>(h)->stats; return BFH_OK; });
 }

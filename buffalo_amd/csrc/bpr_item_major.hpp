@@ -54,6 +54,49 @@ struct ImQueues {
     const int32_t* neg_pre;    // [chunk nnz * num_neg] negatives drawn by bpr_presample_kernel, or null: draw in the walk
 };
 
+// ------------------------------------------------------------------------------------------------
+// The slice schedule (host side; also exported as bfh_bpr_item_major_plan so that it can be checked
+// without a GPU): slice length, merge segments, and per queue the number of slices and the stride of
+// the visiting order.  Ticket t of queue x works on slice (t * stride[x]) mod slices[x] -- a permutation
+// because gcd(stride, slices) == 1; segment s of S takes the tickets [slices*s/S, slices*(s+1)/S).
+// ------------------------------------------------------------------------------------------------
+struct ImPlan {
+    int nq = 0, slice_len = 64;
+    int64_t segments = 1;
+    int64_t q_triples[kImMaxQueues] = {0}, q_slices[kImMaxQueues] = {0}, q_stride[kImMaxQueues] = {0};
+};
+
+static inline int64_t im_gcd(int64_t a, int64_t b) {
+    while (b) { const int64_t t = a % b; a = b; b = t; }
+    return a;
+}
+
+static inline ImPlan im_make_plan(int nq, const int64_t* q_entries, int num_neg, int64_t sync_updates) {
+    ImPlan pl;
+    pl.nq = nq;
+    // the largest multiple of num_neg that fits a wave: the slots of one entry share the user row
+    pl.slice_len = num_neg <= 64 ? (64 / num_neg) * num_neg : 64;
+    int64_t total = 0;
+    for (int x = 0; x < nq; ++x) {
+        pl.q_triples[x] = q_entries[x] * num_neg;
+        total += pl.q_triples[x];
+        pl.q_slices[x] = (pl.q_triples[x] + pl.slice_len - 1) / pl.slice_len;
+        // golden-ratio order: consecutive tickets land ~0.618 of the queue apart, so the waves that run at the same
+        // time work on different items; the stride is bumped until it is coprime with the number of slices
+        int64_t st = static_cast<int64_t>(static_cast<double>(pl.q_slices[x]) * 0.6180339887498949) | 1;
+        while (pl.q_slices[x] > 1 && im_gcd(st, pl.q_slices[x]) != 1) st += 2;
+        pl.q_stride[x] = pl.q_slices[x] > 1 ? st % pl.q_slices[x] : 1;
+        if (pl.q_stride[x] == 0) pl.q_stride[x] = 1;
+    }
+    pl.segments = sync_updates > 0 ? (total + sync_updates / 2) / sync_updates : 1;
+    if (pl.segments < 1) pl.segments = 1;
+    return pl;
+}
+static inline void im_segment_tickets(const ImPlan& pl, int x, int64_t sgm, int64_t* t_beg, int64_t* t_end) {
+    *t_beg = pl.q_slices[x] * sgm / pl.segments;
+    *t_end = pl.q_slices[x] * (sgm + 1) / pl.segments;
+}
+
 __device__ __forceinline__ int xcc_id_raw() {
     unsigned x;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(x));

@@ -178,6 +178,13 @@ int bfh_als_set_mode(void* h, const char* name, int64_t value);
 /* Multi-GPU sharding (one process per GPU, users sharded above this ABI): global position of the
  * shard's first nnz (keeps the counter-based sampler identical to the 1-GPU run) and the number of
  * shards that advance the lr schedule together. */
+/* Host-only (no GPU needed): the slice schedule of the item-major sgd walk for `num_queues` (<= 8) queues holding
+ * queue_entries[x] interactions each.  slice_len = triples per wave work item (the largest multiple of
+ * num_negative_samples <= 64), segments = merge intervals of the call; ticket t of queue x works on slice
+ * (t * queue_stride[x]) mod queue_slices[x], segment s takes the tickets [slices*s/segments, slices*(s+1)/segments).
+ * What CBPRMF's job queue (algo.hpp:28-69) is to the CPU path; exported so that the schedule can be checked on its own. */
+int bfh_bpr_item_major_plan(int num_queues, const int64_t* queue_entries, int num_negative_samples, int64_t sync_updates, int* slice_len,
+                            int64_t* segments, int64_t* queue_slices, int64_t* queue_stride);
 int bfh_bpr_set_shard(void* h, int64_t nnz_offset, int num_shards);
 int bfh_warp_set_shard(void* h, int64_t nnz_offset, int num_shards);
 
