@@ -15,7 +15,12 @@ from buffalo_amd.backend import CyBPR  # noqa: E402
 modes = dict(kv.split("=") for kv in sys.argv[1:])
 epochs = int(modes.pop("epochs", 4))
 lr = float(modes.pop("lr", 0.002))
+shards = int(modes.pop("shards", 1))       # run on the first of `shards` nnz-balanced user shards (what one rank of N sees)
 csr = load_matrix("ml20m", 7)
+if shards > 1:
+    from buffalo_amd.dist import shard_csr
+    u0, u1, ip, keys, _ = shard_csr(csr.indptr, csr.keys, 0, shards)
+    csr = synth.CSR(u1 - u0, csr.num_items, ip, keys, np.ones(keys.shape[0], np.float32))
 U, I, nnz = csr.num_users, csr.num_items, csr.nnz
 P, Q, Qb = synth.init_factors(U, I, 128, seed=7)
 obj = CyBPR()
