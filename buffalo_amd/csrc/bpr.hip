@@ -668,7 +668,8 @@ class BprHandle : public SgdHandle {
 
     template <int K>
     void im_launch_k(const SgdParams& p, const BprConsts& c, const ImQueues& q, int64_t waves, bool drain) {
-        const dim3 grid(static_cast<unsigned>((waves + 3) / 4)), block(256);
+        // "im_single_wave" (test hook): one wave drains every queue in ticket order -- a deterministic sequential run
+        const dim3 grid(im_single_wave_ ? 1u : static_cast<unsigned>((waves + 3) / 4)), block(im_single_wave_ ? 64 : 256);
         if (drain) hipLaunchKernelGGL((bpr_item_major_kernel<K, false, true>), grid, block, 0, stream, p, c, q);
         else if (im_prefetch()) hipLaunchKernelGGL((bpr_item_major_kernel<K, true, false>), grid, block, 0, stream, p, c, q);
         else hipLaunchKernelGGL((bpr_item_major_kernel<K, false, false>), grid, block, 0, stream, p, c, q);
@@ -711,10 +712,10 @@ class BprHandle : public SgdHandle {
         // one run, gone with 8), so the default follows the call's learning rate; "im_blocks" pins it
         const int64_t blocks = im_blocks_ > 0 ? im_blocks_ : std::min<int64_t>(16, std::max<int64_t>(1, static_cast<int64_t>(std::ceil(c.lr * 160.0))));
         BFH_REQUIRE(static_cast<int64_t>(im_nq_) * blocks * Q_rows_ < (int64_t(1) << 32), "hogwild_atomic=3: too many items for the 32-bit sort key");
-        const int nq = im_nq_;
+        const int nq = (im_single_wave_ && im_force_queues_ > 0) ? std::min(im_force_queues_, kImMaxQueues) : im_nq_;
         int slot = t_aux_.begin(stream);
         // ---- entries grouped by (owner queue of the user, item); cached for a resident matrix ----
-        const bool cached = resident_ && im_gen_ == csr_generation_ && im_start_ == start_x && im_next_ == next_x && im_n_ == n && im_built_blocks_ == blocks;
+        const bool cached = resident_ && im_gen_ == csr_generation_ && im_start_ == start_x && im_next_ == next_x && im_n_ == n && im_built_blocks_ == blocks && im_built_nq_ == nq;
         if (!cached) {
             im_key_a_.resize(static_cast<size_t>(n)); im_key_b_.resize(static_cast<size_t>(n));
             im_pos_a_.resize(static_cast<size_t>(n)); im_pos_b_.resize(static_cast<size_t>(n));
@@ -731,7 +732,7 @@ class BprHandle : public SgdHandle {
             BFH_HIP(hipMemcpyAsync(im_qbeg_, im_qbeg_dev_.get(), (nq + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
             sync_stream();
             im_gen_ = resident_ ? csr_generation_ : -1;
-            im_start_ = start_x; im_next_ = next_x; im_n_ = n; im_built_blocks_ = blocks;
+            im_start_ = start_x; im_next_ = next_x; im_n_ = n; im_built_blocks_ = blocks; im_built_nq_ = nq;
         }
         // ---- per-row policy flags ----
         const int64_t waves = im_resident_waves();
@@ -821,7 +822,7 @@ class BprHandle : public SgdHandle {
             q.tickets = im_tickets_.get() + sgm * kImMaxQueues;
             const int64_t grid_waves = std::max<int64_t>(4, std::min(waves, seg_slices));
             slot = t_main_.begin(stream);
-            if (!im_drain_only_) im_launch(p, c, q, grid_waves, false);
+            if (!im_drain_only_ && !im_single_wave_) im_launch(p, c, q, grid_waves, false);
             t_main_.end(slot, stream);
             stats.launches += 1;
             slot = t_aux_.begin(stream);
@@ -1048,6 +1049,7 @@ class BprHandle : public SgdHandle {
     DevBuf<int32_t> im_neg_;
     int64_t im_qbeg_[kImMaxQueues + 1] = {0};
     int64_t im_gen_ = -1, im_n_ = -1, im_expect_done_ = -1, im_built_blocks_ = -1;
+    int im_built_nq_ = -1;
     int im_start_ = -1, im_next_ = -1;
     DevBuf<int32_t> inj_;
 };

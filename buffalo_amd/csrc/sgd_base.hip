@@ -449,6 +449,8 @@ void SgdHandle::set_mode(const std::string& name, int64_t v) {
     else if (name == "im_blocks") { BFH_REQUIRE(v >= 0 && v <= 64, "im_blocks must be in [0,64] (0 = choose from the learning rate)"); im_blocks_ = static_cast<int>(v); }
     else if (name == "im_presample") im_presample_ = v != 0;
     else if (name == "im_drain_only") im_drain_only_ = v != 0;
+    else if (name == "im_single_wave") im_single_wave_ = v != 0;
+    else if (name == "im_force_queues") { BFH_REQUIRE(v >= 0 && v <= 8, "im_force_queues must be in [0,8]"); im_force_queues_ = static_cast<int>(v); }
     else if (name == "im_max_stale") { BFH_REQUIRE(v >= 1, "im_max_stale must be positive"); im_max_stale_ = static_cast<int>(v); }
     else if (name == "xcd_v4") xcd_v4_ = v != 0;
     else if (name == "xcd_hot_tau") { BFH_REQUIRE(v >= 0, "xcd_hot_tau is a permille value >= 0"); xcd_hot_tau_ = static_cast<int>(v); }

@@ -77,6 +77,7 @@ class SgdHandle : public HandleBase {
     // whether the merge sums (0) or averages (1) the replicas' deltas
     int64_t xcd_sync_updates_ = -1;   // default: 2^21 (policy 2), 2^23 (policy 3)
     int xcd_merge_mean_ = 0;
+    int im_single_wave_ = 0, im_force_queues_ = 0;   // test hooks: one wave drains all queues in order; number of queues for that run
     int im_drain_only_ = 0;        // test hook: skip the owner-XCD launch, the atomic drain launch does everything
     int im_drift_budget_milli_ = 1000;  // policy 3: lr-weighted positive steps of a row per merge interval above which its negatives go chip-wide
     int im_presample_ = 1;         // policy 3: draw the call's negatives in CSR order before the walk

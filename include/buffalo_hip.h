@@ -166,7 +166,7 @@ int bfh_als_synchronize(void* h, int device_to_host);
  *   "im_drift_budget"  (3, permille) lr-weighted positive steps of a row per merge interval above which its negative
  *                      updates also go to the chip-wide copy;  "im_blocks" runs an item's entries are cut into per queue (0 = ceil(160 lr));
  *   "im_presample"     (3) 1 = draw the call's negatives in CSR order before the walk;  "xcd_fresh" re-read a row right
- *                      before storing it (prefetching variants);  "im_drain_only" test hook;
+ *                      before storing it (prefetching variants);  "im_drain_only", "im_single_wave", "im_force_queues" test hooks;
  *   "prefetch"         software prefetch of the per-triple rows (user-major: 0/1, default 1; item-major: default 0 = rows
  *                      are read where they are used, 1 = two triples ahead);
  *   "waves_per_cu", "chunk" (nnz positions per wave work item), "als_writeback" (0 = defer), "timing" (1 = record HIP

@@ -187,6 +187,66 @@ def test_item_major_conflict_free(oracle, d, kw, modes):
     assert np.isfinite(P).all() and np.isfinite(Q).all() and np.all(P[:, d:] == 0) and np.all(Q[:, d:] == 0)
 
 
+def _item_major_order(csr, nq, blocks, nn):
+    """The order in which ONE wave draining every queue walks an epoch's triples (indices into the CSR-ordered
+    triple list pos * nn + slot): entries stable-sorted by ((user % nq) * blocks + block) * I + item, cut into
+    slices that bfh_bpr_item_major_plan hands out ticket by ticket (csrc/bpr_item_major.hpp)."""
+    from test_schedule_cpu import plan
+    n, I = csr.nnz, csr.num_items
+    t = np.arange(n, dtype=np.uint64)
+    blk = ((((t * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF)) >> np.uint64(16)) % np.uint64(blocks)).astype(np.int64)
+    key = ((csr.rows().astype(np.int64) % nq) * blocks + blk) * I + csr.keys.astype(np.int64)
+    perm = np.argsort(key, kind="stable")
+    queue = key[perm] // (blocks * I)
+    entries = [int((queue == x).sum()) for x in range(nq)]
+    slice_len, segments, slices, stride = plan(entries, nn, 1 << 40)
+    assert segments == 1
+    order = []
+    for x in range(nq):
+        trip = (perm[queue == x][:, None] * nn + np.arange(nn)[None, :]).reshape(-1)
+        for ticket in range(int(slices[x])):
+            sl = (ticket * int(stride[x])) % int(slices[x])
+            order.append(trip[sl * slice_len:(sl + 1) * slice_len])
+    return np.concatenate(order)
+
+
+@pytest.mark.parametrize("d,nn,blocks", [(48, 2, 3), (128, 1, 1), (200, 3, 8)])
+def test_item_major_single_wave_equals_sequential_replay(oracle, d, nn, blocks):
+    """Whole epochs of the item-major kernel, number for number: one wave draining all queues applies the epoch's
+    triples in a known order; replaying the oracle's triples (same counter sampler) in that order through the
+    sequential update path -- itself pinned on the oracle by test_reference_order_replay -- must give the same model.
+    Also the proof that a row re-read behind an atomic add of the same wave sees that add (the flush protocol)."""
+    from buffalo_amd.backend import CyBPR
+    csr = tiny_csr(U=300, I=200, density=0.08, seed=3)
+    vdim = _vdim(d)
+    opt = bpr_opt(d=d, lr=0.05, min_lr=0.05, num_iters=2, random_seed=5, num_negative_samples=nn)
+    P, Q, Qb = _factors(csr, d, vdim)
+    Pr, Qr, Qbr = P.copy(), Q.copy(), Qb.copy()
+    P0 = P.copy()
+    Po, Qo, Qbo = P[:, :d].copy(), Q[:, :d].copy(), Qb.copy()
+    o = H.run_oracle_sgd(oracle.OracleBPRMF, opt, csr, Po, Qo, Qbo, epochs=2, modes=DET, trace=True)
+    tr = o.get_trace()
+    n = csr.nnz * nn
+    assert len(tr) == 2 * n
+    order = _item_major_order(csr, 8, blocks, nn)
+    assert np.array_equal(np.sort(order), np.arange(n))
+    ref = CyBPR()
+    assert ref.init(H.write_opt(dict(opt, accelerator=True)))
+    ref.set_mode("sequential", 1)
+    ref.initialize_model(Pr, Qr, Qbr, csr.nnz, True)
+    for e in range(2):
+        te = tr[e * n:(e + 1) * n][order]
+        ref.update_triples(np.ascontiguousarray(te[:, 0]), np.ascontiguousarray(te[:, 1]), np.ascontiguousarray(te[:, 2]), 0.05)
+    ref.synchronize(True)
+    H.run_hip_sgd(CyBPR, opt, csr, P, Q, Qb, epochs=2, resident=True,
+                  modes=dict(hogwild_atomic=3, im_single_wave=1, im_force_queues=8, im_blocks=blocks, xcd_sync_updates=1 << 40))
+    assert not np.array_equal(Pr, P0)                      # the replay moved the model
+    for a, b in ((P, Pr), (Q, Qr), (Qb, Qbr)):
+        assert H.relerr(a, b) < 1e-6, H.relerr(a, b)
+    # and the order matters: the CSR-order result is a different model (so the comparison above is not vacuous)
+    assert H.relerr(P[:, :d], Po) > 1e-4
+
+
 def test_compute_loss_matches_oracle(oracle):
     from buffalo_amd.backend import CyBPR
     csr = tiny_csr(U=30, I=40, seed=2)
