@@ -795,6 +795,7 @@ class BprHandle : public SgdHandle {
         for (int i = 0; i < 16; ++i) q.xcd_queue[i] = im_xcd_queue_[i];
         q.hot_user = im_hot_user_.get();
         q.flush_every = im_flush_.get();
+        q.strict = im_single_wave_;
         q.done = reinterpret_cast<unsigned long long*>(scratch_.get() + 1);
         if (im_presample_) {
             im_neg_.resize(static_cast<size_t>(c.total));

@@ -52,6 +52,7 @@ struct ImQueues {
     const uint8_t* hot_user;   // [P_rows] 1: P[u] is updated with atomics
     const uint8_t* flush_every;  // [Q_rows] triples between two flushes of the register-resident item row (1..64)
     const int32_t* neg_pre;    // [chunk nnz * num_neg] negatives drawn by bpr_presample_kernel, or null: draw in the walk
+    int strict;                // test hook: wait for every memory operation of a triple before the next one starts
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -196,6 +197,49 @@ __device__ __forceinline__ void row_atomic_add_full_lines(const Row<K>& r, float
     }
 }
 
+// The same add with the pre-add values returned: `now` = the row right after this wave's add, in the caller's
+// float4-per-lane layout.  (A plain re-read issued behind a no-return atomic is NOT a substitute: measured on gfx950,
+// the load can be served before the atomic is performed at the memory side and then misses the wave's own add.)
+template <int K>
+__device__ __forceinline__ void row_atomic_add_full_lines_fetch(const Row<K>& r, float* __restrict__ base, int lane, int vdim, Row<K>& now) {
+    float nw[K];   // dword-per-lane order
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        nw[k] = 0.f;
+        if (k * 64 < vdim) {
+            const int src = ((k & 3) * 16 + (lane >> 2)) * 4;
+            const int kv = (k >> 2) * 4;
+            const int c0 = __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, r.v[kv + 0]));
+            const int c1 = __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, r.v[kv + 1]));
+            const int c2 = __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, r.v[kv + 2]));
+            const int c3 = __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, r.v[kv + 3]));
+            const int sel = lane & 3;
+            const float v = __builtin_bit_cast(float, sel == 0 ? c0 : (sel == 1 ? c1 : (sel == 2 ? c2 : c3)));
+            const int e = k * 64 + lane;
+            if (e < vdim) nw[k] = __hip_atomic_fetch_add(base + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + v;
+        }
+    }
+    // back to float4-per-lane: register kv*4+c of lane l holds element (kv*64 + l)*4 + c
+    //   = dword register kv*4 + (l >> 4), lane (l & 15)*4 + c
+#pragma unroll
+    for (int rr = 0; rr < K; ++rr) {
+        const int kv = rr >> 2, cc = rr & 3;
+        const int src = ((lane & 15) * 4 + cc) * 4;
+        const int ks = lane >> 4;
+        int got = 0;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int k = kv * 4 + s4;
+            if (k < K && k * 64 < vdim) {
+                const int g = __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, nw[k]));
+                if (ks == s4) got = g;
+            }
+        }
+        const int e = (kv * 64 + lane) * 4 + cc;
+        now.v[rr] = e < vdim ? __builtin_bit_cast(float, got) : 0.f;
+    }
+}
+
 // DRAIN: the clean-up launch (any wave takes any ticket that is left, every update an atomic on the chip-wide copies)
 template <int K, bool PIPE, bool DRAIN>
 __global__ __launch_bounds__(256, K <= 4 ? (PIPE ? 5 : 6) : 1) void bpr_item_major_kernel(SgdParams p, BprConsts c, ImQueues q) {
@@ -217,26 +261,33 @@ __global__ __launch_bounds__(256, K <= 4 ? (PIPE ? 5 : 6) : 1) void bpr_item_maj
     double loss = 0.0;
     unsigned long long processed = 0;
 
-    // push the accumulated step of the register-resident row to the chip-wide matrix.  `reload`: the row is
-    // read back behind the atomics (same wave, same addresses: the memory pipeline keeps them in order) without
-    // waiting for either -- the next triple runs on the local copy and folds the re-read row in when it arrives.
+    // push the accumulated step of the register-resident row to the chip-wide matrix.  `reload` (mid-run): the add
+    // returns what the row held, so `qi_re` = the row with every wave's steps up to and including this flush; nobody
+    // waits for it -- the next triple runs on the local copy and folds `qi_re` in when it has arrived.
     auto flush_item = [&](bool reload) {
         if (cur_i < 0) return;
         float* Qi = p.Q + static_cast<size_t>(cur_i) * vdim;
-        if (c.update_i) {
+        re_pending = false;
+        if (reload && c.update_i) {
+            row_atomic_add_full_lines_fetch<K>(dqi, Qi, lane, vdim, qi_re);
+            if (c.use_bias) {
+                float now = 0.f;
+                if (lane == 0) now = __hip_atomic_fetch_add(p.Qb + cur_i, dbi_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + dbi_acc;
+                bi_re = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, now)));
+            }
+            re_pending = true;
+        } else if (c.update_i) {
             row_atomic_add_full_lines<K>(dqi, Qi, lane, vdim);
             if (c.use_bias && lane == 0) atomic_add_f32(p.Qb + cur_i, dbi_acc);
+        } else if (reload) {   // frozen positives (update_i = false): nothing to push, just refresh the row
+            rload(qi_re, Qi);
+            if (c.use_bias) bi_re = coh_load(p.Qb + cur_i);
+            re_pending = true;
         }
 #pragma unroll
         for (int k = 0; k < K; ++k) dqi.v[k] = 0.f;
         dbi_acc = 0.f;
         since_flush = 0;
-        re_pending = false;
-        if (reload) {
-            rload(qi_re, Qi);
-            if (c.use_bias) bi_re = coh_load(p.Qb + cur_i);
-            re_pending = true;
-        }
     };
 
     for (int qq = 0; qq < q.nq; ++qq) {
@@ -395,6 +446,9 @@ __global__ __launch_bounds__(256, K <= 4 ? (PIPE ? 5 : 6) : 1) void bpr_item_maj
                         else *Bj = bj;
                     }
                 }
+                // test hook (one wave, deterministic order): every store / atomic of this triple is acknowledged before
+                // the next triple reads anything, so the run is sequential in the strict sense
+                if (q.strict) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 processed += 1;
                 since_flush += 1;
                 // a row re-read behind the previous flush has arrived by now: it carries the other waves' steps
