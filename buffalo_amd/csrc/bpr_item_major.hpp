@@ -198,8 +198,9 @@ __device__ __forceinline__ void row_atomic_add_full_lines(const Row<K>& r, float
 }
 
 // The same add with the pre-add values returned: `now` = the row right after this wave's add, in the caller's
-// float4-per-lane layout.  (A plain re-read issued behind a no-return atomic is NOT a substitute: measured on gfx950,
-// the load can be served before the atomic is performed at the memory side and then misses the wave's own add.)
+// float4-per-lane layout -- one instruction instead of an add and a re-read, and no reliance on the order in which
+// the memory side performs an atomic and a later load of other lanes (scripts/micro/atomic_then_load.hip shows the
+// same-lane case is ordered on gfx950; the row's elements change lanes between the two layouts).
 template <int K>
 __device__ __forceinline__ void row_atomic_add_full_lines_fetch(const Row<K>& r, float* __restrict__ base, int lane, int vdim, Row<K>& now) {
     float nw[K];   // dword-per-lane order
