@@ -1,4 +1,12 @@
-// BPRMF on gfx950: fused sampler + pairwise-loss update kernel, loss kernel, C ABI.
+// BPRMF on gfx950: update kernels, loss kernel, C ABI.
+//
+// Two walks over the same (u, i, j) triples (the sampler is a pure function of the triple's position, so both see
+// the same triples):
+//   * bpr_item_major_kernel (bpr_item_major.hpp): the default for optimizer = sgd ("hogwild_atomic" = 3) -- the
+//     positive item's row in registers, users owned by XCDs, negatives in per-XCD replicas;
+//   * bpr_update_kernel (below): user-major -- P[u] in registers.  The deterministic parity mode ("sequential"),
+//     adam / adagrad gradient accumulation, injected triples and the policies 0 / 1 / 2.
+// The rest of this comment describes the user-major kernel.
 //
 // Reference semantics: CBPRMF::worker (/root/reference/lib/algo_impl/bpr/bpr.cc:72-188) -- the CPU
 // path, as BASELINE.json's north_star asks -- behind CuBPR's object surface
@@ -26,7 +34,8 @@
 //     Measured on MI355X (scripts/micro/atomics.hip): uniform 512-B row atomics run at
 //     2.6 G rows/s and a single hot row at 24 ns per update, write-through rows at ~2.3 G rows/s;
 //     on a small catalogue write-through loses most colliding updates (NDCG 0.04 vs 0.27 on the
-//     400-item planted test), so atomics are the default.
+//     400-item planted test), so atomics are this walk's default.  Policy 2 runs it on per-XCD replicas of Q
+//     (plain stores through the XCD's own L2, merged by the delta rule) with the popular rows on atomics.
 #include "sgd_base.hpp"
 
 #include <algorithm>
