@@ -621,6 +621,48 @@ class BPR : public SGD {
             progress_queue_.push(progress_t{(int)job.samples.size(), processed_samples, total_samples, 0.0});
     }
 
+    // The SGD branch of the loop body above (bpr.cc:119-131, 157-171) applied to a GIVEN list of triples, one after
+    // the other: lets a test replay any schedule of an epoch (e.g. the item-major walk of the HIP backend) through
+    // the same arithmetic.  Sequential, single thread; `alpha` is the learning rate of every step.
+    void apply_triples(int64_t n, const int32_t* users, const int32_t* positives, const int32_t* negatives, float alpha) {
+        const bool use_bias = opt_.b("use_bias");
+        const bool update_i = opt_.b("update_i");
+        const bool update_j = opt_.b("update_j");
+        const float reg_u = (float)opt_.d("reg_u"), reg_i = (float)opt_.d("reg_i");
+        const float reg_j = (float)opt_.d("reg_j"), reg_b = (float)opt_.d("reg_b");
+        const int D = D_;
+        std::vector<float> item_deriv(D);
+        for (int64_t t = 0; t < n; ++t) {
+            const int u = users[t], pos = positives[t], neg = negatives[t];
+            float* Pu = &P_[(size_t)u * D];
+            float* Qp = &Q_[(size_t)pos * D];
+            float* Qn = &Q_[(size_t)neg * D];
+            float x_uij = 0.f;
+#pragma omp simd reduction(+ : x_uij)
+            for (int k = 0; k < D; ++k) x_uij += Pu[k] * (Qp[k] - Qn[k]);
+            if (use_bias) x_uij += (Qb_[pos] - Qb_[neg]);
+            float logit = 0.0;
+            if (MAX_EXP < x_uij) {
+                logit = 0.0;
+            } else if (x_uij < -MAX_EXP) {
+                logit = 1.0;
+            } else {
+                logit = exp_table_[(int)((x_uij + MAX_EXP) * (EXP_TABLE_SIZE / MAX_EXP / 2))];
+            }
+            if (update_i || update_j)
+                for (int k = 0; k < D; ++k) item_deriv[k] = logit * Pu[k];
+            if (update_i) {
+                for (int k = 0; k < D; ++k) Qp[k] += alpha * (item_deriv[k] - reg_i * Qp[k]);
+                if (use_bias) Qb_[pos] += alpha * (logit - reg_b * Qb_[pos]);
+            }
+            if (update_j) {
+                for (int k = 0; k < D; ++k) Qn[k] += alpha * (-item_deriv[k] - reg_j * Qn[k]);
+                if (use_bias) Qb_[neg] += alpha * (-logit - reg_b * Qb_[neg]);
+            }
+            for (int k = 0; k < D; ++k) Pu[k] += alpha * (logit * (Qp[k] - Qn[k]) - reg_u * Pu[k]);
+        }
+    }
+
     // bpr.cc:217-225
     double distance(size_t p, size_t q) {
         bool use_bias = opt_.b("use_bias");
@@ -1626,6 +1668,14 @@ void orc_sgd_add_jobs(void* hp, int s, int n, const int64_t* indptr, const int32
 void orc_sgd_update_parameters(void* hp) { ((Handle*)hp)->sgd->update_parameters(); }
 void orc_sgd_wait_until_done(void* hp) { ((Handle*)hp)->sgd->wait_until_done(); }
 double orc_sgd_join(void* hp) { return ((Handle*)hp)->sgd->join(); }
+// test hook: BPR's SGD step applied to an explicit triple list (kind 0 only)
+int orc_bpr_apply_triples(void* hp, int64_t n, const int32_t* u, const int32_t* p, const int32_t* q, double alpha) {
+    Handle* h = (Handle*)hp;
+    BPR* b = h->kind == 0 ? dynamic_cast<BPR*>(h->sgd) : nullptr;
+    if (!b) return 0;
+    b->apply_triples(n, u, p, q, (float)alpha);
+    return 1;
+}
 double orc_sgd_compute_loss(void* hp, int n, const int32_t* u, const int32_t* p, const int32_t* q) {
     Handle* h = (Handle*)hp;
     if (h->kind == 0) return static_cast<BPR*>(h->sgd)->compute_loss(n, u, p, q);

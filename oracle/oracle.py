@@ -64,6 +64,7 @@ def lib():
         "orc_sgd_wait_until_done": (None, [vp]),
         "orc_sgd_join": (f64, [vp]),
         "orc_sgd_compute_loss": (f64, [vp, i32, pi32, pi32, pi32]),
+        "orc_bpr_apply_triples": (i32, [vp, i64, pi32, pi32, pi32, f64]),
         "orc_sgd_stats": (None, [vp, C.POINTER(C.c_longlong)]),
         "orc_sgd_state": (pf, [vp, i32, pi64]),
         "orc_bpr_exp_table": (None, [vp, pf]),
@@ -200,6 +201,13 @@ class _SGDBase(_Base):
                                           _p(positives, C.c_int32), _p(negatives, C.c_int32))
 
     # ---- oracle-only introspection -------------------------------------------------
+    def apply_triples(self, users, positives, negatives, lr):
+        """BPRMF only: the SGD step of bpr.cc:119-171 applied to the given (u, pos, neg) triples in the given order."""
+        n = int(users.shape[0])
+        ok = lib().orc_bpr_apply_triples(self._h, n, _p(_chk(users, np.int32), C.c_int32), _p(_chk(positives, np.int32), C.c_int32),
+                                         _p(_chk(negatives, np.int32), C.c_int32), float(lr))
+        assert ok, "apply_triples is implemented for the BPRMF oracle only"
+
     def trace(self, on=True):
         lib().orc_trace(self._h, int(on))
 

@@ -134,3 +134,26 @@ def relerr(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def item_major_order(csr, nq, blocks, nn):
+    """The order in which ONE wave draining every queue walks an epoch's triples (indices into the CSR-ordered
+    triple list pos * nn + slot): entries stable-sorted by ((user % nq) * blocks + block) * I + item, cut into
+    slices that bfh_bpr_item_major_plan hands out ticket by ticket (csrc/bpr_item_major.hpp)."""
+    from test_schedule_cpu import plan   # bfh_bpr_item_major_plan through ctypes (host-only)
+    n, I = csr.nnz, csr.num_items
+    t = np.arange(n, dtype=np.uint64)
+    blk = ((((t * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF)) >> np.uint64(16)) % np.uint64(blocks)).astype(np.int64)
+    key = ((csr.rows().astype(np.int64) % nq) * blocks + blk) * I + csr.keys.astype(np.int64)
+    perm = np.argsort(key, kind="stable")
+    queue = key[perm] // (blocks * I)
+    entries = [int((queue == x).sum()) for x in range(nq)]
+    slice_len, segments, slices, stride = plan(entries, nn, 1 << 40)
+    assert segments == 1
+    order = []
+    for x in range(nq):
+        trip = (perm[queue == x][:, None] * nn + np.arange(nn)[None, :]).reshape(-1)
+        for ticket in range(int(slices[x])):
+            sl = (ticket * int(stride[x])) % int(slices[x])
+            order.append(trip[sl * slice_len:(sl + 1) * slice_len])
+    return np.concatenate(order)

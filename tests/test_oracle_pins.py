@@ -118,6 +118,52 @@ def test_bpr_epoch_matches_transliteration(oracle, opt_file, optimizer):
         assert np.abs(o.state("gradQ")).max() > 0
 
 
+def test_bpr_apply_triples_replays_any_schedule(oracle, opt_file):
+    """`apply_triples` (the SGD step of bpr.cc:119-171 over an explicit triple list) is what the GPU schedules are
+    replayed through: (a) fed the oracle's own trace it reproduces the oracle's epoch bit for bit; (b) fed the same
+    triples in another order (the item-major walk's) it lands on a different model -- the one the numpy
+    transliteration reaches in that order."""
+    from helpers import item_major_order as _item_major_order
+    csr = tiny_csr(U=60, I=40, density=0.15, seed=4)
+    d, nn = 12, 2
+    rng = np.random.default_rng(2)
+    P = rng.normal(scale=0.3, size=(csr.num_users, d)).astype(np.float32)
+    Q = rng.normal(scale=0.3, size=(csr.num_items, d)).astype(np.float32)
+    Qb = rng.normal(scale=0.1, size=(csr.num_items, 1)).astype(np.float32)
+    kw = dict(d=d, lr=0.05, min_lr=0.05, num_iters=1, random_seed=9, num_negative_samples=nn)
+    P0, Q0, Qb0 = P.copy(), Q.copy(), Qb.copy()
+    o = _bpr(oracle, opt_file, csr, P, Q, Qb, **kw)
+    o.set_modes(sampler="counter", pos_order="csr", inline=True)
+    o.trace(True)
+    o.launch_workers()
+    o.add_jobs(0, csr.num_users, csr.indptr, csr.keys)
+    tr = o.get_trace()
+    o.join()
+    assert len(tr) == csr.nnz * nn
+
+    def replay(order):
+        Pr, Qr, Qbr = P0.copy(), Q0.copy(), Qb0.copy()
+        r = _bpr(oracle, opt_file, csr, Pr, Qr, Qbr, **kw)
+        t = tr[order]
+        r.apply_triples(np.ascontiguousarray(t[:, 0]), np.ascontiguousarray(t[:, 1]), np.ascontiguousarray(t[:, 2]), 0.05)
+        return Pr, Qr, Qbr
+
+    Pa, Qa, Qba = replay(np.arange(len(tr)))
+    np.testing.assert_array_equal(Pa, P)
+    np.testing.assert_array_equal(Qa, Q)
+    np.testing.assert_array_equal(Qba, Qb)
+    order = _item_major_order(csr, 8, 3, nn)
+    Pb, Qb_im, Qbb = replay(order)
+    assert np.abs(Pb - P).max() > 1e-3                      # another order, another model
+    Pn, Qn, Qbn = P0.copy(), Q0.copy(), Qb0.copy()
+    opt, table = bpr_opt(**kw), rn.exp_table()
+    for u, pos, neg in tr[order]:
+        rn.bpr_sgd_step(Pn, Qn, Qbn, u, pos, neg, 0.05, opt, table)
+    np.testing.assert_allclose(Pb, Pn, rtol=2e-5, atol=2e-7)
+    np.testing.assert_allclose(Qb_im, Qn, rtol=2e-5, atol=2e-7)
+    np.testing.assert_allclose(Qbb, Qbn, rtol=2e-5, atol=2e-7)
+
+
 def test_bpr_sampling_quirks(oracle, opt_file):
     """Q-3 (unordered_set order), Q-4 (lower_bound on int64 cumulative counts), verify_neg."""
     csr = tiny_csr(U=8, I=20, seed=5)
