@@ -1,5 +1,6 @@
-"""Statistical parity of the Hogwild policies at BASELINE scale (ML-20M-shaped, d=128):
-sampled training loss per epoch + fixed-sample BPR loss, for policies 0..3 and the CPU oracle."""
+"""Statistical parity of the Hogwild policies at BASELINE scale (ML-20M-shaped, d=128): sampled training loss per epoch +
+fixed-sample BPR loss for hogwild_atomic = 3 (item-major default), 1, 2, 0 and the CPU oracle.  (scripts/xcd_study.py is the
+newer, knob-sweeping version; this one also runs the 64-thread oracle at lr 0.05.)"""
 import json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -24,7 +25,7 @@ def opts(**kw):
     return bpr_options(EPOCHS, lr=LR, min_lr=LR, compute_loss_on_training=True, **kw)
 
 
-for mode in (1, 2, 0):
+for mode in (3, 1, 2, 0):
     P, Q, Qb = synth.init_factors(U, I, 128, seed=7)
     obj = CyBPR()
     assert obj.init(write_opt(opts()))
