@@ -7,7 +7,10 @@ A "step" is one epoch of the hot path: one `add_jobs` pass of the fused sampler 
 over every interaction of the (resident) CSR, followed by `update_parameters` (a no-op for sgd).
 N=1 runs BASELINE.json configs[1]; N>1 is launched by torch.distributed.run, one rank per GPU, users
 sharded, item factors replicated and delta-all-reduced over RCCL once per minibatch (buffalo_amd/dist.py).
-Rank 0 prints ONE JSON line (metric/value/roofline/cpu_baseline ...).
+Rank 0 prints ONE JSON line (metric/value/roofline/cpu_baseline ...).  At N=1 the line also carries an
+`extra` block: the two other inner loops north_star names, measured in the same process after the timed
+region -- ALS at BASELINE configs[2] (MFMA utilisation of the Gramian/solve kernel) and WARP at configs[4]'s
+d=256 on the ML-20M shape (algorithmic GB/s with the measured T) -- each with its own oracle timing.
 """
 import argparse
 import json
@@ -21,7 +24,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TF = 157.3  # same guide: v_mfma_f32_32x32x2_f32, exact fp32 (the type ALS computes in)
 D = 128
+CPU_KIND = "port"
+CPU_WHAT = ("restatement of reference CPU path (oracle/buffalo_oracle.cc, compiled with the reference's flags "
+            "-O3 -fopenmp -mavx2 -mfma; the reference's own C++ cannot be built here: Eigen/json11/spdlog submodules are empty)")
 
 
 def bpr_options(num_iters, seed=7, **kw):
@@ -104,22 +111,182 @@ def cpu_baseline(csr, target_seconds=12.0):
     nnz_p, dt_p = run(probe_users, workers=8)
     want8 = int(min(csr.nnz, max(nnz_p, nnz_p / dt_p * 6.0)))
     nnz8, dt8 = run(min(csr.num_users, int(np.searchsorted(csr.indptr, want8)) + 1), workers=8)
-    return {"value": nnz1 / dt1, "unit": "updates/s", "cores": cores, "kind": "port",
+    return {"value": nnz1 / dt1, "unit": "updates/s", "cores": cores, "kind": CPU_KIND, "what": CPU_WHAT,
             "sample": "first %d users (%d interactions, 1 epoch) of the same matrix, %d std::thread workers, %.1f s"
                       % (n_users, nnz1, cores, dt1),
             "value_8_workers": nnz8 / dt8, "sample_8_workers": "%d interactions, 8 workers, %.1f s" % (nnz8, dt8)}
 
 
+ALS_OPT = {  # ALSOption defaults (/root/reference/buffalo/algo/options.py:66-86) at d=128 (=> iALS++, Q-13)
+    "evaluation_on_learning": False, "compute_loss_on_training": False, "early_stopping_rounds": 0, "save_best": False,
+    "evaluation_period": 1, "save_period": 10, "random_seed": 7, "validation": {}, "adaptive_reg": False, "save_factors": False,
+    "accelerator": True, "d": D, "num_iters": 10, "num_workers": 8, "hyper_threads": 256, "num_cg_max_iters": 3, "reg_u": 0.1,
+    "reg_i": 0.1, "alpha": 8.0, "optimizer": "manual_cg", "cg_tolerance": 1e-10, "block_size": 32, "eps": 1e-10,
+    "model_path": "", "data_opt": {}}
+WARP_D = 256
+WARP_OPT = {  # WARPOption defaults (options.py:286-311) at configs[4]'s d=256
+    "evaluation_on_learning": False, "compute_loss_on_training": False, "early_stopping_rounds": 0, "save_best": False,
+    "evaluation_period": 5, "save_period": 10, "random_seed": 7, "validation": {}, "accelerator": True, "num_workers": 8,
+    "hyper_threads": 256, "num_iters": 10, "d": WARP_D, "threshold": 1.0, "score_func": "dot", "max_trials": 500, "update_i": True,
+    "update_j": True, "reg_u": 0.0, "reg_i": 0.0, "reg_j": 0.0, "optimizer": "adagrad", "lr": 0.05, "min_lr": 0.0001,
+    "beta1": 0.9, "beta2": 0.999, "eps": 1e-10, "per_coordinate_normalize": False, "model_path": "", "data_opt": {}}
+
+
+def _opt_file(opt):
+    path = write_opt(opt)
+    return path
+
+
+def extra_als(csr, seed, epochs=5, cpu=True):
+    """BASELINE configs[2]: ALS (iALS++ at d=128) on the ML-20M shape, one GPU; both CSR orientations resident."""
+    from buffalo_amd import ingest, synth
+    from buffalo_amd.backend import CyALS
+    U, I, nnz = csr.num_users, csr.num_items, csr.nnz
+    rng = np.random.default_rng(seed)
+    vals = (1 + rng.poisson(1.0, size=nnz)).astype(np.float32)      # SURVEY 8(d): counts 1 + Poisson(1)
+    col = ingest.coo_to_csr(csr.keys, csr.rows(), vals, I, U)       # colwise orientation, built on the device (bfh_coo_to_csr)
+    P, Q, _ = synth.init_factors(U, I, D, seed=seed)
+    g = CyALS()
+    path = _opt_file(ALS_OPT)
+    assert g.init(path)
+    os.unlink(path)
+    g.initialize_model(P, Q)
+    g.set_resident_csr(0, csr.indptr, csr.keys, vals)
+    g.set_resident_csr(1, col["indptr"], col["key"], col["val"])
+    g.set_mode("als_writeback", 0)
+
+    def epoch():
+        g.precompute(0)
+        g.partial_update(0, U, csr.indptr, None, None, 0)
+        g.precompute(1)
+        g.partial_update(0, I, col["indptr"], None, None, 1)
+    epoch()
+    g.reset_stats()
+    t0 = time.perf_counter()
+    for _ in range(epochs):
+        epoch()
+    dt = (time.perf_counter() - t0) / epochs
+    st = g.stats()
+    T = D // 32
+    mfma_flop = 2 * nnz * (T * (T + 1) // 2) * 2 * 32 * 32          # issued: upper-triangle 32x32x2 tiles, both half-epochs
+    kernel_s = st["kernel_ms"] / epochs * 1e-3
+    alg_bytes = 2 * nnz * (4 * D + 8) + (U + I) * (8 * D + 8) + (U + I) * 4 * D     # SURVEY 8(d) B_als, both half-epochs
+    out = {"config": "ALS iALS++ (block 32, 3 CG steps), ml20m-shaped synthetic (%d x %d, %d nnz, values 1+Poisson(1)), d=%d, f32, "
+                     "rowwise + colwise CSR and factors resident in HBM" % (U, I, nnz, D),
+           "epoch_ms": dt * 1e3, "interactions_per_s": 2 * nnz / dt, "kernel": "als_gram_kernel (Gramian on MFMA + in-register block CG)",
+           "kernel_ms_per_epoch": kernel_s * 1e3, "gramian_ff_ms_per_epoch": st["aux_ms"] / epochs,
+           "mfma": {"issued_TFLOPs": mfma_flop / kernel_s / 1e12, "peak_TFLOPs": MFMA_F32_PEAK_TF,
+                    "frac": mfma_flop / kernel_s / 1e12 / MFMA_F32_PEAK_TF,
+                    "instruction": "v_mfma_f32_32x32x2_f32", "issued_flop_per_epoch": mfma_flop},
+           "hbm": {"algorithmic_bytes_per_epoch": alg_bytes, "achieved_GBps": alg_bytes / kernel_s / 1e9,
+                   "frac": alg_bytes / kernel_s / 1e9 / HBM_PEAK_GBS}}
+    del g
+    if cpu:
+        from oracle import oracle as orc
+        orc.build()
+        cores = os.cpu_count() or 1
+
+        def run(n_users):
+            Po, Qo, _ = synth.init_factors(n_users, I, D, seed=seed)
+            o = orc.OracleALS()
+            path = _opt_file(dict(ALS_OPT, accelerator=False, num_workers=cores))
+            assert o.init(path)
+            os.unlink(path)
+            o.initialize_model(Po, Qo)
+            m = int(csr.indptr[n_users - 1])
+            ip, k, v = np.ascontiguousarray(csr.indptr[:n_users]), np.ascontiguousarray(csr.keys[:m]), np.ascontiguousarray(vals[:m])
+            t0 = time.perf_counter()
+            o.precompute(0)
+            o.partial_update(0, n_users, ip, k, v, 0)
+            return m, time.perf_counter() - t0
+        m0, d0 = run(int(np.searchsorted(csr.indptr, 200000)) + 1)
+        want = int(min(nnz, max(m0, m0 / d0 * 6.0)))
+        m1, d1 = run(min(U, int(np.searchsorted(csr.indptr, want)) + 1))
+        out["cpu_baseline"] = {"value": m1 / d1, "unit": "interactions/s", "cores": cores, "kind": CPU_KIND, "what": CPU_WHAT,
+                               "sample": "user half-epoch (precompute + partial_update, iALS++) over the first %d interactions of the same "
+                                         "matrix, OpenMP %d threads, %.1f s" % (m1, cores, d1)}
+    return out
+
+
+def extra_warp(csr, seed, epochs=3, cpu=True):
+    """WARP (warp.cc:103-201) at BASELINE configs[4]'s d=256 / adagrad on the ML-20M shape, one GPU."""
+    from buffalo_amd import synth
+    from buffalo_amd.backend import CyWARP
+    U, I, nnz = csr.num_users, csr.num_items, csr.nnz
+    d = WARP_D
+    P, Q, Qb = synth.init_factors(U, I, d, seed=seed, signed=True)
+    Qb *= 0
+    g = CyWARP()
+    path = _opt_file(WARP_OPT)
+    assert g.init(path)
+    os.unlink(path)
+    g.sync_every_epoch = False
+    g.initialize_model(P, Q, Qb, nnz, True)
+    g.set_resident_csr(csr.indptr, csr.keys)
+    g.add_jobs(0, U, csr.indptr, None)      # warm-up epoch (allocations, the positive incidence list)
+    g.update_parameters()
+    eps = []
+    for e in range(epochs):
+        g.reset_stats()
+        t0 = time.perf_counter()
+        g.add_jobs(0, U, csr.indptr, None)
+        g.update_parameters()
+        dt = time.perf_counter() - t0
+        st = g.stats()
+        acc, scored = st["accepted"], st["scored_negatives"]
+        # SURVEY 8(d): per accepted positive (8 + T) rows of 4d bytes + key, per rejected one (2 + T) rows + key; T measured
+        alg = (8 * acc + 2 * (nnz - acc) + scored) * 4 * d + 4 * nnz
+        dev_s = (st["kernel_ms"] + st["aux_ms"]) * 1e-3
+        eps.append({"epoch_ms": dt * 1e3, "trial_kernel_ms": st["kernel_ms"], "sort_and_gather_ms": st["aux_ms"],
+                    "optimizer_ms": st["optimizer_ms"], "positives_per_s": nnz / dt, "mean_scored_negatives_T": scored / nnz,
+                    "accepted_frac": acc / nnz, "algorithmic_bytes": alg, "algorithmic_GBps": alg / dev_s / 1e9,
+                    "hbm_frac": alg / dev_s / 1e9 / HBM_PEAK_GBS})
+    out = {"config": "WARP adagrad, dot score, max_trials 500, ml20m-shaped synthetic (%d x %d, %d nnz), d=%d, f32, CSR + factors + "
+                     "optimizer state resident in HBM" % (U, I, nnz, d),
+           "kernels": "warp_update_kernel (trial loop, gradP in registers) + radix sort of the accepted negatives + grad_gather_kernel x2",
+           "epochs": eps, "epoch_ms": eps[-1]["epoch_ms"], "positives_per_s": eps[-1]["positives_per_s"],
+           "algorithmic_GBps": eps[-1]["algorithmic_GBps"], "hbm_frac": eps[-1]["hbm_frac"]}
+    del g
+    if cpu:
+        from oracle import oracle as orc
+        orc.build()
+        cores = os.cpu_count() or 1
+
+        def run(n_users):
+            m = int(csr.indptr[n_users - 1])
+            Po, Qo, Qbo = synth.init_factors(n_users, I, d, seed=seed, signed=True)
+            o = orc.OracleWARP()
+            path = _opt_file(dict(WARP_OPT, accelerator=False, num_workers=cores, num_iters=1))
+            assert o.init(path)
+            os.unlink(path)
+            o.initialize_model(Po, Qo, Qbo, m)
+            o.set_cumulative_table(np.zeros(I, np.int64), I)
+            o.launch_workers()
+            ip, k = np.ascontiguousarray(csr.indptr[:n_users]), np.ascontiguousarray(csr.keys[:m])
+            t0 = time.perf_counter()
+            o.add_jobs(0, n_users, ip, k)
+            o.join()
+            return m, time.perf_counter() - t0
+        m0, d0 = run(int(np.searchsorted(csr.indptr, 200000)) + 1)
+        want = int(min(nnz, max(m0, m0 / d0 * 6.0)))
+        m1, d1 = run(min(U, int(np.searchsorted(csr.indptr, want)) + 1))
+        out["cpu_baseline"] = {"value": m1 / d1, "unit": "positives/s", "cores": cores, "kind": CPU_KIND, "what": CPU_WHAT,
+                               "sample": "first %d interactions of the same matrix, 1 epoch (add_jobs .. join), %d std::thread workers, %.1f s"
+                                         % (m1, cores, d1)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=250)   # ~2.2 s timed region on one MI355X
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--shape", default="ml20m")
     ap.add_argument("--seed", type=int, default=7)
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--minibatches", type=int, default=1, help="all-reduce points per epoch (N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the ALS / WARP secondary measurements (N=1)")
     ap.add_argument("--mode", action="append", default=[], help="backend knob name=value (e.g. hogwild_atomic=0)")
     args = ap.parse_args()
 
@@ -220,6 +387,8 @@ def main():
         kernel_ms = st["kernel_ms"] / max(st["launches"], 1)
         alg_bytes = bytes_per_update * (st["samples"] / max(st["launches"], 1))
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        # PMC counters need rocprofv3: `traffic` is the per-launch figure of the latest separate --pmc passes of this same
+        # command (scripts/gpu_profile.sh -> scripts/pmc_summary.py -> profiles/pmc_latest.json), not of this process
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
@@ -246,6 +415,7 @@ def main():
                                         "merged by the delta rule %.1f times per epoch" % (st["merges"] / max(steps, 1))}[hog]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": "profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)",
                          "kernel": "bpr_item_major_kernel" if hog == "3" else "bpr_update_kernel", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "launches_per_step": st["launches"] / max(steps, 1),
@@ -256,6 +426,15 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(csr)
+        if world == 1 and not args.no_extra:
+            del obj
+            extra = {}
+            for name, fn in (("als_ml20m_d128", extra_als), ("warp_ml20m_d256", extra_warp)):
+                try:
+                    extra[name] = fn(csr, args.seed, cpu=not args.no_cpu_baseline)
+                except Exception as e:   # the headline line is never lost to a secondary measurement
+                    extra[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+            out["extra"] = extra
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

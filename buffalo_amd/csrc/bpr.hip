@@ -61,6 +61,11 @@ struct BprConsts {
     int64_t rep_stride, rep_bstride;
     const uint8_t* hot;   // [Q_rows] 1 = row stays in the chip-wide matrix and is updated with atomics
     int fresh;            // re-read replica rows right before storing them
+    // adam / adagrad, two-pass accumulation (sgd_base.hpp GatherParams): this kernel only records the logit and the
+    // negative of every triple; the item-side gradient rows are summed by grad_gather_kernel
+    int two_pass;
+    float* coef_out;      // [total]
+    uint32_t* neg_out;    // [total]
 };
 
 // The XCD this wave runs on (0..7), from the hardware register: the address of a wave's item-factor
@@ -283,6 +288,8 @@ __global__ __launch_bounds__(256) void bpr_update_kernel(SgdParams p, BprConsts 
                 if (rep && c.hot) my_pol = (c.hot[my_pos] ? 1 : 0) | (c.hot[my_neg] ? 2 : 0);
             }
             const int n_here = static_cast<int>((t_end - t0) < 64 ? (t_end - t0) : 64);
+            float my_coef = 0.f;   // two-pass accumulation: lane j keeps triple j's logit, stored coalesced after the walk
+            if (!SGD && !INJECT && c.two_pass && valid) c.neg_out[t] = static_cast<uint32_t>(my_neg);
 
             Row<K> qi, qj, qi_n, qj_n;
             float bi = 0.f, bj = 0.f, bi_n = 0.f, bj_n = 0.f;
@@ -417,6 +424,10 @@ __global__ __launch_bounds__(256) void bpr_update_kernel(SgdParams p, BprConsts 
                         gi.v[k] = idv;
                         gj.v[k] = -idv;
                     }
+                    if (!INJECT && c.two_pass) {
+                        if (lane == j) my_coef = logit;
+                        if (c.pcn && lane == 0 && ((t0 + j) % c.num_neg) == c.num_neg - 1) atomicAdd(p.cntP + u, 1);
+                    } else {
                     if (c.update_i) row_atomic_add<K, V4>(gi, p.gradQ + static_cast<size_t>(pos) * vdim, lane, vdim);
                     if (c.update_j) row_atomic_add<K, V4>(gj, p.gradQ + static_cast<size_t>(neg) * vdim, lane, vdim);
                     if (lane == 0) {
@@ -432,6 +443,7 @@ __global__ __launch_bounds__(256) void bpr_update_kernel(SgdParams p, BprConsts 
                                 atomicAdd(p.cntQ + pos, 1);
                             }
                         }
+                    }
                     }
                 }
                 if (PIPE) {
@@ -449,6 +461,7 @@ __global__ __launch_bounds__(256) void bpr_update_kernel(SgdParams p, BprConsts 
                     }
                 }
             }
+            if (!SGD && !INJECT && c.two_pass && valid) c.coef_out[t] = my_coef;
         }
         if (!c.sequential) flush_user();
     }
@@ -805,6 +818,7 @@ class BprHandle : public SgdHandle {
         q.hot_user = im_hot_user_.get();
         q.flush_every = im_flush_.get();
         q.strict = im_single_wave_;
+        q.trace = (im_single_wave_ && im_trace_.size() >= static_cast<size_t>(c.total)) ? im_trace_.get() : nullptr;
         q.done = reinterpret_cast<unsigned long long*>(scratch_.get() + 1);
         if (im_presample_) {
             im_neg_.resize(static_cast<size_t>(c.total));
@@ -923,10 +937,18 @@ class BprHandle : public SgdHandle {
     int64_t rep_bstride() const { return (static_cast<int64_t>(Q_rows_) + 63) / 64 * 64; }
 
     template <bool INJECT>
-    void launch(const SgdParams& p, const BprConsts& c_in) {
+    void launch(const SgdParams& p, const BprConsts& c_in, int start_x = 0, int next_x = 0) {
         BprConsts c = c_in;
         const int64_t n_work = (c.total + c.chunk - 1) / c.chunk;
         const bool reps = c.atomic == 2;
+        // adam / adagrad: P, Q are frozen, so the item-side gradients are summed by the sorted gather (no per-triple atomics)
+        const bool two_pass = !INJECT && optimizer_ != "sgd" && accum_two_pass_ != 0;
+        if (two_pass) {
+            acc_prepare(c.total);
+            c.two_pass = 1;
+            c.coef_out = acc_coef_.get();
+            c.neg_out = acc_neg_.get();
+        }
         int64_t seg_work = n_work;          // work items per launch
         if (reps) {
             xcd_alloc(false);
@@ -953,6 +975,13 @@ class BprHandle : public SgdHandle {
                 t_aux_.end(slot, stream);
                 stats.merges += 1;
             }
+        }
+        if (two_pass) {
+            const int slot = t_aux_.begin(stream);
+            acc_build_positive_list(p, start_x, next_x);
+            const float sab_pos[3] = {1.f, 0.f, 0.f}, sab_neg[3] = {-1.f, 0.f, 0.f};
+            acc_gather(p, num_neg_, update_i_, update_j_, sab_pos, sab_neg, false, use_bias_);
+            t_aux_.end(slot, stream);
         }
     }
 
@@ -987,7 +1016,7 @@ class BprHandle : public SgdHandle {
         c.total = n * num_neg_;
         if (compute_loss_) BFH_HIP(hipMemsetAsync(scratch_.get(), 0, sizeof(double), stream));
         if (c.atomic == 3) launch_item_major(p, c, start_x, next_x);
-        else launch<false>(p, c);
+        else launch<false>(p, c, start_x, next_x);
         if (compute_loss_) BFH_HIP(hipMemcpyAsync(loss_sum, scratch_.get(), sizeof(double), hipMemcpyDeviceToHost, stream));
         sync_stream();
         im_check_done();

@@ -53,6 +53,7 @@ struct ImQueues {
     const uint8_t* flush_every;  // [Q_rows] triples between two flushes of the register-resident item row (1..64)
     const int32_t* neg_pre;    // [chunk nnz * num_neg] negatives drawn by bpr_presample_kernel, or null: draw in the walk
     int strict;                // test hook: wait for every memory operation of a triple before the next one starts
+    int32_t* trace;            // test hook (single-wave runs): sigmoid-table index of every triple in processing order, or null
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -389,6 +390,7 @@ __global__ __launch_bounds__(256, K <= 4 ? (PIPE ? 5 : 6) : 1) void bpr_item_maj
                 if (c.use_bias) x += (bi - bj);
                 const float logit = bpr_logit(x, c.exp_table);
                 if (c.compute_loss) loss += static_cast<double>(log1pf(__expf(-fminf(fmaxf(x, -6.f), 6.f))));
+                if (q.trace && lane == 0) q.trace[processed] = 6.0f < x ? 1000 : (x < -6.0f ? -1 : static_cast<int>((x + 6.0f) * 83.0f));
                 // ---------------- bpr.cc:157-171 (Q-1: the user step sees the updated item rows) ----------------
                 const bool same = item == neg;   // verify_neg == false only: the one row takes both steps in turn
                 Row<K> dj, dpu;

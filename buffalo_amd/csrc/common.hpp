@@ -179,7 +179,7 @@ class EventTimer {
 static inline int vdim_of(int d) { return ((d + 31) / 32) * 32; }  // bpr.cu:266-267, als.cu:251-252
 
 // Stable LSD radix sort of (uint32 key, int32 value) pairs over the low `bits` key bits, on `s`
-// (rocPRIM through hipCUB; implemented in ingest.hip so only that file pays for the headers).
+// (rocprim::radix_sort_pairs; implemented in ingest.hip so only that file pays for the headers).
 void device_sort_pairs_u32(const uint32_t* keys_in, uint32_t* keys_out, const int32_t* vals_in, int32_t* vals_out, int64_t n, int bits,
                            DevBuf<char>& tmp, hipStream_t s);
 

@@ -8,11 +8,13 @@
 // parsed from text; here the ids are 0-based arrays already in memory.
 //
 // Device formulation: one 64-bit key (major << 32 | minor) per record, a stable LSD radix sort over only the
-// bits the two id ranges need (rocPRIM's device radix sort through hipCUB -- the one library primitive on this
-// path, like rocBLAS would be for a plain GEMM), then two trivially parallel passes: split the sorted keys
+// bits the two id ranges need (rocprim::radix_sort_pairs -- the one library primitive on this path, like
+// rocBLAS would be for a plain GEMM), then two trivially parallel passes: split the sorted keys
 // back into minor ids and fill indptr from the positions where the major id changes.  All HBM-bound integer
 // work: 2 x (8 + 4) B per record and radix pass.
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include "common.hpp"
 
@@ -47,10 +49,12 @@ static int bits_for(int64_t range) {   // bits needed for ids in [0, range)
 void device_sort_pairs_u32(const uint32_t* keys_in, uint32_t* keys_out, const int32_t* vals_in, int32_t* vals_out, int64_t n, int bits,
                            DevBuf<char>& tmp, hipStream_t s) {
     size_t bytes = 0;
-    BFH_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, keys_in, keys_out, vals_in, vals_out, n, 0, bits, s));
+    const size_t count = static_cast<size_t>(n);
+    const unsigned end_bit = static_cast<unsigned>(bits);
+    BFH_HIP(rocprim::radix_sort_pairs(nullptr, bytes, keys_in, keys_out, vals_in, vals_out, count, 0u, end_bit, s));
     if (tmp.size() < bytes) tmp.resize(bytes ? bytes : 1);
     bytes = tmp.size();
-    BFH_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.get(), bytes, keys_in, keys_out, vals_in, vals_out, n, 0, bits, s));
+    BFH_HIP(rocprim::radix_sort_pairs(tmp.get(), bytes, keys_in, keys_out, vals_in, vals_out, count, 0u, end_bit, s));
 }
 
 static void coo_to_csr(const int32_t* major, const int32_t* minor, const float* vals, int64_t nnz, int num_major, int num_minor, int64_t* indptr,
@@ -88,9 +92,10 @@ static void coo_to_csr(const int32_t* major, const int32_t* minor, const float* 
     BFH_HIP(hipGetLastError());
     const int end_bit = 32 + bits_for(num_major);   // the minor word is sorted over the bits it uses, the gap above it is all zero
     size_t tmp_bytes = 0;
-    BFH_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_kin.get(), d_kout.get(), d_vin.get(), d_vout.get(), nnz, 0, end_bit, stream));
+    const size_t count = static_cast<size_t>(nnz);
+    BFH_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_kin.get(), d_kout.get(), d_vin.get(), d_vout.get(), count, 0u, static_cast<unsigned>(end_bit), stream));
     d_tmp.resize(tmp_bytes ? tmp_bytes : 1);
-    BFH_HIP(hipcub::DeviceRadixSort::SortPairs(d_tmp.get(), tmp_bytes, d_kin.get(), d_kout.get(), d_vin.get(), d_vout.get(), nnz, 0, end_bit, stream));
+    BFH_HIP(rocprim::radix_sort_pairs(d_tmp.get(), tmp_bytes, d_kin.get(), d_kout.get(), d_vin.get(), d_vout.get(), count, 0u, static_cast<unsigned>(end_bit), stream));
     hipLaunchKernelGGL(ingest_unpack_kernel, dim3(blocks), dim3(256), 0, stream, d_kout.get(), nnz, num_major, d_minor.get(), d_indptr.get());
     BFH_HIP(hipGetLastError());
     BFH_HIP(hipEventRecord(e1, stream));

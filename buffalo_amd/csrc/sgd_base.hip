@@ -179,6 +179,211 @@ __global__ void sgd_update_bias_kernel(float* __restrict__ X, float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
+// grad_gather_kernel: the item side of gradient accumulation (see GatherParams in sgd_base.hpp).
+// A wave owns kGatherChunk consecutive incidences of the item-sorted list.  Per 64 incidences the lanes
+// fetch (item, index), the user and the coefficient in parallel (coalesced list reads + two 4-byte gathers);
+// the wave then walks them with UN user rows in flight (dword per lane: element k*64+lane, so every load and
+// every flushed atomic covers whole 128-B lines), sums  c * P[u]  in registers while the item stays the same
+// and pushes the run with one atomic row add.  Bound: HBM / Infinity-Cache gathers of 4*vdim bytes per incidence.
+// ------------------------------------------------------------------------------------------------
+constexpr int kGatherChunk = 256;
+
+template <int K, int UN, bool QTERM>
+__global__ __launch_bounds__(256) void grad_gather_kernel(GatherParams g) {
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    const int64_t wave0 = static_cast<int64_t>(blockIdx.x) * wpb + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t nwaves = static_cast<int64_t>(gridDim.x) * wpb;
+    const int vdim = g.vdim;
+    const int64_t n_work = (g.n + kGatherChunk - 1) / kGatherChunk;
+    for (int64_t w = wave0; w < n_work; w += nwaves) {
+        const int64_t k_beg = w * kGatherChunk;
+        const int64_t k_end = (k_beg + kGatherChunk < g.n) ? k_beg + kGatherChunk : g.n;
+        int cur = -1, cnt = 0;
+        float csum = 0.f;
+        float acc[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] = 0.f;
+        auto flush = [&]() {
+            if (cur >= 0 && cnt > 0) {
+                float* dst = g.gradQ + static_cast<size_t>(cur) * vdim;
+                const float qs = g.a * csum + g.b * static_cast<float>(cnt);
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const int e = k * 64 + lane;
+                    if (e < vdim) {
+                        float v = g.sign * acc[k];
+                        if (QTERM) v += qs * g.Q[static_cast<size_t>(cur) * vdim + e];
+                        atomic_add_f32(dst + e, v);
+                    }
+                }
+                if (lane == 0) {
+                    if (g.gradQb) atomic_add_f32(g.gradQb + cur, g.sign * csum);
+                    if (g.cntQ) atomicAdd(g.cntQ + cur, cnt);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) acc[k] = 0.f;
+            csum = 0.f;
+            cnt = 0;
+        };
+        for (int64_t k0 = k_beg; k0 < k_end; k0 += 64) {
+            const int64_t kk = k0 + lane;
+            int my_item = -1, my_u = -1;
+            float my_c = 0.f;
+            if (kk < k_end) {
+                const uint32_t it = g.inc_key[kk];
+                if (it < static_cast<uint32_t>(g.Q_rows)) {
+                    const int32_t idx = g.inc_idx[kk];
+                    bool any = false;
+                    if (g.pos_list) {
+                        const int64_t base = static_cast<int64_t>(idx) * g.num_neg;
+                        for (int sl = 0; sl < g.num_neg; ++sl) {
+                            if (!g.accept || g.accept[base + sl] < static_cast<uint32_t>(g.Q_rows)) {
+                                my_c += g.coef[base + sl];
+                                any = true;
+                            }
+                        }
+                        if (any) my_u = g.rows[idx];
+                    } else if (!g.accept || g.accept[idx] < static_cast<uint32_t>(g.Q_rows)) {
+                        my_c = g.coef[idx];
+                        my_u = g.rows[idx / g.num_neg];
+                        any = true;
+                    }
+                    if (any) my_item = static_cast<int>(it);
+                }
+            }
+            const int n_here = static_cast<int>((k_end - k0) < 64 ? (k_end - k0) : 64);
+            for (int j0 = 0; j0 < n_here; j0 += UN) {
+                float r[UN][K];
+#pragma unroll
+                for (int s = 0; s < UN; ++s) {
+                    const int u = __builtin_amdgcn_readlane(my_u, (j0 + s) & 63);
+                    if (u >= 0) {
+                        const float* src = g.P + static_cast<size_t>(u) * vdim;
+#pragma unroll
+                        for (int k = 0; k < K; ++k) {
+                            const int e = k * 64 + lane;
+                            r[s][k] = e < vdim ? src[e] : 0.f;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < UN; ++s) {
+                    const int u = __builtin_amdgcn_readlane(my_u, (j0 + s) & 63);
+                    if (u >= 0) {
+                        const int item = __builtin_amdgcn_readlane(my_item, (j0 + s) & 63);
+                        if (item != cur) {
+                            flush();
+                            cur = item;
+                        }
+                        const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_c), (j0 + s) & 63));
+#pragma unroll
+                        for (int k = 0; k < K; ++k) acc[k] += c * r[s][k];
+                        csum += c;
+                        cnt += 1;
+                    }
+                }
+            }
+        }
+        flush();
+    }
+}
+
+__global__ __launch_bounds__(256) void incidence_iota_kernel(const int32_t* __restrict__ keys, int64_t n, uint32_t* __restrict__ key_out,
+                                                             int32_t* __restrict__ idx_out) {
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (t >= n) return;
+    if (key_out) key_out[t] = static_cast<uint32_t>(keys[t]);
+    idx_out[t] = static_cast<int32_t>(t);
+}
+
+void launch_incidence_iota(const int32_t* keys, int64_t n, uint32_t* key_out, int32_t* idx_out, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(incidence_iota_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, keys, n, key_out, idx_out);
+    BFH_HIP(hipGetLastError());
+}
+
+template <int K, int UN>
+static void launch_grad_gather_k(const GatherParams& g, dim3 grid, hipStream_t s) {
+    if (g.a != 0.f || g.b != 0.f) hipLaunchKernelGGL((grad_gather_kernel<K, UN, true>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((grad_gather_kernel<K, UN, false>), grid, dim3(256), 0, s, g);
+}
+
+void launch_grad_gather(const GatherParams& g, int64_t max_waves, hipStream_t s) {
+    if (g.n <= 0) return;
+    const int64_t n_work = (g.n + kGatherChunk - 1) / kGatherChunk;
+    const int64_t waves = std::max<int64_t>(1, std::min(max_waves, n_work));
+    const dim3 grid(static_cast<unsigned>((waves + 3) / 4));
+    const int K = (g.vdim + 63) / 64;
+    if (K <= 1) launch_grad_gather_k<1, 8>(g, grid, s);
+    else if (K <= 2) launch_grad_gather_k<2, 8>(g, grid, s);
+    else if (K <= 4) launch_grad_gather_k<4, 8>(g, grid, s);
+    else if (K <= 8) launch_grad_gather_k<8, 4>(g, grid, s);
+    else launch_grad_gather_k<16, 2>(g, grid, s);
+    BFH_HIP(hipGetLastError());
+}
+
+static int acc_bits_for(int64_t range) {
+    int b = 1;
+    while ((int64_t(1) << b) < range) ++b;
+    return b;
+}
+
+void SgdHandle::acc_prepare(int64_t triples) {
+    const size_t n = static_cast<size_t>(triples);
+    if (acc_coef_.size() < n) acc_coef_.resize(n);
+    if (acc_neg_.size() < n) acc_neg_.resize(n);
+    if (acc_key_b_.size() < n) acc_key_b_.resize(n);
+    if (acc_idx_b_.size() < n) acc_idx_b_.resize(n);
+    if (acc_iota_n_ < triples) {
+        acc_iota_.resize(n);
+        launch_incidence_iota(nullptr, triples, nullptr, acc_iota_.get(), stream);
+        acc_iota_n_ = triples;
+    }
+}
+
+void SgdHandle::acc_build_positive_list(const SgdParams& p, int start_x, int next_x) {
+    const int64_t n = p.chunk_nnz;
+    BFH_REQUIRE(n < (int64_t(1) << 31), "gradient gather: chunk of 2^31 or more interactions");
+    if (resident_ && acc_pos_gen_ == csr_generation_ && acc_pos_start_ == start_x && acc_pos_next_ == next_x && acc_pos_n_ == n) return;
+    if (acc_pkey_.size() < static_cast<size_t>(n)) acc_pkey_.resize(static_cast<size_t>(n));
+    if (acc_pidx_.size() < static_cast<size_t>(n)) acc_pidx_.resize(static_cast<size_t>(n));
+    // the chunk's keys are the sort keys as they are (item ids are non-negative int32)
+    device_sort_pairs_u32(reinterpret_cast<const uint32_t*>(p.keys), acc_pkey_.get(), acc_iota_.get(), acc_pidx_.get(), n, acc_bits_for(Q_rows_),
+                          acc_tmp_, stream);
+    acc_pos_gen_ = resident_ ? csr_generation_ : -1;
+    acc_pos_start_ = start_x; acc_pos_next_ = next_x; acc_pos_n_ = n;
+}
+
+void SgdHandle::acc_gather(const SgdParams& p, int num_neg, bool do_pos, bool do_neg, const float sab_pos[3], const float sab_neg[3],
+                           bool use_accept, bool with_bias) {
+    const int64_t n = p.chunk_nnz, triples = n * num_neg;
+    GatherParams g{};
+    g.rows = p.rows;
+    g.coef = acc_coef_.get();
+    g.accept = use_accept ? acc_neg_.get() : nullptr;
+    g.P = p.P; g.Q = p.Q;
+    g.gradQ = p.gradQ;
+    g.gradQb = with_bias ? p.gradQb : nullptr;
+    g.cntQ = pcn_ ? p.cntQ : nullptr;
+    g.num_neg = num_neg; g.vdim = vdim_; g.Q_rows = Q_rows_;
+    const int64_t waves = static_cast<int64_t>(num_cus_) * (waves_per_cu_ > 0 ? waves_per_cu_ : 16);
+    if (do_pos) {
+        g.inc_key = acc_pkey_.get(); g.inc_idx = acc_pidx_.get(); g.n = n; g.pos_list = 1;
+        g.sign = sab_pos[0]; g.a = sab_pos[1]; g.b = sab_pos[2];
+        launch_grad_gather(g, waves, stream);
+    }
+    if (do_neg) {
+        device_sort_pairs_u32(acc_neg_.get(), acc_key_b_.get(), acc_iota_.get(), acc_idx_b_.get(), triples, acc_bits_for(static_cast<int64_t>(Q_rows_) + 1),
+                              acc_tmp_, stream);
+        g.inc_key = acc_key_b_.get(); g.inc_idx = acc_idx_b_.get(); g.n = triples; g.pos_list = 0;
+        g.sign = sab_neg[0]; g.a = sab_neg[1]; g.b = sab_neg[2];
+        launch_grad_gather(g, waves, stream);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 SgdHandle::~SgdHandle() {
     if (stream) (void)hipStreamDestroy(stream);
 }
@@ -450,10 +655,12 @@ void SgdHandle::set_mode(const std::string& name, int64_t v) {
     else if (name == "im_presample") im_presample_ = v != 0;
     else if (name == "im_drain_only") im_drain_only_ = v != 0;
     else if (name == "im_single_wave") im_single_wave_ = v != 0;
+    else if (name == "im_trace") { BFH_REQUIRE(v >= 0, "im_trace is a capacity in triples"); im_trace_.resize(static_cast<size_t>(v), true, stream); sync_stream(); }
     else if (name == "im_force_queues") { BFH_REQUIRE(v >= 0 && v <= 8, "im_force_queues must be in [0,8]"); im_force_queues_ = static_cast<int>(v); }
     else if (name == "im_max_stale") { BFH_REQUIRE(v >= 1, "im_max_stale must be positive"); im_max_stale_ = static_cast<int>(v); }
     else if (name == "xcd_v4") xcd_v4_ = v != 0;
     else if (name == "xcd_hot_tau") { BFH_REQUIRE(v >= 0, "xcd_hot_tau is a permille value >= 0"); xcd_hot_tau_ = static_cast<int>(v); }
+    else if (name == "accum_two_pass") accum_two_pass_ = v != 0;
     else if (name == "prefetch") prefetch_ = static_cast<int>(v);
     else if (name == "waves_per_cu") waves_per_cu_ = static_cast<int>(v);
     else if (name == "chunk") { BFH_REQUIRE(v >= 64 && v % 64 == 0, "chunk must be a positive multiple of 64"); chunk_ = static_cast<int>(v); chunk_set_ = true; }
@@ -469,6 +676,7 @@ void SgdHandle::device_buffer(const std::string& name, void** p, size_t* bytes) 
         {"countP", cntP_.get(), cntP_.bytes()}, {"countQ", cntQ_.get(), cntQ_.bytes()},
         {"velP", velP_.get(), velP_.bytes()}, {"velQ", velQ_.get(), velQ_.bytes()},
         {"momP", momP_.get(), momP_.bytes()}, {"momQ", momQ_.get(), momQ_.bytes()},
+        {"im_trace", im_trace_.get(), im_trace_.bytes()},
     };
     for (auto& t : tab)
         if (name == t.n) {

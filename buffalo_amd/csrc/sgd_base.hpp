@@ -26,6 +26,40 @@ struct SgdParams {  // kernel-visible constants
     uint32_t seed, epoch;
 };
 
+// ------------------------------------------------------------------------------------------------
+// Gradient accumulation without per-triple atomics (adam / adagrad BPRMF: bpr.cc:138-156; WARP:
+// warp.cc:151-165).  P and Q are frozen inside an epoch, so the three gradient rows of a triple are
+// plain sums and any grouping of the terms is the reference's result up to fp32 summation order:
+//   pass 1 (user-major, the update kernels): score, coefficient c_t (sigmoid-table logit / WARP's Phi) and
+//          the negative of every triple -> two 4-byte arrays; gradP[u] is summed in registers over the
+//          user's run (owner computes);
+//   pass 2 (`grad_gather_kernel`): the triples seen from the item side.  The incidences (item, triple)
+//          are sorted by item -- positives once per resident matrix (that is the CSC order), negatives
+//          with one radix sort per call -- and a wave sums  sign * c_t * P[u_t]  over a run of one item's
+//          incidences in registers: gradQ receives ONE atomic row add per run instead of one per triple.
+// The item-side row term of WARP ( -reg * q, and -/+ Phi * q for the L2 score, warp.cc:42-52) factors
+// out of the sum:  (a * sum c + b * n) * q_item, added at the flush.
+// ------------------------------------------------------------------------------------------------
+struct GatherParams {
+    const uint32_t* inc_key;   // [n] item of every incidence, ascending; entries >= Q_rows (rejected positives) are ignored
+    const int32_t* inc_idx;    // [n] pos_list: chunk-local nnz position; else chunk-local triple index (position * num_neg + slot)
+    int64_t n;
+    const int32_t* rows;       // [chunk nnz] user of every nnz position
+    const float* coef;         // [chunk nnz * num_neg] coefficient of every triple (pass 1)
+    const uint32_t* accept;    // [chunk nnz * num_neg] or null: the triple counts only if accept[t] < Q_rows (WARP: its negative)
+    const float* P;
+    const float* Q;            // read only when a != 0 or b != 0
+    float* gradQ;
+    float* gradQb;             // or null
+    int* cntQ;                 // or null (per_coordinate_normalize)
+    int num_neg, vdim, Q_rows;
+    int pos_list;              // 1: one incidence per nnz position, coefficient = sum over its slots
+    float sign, a, b;          // gradQ[item] += sign * sum(c p_u) + (a * sum(c) + b * n) * q_item
+};
+void launch_grad_gather(const GatherParams& g, int64_t max_waves, hipStream_t s);
+// key[t] = keys[t], idx[t] = t   (the unsorted positive incidence list of a chunk)
+void launch_incidence_iota(const int32_t* keys, int64_t n, uint32_t* key_out, int32_t* idx_out, hipStream_t s);
+
 class SgdHandle : public HandleBase {
  public:
     explicit SgdHandle(int kind) : kind_(kind) {}
@@ -53,6 +87,12 @@ class SgdHandle : public HandleBase {
     void advance_progress(int start_x, int next_x, const int64_t* indptr_host);
     virtual void parse_specific() = 0;
     virtual bool project_unit_ball() const { return false; }
+    // two-pass accumulation: buffers of pass 1 for a chunk of `triples` triples; the item-sorted positive incidence
+    // list of the staged chunk (cached for a resident matrix); the item-side gather over both lists
+    void acc_prepare(int64_t triples);
+    void acc_build_positive_list(const SgdParams& p, int start_x, int next_x);
+    void acc_gather(const SgdParams& p, int num_neg, bool do_pos, bool do_neg, const float sab_pos[3], const float sab_neg[3], bool use_accept,
+                    bool with_bias);
 
  public:
     int kind_;  // 0 bpr, 1 warp
@@ -79,12 +119,14 @@ class SgdHandle : public HandleBase {
     int xcd_merge_mean_ = 0;
     int im_single_wave_ = 0, im_force_queues_ = 0;   // test hooks: one wave drains all queues in order; number of queues for that run
     int im_drain_only_ = 0;        // test hook: skip the owner-XCD launch, the atomic drain launch does everything
+    DevBuf<int32_t> im_trace_;     // test hook ("im_trace" = capacity): table index of every triple of a single-wave call
     int im_drift_budget_milli_ = 1000;  // policy 3: lr-weighted positive steps of a row per merge interval above which its negatives go chip-wide
     int im_presample_ = 1;         // policy 3: draw the call's negatives in CSR order before the walk
     int im_blocks_ = 0;            // policy 3: runs an item's entries are cut into inside a queue (0 = from the learning rate)
     int im_max_stale_ = 64;        // policy 3: updates of one item row that may be in flight unseen by the other waves
     int xcd_fresh_ = -1, xcd_v4_ = 0;  // re-read before store; float4-per-lane rows (hot-row atomics then cost 4x the line operations)
     int xcd_hot_tau_ = 100;        // permille: tolerated collision probability of a replica row (0 = no hot rows)
+    int accum_two_pass_ = 1;       // adam / adagrad / WARP: item-side gradients by the sorted gather (0: one atomic row add per triple)
     int64_t csr_generation_ = 0;   // bumped by set_resident_csr
     bool chunk_set_ = false;
 
@@ -100,6 +142,17 @@ class SgdHandle : public HandleBase {
     bool have_cum_ = false;
     int64_t cum_total_ = 0;
     int num_cus_ = 256;
+
+    // two-pass accumulation
+    DevBuf<float> acc_coef_;                 // [triples] pass-1 coefficient
+    DevBuf<uint32_t> acc_neg_;               // [triples] pass-1 negative (Q_rows: none)
+    DevBuf<uint32_t> acc_key_a_, acc_key_b_; // sort input / output keys (negatives)
+    DevBuf<int32_t> acc_iota_, acc_idx_b_;   // 0..n-1, sorted triple indices
+    DevBuf<uint32_t> acc_pkey_;              // positives sorted by item
+    DevBuf<int32_t> acc_pidx_;
+    DevBuf<char> acc_tmp_;
+    int64_t acc_iota_n_ = 0, acc_pos_gen_ = -1, acc_pos_n_ = -1;
+    int acc_pos_start_ = -1, acc_pos_next_ = -1;
 
     EventTimer t_main_, t_opt_, t_aux_;
 };

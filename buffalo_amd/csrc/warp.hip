@@ -27,6 +27,11 @@ struct WarpConsts {
     int64_t total;
     double* loss_out;        // [0] partial loss sum
     unsigned long long* cnt; // [0] scored negatives, [1] accepted positives
+    // two-pass accumulation (sgd_base.hpp GatherParams): record Phi and the violating negative of every accepted
+    // positive (Q_rows: rejected); the two item-side gradient rows are summed by grad_gather_kernel
+    int two_pass;
+    float* coef_out;         // [total]
+    uint32_t* neg_out;       // [total]
 };
 
 template <int K>
@@ -101,6 +106,8 @@ __global__ __launch_bounds__(256) void warp_update_kernel(SgdParams p, WarpConst
                 my_pos = p.keys[t];
             }
             const int n_here = static_cast<int>((t_end - t0) < 64 ? (t_end - t0) : 64);
+            float my_phi = 0.f;                                     // two-pass: lane j keeps positive j's Phi / negative,
+            uint32_t my_nego = static_cast<uint32_t>(p.Q_rows);    // stored coalesced after the walk
             for (int j = 0; j < n_here; ++j) {
                 const int u = __builtin_amdgcn_readlane(my_u, j);
                 const int pos = __builtin_amdgcn_readlane(my_pos, j);
@@ -201,15 +208,27 @@ __global__ __launch_bounds__(256) void warp_update_kernel(SgdParams p, WarpConst
                     gi.v[k] = idv - c.reg_i * qi.v[k];
                     gj.v[k] = jdv - c.reg_j * qj.v[k];
                 }
-                watomic<K>(gi, p.gradQ + static_cast<size_t>(pos) * vdim, lane, vdim);
-                watomic<K>(gj, p.gradQ + static_cast<size_t>(neg) * vdim, lane, vdim);
-                if (c.pcn && lane == 0) {
-                    atomicAdd(p.cntP + u, 1);
-                    atomicAdd(p.cntQ + pos, 1);
-                    atomicAdd(p.cntQ + neg, 1);
+                if (c.two_pass) {
+                    if (lane == j) {
+                        my_phi = Phi;
+                        my_nego = static_cast<uint32_t>(neg);
+                    }
+                    if (c.pcn && lane == 0) atomicAdd(p.cntP + u, 1);
+                } else {
+                    watomic<K>(gi, p.gradQ + static_cast<size_t>(pos) * vdim, lane, vdim);
+                    watomic<K>(gj, p.gradQ + static_cast<size_t>(neg) * vdim, lane, vdim);
+                    if (c.pcn && lane == 0) {
+                        atomicAdd(p.cntP + u, 1);
+                        atomicAdd(p.cntQ + pos, 1);
+                        atomicAdd(p.cntQ + neg, 1);
+                    }
                 }
                 loss += static_cast<double>(uj - ui) + c.threshold;
                 accepted += 1;
+            }
+            if (c.two_pass && t < t_end) {
+                c.coef_out[t] = my_phi;
+                c.neg_out[t] = my_nego;
             }
         }
         flush_user();
@@ -277,6 +296,13 @@ class WarpHandle : public SgdHandle {
         c.cnt = cnt_.get();
         BFH_HIP(hipMemsetAsync(scratch_.get(), 0, sizeof(double), stream));
         BFH_HIP(hipMemsetAsync(cnt_.get(), 0, 2 * sizeof(unsigned long long), stream));
+        const bool two_pass = accum_two_pass_ != 0;
+        if (two_pass) {
+            acc_prepare(n);
+            c.two_pass = 1;
+            c.coef_out = acc_coef_.get();
+            c.neg_out = acc_neg_.get();
+        }
         const int64_t n_work = (c.total + c.chunk - 1) / c.chunk;
         dim3 block(256), grid(1);
         if (sequential_) {
@@ -296,6 +322,15 @@ class WarpHandle : public SgdHandle {
         else hipLaunchKernelGGL(warp_update_kernel<16>, grid, block, 0, stream, p, c);
         BFH_HIP(hipGetLastError());
         t_main_.end(slot, stream);
+        if (two_pass) {
+            // gi = Phi * p_u - reg_i q_i, gj = -Phi * p_u - reg_j q_j (warp.cc:30-40); L2 score (Q-11, warp.cc:42-52):
+            // gi = Phi * (p_u - q_i) - reg_i q_i, gj = -Phi * (p_u - q_j) - reg_j q_j
+            const int slot2 = t_aux_.begin(stream);
+            acc_build_positive_list(p, start_x, next_x);
+            const float sab_pos[3] = {1.f, l2_ ? -1.f : 0.f, -reg_i_}, sab_neg[3] = {-1.f, l2_ ? 1.f : 0.f, -reg_j_};
+            acc_gather(p, 1, true, true, sab_pos, sab_neg, true, false);
+            t_aux_.end(slot2, stream);
+        }
         unsigned long long cnt[2] = {0, 0};
         BFH_HIP(hipMemcpyAsync(loss_sum, scratch_.get(), sizeof(double), hipMemcpyDeviceToHost, stream));
         BFH_HIP(hipMemcpyAsync(cnt, cnt_.get(), sizeof(cnt), hipMemcpyDeviceToHost, stream));

@@ -78,19 +78,34 @@ def test_reference_order_replay(oracle):
     assert H.relerr(P[:, :d], Po) < 1e-5 and H.relerr(Q[:, :d], Qo) < 1e-5 and H.relerr(Qb, Qbo) < 1e-5
 
 
-@pytest.mark.parametrize("optimizer,pcn", [("adagrad", False), ("adam", True), ("adam", False)])
-def test_accumulate_modes_parallel(oracle, optimizer, pcn):
-    """adam / adagrad freeze P,Q inside an epoch, so the fully parallel kernel must agree with the
-    sequential oracle up to fp32 summation order (incl. Q-5, Q-6, Q-9)."""
+@pytest.mark.parametrize("optimizer,pcn,kw,hip", [
+    ("adagrad", False, {}, {}),
+    ("adam", True, {}, {}),
+    ("adam", False, {}, {}),
+    ("adagrad", False, {}, dict(accum_two_pass=0)),                  # one atomic row add per triple and row
+    ("adam", True, {}, dict(accum_two_pass=0)),
+    ("adagrad", True, dict(update_j=False, use_bias=False), {}),    # only the positive list is gathered
+    ("adam", False, dict(update_i=False, num_negative_samples=3, d=128), dict(n_chunks=3)),
+    ("adagrad", False, dict(num_negative_samples=1, d=200), dict(resident=True)),   # cached positive list
+])
+def test_accumulate_modes_parallel(oracle, optimizer, pcn, kw, hip):
+    """adam / adagrad freeze P,Q inside an epoch, so the fully parallel path must agree with the
+    sequential oracle up to fp32 summation order (incl. Q-5, Q-6, Q-9).  Default: two passes -- the update kernel
+    records (logit, negative) per triple and keeps gradP in registers, grad_gather_kernel sums the item-side rows
+    over the item-sorted incidence lists; accum_two_pass=0: per-triple atomic row adds."""
     from buffalo_amd.backend import CyBPR
     csr = tiny_csr(U=64, I=80, density=0.2, seed=5)
-    d, vdim = 48, 64
-    opt = bpr_opt(d=d, lr=0.03, num_iters=3, random_seed=3, optimizer=optimizer, per_coordinate_normalize=pcn,
-                  num_negative_samples=2)
-    P, Q, Qb = _factors(csr, d, vdim)
+    kw = dict(kw)
+    d = kw.pop("d", 48)
+    vdim = _vdim(d)
+    kw.setdefault("num_negative_samples", 2)
+    opt = bpr_opt(d=d, lr=0.03, num_iters=3, random_seed=3, optimizer=optimizer, per_coordinate_normalize=pcn, **kw)
+    P, Q, Qb = _factors(csr, d, vdim, bias=opt["use_bias"])
     Po, Qo, Qbo = P[:, :d].copy(), Q[:, :d].copy(), Qb.copy()
-    H.run_oracle_sgd(oracle.OracleBPRMF, opt, csr, Po, Qo, Qbo, epochs=3, modes=DET)
-    H.run_hip_sgd(CyBPR, opt, csr, P, Q, Qb, epochs=3, modes=dict(chunk=64))
+    hip = dict(hip)
+    n_chunks, resident = hip.pop("n_chunks", 1), hip.pop("resident", False)
+    H.run_oracle_sgd(oracle.OracleBPRMF, opt, csr, Po, Qo, Qbo, epochs=3, n_chunks=n_chunks, modes=DET)
+    H.run_hip_sgd(CyBPR, opt, csr, P, Q, Qb, epochs=3, n_chunks=n_chunks, resident=resident, modes=dict(chunk=64, **hip))
     assert H.relerr(P[:, :d], Po) < 1e-4, H.relerr(P[:, :d], Po)
     assert H.relerr(Q[:, :d], Qo) < 1e-4, H.relerr(Q[:, :d], Qo)
     assert H.relerr(Qb, Qbo) < 1e-4
@@ -192,44 +207,79 @@ _item_major_order = H.item_major_order
 
 @pytest.mark.parametrize("d,nn,blocks", [(48, 2, 3), (128, 1, 1), (200, 3, 8)])
 def test_item_major_single_wave_equals_sequential_replay(oracle, d, nn, blocks):
-    """Whole epochs of the item-major kernel against the sequential update path: one wave draining all queues applies
-    the epoch's triples in a known order; replaying the oracle's triples (same counter sampler) in that order through
-    the sequential kernel -- itself pinned on the oracle by test_reference_order_replay -- must give the same model.
-    Tolerance: the two kernels sum a dot product in different lane orders, and two epochs at lr 0.05 through the
-    discontinuous sigmoid table amplify last-bit differences to ~1e-3 of max|value| (the numpy transliteration and
-    the oracle differ by 2e-4 on the same triples in the SAME order); applying the same triples in CSR order instead
-    moves the model by 5-12 %, so 3e-3 separates "same order, same arithmetic" from any scheduling or logic error
-    by more than a factor of ten -- which the last assertion checks."""
+    """Whole epochs of the item-major kernel against the ORACLE's arithmetic: one wave draining all queues applies the
+    epoch's triples in a known order (bfh_bpr_item_major_plan); the oracle's own triples of that epoch (same counter
+    sampler), re-ordered that way and pushed through `oracle.apply_triples` -- the loop body of bpr.cc:119-171 over an
+    explicit list -- must give the same model.
+
+    Why this is a tolerance and not bit equality, quantified: the kernel sums a dot product per lane (float4 columns)
+    and then across lanes, the oracle left to right (omp simd), so x_uij differs in its last bits -- and the sigmoid
+    table index `(int)((x + 6) * 83)` (Q-2) is discontinuous in x.  The kernel records the table index of every triple
+    (test hook "im_trace"), the replay records its own: `flips` = the triples where the two took DIFFERENT table entries
+    (a float32 score within rounding of a boundary, or downstream of such a triple).  Every flipped triple steps its
+    rows by lr * (one table increment, <= 0.003) * |row| differently and later triples inherit it; with no flip the
+    models agree to the 1e-5 rounding floor of the deterministic CSR-order tests.  The bound is exactly that: 1e-5 +
+    2 * flips * lr * max-table-increment (of max|value|).  A scheduling or logic error (a triple applied twice, a stale
+    row, a wrong negative) shows up as thousands of differing indices and a model 5-12 % away (the CSR-order model
+    below)."""
+    import torch
     from buffalo_amd.backend import CyBPR
+    import ref_numpy as R
     csr = tiny_csr(U=300, I=200, density=0.08, seed=3)
     vdim = _vdim(d)
-    opt = bpr_opt(d=d, lr=0.05, min_lr=0.05, num_iters=2, random_seed=5, num_negative_samples=nn)
+    lr = 0.05
+    opt = bpr_opt(d=d, lr=lr, min_lr=lr, num_iters=2, random_seed=5, num_negative_samples=nn)
     P, Q, Qb = _factors(csr, d, vdim)
-    Pr, Qr, Qbr = P.copy(), Q.copy(), Qb.copy()
     P0 = P.copy()
-    Po, Qo, Qbo = P[:, :d].copy(), Q[:, :d].copy(), Qb.copy()
+    Po, Qo, Qbo = P[:, :d].copy(), Q[:, :d].copy(), Qb.copy()           # the oracle's own CSR-order epochs (for the triples)
+    Pr, Qr, Qbr = P[:, :d].copy(), Q[:, :d].copy(), Qb.copy()           # the replay through oracle.apply_triples
     o = H.run_oracle_sgd(oracle.OracleBPRMF, opt, csr, Po, Qo, Qbo, epochs=2, modes=DET, trace=True)
     tr = o.get_trace()
     n = csr.nnz * nn
     assert len(tr) == 2 * n
     order = _item_major_order(csr, 8, blocks, nn)
     assert np.array_equal(np.sort(order), np.arange(n))
-    ref = CyBPR()
-    assert ref.init(H.write_opt(dict(opt, accelerator=True)))
-    ref.set_mode("sequential", 1)
-    ref.initialize_model(Pr, Qr, Qbr, csr.nnz, True)
+    rep = oracle.OracleBPRMF()
+    assert rep.init(H.write_opt(opt))
+    rep.initialize_model(Pr, Qr, Qbr, csr.nnz)
+    # the item-major kernel, one wave, the same two epochs, recording its table indices
+    obj = CyBPR()
+    assert obj.init(H.write_opt(dict(opt, accelerator=True)))
+    for k, v in dict(hogwild_atomic=3, im_single_wave=1, im_force_queues=8, im_blocks=blocks, xcd_sync_updates=1 << 40, im_trace=n).items():
+        obj.set_mode(k, v)
+    obj.initialize_model(P, Q, Qb, csr.nnz, True)
+    obj.set_cumulative_table(H.cum_table(csr, opt), csr.num_items)
+    obj.set_resident_csr(csr.indptr, csr.keys)
+    table = R.exp_table()
+    flips = 0
     for e in range(2):
-        te = tr[e * n:(e + 1) * n][order]
-        ref.update_triples(np.ascontiguousarray(te[:, 0]), np.ascontiguousarray(te[:, 1]), np.ascontiguousarray(te[:, 2]), 0.05)
-    ref.synchronize(True)
-    H.run_hip_sgd(CyBPR, opt, csr, P, Q, Qb, epochs=2, resident=True,
-                  modes=dict(hogwild_atomic=3, im_single_wave=1, im_force_queues=8, im_blocks=blocks, xcd_sync_updates=1 << 40))
-    assert not np.array_equal(Pr, P0)                      # the replay moved the model
-    tol = 3e-3
-    for a, b in ((P, Pr), (Q, Qr), (Qb, Qbr)):
-        assert H.relerr(a, b) < tol, H.relerr(a, b)
+        te = np.ascontiguousarray(tr[e * n:(e + 1) * n][order])
+        obj.add_jobs(0, csr.num_users, csr.indptr, None)
+        obj.update_parameters()
+        idx_hip = obj.device_tensor("im_trace", (n,), dtype="int32").cpu().numpy()
+        torch.cuda.synchronize()
+        # the oracle's model BEFORE each of its steps gives the index the reference arithmetic takes (numpy float32, same loop)
+        Pn, Qn, Qbn = Pr.copy(), Qr.copy(), Qbr.copy()
+        idx_ref = np.empty(n, np.int32)
+        for t, (u, i, j) in enumerate(te):
+            x = np.float32(np.float32(np.dot(Pn[u], Qn[i] - Qn[j])) + np.float32(Qbn[i, 0] - Qbn[j, 0]))
+            idx_ref[t] = 1000 if x > 6 else (-1 if x < -6 else int(np.float32(x + np.float32(6)) * np.float32(83)))
+            R.bpr_sgd_step(Pn, Qn, Qbn, u, i, j, lr, opt, table)
+        flips += int((idx_hip != idx_ref).sum())
+        assert np.abs(idx_hip - idx_ref).max() <= 1                 # neighbouring table entries only: rounding, never another triple
+        rep.apply_triples(np.ascontiguousarray(te[:, 0]), np.ascontiguousarray(te[:, 1]), np.ascontiguousarray(te[:, 2]), lr)
+    obj.synchronize(True)
+    assert not np.array_equal(Pr, P0[:, :d])                      # the replay moved the model
+    step = float(np.abs(np.diff(table)).max())                    # largest logit increment between two table entries
+    tol = 1e-5 + 2.0 * flips * lr * step
+    errs = (H.relerr(P[:, :d], Pr), H.relerr(Q[:, :d], Qr), H.relerr(Qb, Qbr))
+    print("\nitem-major replay d=%d nn=%d blocks=%d: %d triples, %d took a neighbouring table entry, max table increment %.2e, "
+          "tol %.2e, errors %s" % (d, nn, blocks, 2 * n, flips, step, tol, errs))
+    assert flips <= 2 * n // 200                                    # < 0.5 % of the triples sit at a boundary
+    for err in errs:
+        assert err < tol, (err, tol, flips)
     # the order matters far more than that: the CSR-order model is somewhere else (the comparison is not vacuous)
-    assert H.relerr(P[:, :d], Po) > 10 * tol and H.relerr(Pr[:, :d], Po) > 10 * tol
+    assert H.relerr(P[:, :d], Po) > 10 * max(tol, 1e-3) and H.relerr(Pr, Po) > 10 * max(tol, 1e-3)
 
 
 def test_compute_loss_matches_oracle(oracle):

@@ -31,11 +31,15 @@ def _run_pair(oracle, csr, d, opt, epochs, scale, modes=None, seed=3):
     (256, dict(max_trials=30, threshold=0.5, reg_u=0.01, reg_i=0.02, reg_j=0.03), 0.1),
     (40, dict(max_trials=8, threshold=0.2, optimizer="adam", per_coordinate_normalize=True), 0.4),
     (32, dict(max_trials=20, threshold=0.5, score_func="l2"), 0.4),
+    (96, dict(max_trials=12, threshold=0.4, score_func="l2", reg_i=0.02, reg_j=0.01, per_coordinate_normalize=True), 0.3),
 ])
-def test_epochs_match_oracle(oracle, d, kw, scale):
+@pytest.mark.parametrize("two_pass", [1, 0])
+def test_epochs_match_oracle(oracle, d, kw, scale, two_pass):
+    """two_pass=1 (default): the item-side gradient rows are summed by the sorted gather (grad_gather_kernel);
+    two_pass=0: one atomic row add per accepted positive and row."""
     csr = tiny_csr(U=48, I=90, density=0.12, seed=17)
     opt = warp_opt(d=d, random_seed=11, num_iters=3, lr=0.05, **kw)
-    o, obj, (P, Q), (Po, Qo) = _run_pair(oracle, csr, d, opt, 3, scale, modes=dict(chunk=64))
+    o, obj, (P, Q), (Po, Qo) = _run_pair(oracle, csr, d, opt, 3, scale, modes=dict(chunk=64, accum_two_pass=two_pass))
     so, sg = o.stats(), obj.stats()
     assert sg["scored_negatives"] == so["scored_negatives"]      # identical trial sequences (Q-10)
     assert sg["accepted"] == so["updates"]
@@ -51,7 +55,8 @@ def test_sequential_equals_parallel(oracle):
     csr = tiny_csr(U=40, I=64, density=0.15, seed=23)
     opt = warp_opt(d=64, random_seed=5, num_iters=2, max_trials=16, threshold=0.4)
     outs = []
-    for modes in (dict(sequential=1), dict(chunk=64), dict(chunk=256, waves_per_cu=4)):
+    for modes in (dict(sequential=1, accum_two_pass=0), dict(sequential=1), dict(chunk=64), dict(chunk=256, waves_per_cu=4),
+                  dict(chunk=64, accum_two_pass=0)):
         _, obj, (P, Q), _ = _run_pair(oracle, csr, 64, opt, 2, 0.3, modes=modes)
         outs.append((P, Q, obj.stats()["scored_negatives"]))
     for P, Q, sc in outs[1:]:
