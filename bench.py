@@ -305,13 +305,19 @@ def main():
     if "BFH_DEVICE_OVERRIDE" in os.environ:
         local_rank = int(os.environ["BFH_DEVICE_OVERRIDE"])
     torch.cuda.set_device(local_rank)
+    comm_mode = "none"
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("BFH_DIST_BACKEND", "nccl")
+        # torch.distributed is the control plane only (rendezvous, barrier, max of the elapsed times: gloo on CPU tensors);
+        # the data plane is the library's own RCCL rank (bfh_comm_*).  BFH_COMM=torch (or a gloo-only test run) selects the
+        # older path that all-reduces the backend's buffers through torch.distributed instead.
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("cpu:gloo,cuda:nccl")
+            comm_mode = os.environ.get("BFH_COMM", "library")
         else:
             dist.init_process_group(backend)
+            comm_mode = "torch"
     assert world == args.gpus, "WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus)
 
     csr = load_matrix(args.shape, args.seed)
@@ -347,7 +353,25 @@ def main():
     obj.set_cumulative_table(np.zeros(I, np.int64), I)
     obj.set_resident_csr(ip, keys)        # inputs resident in HBM before the timed region starts
     obj.set_shard(nnz_off, world)
-    dp = DataParallelSGD(HipEngine(obj, I, D, opt["optimizer"]), opt["optimizer"]) if world > 1 else None
+    comm, comm_note = None, None
+    if comm_mode == "library":
+        from buffalo_amd.backend import Comm
+        ok = 1
+        try:
+            uid = torch.frombuffer(bytearray(Comm.unique_id() if rank == 0 else bytes(128)), dtype=torch.uint8).clone()
+            dist.broadcast(uid, src=0)                       # CPU tensor -> gloo
+            comm = Comm(world, rank, bytes(uid.numpy().tobytes()), local_rank)
+            comm.self_test()
+        except Exception as e:                                # every rank must take the same path
+            ok, comm_note = 0, "%s: %s" % (type(e).__name__, e)
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            obj.set_comm(comm)
+        else:
+            comm, comm_mode = None, "torch"
+            comm_note = "library communicator unavailable (%s): fell back to torch.distributed" % comm_note
+    dp = DataParallelSGD(HipEngine(obj, I, D, opt["optimizer"]), opt["optimizer"]) if (world > 1 and comm_mode == "torch") else None
     edges = np.linspace(0, n_local_users, (args.minibatches if world > 1 else 1) + 1).astype(int)
 
     def step():
@@ -361,8 +385,9 @@ def main():
         obj.update_parameters()
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            dist.all_reduce(torch.zeros(1))                  # CPU tensor: a gloo barrier that never touches the data plane
         torch.cuda.synchronize()
 
     for _ in range(warmup):
@@ -372,10 +397,12 @@ def main():
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    if comm is not None:
+        obj.comm_flush()                                     # the exchange still in flight belongs to the timed region
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     st = obj.stats()
@@ -404,8 +431,10 @@ def main():
             "config": {"workload": "BPRMF sgd, %s-shaped synthetic (%d x %d, %d nnz%s), d=%d, 1 negative/positive, "
                                    "uniform sampling + verify_neg, CSR + factors resident in HBM"
                                    % (args.shape, U, I, nnz, "" if args.scaling == "strong" or world == 1 else " per GPU", D),
-                       "parallelism": "1 GPU" if world == 1 else "dp%d: users sharded, Q replicated, %d RCCL delta all-reduce/epoch"
-                                      % (world, args.minibatches),
+                       "parallelism": "1 GPU" if world == 1 else "dp%d: users sharded, Q replicated, %.1f RCCL delta all-reduce/epoch (%s)"
+                                      % (world, (st["exchanges"] / max(steps, 1)) if comm is not None else args.minibatches,
+                                         "inside the library, pipelined behind the next walk" if comm is not None
+                                         else (comm_note or "through torch.distributed")),
                        "hogwild": {"0": "write-through (sc1) racy stores on item rows", "1": "fp32 atomics on item rows",
                                    "2": "per-XCD item-factor replicas (plain stores through the XCD's L2, merged by the delta rule "
                                         "%.1f times per epoch); popular rows stay chip-wide on fp32 atomics"
@@ -437,7 +466,9 @@ def main():
             out["extra"] = extra
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()
+        dist.all_reduce(torch.zeros(1))
+        del obj
+        comm = None
         dist.destroy_process_group()
 
 

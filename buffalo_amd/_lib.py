@@ -21,7 +21,7 @@ class Stats(C.Structure):
     _fields_ = [("samples", C.c_int64), ("scored_negatives", C.c_int64), ("accepted", C.c_int64),
                 ("launches", C.c_int64), ("kernel_ms", C.c_double), ("optimizer_ms", C.c_double),
                 ("aux_ms", C.c_double), ("h2d_bytes", C.c_double), ("d2h_bytes", C.c_double),
-                ("merges", C.c_int64)]
+                ("merges", C.c_int64), ("exchanges", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -55,6 +55,8 @@ def _sgd_sigs(pfx):
         pfx + "stream": (_vp, [_vp]),
         pfx + "get_stats": (_i32, [_vp, C.POINTER(Stats)]),
         pfx + "reset_stats": (_i32, [_vp]),
+        pfx + "set_comm": (_i32, [_vp, _vp]),
+        pfx + "comm_flush": (_i32, [_vp]),
     }
 
 
@@ -64,6 +66,15 @@ SIGNATURES = {
     "bfh_device_count": (_i32, []),
     "bfh_bpr_update_triples": (_i32, [_vp, _i64, _pi32, _pi32, _pi32, _f64]),
     "bfh_bpr_item_major_plan": (_i32, [_i32, _pi64, _i32, _i64, C.POINTER(C.c_int), _pi64, _pi64, _pi64]),
+    "bfh_comm_unique_id": (_i32, [C.c_char_p, _sz]),
+    "bfh_comm_create": (_vp, [_i32, _i32, C.c_char_p, _i32]),
+    "bfh_comm_destroy": (None, [_vp]),
+    "bfh_comm_rank": (_i32, [_vp]),
+    "bfh_comm_size": (_i32, [_vp]),
+    "bfh_comm_self_test": (_i32, [_vp]),
+    "bfh_comm_all_reduce_f64": (_i32, [_vp, _pf64, _i32]),
+    "bfh_als_set_comm": (_i32, [_vp, _vp]),
+    "bfh_als_publish_rows": (_i32, [_vp, _i32, _pi32, _i32]),
     "bfh_als_create": (_vp, []),
     "bfh_als_destroy": (None, [_vp]),
     "bfh_als_init": (_i32, [_vp, C.c_char_p]),

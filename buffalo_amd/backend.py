@@ -48,6 +48,46 @@ class _DeviceView:
         self._owner = owner
 
 
+class Comm:
+    """One RCCL rank (`bfh_comm_*`): the multi-GPU plumbing inside the library.  Rank 0 makes the id with
+    `Comm.unique_id()` and hands the 128 bytes to the other ranks (any side channel); every rank then builds
+    `Comm(world, rank, uid, device)` and attaches it with `obj.set_comm(comm)`.  Keep it alive as long as the objects."""
+
+    def __init__(self, world, rank, uid, device):
+        self._L = lib()
+        if len(uid) != 128:
+            raise ValueError("the RCCL unique id is 128 bytes")
+        self._h = self._L.bfh_comm_create(int(world), int(rank), bytes(uid), int(device))
+        if not self._h:
+            raise BuffaloHipError((self._L.bfh_last_error(None) or b"comm_create failed").decode())
+        self.world, self.rank = int(world), int(rank)
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        L = lib()
+        if L.bfh_comm_unique_id(buf, 128) < 0:
+            raise BuffaloHipError((L.bfh_last_error(None) or b"comm_unique_id failed").decode())
+        return buf.raw
+
+    def self_test(self):
+        check(self._h, self._L.bfh_comm_self_test(self._h))
+
+    def all_reduce(self, values):
+        """Sum of a small list of host doubles over the ranks (loss sums)."""
+        arr = (C.c_double * len(values))(*[float(v) for v in values])
+        check(self._h, self._L.bfh_comm_all_reduce_f64(self._h, arr, len(values)))
+        return [float(v) for v in arr]
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._L.bfh_comm_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
 class _Base:
     _PFX = None
 
@@ -92,6 +132,11 @@ class _Base:
 
     def stream(self):
         return getattr(self._L, self._PFX + "stream")(self._h)
+
+    def set_comm(self, comm):
+        """Attach an RCCL rank (`Comm`); None detaches.  From then on the object exchanges with its peers by itself."""
+        self._keep["comm"] = comm
+        self._call("set_comm", comm._h if comm is not None else None)
 
     def device_buffer(self, name):
         p, n = C.c_void_p(), C.c_size_t()
@@ -180,6 +225,10 @@ class _SgdBase(_Base):
     def set_shard(self, nnz_offset, num_shards):
         self._call("set_shard", int(nnz_offset), int(num_shards))
 
+    def comm_flush(self):
+        """Finish the exchange that is still in flight (the model then holds every rank's updates)."""
+        self._call("comm_flush")
+
 
 class CyBPR(_SgdBase):
     _PFX = "bfh_bpr_"
@@ -231,6 +280,12 @@ class CyALS(_Base):
 
     def synchronize(self, device_to_host):
         self._call("synchronize", int(bool(device_to_host)))
+
+    def publish_rows(self, axis, bounds):
+        """Multi-GPU: after `partial_update` on this rank's rows of `axis`, exchange the solved row blocks
+        (`bounds` = world_size + 1 row boundaries, the same on every rank)."""
+        b = np.ascontiguousarray(bounds, dtype=np.int32)
+        self._call("publish_rows", int(axis), _ptr(b, C.c_int32), int(b.shape[0]))
 
 
 class CyCFR(_Base):

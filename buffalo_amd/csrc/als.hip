@@ -72,6 +72,12 @@ int bfh_als_device_buffer(void* h, const char* name, void** dptr, size_t* bytes)
     return guarded(h, [&] { static_cast<AlsHandle*>(h)->device_buffer(name ? name : "", dptr, bytes); return BFH_OK; });
 }
 void* bfh_als_stream(void* h) { return h ? static_cast<void*>(static_cast<AlsHandle*>(h)->stream) : nullptr; }
+int bfh_als_set_comm(void* h, void* comm) {
+    return guarded(h, [&] { static_cast<AlsHandle*>(h)->set_comm(static_cast<bfh::Comm*>(comm)); return BFH_OK; });
+}
+int bfh_als_publish_rows(void* h, int axis, const int* bounds, int n_bounds) {
+    return guarded(h, [&] { static_cast<AlsHandle*>(h)->publish_rows(axis, bounds, n_bounds); return BFH_OK; });
+}
 int bfh_als_get_stats(void* h, bfh_stats* out) {
     return guarded(h, [&] { *out = static_cast<AlsHandle*>(h)->stats; return BFH_OK; });
 }

@@ -20,6 +20,7 @@
 #include <type_traits>
 
 #include "common.hpp"
+#include "comm.hpp"
 
 namespace bfh {
 
@@ -2050,6 +2051,33 @@ class AlsHandle : public HandleBase {
         BFH_HIP(hipStreamSynchronize(stream));
     }
 
+    // Multi-GPU: rows of the side being solved are sharded, both factor matrices replicated.
+    // After a half-epoch in which rank r solved rows [bounds[r], bounds[r+1]) every rank receives every block: the uneven
+    // all-gather as one group of ncclBroadcast calls (direct xGMI copies).  Every row is solved by exactly one rank from
+    // identical inputs, so the replicas stay bit-identical to the single-GPU run.
+    void publish_rows(int axis, const int* bounds, int n_bounds) {
+        BFH_REQUIRE(model_, "publish_rows before initialize_model");
+        BFH_REQUIRE(comm_, "publish_rows before bfh_als_set_comm");
+        BFH_REQUIRE(axis == 0 || axis == 1, "axis must be 0 or 1");
+        BFH_REQUIRE(bounds && n_bounds == comm_->size() + 1, "publish_rows: need world_size + 1 row boundaries");
+        const int rows = axis == 0 ? P_rows_ : Q_rows_;
+        BFH_REQUIRE(bounds[0] == 0 && bounds[n_bounds - 1] == rows, "publish_rows: boundaries must cover [0, rows)");
+        float* F = axis == 0 ? P_.get() : Q_.get();
+        comm_->group_start();
+        for (int r = 0; r + 1 < n_bounds; ++r) {
+            BFH_REQUIRE(bounds[r] <= bounds[r + 1], "publish_rows: boundaries must ascend");
+            const size_t cnt = static_cast<size_t>(bounds[r + 1] - bounds[r]) * vdim_;
+            comm_->broadcast_bytes(F + static_cast<size_t>(bounds[r]) * vdim_, cnt * sizeof(float), r, stream);
+        }
+        comm_->group_end();
+        BFH_HIP(hipStreamSynchronize(stream));
+        stats.exchanges += 1;
+    }
+    void set_comm(Comm* c) {
+        BFH_REQUIRE(!c || c->device == device, "set_comm: the communicator lives on another device than this handle");
+        comm_ = c;
+    }
+
     void set_mode(const std::string& name, int64_t v) {
         if (name == "als_writeback") writeback_ = v != 0;
         else if (name == "als_v1") force_v1_ = v != 0;
@@ -2093,6 +2121,7 @@ class AlsHandle : public HandleBase {
     DevBuf<float> scratch_;
     std::map<std::tuple<int, int, int>, std::unique_ptr<WorkList>> work_cache_;
     EventTimer t_main_, t_aux_;
+    Comm* comm_ = nullptr;   // not owned
 };
 
 }  // namespace bfh

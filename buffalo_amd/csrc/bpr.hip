@@ -40,6 +40,8 @@
 
 #include <algorithm>
 
+#include "comm.hpp"
+
 namespace bfh {
 
 struct BprConsts {
@@ -784,7 +786,16 @@ class BprHandle : public SgdHandle {
         const double inflight = (!im_prefetch() ? 0.25 : (c.fresh ? 0.5 : 2.0)) * queue_waves;
         const double tau = xcd_hot_tau_ * 1e-3;
         // the staleness budgets are stated for lr = 0.05 and scale with 1 / lr: what matters is how far a row moves
-        const int64_t sync_updates = xcd_sync_updates_ > 0 ? xcd_sync_updates_ : int64_t(1) << 23;
+        int64_t sync_updates = xcd_sync_updates_ > 0 ? xcd_sync_updates_ : int64_t(1) << 23;
+        if (comm_) {
+            // multi-GPU: every merge segment is an exchange point, and the exchange of a segment travels behind the NEXT
+            // segment's walk -- one segment late.  A late delta costs more the longer the interval and the larger lr: at
+            // BASELINE scale and the reference's default lr, 8 ranks with ONE delayed exchange per epoch leave the popular
+            // items' biases 40 % off the single-process run, two 14 %, four 1.5 % (profiles/r02_local_sgd_study_*.json), so a
+            // call is cut into at least 4 exchange segments, more at large lr; "comm_segments" pins it
+            const int64_t segs = comm_segments_ > 0 ? comm_segments_ : std::min<int64_t>(8, std::max<int64_t>(4, static_cast<int64_t>(std::ceil(c.lr * 80.0))));
+            sync_updates = std::min<int64_t>(sync_updates, std::max<int64_t>(1, (c.total + segs - 1) / segs));
+        }
         int64_t q_entries[kImMaxQueues] = {0};
         for (int x = 0; x < nq; ++x) q_entries[x] = im_qbeg_[x + 1] - im_qbeg_[x];
         const ImPlan plan = im_make_plan(nq, q_entries, num_neg_, sync_updates);
@@ -851,9 +862,16 @@ class BprHandle : public SgdHandle {
             stats.launches += 1;
             slot = t_aux_.begin(stream);
             im_launch(p, c, q, grid_waves, true);
+            // multi-GPU: the other ranks' deltas of the previous exchange point land in Q before the replicas are folded in and
+            // refreshed; this segment's own delta goes out behind the merge and travels while the next walk runs
+            exchange_finish(true);
             xcd_merge(sgm + 1 < segments, c.hot, true);
             t_aux_.end(slot, stream);
             stats.merges += 1;
+            if (comm_) {
+                exchange_weights(static_cast<double>(seg_slices) * plan.slice_len, c.lr, num_neg_, uniform_);
+                exchange_begin();
+            }
         }
         im_expect_done_ = c.total;
     }
@@ -1015,8 +1033,22 @@ class BprHandle : public SgdHandle {
         BprConsts c = consts(current_lr());
         c.total = n * num_neg_;
         if (compute_loss_) BFH_HIP(hipMemsetAsync(scratch_.get(), 0, sizeof(double), stream));
-        if (c.atomic == 3) launch_item_major(p, c, start_x, next_x);
-        else launch<false>(p, c, start_x, next_x);
+        if (comm_ && optimizer_ == "sgd") {
+            exchange_arm();
+            // the popularity every rank weighs its rows by: the resident matrix when there is one, else this call's chunk
+            exchange_histogram(resident_ ? keys_.get() : p.keys, resident_ ? resident_nnz_ : n);
+        }
+        if (c.atomic == 3) {
+            launch_item_major(p, c, start_x, next_x);
+        } else {
+            if (optimizer_ == "sgd") exchange_finish();
+            launch<false>(p, c, start_x, next_x);
+            if (comm_ && optimizer_ == "sgd") {
+                exchange_weights(static_cast<double>(c.total), c.lr, num_neg_, uniform_);
+                exchange_begin();
+            }
+        }
+        if (comm_ && !comm_overlap_) exchange_finish();
         if (compute_loss_) BFH_HIP(hipMemcpyAsync(loss_sum, scratch_.get(), sizeof(double), hipMemcpyDeviceToHost, stream));
         sync_stream();
         im_check_done();
@@ -1028,6 +1060,7 @@ class BprHandle : public SgdHandle {
     void update_triples(int64_t n, const int32_t* users, const int32_t* pos, const int32_t* neg, double lr) {
         BFH_REQUIRE(model_on_gpu_, "update_triples before initialize_model(..., set_gpu=True)");
         if (n <= 0) return;
+        exchange_finish();
         inj_.resize(static_cast<size_t>(3 * n));
         BFH_HIP(hipMemcpyAsync(inj_.get(), users, n * sizeof(int32_t), hipMemcpyHostToDevice, stream));
         BFH_HIP(hipMemcpyAsync(inj_.get() + n, pos, n * sizeof(int32_t), hipMemcpyHostToDevice, stream));
@@ -1052,6 +1085,7 @@ class BprHandle : public SgdHandle {
     double compute_loss(int n, const int32_t* users, const int32_t* pos, const int32_t* neg) {
         BFH_REQUIRE(model_on_gpu_, "compute_loss before initialize_model(..., set_gpu=True)");
         if (n <= 0) return 0.0;  // the reference divides by zero here (bpr.cc:243); callers guard (bpr.py:141)
+        exchange_finish();
         inj_.resize(static_cast<size_t>(3) * n);
         BFH_HIP(hipMemcpyAsync(inj_.get(), users, n * sizeof(int32_t), hipMemcpyHostToDevice, stream));
         BFH_HIP(hipMemcpyAsync(inj_.get() + n, pos, n * sizeof(int32_t), hipMemcpyHostToDevice, stream));
@@ -1187,6 +1221,12 @@ int bfh_bpr_item_major_plan(int num_queues, const int64_t* queue_entries, int nu
         queue_stride[x] = pl.q_stride[x];
     }
     return BFH_OK;
+}
+int bfh_bpr_set_comm(void* h, void* comm) {
+    return guarded(h, [&] { static_cast<BprHandle*>(h)->set_comm(static_cast<bfh::Comm*>(comm)); return BFH_OK; });
+}
+int bfh_bpr_comm_flush(void* h) {
+    return guarded(h, [&] { static_cast<BprHandle*>(h)->exchange_finish(); static_cast<BprHandle*>(h)->sync_stream(); return BFH_OK; });
 }
 int bfh_bpr_get_stats(void* h, bfh_stats* out) {
     return guarded(h, [&] { *out = static_cast<BprHandle*>(h)->stats; return BFH_OK; });

@@ -1,0 +1,167 @@
+// bfh_comm_*: RCCL communicator objects for the data-parallel paths (users sharded, item factors replicated;
+// ALS rows sharded) -- SURVEY.md section 8(e).  The reference has no multi-device code.
+#include "comm.hpp"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace bfh {
+
+namespace {
+
+struct Rccl {
+    void* lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+Rccl& rccl() {
+    static Rccl r = [] {
+        Rccl x;
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) {
+            x.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (x.lib) break;
+        }
+        if (!x.lib) throw Error(BFH_ERR_HIP, std::string("librccl.so.1 could not be loaded: ") + (dlerror() ? dlerror() : "?"));
+        auto sym = [&](const char* name) {
+            void* p = dlsym(x.lib, name);
+            if (!p) throw Error(BFH_ERR_HIP, std::string("librccl: missing symbol ") + name);
+            return p;
+        };
+        x.GetUniqueId = reinterpret_cast<decltype(x.GetUniqueId)>(sym("ncclGetUniqueId"));
+        x.CommInitRank = reinterpret_cast<decltype(x.CommInitRank)>(sym("ncclCommInitRank"));
+        x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(sym("ncclCommDestroy"));
+        x.AllReduce = reinterpret_cast<decltype(x.AllReduce)>(sym("ncclAllReduce"));
+        x.Broadcast = reinterpret_cast<decltype(x.Broadcast)>(sym("ncclBroadcast"));
+        x.GroupStart = reinterpret_cast<decltype(x.GroupStart)>(sym("ncclGroupStart"));
+        x.GroupEnd = reinterpret_cast<decltype(x.GroupEnd)>(sym("ncclGroupEnd"));
+        x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(sym("ncclGetErrorString"));
+        return x;
+    }();
+    return r;
+}
+
+void check(ncclResult_t r, const char* what) {
+    if (r != ncclSuccess) throw Error(BFH_ERR_HIP, std::string("RCCL ") + what + ": " + rccl().GetErrorString(r));
+}
+
+}  // namespace
+
+void Comm::unique_id(char* out128) {
+    ncclUniqueId id;
+    check(rccl().GetUniqueId(&id), "ncclGetUniqueId");
+    static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+    std::memcpy(out128, &id, sizeof(id));
+}
+
+Comm::Comm(int n_ranks, int rank, const char* id128, int dev) {
+    BFH_REQUIRE(n_ranks >= 1 && rank >= 0 && rank < n_ranks && id128, "comm_create: bad rank / size / id");
+    device = dev;
+    rank_ = rank;
+    size_ = n_ranks;
+    BFH_HIP(hipSetDevice(dev));
+    BFH_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    ncclComm_t c = nullptr;
+    check(rccl().CommInitRank(&c, n_ranks, id, rank), "ncclCommInitRank");
+    comm_ = c;
+}
+
+Comm::~Comm() {
+    if (comm_) (void)rccl().CommDestroy(static_cast<ncclComm_t>(comm_));
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+void Comm::all_reduce_f32(const float* send, float* recv, size_t count, hipStream_t s) {
+    if (count) check(rccl().AllReduce(send, recv, count, ncclFloat32, ncclSum, static_cast<ncclComm_t>(comm_), s), "ncclAllReduce(f32)");
+}
+void Comm::all_reduce_i32(const int* send, int* recv, size_t count, hipStream_t s) {
+    if (count) check(rccl().AllReduce(send, recv, count, ncclInt32, ncclSum, static_cast<ncclComm_t>(comm_), s), "ncclAllReduce(i32)");
+}
+void Comm::all_reduce_f64(const double* send, double* recv, size_t count, hipStream_t s) {
+    if (count) check(rccl().AllReduce(send, recv, count, ncclFloat64, ncclSum, static_cast<ncclComm_t>(comm_), s), "ncclAllReduce(f64)");
+}
+void Comm::broadcast_bytes(void* buf, size_t bytes, int root, hipStream_t s) {
+    if (bytes) check(rccl().Broadcast(buf, buf, bytes, ncclInt8, root, static_cast<ncclComm_t>(comm_), s), "ncclBroadcast");
+}
+void Comm::group_start() { check(rccl().GroupStart(), "ncclGroupStart"); }
+void Comm::group_end() { check(rccl().GroupEnd(), "ncclGroupEnd"); }
+
+}  // namespace bfh
+
+using bfh::Comm;
+using bfh::guarded;
+
+extern "C" {
+
+int bfh_comm_unique_id(char* out, size_t bytes) {
+    try {
+        if (!out || bytes < 128) throw bfh::Error(BFH_ERR_INVALID, "comm_unique_id: need a 128-byte buffer");
+        Comm::unique_id(out);
+        return BFH_OK;
+    } catch (const bfh::Error& e) {
+        bfh::g_create_error = e.what();
+        return e.code;
+    } catch (const std::exception& e) {
+        bfh::g_create_error = e.what();
+        return BFH_ERR_HIP;
+    }
+}
+
+void* bfh_comm_create(int n_ranks, int rank, const char* unique_id, int device) {
+    try {
+        return new Comm(n_ranks, rank, unique_id, device);
+    } catch (const std::exception& e) {
+        bfh::g_create_error = e.what();
+        return nullptr;
+    }
+}
+
+void bfh_comm_destroy(void* c) { delete static_cast<Comm*>(c); }
+int bfh_comm_rank(void* c) { return c ? static_cast<Comm*>(c)->rank() : BFH_ERR_INVALID; }
+int bfh_comm_size(void* c) { return c ? static_cast<Comm*>(c)->size() : BFH_ERR_INVALID; }
+
+// every rank contributes rank + 1 per element; all must read n (n + 1) / 2 back
+int bfh_comm_self_test(void* c) {
+    return guarded(c, [&] {
+        Comm* cm = static_cast<Comm*>(c);
+        const int n = 1024;
+        bfh::DevBuf<float> buf;
+        buf.resize(n);
+        std::vector<float> host(n, static_cast<float>(cm->rank() + 1));
+        BFH_HIP(hipMemcpyAsync(buf.get(), host.data(), n * sizeof(float), hipMemcpyHostToDevice, cm->comm_stream()));
+        cm->all_reduce_f32(buf.get(), buf.get(), n, cm->comm_stream());
+        BFH_HIP(hipMemcpyAsync(host.data(), buf.get(), n * sizeof(float), hipMemcpyDeviceToHost, cm->comm_stream()));
+        BFH_HIP(hipStreamSynchronize(cm->comm_stream()));
+        const float want = 0.5f * cm->size() * (cm->size() + 1);
+        for (float v : host)
+            if (v != want) throw bfh::Error(BFH_ERR_HIP, "comm self test: all-reduce returned " + std::to_string(v) + ", expected " + std::to_string(want));
+        return BFH_OK;
+    });
+}
+
+// sum all-reduce of a host double array (loss sums, counters) through a staging buffer
+int bfh_comm_all_reduce_f64(void* c, double* values, int n) {
+    return guarded(c, [&] {
+        Comm* cm = static_cast<Comm*>(c);
+        BFH_REQUIRE(values && n >= 0, "comm_all_reduce_f64: bad arguments");
+        if (n == 0) return BFH_OK;
+        bfh::DevBuf<double> buf;
+        buf.resize(static_cast<size_t>(n));
+        BFH_HIP(hipMemcpyAsync(buf.get(), values, n * sizeof(double), hipMemcpyHostToDevice, cm->comm_stream()));
+        cm->all_reduce_f64(buf.get(), buf.get(), static_cast<size_t>(n), cm->comm_stream());
+        BFH_HIP(hipMemcpyAsync(values, buf.get(), n * sizeof(double), hipMemcpyDeviceToHost, cm->comm_stream()));
+        BFH_HIP(hipStreamSynchronize(cm->comm_stream()));
+        return BFH_OK;
+    });
+}
+
+}  // extern "C"

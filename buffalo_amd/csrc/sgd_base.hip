@@ -4,6 +4,8 @@
 
 #include <algorithm>
 
+#include "comm.hpp"
+
 namespace bfh {
 
 // ------------------------------------------------------------------------------------------------
@@ -298,6 +300,12 @@ __global__ __launch_bounds__(256) void incidence_iota_kernel(const int32_t* __re
     idx_out[t] = static_cast<int32_t>(t);
 }
 
+// per_coordinate_normalize counts of a list that is not gathered (update_i / update_j == false still count: bpr.cc:139-143, 175-181)
+__global__ __launch_bounds__(256) void incidence_count_kernel(const uint32_t* __restrict__ item, int64_t n, int q_rows, int* __restrict__ cnt) {
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (t < n && item[t] < static_cast<uint32_t>(q_rows)) atomicAdd(cnt + item[t], 1);
+}
+
 void launch_incidence_iota(const int32_t* keys, int64_t n, uint32_t* key_out, int32_t* idx_out, hipStream_t s) {
     if (n <= 0) return;
     hipLaunchKernelGGL(incidence_iota_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, keys, n, key_out, idx_out);
@@ -373,6 +381,15 @@ void SgdHandle::acc_gather(const SgdParams& p, int num_neg, bool do_pos, bool do
         g.inc_key = acc_pkey_.get(); g.inc_idx = acc_pidx_.get(); g.n = n; g.pos_list = 1;
         g.sign = sab_pos[0]; g.a = sab_pos[1]; g.b = sab_pos[2];
         launch_grad_gather(g, waves, stream);
+    } else if (pcn_ && n > 0) {
+        hipLaunchKernelGGL(incidence_count_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, stream,
+                           reinterpret_cast<const uint32_t*>(p.keys), n, Q_rows_, p.cntQ);
+        BFH_HIP(hipGetLastError());
+    }
+    if (!do_neg && pcn_ && triples > 0) {
+        hipLaunchKernelGGL(incidence_count_kernel, dim3(static_cast<unsigned>((triples + 255) / 256)), dim3(256), 0, stream, acc_neg_.get(), triples,
+                           Q_rows_, p.cntQ);
+        BFH_HIP(hipGetLastError());
     }
     if (do_neg) {
         device_sort_pairs_u32(acc_neg_.get(), acc_key_b_.get(), acc_iota_.get(), acc_idx_b_.get(), triples, acc_bits_for(static_cast<int64_t>(Q_rows_) + 1),
@@ -384,7 +401,183 @@ void SgdHandle::acc_gather(const SgdParams& p, int num_neg, bool do_pos, bool do
 }
 
 // ------------------------------------------------------------------------------------------------
+// Delta exchange between ranks (see sgd_base.hpp).  Elementwise streaming kernels over Q | Qb.
+// ------------------------------------------------------------------------------------------------
+// S = X - Z  (what this rank changed since the state Z every rank agrees on)
+__global__ __launch_bounds__(256) void delta_begin_kernel(const float* __restrict__ X, const float* __restrict__ Z, float* __restrict__ S, int64_t n) {
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * 256) S[i] = X[i] - Z[i];
+}
+// Z <- Z + w R: the agreed state advances by the combined deltas -- the same arithmetic on every rank, so Z stays
+// bit-identical.  w (per row, exchange_weight_kernel) interpolates between the SUM of the ranks' deltas (rows that
+// received few updates in the interval: the deltas are independent steps) and their MEAN (rows every rank has driven to
+// its local equilibrium: the deltas are N estimates of the same move).  X: if this rank kept working since `begin`
+// (progressed) its own delta is replaced by the combination, X += w R - S; otherwise X <- Z exactly, which makes the
+// replicas bit-identical after a flush.
+__global__ __launch_bounds__(256) void delta_finish_kernel(float* __restrict__ X, float* __restrict__ Z, const float* __restrict__ S,
+                                                           const float* __restrict__ R, const float* __restrict__ W, int row_len, int64_t n,
+                                                           int progressed) {
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * 256) {
+        const float r = W[i / row_len] * R[i];
+        const float zn = Z[i] + r;
+        X[i] = progressed ? X[i] + (r - S[i]) : zn;
+        Z[i] = zn;
+    }
+}
+// Row i receives m = upd[i] * share updates per rank in one exchange interval (upd = updates of the row per epoch over all
+// ranks, share = this rank's part of the epoch inside the interval).  Under SGD a row contracts towards its equilibrium by
+// exp(-x), x = lr * k0 * m (k0: the curvature of the pairwise logistic loss, at most 1/4); n deltas that started from the
+// same row therefore combine like ONE run of n m updates when scaled by  w = (1 - exp(-n x)) / (n (1 - exp(-x))):
+// w -> 1 for cold rows (sum), w -> 1/n for saturated ones (mean).  Measured against the single-process run at BASELINE
+// scale: profiles/r02_local_sgd_study_*.json (without it the popular items' biases overshoot 4.5x at 8 ranks).
+__global__ void exchange_weight_kernel(const int* __restrict__ gcnt, const int64_t* __restrict__ cum, int64_t cum_total, int rows, double pos_scale,
+                                       double neg_total, double neg_uniform, double share, double lr_k0, int n_ranks, float* __restrict__ W) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    double pneg = neg_uniform;
+    if (cum) pneg = static_cast<double>(cum[i] - (i ? cum[i - 1] : 0)) / static_cast<double>(cum_total);
+    const double m = (gcnt[i] * pos_scale + neg_total * pneg) * share;
+    const double x = lr_k0 * m;
+    double w = 1.0;
+    if (n_ranks > 1 && x > 1e-9) w = -expm1(-n_ranks * x) / (n_ranks * -expm1(-x));
+    W[i] = static_cast<float>(w);
+}
+// X = Z + R  (gradients: state after the last optimizer step + every rank's accumulation since)
+__global__ __launch_bounds__(256) void delta_apply_kernel(float* __restrict__ X, const float* __restrict__ Z, const float* __restrict__ R, int64_t n) {
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * 256) X[i] = Z[i] + R[i];
+}
+
+static inline dim3 stream_grid(int64_t n) { return dim3(static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 4096)))); }
+
+void SgdHandle::set_comm(Comm* c) {
+    if (x_pending_) exchange_finish();
+    comm_ = c;
+    x_inited_ = false;
+    if (c) {
+        BFH_REQUIRE(c->device == device, "set_comm: the communicator lives on another device than this handle");
+        if (!x_ready_) BFH_HIP(hipEventCreateWithFlags(&x_ready_, hipEventDisableTiming));
+        if (!x_done_) BFH_HIP(hipEventCreateWithFlags(&x_done_, hipEventDisableTiming));
+    }
+}
+
+// Z <- the replicated state as it is now.  Called before the first local change of a model (initialize_model uploaded the
+// same Q / Qb on every rank; the gradient buffers start at zero), so Z is identical on every rank.
+void SgdHandle::exchange_arm() {
+    if (!comm_ || x_inited_ || !model_on_gpu_) return;
+    const size_t n = x_count(), nq = static_cast<size_t>(Q_rows_) * vdim_;
+    if (xZ_.size() < n) { xZ_.resize(n); xS_.resize(n); xR_.resize(n); }
+    const bool grad = optimizer_ != "sgd";
+    BFH_HIP(hipMemcpyAsync(xZ_.get(), grad ? gradQ_.get() : Q_.get(), nq * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    BFH_HIP(hipMemcpyAsync(xZ_.get() + nq, grad ? gradQb_.get() : Qb_.get(), static_cast<size_t>(Q_rows_) * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    if (!grad) {
+        // per-row combination weights (1 until exchange_weights computes them) and the popularity of every item over ALL ranks
+        xW_.resize(static_cast<size_t>(Q_rows_));
+        std::vector<float> ones(static_cast<size_t>(Q_rows_), 1.0f);
+        BFH_HIP(hipMemcpyAsync(xW_.get(), ones.data(), ones.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+        sync_stream();
+        x_gcnt_ready_ = false;
+    }
+    x_inited_ = true;
+    x_pending_ = false;
+}
+
+// Global item popularity (positives per item over every rank's shard) from this rank's keys: one int all-reduce, once per model.
+void SgdHandle::exchange_histogram(const int32_t* keys, int64_t n) {
+    if (!comm_ || x_gcnt_ready_) return;
+    x_gcnt_.resize(static_cast<size_t>(Q_rows_), true, stream);
+    if (n > 0) {
+        hipLaunchKernelGGL(incidence_count_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, stream,
+                           reinterpret_cast<const uint32_t*>(keys), n, Q_rows_, x_gcnt_.get());
+        BFH_HIP(hipGetLastError());
+    }
+    comm_->all_reduce_i32(x_gcnt_.get(), x_gcnt_.get(), static_cast<size_t>(Q_rows_), stream);
+    sync_stream();
+    double tot[1] = {static_cast<double>(n)};
+    if (comm_->size() > 1) {
+        DevBuf<double> d;
+        d.resize(1);
+        BFH_HIP(hipMemcpyAsync(d.get(), tot, sizeof(double), hipMemcpyHostToDevice, stream));
+        comm_->all_reduce_f64(d.get(), d.get(), 1, stream);
+        BFH_HIP(hipMemcpyAsync(tot, d.get(), sizeof(double), hipMemcpyDeviceToHost, stream));
+        sync_stream();
+    }
+    x_gcnt_total_ = tot[0];
+    x_gcnt_ready_ = true;
+}
+
+// weights of the exchange interval that is about to begin: `interval_triples` = this rank's triples inside it
+void SgdHandle::exchange_weights(double interval_triples, double lr, int num_neg, bool uniform) {
+    if (!comm_ || !x_gcnt_ready_) return;
+    const double glob_triples = static_cast<double>(num_nnz_) * num_neg;          // one epoch over all ranks
+    const double pos_scale = x_gcnt_total_ > 0 ? static_cast<double>(num_nnz_) / x_gcnt_total_ * num_neg : 0.0;   // counted keys -> the whole matrix
+    const double share = glob_triples > 0 ? interval_triples / glob_triples : 0.0;
+    hipLaunchKernelGGL(exchange_weight_kernel, dim3((Q_rows_ + 255) / 256), dim3(256), 0, stream, static_cast<const int*>(x_gcnt_.get()),
+                       uniform ? nullptr : static_cast<const int64_t*>(cum_.get()), cum_total_, Q_rows_, pos_scale, glob_triples, uniform ? 1.0 / Q_rows_ : 0.0,
+                       share, lr * comm_stiffness_milli_ * 1e-3, comm_->size(), xW_.get());
+    BFH_HIP(hipGetLastError());
+}
+
+// Q | Qb -> S (and Z), one all-reduce on the communicator's stream behind everything issued on `stream` so far
+void SgdHandle::exchange_begin() {
+    if (!comm_ || comm_->size() < 1 || !model_on_gpu_) return;
+    if (x_pending_) exchange_finish(true);
+    const int64_t nq = static_cast<int64_t>(Q_rows_) * vdim_;
+    const bool grad = optimizer_ != "sgd";
+    BFH_REQUIRE(!grad, "exchange_begin is the Hogwild (sgd) exchange");
+    BFH_REQUIRE(x_inited_, "exchange_begin before exchange_arm");
+    float* S = xS_.get();
+    hipLaunchKernelGGL(delta_begin_kernel, stream_grid(nq), dim3(256), 0, stream, static_cast<const float*>(Q_.get()),
+                       static_cast<const float*>(xZ_.get()), S, nq);
+    hipLaunchKernelGGL(delta_begin_kernel, stream_grid(Q_rows_), dim3(256), 0, stream, static_cast<const float*>(Qb_.get()),
+                       static_cast<const float*>(xZ_.get() + nq), S + nq, static_cast<int64_t>(Q_rows_));
+    BFH_HIP(hipGetLastError());
+    BFH_HIP(hipEventRecord(x_ready_, stream));
+    BFH_HIP(hipStreamWaitEvent(comm_->comm_stream(), x_ready_, 0));
+    comm_->all_reduce_f32(S, xR_.get(), static_cast<size_t>(nq) + static_cast<size_t>(Q_rows_), comm_->comm_stream());
+    BFH_HIP(hipEventRecord(x_done_, comm_->comm_stream()));
+    x_pending_ = true;
+    stats.exchanges += 1;
+}
+
+void SgdHandle::exchange_finish(bool progressed) {
+    if (!x_pending_) return;
+    const int64_t nq = static_cast<int64_t>(Q_rows_) * vdim_;
+    BFH_HIP(hipStreamWaitEvent(stream, x_done_, 0));
+    hipLaunchKernelGGL(delta_finish_kernel, stream_grid(nq), dim3(256), 0, stream, Q_.get(), xZ_.get(), static_cast<const float*>(xS_.get()),
+                       static_cast<const float*>(xR_.get()), static_cast<const float*>(xW_.get()), vdim_, nq, progressed ? 1 : 0);
+    hipLaunchKernelGGL(delta_finish_kernel, stream_grid(Q_rows_), dim3(256), 0, stream, Qb_.get(), xZ_.get() + nq, static_cast<const float*>(xS_.get() + nq),
+                       static_cast<const float*>(xR_.get() + nq), static_cast<const float*>(xW_.get()), 1, static_cast<int64_t>(Q_rows_), progressed ? 1 : 0);
+    BFH_HIP(hipGetLastError());
+    x_pending_ = false;
+}
+
+// adam / adagrad / WARP: sum what every rank accumulated into gradQ | gradQb (| counts) since the last optimizer step
+void SgdHandle::exchange_gradients() {
+    if (!comm_ || optimizer_ == "sgd") return;
+    const int64_t nq = static_cast<int64_t>(Q_rows_) * vdim_;
+    float* S = xS_.get();
+    // Z holds the residue the gradient buffers kept after the last step (Q-6: they are never re-zeroed); zero before the first
+    hipLaunchKernelGGL(delta_begin_kernel, stream_grid(nq), dim3(256), 0, stream, static_cast<const float*>(gradQ_.get()),
+                       static_cast<const float*>(xZ_.get()), S, nq);
+    hipLaunchKernelGGL(delta_begin_kernel, stream_grid(Q_rows_), dim3(256), 0, stream, static_cast<const float*>(gradQb_.get()),
+                       static_cast<const float*>(xZ_.get() + nq), S + nq, static_cast<int64_t>(Q_rows_));
+    BFH_HIP(hipGetLastError());
+    comm_->group_start();
+    comm_->all_reduce_f32(S, xR_.get(), static_cast<size_t>(nq) + static_cast<size_t>(Q_rows_), stream);
+    if (pcn_) comm_->all_reduce_i32(cntQ_.get(), cntQ_.get(), static_cast<size_t>(Q_rows_), stream);
+    comm_->group_end();
+    hipLaunchKernelGGL(delta_apply_kernel, stream_grid(nq), dim3(256), 0, stream, gradQ_.get(), static_cast<const float*>(xZ_.get()),
+                       static_cast<const float*>(xR_.get()), nq);
+    hipLaunchKernelGGL(delta_apply_kernel, stream_grid(Q_rows_), dim3(256), 0, stream, gradQb_.get(), static_cast<const float*>(xZ_.get() + nq),
+                       static_cast<const float*>(xR_.get() + nq), static_cast<int64_t>(Q_rows_));
+    BFH_HIP(hipGetLastError());
+    stats.exchanges += 1;
+}
+
+// ------------------------------------------------------------------------------------------------
 SgdHandle::~SgdHandle() {
+    if (x_pending_ && x_done_) (void)hipEventSynchronize(x_done_);
+    if (x_ready_) (void)hipEventDestroy(x_ready_);
+    if (x_done_) (void)hipEventDestroy(x_done_);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -457,6 +650,9 @@ void SgdHandle::initialize_model(float* P, int P_rows, float* Q, float* Qb, int 
     epoch_ = 0;
     processed_ = 0;
     model_on_gpu_ = true;
+    if (x_pending_ && x_done_) (void)hipEventSynchronize(x_done_);
+    x_pending_ = false;
+    x_inited_ = false;
     sync_stream();
 }
 
@@ -576,6 +772,7 @@ void SgdHandle::harvest_timers() {
 
 void SgdHandle::synchronize(bool device_to_host) {
     BFH_REQUIRE(hostP_ && model_on_gpu_, "synchronize before initialize_model(..., set_gpu=True)");
+    exchange_finish();
     const size_t np = static_cast<size_t>(P_rows_) * vdim_, nq = static_cast<size_t>(Q_rows_) * vdim_;
     const hipMemcpyKind kind = device_to_host ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice;
     if (device_to_host) {
@@ -595,6 +792,10 @@ void SgdHandle::synchronize(bool device_to_host) {
 void SgdHandle::update_parameters() {
     BFH_REQUIRE(model_on_gpu_, "update_parameters before initialize_model(..., set_gpu=True)");
     if (optimizer_ != "sgd") {
+        if (comm_) {
+            exchange_arm();
+            exchange_gradients();
+        }
         const bool adam = optimizer_ == "adam";
         const double beta1 = beta1_, beta2 = beta1_;  // Q-5: beta2 is read from "beta1" (lib/algo.cc:396)
         OptConsts k;
@@ -632,6 +833,11 @@ void SgdHandle::update_parameters() {
             BFH_HIP(hipMemsetAsync(cntP_.get(), 0, cntP_.bytes(), stream));
             BFH_HIP(hipMemsetAsync(cntQ_.get(), 0, cntQ_.bytes(), stream));
         }
+        if (comm_ && x_inited_) {   // what the gradient buffers keep after the step (Q-6) is the base of the next delta
+            const size_t nq = static_cast<size_t>(Q_rows_) * vdim_;
+            BFH_HIP(hipMemcpyAsync(xZ_.get(), gradQ_.get(), nq * sizeof(float), hipMemcpyDeviceToDevice, stream));
+            BFH_HIP(hipMemcpyAsync(xZ_.get() + nq, gradQb_.get(), static_cast<size_t>(Q_rows_) * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        }
         t_opt_.end(slot, stream);
     }
     iters_ += 1;
@@ -661,6 +867,9 @@ void SgdHandle::set_mode(const std::string& name, int64_t v) {
     else if (name == "xcd_v4") xcd_v4_ = v != 0;
     else if (name == "xcd_hot_tau") { BFH_REQUIRE(v >= 0, "xcd_hot_tau is a permille value >= 0"); xcd_hot_tau_ = static_cast<int>(v); }
     else if (name == "accum_two_pass") accum_two_pass_ = v != 0;
+    else if (name == "comm_overlap") comm_overlap_ = v != 0;
+    else if (name == "comm_stiffness") { BFH_REQUIRE(v >= 0, "comm_stiffness is a permille value >= 0 (0: plain sum of the deltas)"); comm_stiffness_milli_ = static_cast<int>(v); }
+    else if (name == "comm_segments") { BFH_REQUIRE(v >= 0 && v <= 64, "comm_segments must be in [0,64] (0 = from the learning rate)"); comm_segments_ = static_cast<int>(v); }
     else if (name == "prefetch") prefetch_ = static_cast<int>(v);
     else if (name == "waves_per_cu") waves_per_cu_ = static_cast<int>(v);
     else if (name == "chunk") { BFH_REQUIRE(v >= 64 && v % 64 == 0, "chunk must be a positive multiple of 64"); chunk_ = static_cast<int>(v); chunk_set_ = true; }
@@ -670,6 +879,10 @@ void SgdHandle::set_mode(const std::string& name, int64_t v) {
 }
 
 void SgdHandle::device_buffer(const std::string& name, void** p, size_t* bytes) {
+    if (x_pending_) {   // the caller is about to read (or all-reduce) the replicated tensors itself
+        exchange_finish();
+        sync_stream();
+    }
     struct { const char* n; void* ptr; size_t b; } tab[] = {
         {"P", P_.get(), P_.bytes()}, {"Q", Q_.get(), Q_.bytes()}, {"Qb", Qb_.get(), Qb_.bytes()},
         {"gradP", gradP_.get(), gradP_.bytes()}, {"gradQ", gradQ_.get(), gradQ_.bytes()}, {"gradQb", gradQb_.get(), gradQb_.bytes()},

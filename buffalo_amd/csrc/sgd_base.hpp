@@ -6,6 +6,8 @@
 
 namespace bfh {
 
+class Comm;
+
 struct SgdParams {  // kernel-visible constants
     float* P;
     float* Q;
@@ -79,6 +81,23 @@ class SgdHandle : public HandleBase {
     void device_buffer(const std::string& name, void** p, size_t* bytes);
     void sync_stream() { BFH_HIP(hipStreamSynchronize(stream)); }
     void harvest_timers();
+    // ---- multi-GPU (one process per GPU, users sharded, item factors replicated) -------------
+    // Hogwild sgd: local SGD on the rank's replica of Q / Qb; what the rank changed since the state Z all ranks agree on is
+    // summed over the ranks with ONE all-reduce per exchange point.  The exchange is pipelined one deep on the communicator's
+    // stream: `exchange_begin` publishes S = Q - Z and returns, the next walk runs on the local replica, and
+    // `exchange_finish` (at the next exchange point, or before anything reads Q) advances Z <- Z + R (R = summed deltas: the
+    // same arithmetic on every rank, Z stays bit-identical) and folds in what the OTHER ranks sent, Q += R - S -- or, when the
+    // rank has not worked since `begin` (a flush), Q <- Z exactly, so flushed replicas are bit-identical.  Every delta is
+    // applied exactly once everywhere.
+    // adam / adagrad / WARP: the gradient deltas (gradQ, gradQb, counts) are summed once per update_parameters, before
+    // the (then identical) optimizer step -- exactly the single-GPU result up to summation order (algo.cc:382).
+    void set_comm(Comm* c);
+    void exchange_arm();         // first exchange point of a model: capture the state every rank starts from
+    void exchange_begin();
+    void exchange_finish(bool progressed = false);   // progressed: this rank changed Q since exchange_begin
+    void exchange_gradients();   // synchronous; called by update_parameters
+    void exchange_histogram(const int32_t* keys, int64_t n);
+    void exchange_weights(double interval_triples, double lr, int num_neg, bool uniform);
 
  protected:
     // stage the chunk [start_x,next_x) (keys + row ids) and fill `pr`; returns chunk nnz
@@ -153,6 +172,19 @@ class SgdHandle : public HandleBase {
     DevBuf<char> acc_tmp_;
     int64_t acc_iota_n_ = 0, acc_pos_gen_ = -1, acc_pos_n_ = -1;
     int acc_pos_start_ = -1, acc_pos_next_ = -1;
+
+    Comm* comm_ = nullptr;          // not owned
+    int comm_overlap_ = 1;          // leave the last exchange of a call in flight (finished by the next exchange point / reader)
+    int comm_segments_ = 0;         // exchange segments per partial_update call (0: from the learning rate)
+    bool x_inited_ = false, x_pending_ = false;
+    DevBuf<float> xZ_, xS_, xR_;    // [Q_rows * vdim + ceil4(Q_rows)]: state at the last exchange, own delta, summed deltas
+    DevBuf<float> xW_;              // [Q_rows] combination weight of every row for the exchange in flight (sum .. mean)
+    DevBuf<int> x_gcnt_;            // [Q_rows] positives per item over all ranks
+    double x_gcnt_total_ = 0;
+    bool x_gcnt_ready_ = false;
+    int comm_stiffness_milli_ = 250;   // k0 of the saturation model (permille); 0: plain sum
+    hipEvent_t x_ready_ = nullptr, x_done_ = nullptr;
+    size_t x_count() const { return static_cast<size_t>(Q_rows_) * vdim_ + ((static_cast<size_t>(Q_rows_) + 3) / 4) * 4; }
 
     EventTimer t_main_, t_opt_, t_aux_;
 };

@@ -7,15 +7,20 @@
 //
 // Kernel shape (wave64): a wave owns `chunk` consecutive nnz positions, keeps P[u] in registers
 // (K = vdim/64 dwords per lane) across the user's run, and for every positive
-//   * draws 64 candidate negatives at once (one Philox draw per lane) and tests them against the
-//     user's sorted key run in parallel ("seen" negatives are not counted, warp.cc:137-138),
+//   * takes the first S unseen candidate negatives from a pre-pass (warp_presample_kernel: one thread per positive
+//     in CSR order draws Philox candidates and tests them against the user's sorted key run -- "seen" negatives are
+//     not counted, warp.cc:137-138 -- so the dependent binary-search chain is off the wave's critical path and runs in
+//     cached key runs); beyond S it draws 64 candidates at once (one Philox draw per lane) and tests them in parallel,
 //   * scores unseen candidates in draw order, 1/2/4 rows per step (speculation grows when early
 //     candidates do not violate the margin), emulating the reference's trial counter exactly
 //     (Q-10: the k-th counted candidate is scored at trial = 2k),
-//   * accumulates the three gradient rows (gradP in registers per run, gradQ rows by fp32 atomics).
+//   * accumulates gradP in registers per run; the item-side rows go through the sorted gather of sgd_base.hpp
+//     (or, accum_two_pass = 0, fp32 atomics).
 // P and Q are frozen during the epoch (only gradients change), so results are independent of the
 // order in which waves run, up to fp32 summation order.
 #include "sgd_base.hpp"
+
+#include "comm.hpp"
 
 namespace bfh {
 
@@ -32,7 +37,33 @@ struct WarpConsts {
     int two_pass;
     float* coef_out;         // [total]
     uint32_t* neg_out;       // [total]
+    // pre-drawn unseen candidates (warp_presample_kernel): cand[t * S + k] = k-th unseen draw of positive t (-1: the attempt
+    // cap was reached first), next_attempt[t] = the attempt the in-kernel sampler continues from
+    const int32_t* cand;
+    const int32_t* next_attempt;
 };
+
+constexpr uint32_t kWarpAttemptCap = 64 * 64;   // draws per positive before giving up on "seen" candidates (the reference never does)
+
+template <int S>
+__global__ __launch_bounds__(256) void warp_presample_kernel(SgdParams p, int64_t total, int32_t* __restrict__ cand, int32_t* __restrict__ next_attempt) {
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int u = p.rows[t];
+    const int64_t ubeg = (u == 0 ? 0 : p.indptr[u - 1]) - p.shift;
+    const int64_t uend = p.indptr[u] - p.shift;
+    const uint64_t gpos = static_cast<uint64_t>(p.nnz_offset + p.shift + t);
+    int k = 0;
+    uint32_t a = 0;
+    for (; a < kWarpAttemptCap && k < S; ++a) {
+        uint32_t o0, o1;
+        counter_draw(p.seed, 1u, gpos, 0u, p.epoch, a, o0, o1);
+        const int c = static_cast<int>((static_cast<uint64_t>(o0) * static_cast<uint32_t>(p.Q_rows)) >> 32);
+        if (!sorted_contains(p.keys, ubeg, uend, c)) cand[t * S + k++] = c;
+    }
+    for (; k < S; ++k) cand[t * S + k] = -1;
+    next_attempt[t] = static_cast<int32_t>(a);
+}
 
 template <int K>
 struct WRow {
@@ -74,7 +105,8 @@ __device__ __forceinline__ float wscore_part(const WRow<K>& u, const WRow<K>& i,
 
 constexpr int WARP_SPEC = 4;  // max candidate rows scored per step
 
-template <int K>
+// S: candidates per positive taken from the pre-pass (0: none, every candidate is drawn in the kernel)
+template <int K, int S>
 __global__ __launch_bounds__(256) void warp_update_kernel(SgdParams p, WarpConsts c) {
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
@@ -108,6 +140,17 @@ __global__ __launch_bounds__(256) void warp_update_kernel(SgdParams p, WarpConst
             const int n_here = static_cast<int>((t_end - t0) < 64 ? (t_end - t0) : 64);
             float my_phi = 0.f;                                     // two-pass: lane j keeps positive j's Phi / negative,
             uint32_t my_nego = static_cast<uint32_t>(p.Q_rows);    // stored coalesced after the walk
+            int my_c[S > 0 ? S : 1];
+            int my_next = 0;
+            if constexpr (S > 0) {
+#pragma unroll
+                for (int s4 = 0; s4 < S; s4 += 4) {
+                    int4 v = make_int4(-1, -1, -1, -1);
+                    if (t < t_end) v = *reinterpret_cast<const int4*>(c.cand + t * S + s4);
+                    my_c[s4] = v.x; my_c[s4 + 1] = v.y; my_c[s4 + 2] = v.z; my_c[s4 + 3] = v.w;
+                }
+                if (t < t_end) my_next = c.next_attempt[t];
+            }
             for (int j = 0; j < n_here; ++j) {
                 const int u = __builtin_amdgcn_readlane(my_u, j);
                 const int pos = __builtin_amdgcn_readlane(my_pos, j);
@@ -132,11 +175,66 @@ __global__ __launch_bounds__(256) void warp_update_kernel(SgdParams p, WarpConst
                 float uj = 0.f;
                 WRow<K> qj;
                 int bsz = 1;
-                for (uint32_t round = 0; round < 64 && !done; ++round) {  // the reference never gives up on "seen" draws
+                // score up to nb candidates (in draw order): load the rows together, then decide one after the other
+                auto score = [&](const int (&cl)[WARP_SPEC], int nb) {
+                    WRow<K> cr[WARP_SPEC];
+                    float sc[WARP_SPEC];
+#pragma unroll
+                    for (int s = 0; s < WARP_SPEC; ++s)
+                        if (s < nb) wload<K>(cr[s], p.Q + static_cast<size_t>(cl[s]) * vdim, lane, vdim);
+#pragma unroll
+                    for (int s = 0; s < WARP_SPEC; ++s)
+                        if (s < nb) sc[s] = wave_sum(wscore_part<K>(pu, cr[s], l2));
+#pragma unroll
+                    for (int s = 0; s < WARP_SPEC; ++s) {
+                        if (s < nb && !done) {
+                            if (1 + 2 * kcount > c.max_trial) {  // `while (trial <= max_trial)` fails
+                                done = true;
+                            } else {
+                                kcount += 1;
+                                scored += 1;
+                                if (static_cast<double>(ui - sc[s]) < c.threshold) {
+                                    found = true;
+                                    done = true;
+                                    neg = cl[s];
+                                    uj = sc[s];
+                                    qj = cr[s];
+                                }
+                            }
+                        }
+                    }
+                    if (bsz < WARP_SPEC) bsz <<= 1;
+                };
+                uint32_t a0 = 0;       // attempt the in-kernel sampler starts from
+                if constexpr (S > 0) {
+                    // pre-drawn candidates: batches of 1, 2, 4, 4 ... at compile-time register indices
+                    a0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(my_next, j));
+#define BFH_WARP_BATCH(B0, BS)                                                                   \
+                    if (!done && (B0) < S) {                                                     \
+                        int cl[WARP_SPEC];                                                       \
+                        int nb = 0;                                                              \
+                        _Pragma("unroll") for (int s = 0; s < WARP_SPEC; ++s) {                  \
+                            cl[s] = 0;                                                           \
+                            if (s < (BS) && (B0) + s < S) {                                      \
+                                const int cc = __builtin_amdgcn_readlane(my_c[((B0) + s) < S ? ((B0) + s) : 0], j); \
+                                if (cc >= 0 && nb == s) { cl[s] = cc; nb = s + 1; }              \
+                            }                                                                    \
+                        }                                                                        \
+                        if (nb > 0) score(cl, nb);                                               \
+                    }
+                    BFH_WARP_BATCH(0, 1)
+                    BFH_WARP_BATCH(1, 2)
+                    BFH_WARP_BATCH(3, 4)
+                    BFH_WARP_BATCH(7, 4)
+#undef BFH_WARP_BATCH
+                    if (!done && 1 + 2 * kcount > c.max_trial) done = true;
+                }
+                for (; a0 < kWarpAttemptCap && !done; a0 += 64) {  // the reference never gives up on "seen" draws
                     uint32_t o0, o1;
-                    counter_draw(p.seed, 1u, gpos, 0u, p.epoch, round * 64 + lane, o0, o1);
+                    const uint32_t attempt = a0 + lane;
+                    counter_draw(p.seed, 1u, gpos, 0u, p.epoch, attempt, o0, o1);
                     const int cand = static_cast<int>((static_cast<uint64_t>(o0) * static_cast<uint32_t>(p.Q_rows)) >> 32);
-                    const bool seen = sorted_contains(p.keys, ubeg, uend, cand);
+                    const bool seen = attempt >= kWarpAttemptCap || sorted_contains(p.keys, ubeg, uend, cand);
                     unsigned long long unseen = __ballot(!seen);
                     while (unseen != 0ull && !done) {
                         // up to bsz next unseen candidates, in draw order
@@ -154,33 +252,7 @@ __global__ __launch_bounds__(256) void warp_update_kernel(SgdParams p, WarpConst
                             }
                         }
                         unseen = m;
-                        WRow<K> cr[WARP_SPEC];
-                        float sc[WARP_SPEC];
-#pragma unroll
-                        for (int s = 0; s < WARP_SPEC; ++s)
-                            if (s < nb) wload<K>(cr[s], p.Q + static_cast<size_t>(cl[s]) * vdim, lane, vdim);
-#pragma unroll
-                        for (int s = 0; s < WARP_SPEC; ++s)
-                            if (s < nb) sc[s] = wave_sum(wscore_part<K>(pu, cr[s], l2));
-#pragma unroll
-                        for (int s = 0; s < WARP_SPEC; ++s) {
-                            if (s < nb && !done) {
-                                if (1 + 2 * kcount > c.max_trial) {  // `while (trial <= max_trial)` fails
-                                    done = true;
-                                } else {
-                                    kcount += 1;
-                                    scored += 1;
-                                    if (static_cast<double>(ui - sc[s]) < c.threshold) {
-                                        found = true;
-                                        done = true;
-                                        neg = cl[s];
-                                        uj = sc[s];
-                                        qj = cr[s];
-                                    }
-                                }
-                            }
-                        }
-                        if (bsz < WARP_SPEC) bsz <<= 1;
+                        score(cl, nb);
                     }
                     if (!done && 1 + 2 * kcount > c.max_trial) done = true;
                 }
@@ -297,6 +369,20 @@ class WarpHandle : public SgdHandle {
         BFH_HIP(hipMemsetAsync(scratch_.get(), 0, sizeof(double), stream));
         BFH_HIP(hipMemsetAsync(cnt_.get(), 0, 2 * sizeof(unsigned long long), stream));
         const bool two_pass = accum_two_pass_ != 0;
+        // candidates from the pre-pass: 4 while most positives accept one of their first draws, 8 once they do not
+        const int S = presample_ < 0 ? (last_T_ > 2.0 ? 8 : 4) : presample_;
+        if (S > 0) {
+            if (cand_.size() < static_cast<size_t>(n) * S) cand_.resize(static_cast<size_t>(n) * S);
+            if (next_.size() < static_cast<size_t>(n)) next_.resize(static_cast<size_t>(n));
+            const int slot0 = t_aux_.begin(stream);
+            const dim3 g0(static_cast<unsigned>((n + 255) / 256)), b0(256);
+            if (S == 4) hipLaunchKernelGGL(warp_presample_kernel<4>, g0, b0, 0, stream, p, n, cand_.get(), next_.get());
+            else hipLaunchKernelGGL(warp_presample_kernel<8>, g0, b0, 0, stream, p, n, cand_.get(), next_.get());
+            BFH_HIP(hipGetLastError());
+            t_aux_.end(slot0, stream);
+            c.cand = cand_.get();
+            c.next_attempt = next_.get();
+        }
         if (two_pass) {
             acc_prepare(n);
             c.two_pass = 1;
@@ -308,18 +394,25 @@ class WarpHandle : public SgdHandle {
         if (sequential_) {
             block = dim3(64);
         } else {
-            const int wpc = waves_per_cu_ > 0 ? waves_per_cu_ : 16;
+            const int wpc = waves_per_cu_ > 0 ? waves_per_cu_ : (vdim_ <= 256 ? 24 : 16);   // 24: what 75-79 VGPRs / 106 SGPRs admit
             int64_t waves = static_cast<int64_t>(num_cus_) * wpc;
             if (waves > n_work) waves = n_work;
             grid = dim3(static_cast<unsigned>((waves + 3) / 4));
         }
         const int slot = t_main_.begin(stream);
         const int K = (vdim_ + 63) / 64;
-        if (K <= 1) hipLaunchKernelGGL(warp_update_kernel<1>, grid, block, 0, stream, p, c);
-        else if (K <= 2) hipLaunchKernelGGL(warp_update_kernel<2>, grid, block, 0, stream, p, c);
-        else if (K <= 4) hipLaunchKernelGGL(warp_update_kernel<4>, grid, block, 0, stream, p, c);
-        else if (K <= 8) hipLaunchKernelGGL(warp_update_kernel<8>, grid, block, 0, stream, p, c);
-        else hipLaunchKernelGGL(warp_update_kernel<16>, grid, block, 0, stream, p, c);
+#define BFH_WARP_LAUNCH(SS)                                                                                         \
+        do {                                                                                                        \
+            if (K <= 1) hipLaunchKernelGGL((warp_update_kernel<1, SS>), grid, block, 0, stream, p, c);               \
+            else if (K <= 2) hipLaunchKernelGGL((warp_update_kernel<2, SS>), grid, block, 0, stream, p, c);          \
+            else if (K <= 4) hipLaunchKernelGGL((warp_update_kernel<4, SS>), grid, block, 0, stream, p, c);          \
+            else if (K <= 8) hipLaunchKernelGGL((warp_update_kernel<8, SS>), grid, block, 0, stream, p, c);          \
+            else hipLaunchKernelGGL((warp_update_kernel<16, SS>), grid, block, 0, stream, p, c);                     \
+        } while (0)
+        if (S == 0) BFH_WARP_LAUNCH(0);
+        else if (S == 4) BFH_WARP_LAUNCH(4);
+        else BFH_WARP_LAUNCH(8);
+#undef BFH_WARP_LAUNCH
         BFH_HIP(hipGetLastError());
         t_main_.end(slot, stream);
         if (two_pass) {
@@ -340,6 +433,7 @@ class WarpHandle : public SgdHandle {
         stats.samples += n;
         stats.scored_negatives += static_cast<int64_t>(cnt[0]);
         stats.accepted += static_cast<int64_t>(cnt[1]);
+        last_T_ = static_cast<double>(cnt[0]) / static_cast<double>(n);
         advance_progress(start_x, next_x, indptr);
     }
 
@@ -364,6 +458,9 @@ class WarpHandle : public SgdHandle {
     }
 
     int max_trial_ = 0;
+    int presample_ = -1;      // "warp_presample": candidates per positive from the pre-pass (0, 4, 8; -1: from the last call's T)
+    double last_T_ = 0.0;     // scored negatives per positive of the previous call
+    DevBuf<int32_t> cand_, next_;
     double threshold_ = 0;
     bool l2_ = false;
     DevBuf<unsigned long long> cnt_;
@@ -434,7 +531,16 @@ int bfh_warp_set_resident_csr(void* h, const int64_t* indptr, const int32_t* key
     return guarded(h, [&] { static_cast<WarpHandle*>(h)->set_resident_csr(indptr, keys, nnz); return BFH_OK; });
 }
 int bfh_warp_set_mode(void* h, const char* name, int64_t value) {
-    return guarded(h, [&] { static_cast<WarpHandle*>(h)->set_mode(name ? name : "", value); return BFH_OK; });
+    return guarded(h, [&] {
+        WarpHandle* w = static_cast<WarpHandle*>(h);
+        if (name && std::string(name) == "warp_presample") {
+            BFH_REQUIRE(value == -1 || value == 0 || value == 4 || value == 8, "warp_presample must be -1 (auto), 0, 4 or 8");
+            w->presample_ = static_cast<int>(value);
+        } else {
+            w->set_mode(name ? name : "", value);
+        }
+        return BFH_OK;
+    });
 }
 int bfh_warp_set_shard(void* h, int64_t nnz_offset, int num_shards) {
     return guarded(h, [&] {
@@ -448,6 +554,12 @@ int bfh_warp_device_buffer(void* h, const char* name, void** dptr, size_t* bytes
     return guarded(h, [&] { static_cast<WarpHandle*>(h)->device_buffer(name ? name : "", dptr, bytes); return BFH_OK; });
 }
 void* bfh_warp_stream(void* h) { return h ? static_cast<void*>(static_cast<WarpHandle*>(h)->stream) : nullptr; }
+int bfh_warp_set_comm(void* h, void* comm) {
+    return guarded(h, [&] { static_cast<WarpHandle*>(h)->set_comm(static_cast<bfh::Comm*>(comm)); return BFH_OK; });
+}
+int bfh_warp_comm_flush(void* h) {
+    return guarded(h, [&] { static_cast<WarpHandle*>(h)->exchange_finish(); static_cast<WarpHandle*>(h)->sync_stream(); return BFH_OK; });
+}
 int bfh_warp_get_stats(void* h, bfh_stats* out) {
     return guarded(h, [&] { *out = static_cast<WarpHandle*>(h)->stats; return BFH_OK; });
 }

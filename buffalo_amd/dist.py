@@ -80,25 +80,84 @@ class DeltaAllReduce:
         self._sync()
 
 
+class PipelinedDeltaExchange:
+    """The exchange rule a handle applies by itself once an RCCL rank is attached (`obj.set_comm(Comm(...))`:
+    csrc/sgd_base.hip `exchange_begin` / `exchange_finish`), restated on torch tensors so that the protocol runs under
+    gloo on CPU.  One exchange is in flight at a time:
+
+        begin():   finish(progressed=True);  S = T - Z;  R = all_reduce(S)  (asynchronous)
+        finish():  wait;  Z += R;  T += R - S  if the rank worked on T since begin, else  T = Z
+
+    `Z` (the state every rank agrees on) advances by the same arithmetic everywhere and stays bit-identical; a flush
+    (finish without local progress) therefore leaves bit-identical replicas; every local delta is applied exactly once
+    on every rank; and between `begin` and `finish` the rank keeps working on its replica -- the all-reduce travels
+    behind the next walk instead of in front of it."""
+
+    def __init__(self, tensors, group=None):
+        import torch
+        self.tensors = [t for t in tensors if t is not None and t.numel() > 0]
+        self.group = group
+        self.Z = [t.clone() for t in self.tensors]
+        self.S = [torch.empty_like(t) for t in self.tensors]
+        self.R = [torch.empty_like(t) for t in self.tensors]
+        self.work = None
+
+    def begin(self):
+        import torch
+        import torch.distributed as dist
+        self.finish(progressed=True)
+        for t, z, s_, r in zip(self.tensors, self.Z, self.S, self.R):
+            torch.sub(t, z, out=s_)
+            r.copy_(s_)
+        self.work = [dist.all_reduce(r, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for r in self.R]
+
+    def finish(self, progressed=False):
+        if self.work is None:
+            return
+        for w in self.work:
+            w.wait()
+        self.work = None
+        for t, z, s_, r in zip(self.tensors, self.Z, self.S, self.R):
+            z.add_(r)
+            if progressed:
+                t.add_(r - s_)
+            else:
+                t.copy_(z)
+
+
 class DataParallelSGD:
-    """Drives one accelerator object (CyBPR / CyWARP surface) on this rank's user shard.
+    """Drives one accelerator object (CyBPR / CyWARP surface) on this rank's user shard, exchanging through
+    torch.distributed (the CPU tests with the oracle as the engine; `bench.py` with BFH_COMM=torch).  The product path
+    on GPUs is the library's own communicator: `obj.set_comm(Comm(...))` and plain `add_jobs` / `update_parameters`.
 
     `engine` must offer add_jobs / update_parameters plus `replicated_tensors(kind)` returning the
     torch views to all-reduce; `HipEngine` adapts the HIP backend, the CPU tests plug the oracle in.
+    `pipelined` (sgd only) uses PipelinedDeltaExchange -- the rule the library applies -- instead of the blocking
+    DeltaAllReduce; call `flush()` before reading the model.
     """
 
-    def __init__(self, engine, optimizer, group=None):
+    def __init__(self, engine, optimizer, group=None, pipelined=False):
         self.engine = engine
         self.sgd = optimizer == "sgd"
-        self.sync = DeltaAllReduce(engine.replicated_tensors("model" if self.sgd else "grad"), group)
+        self.pipe = PipelinedDeltaExchange(engine.replicated_tensors("model"), group) if (pipelined and self.sgd) else None
+        self.sync = None if self.pipe else DeltaAllReduce(engine.replicated_tensors("model" if self.sgd else "grad"), group)
 
     def minibatch(self, start_x, next_x, indptr, keys):
         """One `add_jobs` over [start_x,next_x) of the local shard + the item-side exchange."""
+        if self.pipe is not None:
+            out = self.engine.add_jobs(start_x, next_x, indptr, keys)
+            self.engine.wait()
+            self.pipe.begin()
+            return out
         self.sync.begin()
         out = self.engine.add_jobs(start_x, next_x, indptr, keys)
         self.engine.wait()
         self.sync.finish()
         return out
+
+    def flush(self):
+        if self.pipe is not None:
+            self.pipe.finish()
 
     def end_epoch(self):
         self.engine.update_parameters()
@@ -174,6 +233,28 @@ class DataParallelALS:
 
     def epoch(self):
         """als.py:165-171: rowwise then colwise half-epoch; returns the summed (nume, deno)."""
+        n0, d0 = self.half_epoch(0)
+        n1, d1 = self.half_epoch(1)
+        return n0 + n1, d0 + d1
+
+
+class CommDataParallelALS:
+    """DataParallelALS on the library's own communicator: `obj` is a CyALS with both orientations resident and
+    `obj.set_comm(comm)` done; the solved row blocks travel with `bfh_als_publish_rows` (a group of ncclBroadcast)."""
+
+    def __init__(self, obj, comm, indptrs, num_users, num_items):
+        self.obj, self.comm, self.indptr, self.rows = obj, comm, indptrs, (num_users, num_items)
+        self.bounds = [shard_bounds(ip, comm.world) for ip in indptrs]
+        obj.set_mode("als_writeback", 0)
+
+    def half_epoch(self, axis):
+        self.obj.precompute(axis)
+        b = self.bounds[axis]
+        nume, deno = self.obj.partial_update(b[self.comm.rank], b[self.comm.rank + 1], self.indptr[axis], None, None, axis)
+        self.obj.publish_rows(axis, b)
+        return tuple(self.comm.all_reduce([nume, deno])) if self.comm.world > 1 else (nume, deno)
+
+    def epoch(self):
         n0, d0 = self.half_epoch(0)
         n1, d1 = self.half_epoch(1)
         return n0 + n1, d0 + d1

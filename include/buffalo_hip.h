@@ -59,6 +59,7 @@ typedef struct {
     double aux_ms;            /* everything else the backend launched (precompute, loss, ...)     */
     double h2d_bytes, d2h_bytes;
     int64_t merges;           /* BPRMF policy 2: reconciliations of the per-XCD item-factor replicas */
+    int64_t exchanges;        /* multi-GPU: all-reduce exchange points (bfh_*_set_comm) */
 } bfh_stats;
 
 const char* bfh_version(void);
@@ -203,6 +204,37 @@ int bfh_als_device_buffer(void* h, const char* name, void** dptr, size_t* bytes)
 void* bfh_bpr_stream(void* h);
 void* bfh_warp_stream(void* h);
 void* bfh_als_stream(void* h);
+
+/* ---- Multi-GPU inside the library (SURVEY.md section 8(b) "_set_devices" / 8(e)): one process per GPU, one RCCL rank per
+ * process.  The reference has no multi-device code; a binding drives it like this:
+ *   rank 0:      bfh_comm_unique_id(id, 128)  -> hand the 128 bytes to every rank (MPI / a file / torch's store)
+ *   every rank:  comm = bfh_comm_create(world, rank, id, device);  bfh_{bpr,warp,als}_set_comm(h, comm)
+ * and from then on the handle exchanges by itself over RCCL / xGMI:
+ *   BPRMF sgd  -- users (P rows + their CSR rows) sharded, Q / Qb replicated: every exchange point (a merge segment of
+ *                 partial_update) sums what the ranks changed, Q <- Q_sync + sum_r (Q_r - Q_sync), with ONE ncclAllReduce of
+ *                 Q | Qb on the communicator's stream, pipelined one deep: the delta travels while the next walk runs and is
+ *                 folded in at the next exchange point ("comm_overlap" = 0: before partial_update returns);
+ *                 bfh_*_comm_flush / synchronize / compute_loss finish what is in flight;
+ *   adam / adagrad / WARP -- update_parameters sums gradQ | gradQb (| counts) over the ranks before the (then identical)
+ *                 optimizer step: exactly the single-GPU result up to summation order (lib/algo.cc:382);
+ *   ALS        -- rows of the side being solved sharded, both factor matrices replicated: after partial_update on its
+ *                 rows a rank calls bfh_als_publish_rows(h, axis, bounds, world + 1), the uneven all-gather of the solved
+ *                 row blocks (a group of ncclBroadcast); FF is recomputed per rank from the identical replica.
+ * The communicator is not owned by the handle: destroy the handles first.  bfh_comm_all_reduce_f64 sums host doubles
+ * (loss sums) over the ranks. */
+int bfh_comm_unique_id(char* out, size_t bytes);
+void* bfh_comm_create(int n_ranks, int rank, const char* unique_id, int device);
+void bfh_comm_destroy(void* comm);
+int bfh_comm_rank(void* comm);
+int bfh_comm_size(void* comm);
+int bfh_comm_self_test(void* comm);
+int bfh_comm_all_reduce_f64(void* comm, double* values, int n);
+int bfh_bpr_set_comm(void* h, void* comm);
+int bfh_warp_set_comm(void* h, void* comm);
+int bfh_als_set_comm(void* h, void* comm);
+int bfh_bpr_comm_flush(void* h);
+int bfh_warp_comm_flush(void* h);
+int bfh_als_publish_rows(void* h, int axis, const int* bounds, int n_bounds);
 
 int bfh_bpr_get_stats(void* h, bfh_stats* out);
 int bfh_warp_get_stats(void* h, bfh_stats* out);

@@ -55,8 +55,9 @@ def test_sequential_equals_parallel(oracle):
     csr = tiny_csr(U=40, I=64, density=0.15, seed=23)
     opt = warp_opt(d=64, random_seed=5, num_iters=2, max_trials=16, threshold=0.4)
     outs = []
-    for modes in (dict(sequential=1, accum_two_pass=0), dict(sequential=1), dict(chunk=64), dict(chunk=256, waves_per_cu=4),
-                  dict(chunk=64, accum_two_pass=0)):
+    for modes in (dict(sequential=1, accum_two_pass=0, warp_presample=0), dict(sequential=1), dict(chunk=64), dict(chunk=256, waves_per_cu=4),
+                  dict(chunk=64, accum_two_pass=0), dict(chunk=64, warp_presample=0), dict(chunk=128, warp_presample=8),
+                  dict(chunk=64, warp_presample=4, accum_two_pass=0)):
         _, obj, (P, Q), _ = _run_pair(oracle, csr, 64, opt, 2, 0.3, modes=modes)
         outs.append((P, Q, obj.stats()["scored_negatives"]))
     for P, Q, sc in outs[1:]:
