@@ -192,6 +192,10 @@ class _SgdBase(_Base):
     def synchronize(self, device_to_host):
         self._call("synchronize", int(bool(device_to_host)))
 
+    def flush_host(self):
+        """With `set_mode("lazy_sync", 1)` a `synchronize(True)` only marks the numpy arrays stale; this copies now."""
+        self._call("synchronize", 2)
+
     def update_parameters(self):
         self._call("update_parameters")
         if self.sync_every_epoch:

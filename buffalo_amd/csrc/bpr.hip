@@ -726,6 +726,14 @@ class BprHandle : public SgdHandle {
         return static_cast<int64_t>(num_cus_) * it->second * 4;
     }
 
+    // the item-major regrouping sorts 32-bit keys (queue, block, item) with 32-bit entry indices: catalogues / chunks beyond
+    // that fall back to policy 1 instead of failing (about 33 M items at lr >= 0.1, or 2^31 interactions per call)
+    bool im_fits(const BprConsts& c, int64_t n) {
+        im_probe();
+        const int64_t blocks = im_blocks_ > 0 ? im_blocks_ : std::min<int64_t>(16, std::max<int64_t>(1, static_cast<int64_t>(std::ceil(c.lr * 160.0))));
+        return n < (int64_t(1) << 31) && static_cast<int64_t>(im_nq_) * blocks * Q_rows_ < (int64_t(1) << 32);
+    }
+
     // one call of the item-major path over the staged chunk [start_x, next_x)
     void launch_item_major(const SgdParams& p, BprConsts c, int start_x, int next_x) {
         im_probe();
@@ -739,7 +747,8 @@ class BprHandle : public SgdHandle {
         const int nq = (im_single_wave_ && im_force_queues_ > 0) ? std::min(im_force_queues_, kImMaxQueues) : im_nq_;
         int slot = t_aux_.begin(stream);
         // ---- entries grouped by (owner queue of the user, item); cached for a resident matrix ----
-        const bool cached = resident_ && im_gen_ == csr_generation_ && im_start_ == start_x && im_next_ == next_x && im_n_ == n && im_built_blocks_ == blocks && im_built_nq_ == nq;
+        const bool keeps = resident_ || (auto_resident_ && !chunks_.empty());   // the staged chunk lives on in HBM under csr_generation_
+        const bool cached = keeps && im_gen_ == csr_generation_ && im_start_ == start_x && im_next_ == next_x && im_n_ == n && im_built_blocks_ == blocks && im_built_nq_ == nq;
         if (!cached) {
             im_key_a_.resize(static_cast<size_t>(n)); im_key_b_.resize(static_cast<size_t>(n));
             im_pos_a_.resize(static_cast<size_t>(n)); im_pos_b_.resize(static_cast<size_t>(n));
@@ -755,7 +764,7 @@ class BprHandle : public SgdHandle {
             BFH_HIP(hipGetLastError());
             BFH_HIP(hipMemcpyAsync(im_qbeg_, im_qbeg_dev_.get(), (nq + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
             sync_stream();
-            im_gen_ = resident_ ? csr_generation_ : -1;
+            im_gen_ = keeps ? csr_generation_ : -1;
             im_start_ = start_x; im_next_ = next_x; im_n_ = n; im_built_blocks_ = blocks; im_built_nq_ = nq;
         }
         // ---- per-row policy flags ----
@@ -774,11 +783,14 @@ class BprHandle : public SgdHandle {
                 itemcnt_gen_ = csr_generation_;
             }
             cnt_triples = static_cast<double>(resident_nnz_) * num_neg_;
+        } else if (keeps && itemcnt_gen_ == csr_generation_ && itemcnt_start_ == start_x && itemcnt_next_ == next_x) {
+            // the histogram of this very chunk (auto-resident) is still there
         } else {
             BFH_HIP(hipMemsetAsync(itemcnt_.get(), 0, itemcnt_.bytes(), stream));
             hipLaunchKernelGGL(item_count_kernel, dim3(static_cast<unsigned>(std::min<int64_t>((n + 255) / 256, 4096))), dim3(256), 0, stream, p.keys, n,
                                itemcnt_.get());
-            itemcnt_gen_ = -1;
+            itemcnt_gen_ = keeps ? csr_generation_ : -1;
+            itemcnt_start_ = start_x; itemcnt_next_ = next_x;
         }
         const double queue_waves = static_cast<double>(waves) / nq;
         // rows a queue's waves hold between the load and the store of one update: the current and the prefetched
@@ -1038,6 +1050,7 @@ class BprHandle : public SgdHandle {
             // the popularity every rank weighs its rows by: the resident matrix when there is one, else this call's chunk
             exchange_histogram(resident_ ? keys_.get() : p.keys, resident_ ? resident_nnz_ : n);
         }
+        if (c.atomic == 3 && !im_fits(c, n)) c.atomic = 1;   // 32-bit sort key / entry index exhausted: the user-major atomic walk
         if (c.atomic == 3) {
             launch_item_major(p, c, start_x, next_x);
         } else {
@@ -1110,6 +1123,7 @@ class BprHandle : public SgdHandle {
     DevBuf<int> itemcnt_;          // policy 2: updates per item row (popularity)
     DevBuf<uint8_t> hot_;
     int64_t itemcnt_gen_ = -1;
+    int itemcnt_start_ = -1, itemcnt_next_ = -1;
     std::map<const void*, int> occupancy_;   // kernel -> resident 256-thread blocks per CU
     // policy 3
     int im_nq_ = 0, im_xcd_queue_[16];
@@ -1152,7 +1166,13 @@ void* bfh_bpr_create(void) {
 }
 void bfh_bpr_destroy(void* h) { delete static_cast<BprHandle*>(h); }
 int bfh_bpr_set_device(void* h, int device) {
-    return guarded(h, [&] { static_cast<BprHandle*>(h)->device = device; BFH_HIP(hipSetDevice(device)); return BFH_OK; });
+    return guarded(h, [&] {
+        BFH_REQUIRE(!static_cast<BprHandle*>(h)->stream || static_cast<BprHandle*>(h)->device == device,
+                    "set_device after init: the handle's stream and buffers live on the device it was initialised on");
+        static_cast<BprHandle*>(h)->device = device;
+        BFH_HIP(hipSetDevice(device));
+        return BFH_OK;
+    });
 }
 int bfh_bpr_init(void* h, const char* opt_json_path) {
     int ok = 0;
@@ -1182,7 +1202,7 @@ int bfh_bpr_update_parameters(void* h) {
     return guarded(h, [&] { static_cast<BprHandle*>(h)->update_parameters(); return BFH_OK; });
 }
 int bfh_bpr_synchronize(void* h, int device_to_host) {
-    return guarded(h, [&] { static_cast<BprHandle*>(h)->synchronize(device_to_host != 0); return BFH_OK; });
+    return guarded(h, [&] { static_cast<BprHandle*>(h)->synchronize(device_to_host != 0, device_to_host == 2); return BFH_OK; });
 }
 int bfh_bpr_compute_loss(void* h, int n, const int32_t* users, const int32_t* positives, const int32_t* negatives, double* loss) {
     return guarded(h, [&] { *loss = static_cast<BprHandle*>(h)->compute_loss(n, users, positives, negatives); return BFH_OK; });

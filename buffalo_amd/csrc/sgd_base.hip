@@ -354,13 +354,14 @@ void SgdHandle::acc_prepare(int64_t triples) {
 void SgdHandle::acc_build_positive_list(const SgdParams& p, int start_x, int next_x) {
     const int64_t n = p.chunk_nnz;
     BFH_REQUIRE(n < (int64_t(1) << 31), "gradient gather: chunk of 2^31 or more interactions");
-    if (resident_ && acc_pos_gen_ == csr_generation_ && acc_pos_start_ == start_x && acc_pos_next_ == next_x && acc_pos_n_ == n) return;
+    const bool keeps = resident_ || (auto_resident_ && !chunks_.empty());
+    if (keeps && acc_pos_gen_ == csr_generation_ && acc_pos_start_ == start_x && acc_pos_next_ == next_x && acc_pos_n_ == n) return;
     if (acc_pkey_.size() < static_cast<size_t>(n)) acc_pkey_.resize(static_cast<size_t>(n));
     if (acc_pidx_.size() < static_cast<size_t>(n)) acc_pidx_.resize(static_cast<size_t>(n));
     // the chunk's keys are the sort keys as they are (item ids are non-negative int32)
     device_sort_pairs_u32(reinterpret_cast<const uint32_t*>(p.keys), acc_pkey_.get(), acc_iota_.get(), acc_pidx_.get(), n, acc_bits_for(Q_rows_),
                           acc_tmp_, stream);
-    acc_pos_gen_ = resident_ ? csr_generation_ : -1;
+    acc_pos_gen_ = keeps ? csr_generation_ : -1;
     acc_pos_start_ = start_x; acc_pos_next_ = next_x; acc_pos_n_ = n;
 }
 
@@ -424,22 +425,25 @@ __global__ __launch_bounds__(256) void delta_finish_kernel(float* __restrict__ X
     }
 }
 // Row i receives m = upd[i] * share updates per rank in one exchange interval (upd = updates of the row per epoch over all
-// ranks, share = this rank's part of the epoch inside the interval).  Under SGD a row contracts towards its equilibrium by
-// exp(-x), x = lr * k0 * m (k0: the curvature of the pairwise logistic loss, at most 1/4); n deltas that started from the
-// same row therefore combine like ONE run of n m updates when scaled by  w = (1 - exp(-n x)) / (n (1 - exp(-x))):
-// w -> 1 for cold rows (sum), w -> 1/n for saturated ones (mean).  Measured against the single-process run at BASELINE
-// scale: profiles/r02_local_sgd_study_*.json (without it the popular items' biases overshoot 4.5x at 8 ranks).
+// ranks, share = this rank's part of the epoch inside the interval).  Under SGD a coordinate with curvature k contracts
+// towards its equilibrium by exp(-x), x = lr * k * m; n deltas that started from the same state therefore combine like ONE
+// run of n m updates when scaled by  w = (1 - exp(-n x)) / (n (1 - exp(-x))):  w -> 1 for cold rows (the deltas are
+// independent steps: SUM), w -> 1/n for saturated ones (n estimates of the same move: MEAN).  Two curvatures: the item
+// bias sees the logistic loss itself (k_b = 1/4 at most), a factor row sees reg + sigma' |p|^2 (k_q ~ the regulariser
+// while the factors are small).  Measured against the single-process run at BASELINE scale, 8 ranks
+// (profiles/r02_local_sgd_study_*): the plain sum leaves |Qb| 4.5x and |Q| 2x too large (lr 0.002) or diverges (lr 0.05);
+// with the weights and 4 exchange points per epoch loss, |P|, |Q|, |Qb| land within 0.01 / 0.1 / 3.5 / 1.5 %.
 __global__ void exchange_weight_kernel(const int* __restrict__ gcnt, const int64_t* __restrict__ cum, int64_t cum_total, int rows, double pos_scale,
-                                       double neg_total, double neg_uniform, double share, double lr_k0, int n_ranks, float* __restrict__ W) {
+                                       double neg_total, double neg_uniform, double share, double lr_kq, double lr_kb, int n_ranks,
+                                       float* __restrict__ W, float* __restrict__ Wb) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows) return;
     double pneg = neg_uniform;
     if (cum) pneg = static_cast<double>(cum[i] - (i ? cum[i - 1] : 0)) / static_cast<double>(cum_total);
     const double m = (gcnt[i] * pos_scale + neg_total * pneg) * share;
-    const double x = lr_k0 * m;
-    double w = 1.0;
-    if (n_ranks > 1 && x > 1e-9) w = -expm1(-n_ranks * x) / (n_ranks * -expm1(-x));
-    W[i] = static_cast<float>(w);
+    auto weight = [&](double x) { return (n_ranks > 1 && x > 1e-9) ? -expm1(-n_ranks * x) / (n_ranks * -expm1(-x)) : 1.0; };
+    W[i] = static_cast<float>(weight(lr_kq * m));
+    Wb[i] = static_cast<float>(weight(lr_kb * m));
 }
 // X = Z + R  (gradients: state after the last optimizer step + every rank's accumulation since)
 __global__ __launch_bounds__(256) void delta_apply_kernel(float* __restrict__ X, const float* __restrict__ Z, const float* __restrict__ R, int64_t n) {
@@ -471,8 +475,10 @@ void SgdHandle::exchange_arm() {
     if (!grad) {
         // per-row combination weights (1 until exchange_weights computes them) and the popularity of every item over ALL ranks
         xW_.resize(static_cast<size_t>(Q_rows_));
+        xWb_.resize(static_cast<size_t>(Q_rows_));
         std::vector<float> ones(static_cast<size_t>(Q_rows_), 1.0f);
         BFH_HIP(hipMemcpyAsync(xW_.get(), ones.data(), ones.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+        BFH_HIP(hipMemcpyAsync(xWb_.get(), ones.data(), ones.size() * sizeof(float), hipMemcpyHostToDevice, stream));
         sync_stream();
         x_gcnt_ready_ = false;
     }
@@ -512,7 +518,7 @@ void SgdHandle::exchange_weights(double interval_triples, double lr, int num_neg
     const double share = glob_triples > 0 ? interval_triples / glob_triples : 0.0;
     hipLaunchKernelGGL(exchange_weight_kernel, dim3((Q_rows_ + 255) / 256), dim3(256), 0, stream, static_cast<const int*>(x_gcnt_.get()),
                        uniform ? nullptr : static_cast<const int64_t*>(cum_.get()), cum_total_, Q_rows_, pos_scale, glob_triples, uniform ? 1.0 / Q_rows_ : 0.0,
-                       share, lr * comm_stiffness_milli_ * 1e-3, comm_->size(), xW_.get());
+                       share, lr * comm_stiffness_q_milli_ * 1e-3, lr * comm_stiffness_milli_ * 1e-3, comm_->size(), xW_.get(), xWb_.get());
     BFH_HIP(hipGetLastError());
 }
 
@@ -545,7 +551,7 @@ void SgdHandle::exchange_finish(bool progressed) {
     hipLaunchKernelGGL(delta_finish_kernel, stream_grid(nq), dim3(256), 0, stream, Q_.get(), xZ_.get(), static_cast<const float*>(xS_.get()),
                        static_cast<const float*>(xR_.get()), static_cast<const float*>(xW_.get()), vdim_, nq, progressed ? 1 : 0);
     hipLaunchKernelGGL(delta_finish_kernel, stream_grid(Q_rows_), dim3(256), 0, stream, Qb_.get(), xZ_.get() + nq, static_cast<const float*>(xS_.get() + nq),
-                       static_cast<const float*>(xR_.get() + nq), static_cast<const float*>(xW_.get()), 1, static_cast<int64_t>(Q_rows_), progressed ? 1 : 0);
+                       static_cast<const float*>(xR_.get() + nq), static_cast<const float*>(xWb_.get()), 1, static_cast<int64_t>(Q_rows_), progressed ? 1 : 0);
     BFH_HIP(hipGetLastError());
     x_pending_ = false;
 }
@@ -574,7 +580,33 @@ void SgdHandle::exchange_gradients() {
 }
 
 // ------------------------------------------------------------------------------------------------
+// 64-bit mix of ~2K sampled keys + both ends + the length: cheap enough to run on every call, and a chunk whose content
+// changed under the same row range is caught unless it agrees with the old one at every sampled position
+static uint64_t sample_signature(const int32_t* keys, int64_t n) {
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ static_cast<uint64_t>(n);
+    auto mix = [&](uint64_t v) {
+        h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+        h *= 0xff51afd7ed558ccdull;
+        h ^= h >> 33;
+    };
+    const int64_t edge = std::min<int64_t>(n, 64);
+    for (int64_t i = 0; i < edge; ++i) mix(static_cast<uint32_t>(keys[i]));
+    for (int64_t i = n - edge; i < n; ++i) mix(static_cast<uint32_t>(keys[i]));
+    const int64_t samples = 2048, stride = std::max<int64_t>(1, n / samples);
+    for (int64_t i = stride / 2; i < n; i += stride) mix((static_cast<uint64_t>(i) << 32) | static_cast<uint32_t>(keys[i]));
+    return h;
+}
+
+void SgdHandle::unpin_host() {
+    for (auto& p : pinned_) (void)hipHostUnregister(p.first);
+    pinned_.clear();
+}
+
 SgdHandle::~SgdHandle() {
+    if (host_stale_ && model_on_gpu_ && hostP_) {   // lazy_sync: the deferred copy-back happens at the latest here
+        try { synchronize(true, true); } catch (...) {}
+    }
+    unpin_host();
     if (x_pending_ && x_done_) (void)hipEventSynchronize(x_done_);
     if (x_ready_) (void)hipEventDestroy(x_ready_);
     if (x_done_) (void)hipEventDestroy(x_done_);
@@ -625,11 +657,22 @@ bool SgdHandle::init(const char* opt_path) {
 void SgdHandle::initialize_model(float* P, int P_rows, float* Q, float* Qb, int Q_rows, int64_t num_nnz, bool set_gpu) {
     BFH_REQUIRE(inited_, "initialize_model called before init");
     BFH_REQUIRE(P && Q && Qb && P_rows > 0 && Q_rows > 0, "initialize_model: null factors or empty shapes");
+    if (host_stale_ && model_on_gpu_ && hostP_) synchronize(true, true);   // lazy_sync: the previous model's arrays are still owed
     hostP_ = P; hostQ_ = Q; hostQb_ = Qb;
     P_rows_ = P_rows; Q_rows_ = Q_rows;
     num_nnz_ = num_nnz;
     if (!set_gpu) return;  // bpr.cu:293-298: only record host pointers
     const size_t np = static_cast<size_t>(P_rows) * vdim_, nq = static_cast<size_t>(Q_rows) * vdim_;
+    unpin_host();
+    if (pin_host_) {   // best effort: a refusal (already registered, exotic memory) just leaves the copies pageable
+        auto pin = [&](void* p, size_t bytes) {
+            if (hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess) pinned_.emplace_back(p, bytes);
+            else (void)hipGetLastError();
+        };
+        pin(P, np * sizeof(float));
+        pin(Q, nq * sizeof(float));
+        pin(Qb, static_cast<size_t>(Q_rows) * sizeof(float));
+    }
     P_.resize(np); Q_.resize(nq); Qb_.resize(Q_rows);
     BFH_HIP(hipMemcpyAsync(P_.get(), P, np * sizeof(float), hipMemcpyHostToDevice, stream));
     BFH_HIP(hipMemcpyAsync(Q_.get(), Q, nq * sizeof(float), hipMemcpyHostToDevice, stream));
@@ -666,6 +709,7 @@ void SgdHandle::set_placeholder(const int64_t* indptr, size_t batch_size) {
     if (!resident_) {
         keys_.resize(batch_size);
         rows_.resize(batch_size);
+        chunks_.clear();
     }
     placeholder_set_ = true;
     sync_stream();
@@ -725,6 +769,27 @@ int64_t SgdHandle::stage_chunk(int start_x, int next_x, const int64_t* indptr, c
             // caller insists on passing keys although a resident CSR exists: honour the resident copy
             pr->keys = keys_.get() + beg;
             pr->rows = rows_.get() + beg;
+        } else if (auto_resident_) {
+            // every chunk keeps its place in a full-size device copy of the matrix; it is uploaded when its row range is new or
+            // the sampled checksum of the host buffer differs from the one it was uploaded with
+            const int64_t total = indptr_host_.empty() ? n : indptr_host_.back();
+            BFH_REQUIRE(end <= total, "partial_update: indptr disagrees with the placeholder's");
+            if (keys_.size() < static_cast<size_t>(total)) {
+                keys_.resize(static_cast<size_t>(total));
+                rows_.resize(static_cast<size_t>(total));
+                chunks_.clear();
+            }
+            const uint64_t sig = sample_signature(keys, n);
+            auto it = chunks_.find({start_x, next_x});
+            if (it == chunks_.end() || it->second.n != n || it->second.sig != sig) {
+                BFH_HIP(hipMemcpyAsync(keys_.get() + beg, keys, n * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+                stats.h2d_bytes += static_cast<double>(n * sizeof(int32_t));
+                launch_fill_rows(indptr_.get(), start_x, next_x, beg, n, rows_.get() + beg, stream);
+                chunks_[{start_x, next_x}] = ChunkSig{n, sig};
+                csr_generation_ += 1;   // whatever was derived from the old content (item-major regrouping, incidence lists) is stale
+            }
+            pr->keys = keys_.get() + beg;
+            pr->rows = rows_.get() + beg;
         } else {
             BFH_REQUIRE(static_cast<size_t>(n) <= keys_.size(), "partial_update: chunk larger than the placeholder batch_size");
             BFH_HIP(hipMemcpyAsync(keys_.get(), keys, n * sizeof(int32_t), hipMemcpyHostToDevice, stream));
@@ -770,9 +835,15 @@ void SgdHandle::harvest_timers() {
     stats.aux_ms += t_aux_.drain();
 }
 
-void SgdHandle::synchronize(bool device_to_host) {
+void SgdHandle::synchronize(bool device_to_host, bool force) {
     BFH_REQUIRE(hostP_ && model_on_gpu_, "synchronize before initialize_model(..., set_gpu=True)");
     exchange_finish();
+    if (device_to_host && lazy_sync_ && !force) {   // the copy is owed until synchronize(2) / destroy / the next initialize_model
+        host_stale_ = true;
+        sync_stream();
+        return;
+    }
+    if (device_to_host) host_stale_ = false;
     const size_t np = static_cast<size_t>(P_rows_) * vdim_, nq = static_cast<size_t>(Q_rows_) * vdim_;
     const hipMemcpyKind kind = device_to_host ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice;
     if (device_to_host) {
@@ -867,8 +938,12 @@ void SgdHandle::set_mode(const std::string& name, int64_t v) {
     else if (name == "xcd_v4") xcd_v4_ = v != 0;
     else if (name == "xcd_hot_tau") { BFH_REQUIRE(v >= 0, "xcd_hot_tau is a permille value >= 0"); xcd_hot_tau_ = static_cast<int>(v); }
     else if (name == "accum_two_pass") accum_two_pass_ = v != 0;
+    else if (name == "auto_resident") auto_resident_ = v != 0;
+    else if (name == "lazy_sync") lazy_sync_ = v != 0;
+    else if (name == "pin_host") pin_host_ = v != 0;
     else if (name == "comm_overlap") comm_overlap_ = v != 0;
     else if (name == "comm_stiffness") { BFH_REQUIRE(v >= 0, "comm_stiffness is a permille value >= 0 (0: plain sum of the deltas)"); comm_stiffness_milli_ = static_cast<int>(v); }
+    else if (name == "comm_stiffness_q") { BFH_REQUIRE(v >= 0, "comm_stiffness_q is a permille value >= 0"); comm_stiffness_q_milli_ = static_cast<int>(v); }
     else if (name == "comm_segments") { BFH_REQUIRE(v >= 0 && v <= 64, "comm_segments must be in [0,64] (0 = from the learning rate)"); comm_segments_ = static_cast<int>(v); }
     else if (name == "prefetch") prefetch_ = static_cast<int>(v);
     else if (name == "waves_per_cu") waves_per_cu_ = static_cast<int>(v);

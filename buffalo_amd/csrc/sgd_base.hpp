@@ -73,7 +73,7 @@ class SgdHandle : public HandleBase {
     void initialize_model(float* P, int P_rows, float* Q, float* Qb, int Q_rows, int64_t num_nnz, bool set_gpu);
     void set_placeholder(const int64_t* indptr, size_t batch_size);
     void set_cumulative_table(const int64_t* table);
-    void synchronize(bool device_to_host);
+    void synchronize(bool device_to_host, bool force = false);
     void update_parameters();
     // ---- extensions --------------------------------------------------------------------------
     void set_resident_csr(const int64_t* indptr, const int32_t* keys, int64_t nnz);
@@ -145,6 +145,17 @@ class SgdHandle : public HandleBase {
     int im_max_stale_ = 64;        // policy 3: updates of one item row that may be in flight unseen by the other waves
     int xcd_fresh_ = -1, xcd_v4_ = 0;  // re-read before store; float4-per-lane rows (hot-row atomics then cost 4x the line operations)
     int xcd_hot_tau_ = 100;        // permille: tolerated collision probability of a replica row (0 = no hot rows)
+    // the reference's call pattern hands the chunk's keys over on EVERY call (cuda/_bpr.pyx:60-74) and copies the model back
+    // after every epoch.  auto_resident: a chunk seen before -- same row range, same length, same sampled checksum of the host
+    // buffer -- is served from its copy in HBM (and keeps its item-major regrouping); lazy_sync: synchronize(device_to_host)
+    // only marks the host arrays stale, the copy happens on synchronize(2) / destroy (default off = the reference behaviour);
+    // pin_host: the caller's factor arrays are page-locked for the duration of the model (D2H at PCIe rate)
+    int auto_resident_ = 1, lazy_sync_ = 0, pin_host_ = 1;
+    bool host_stale_ = false;
+    struct ChunkSig { int64_t n; uint64_t sig; };
+    std::map<std::pair<int, int>, ChunkSig> chunks_;
+    std::vector<std::pair<void*, size_t>> pinned_;
+    void unpin_host();
     int accum_two_pass_ = 1;       // adam / adagrad / WARP: item-side gradients by the sorted gather (0: one atomic row add per triple)
     int64_t csr_generation_ = 0;   // bumped by set_resident_csr
     bool chunk_set_ = false;
@@ -178,11 +189,12 @@ class SgdHandle : public HandleBase {
     int comm_segments_ = 0;         // exchange segments per partial_update call (0: from the learning rate)
     bool x_inited_ = false, x_pending_ = false;
     DevBuf<float> xZ_, xS_, xR_;    // [Q_rows * vdim + ceil4(Q_rows)]: state at the last exchange, own delta, summed deltas
-    DevBuf<float> xW_;              // [Q_rows] combination weight of every row for the exchange in flight (sum .. mean)
+    DevBuf<float> xW_, xWb_;        // [Q_rows] combination weight of every factor row / bias for the exchange in flight (sum .. mean)
     DevBuf<int> x_gcnt_;            // [Q_rows] positives per item over all ranks
     double x_gcnt_total_ = 0;
     bool x_gcnt_ready_ = false;
-    int comm_stiffness_milli_ = 250;   // k0 of the saturation model (permille); 0: plain sum
+    int comm_stiffness_milli_ = 250;   // curvature the saturation model assumes for the biases (permille); 0: plain sum
+    int comm_stiffness_q_milli_ = 25;  // ... and for the factor rows (the reference's default regulariser)
     hipEvent_t x_ready_ = nullptr, x_done_ = nullptr;
     size_t x_count() const { return static_cast<size_t>(Q_rows_) * vdim_ + ((static_cast<size_t>(Q_rows_) + 3) / 4) * 4; }
 

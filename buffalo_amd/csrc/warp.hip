@@ -492,7 +492,13 @@ void* bfh_warp_create(void) {
 }
 void bfh_warp_destroy(void* h) { delete static_cast<WarpHandle*>(h); }
 int bfh_warp_set_device(void* h, int device) {
-    return guarded(h, [&] { static_cast<WarpHandle*>(h)->device = device; BFH_HIP(hipSetDevice(device)); return BFH_OK; });
+    return guarded(h, [&] {
+        BFH_REQUIRE(!static_cast<WarpHandle*>(h)->stream || static_cast<WarpHandle*>(h)->device == device,
+                    "set_device after init: the handle's stream and buffers live on the device it was initialised on");
+        static_cast<WarpHandle*>(h)->device = device;
+        BFH_HIP(hipSetDevice(device));
+        return BFH_OK;
+    });
 }
 int bfh_warp_init(void* h, const char* opt_json_path) {
     int ok = 0;
@@ -522,7 +528,7 @@ int bfh_warp_update_parameters(void* h) {
     return guarded(h, [&] { static_cast<WarpHandle*>(h)->update_parameters(); return BFH_OK; });
 }
 int bfh_warp_synchronize(void* h, int device_to_host) {
-    return guarded(h, [&] { static_cast<WarpHandle*>(h)->synchronize(device_to_host != 0); return BFH_OK; });
+    return guarded(h, [&] { static_cast<WarpHandle*>(h)->synchronize(device_to_host != 0, device_to_host == 2); return BFH_OK; });
 }
 int bfh_warp_compute_loss(void* h, int n, const int32_t* users, const int32_t* positives, const int32_t* negatives, double* loss) {
     return guarded(h, [&] { *loss = static_cast<WarpHandle*>(h)->compute_loss(n, users, positives, negatives); return BFH_OK; });

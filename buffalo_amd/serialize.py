@@ -19,7 +19,40 @@ import sys
 import threading
 import types
 
-from .misc import Option
+
+
+class Option(dict):
+    """Attribute dict that pickles like `buffalo.misc._aux.Option` (/root/reference/buffalo/misc/_aux.py:16-56): stock
+    buffalo's class is a dict subclass that mirrors its items into the instance `__dict__` and pickles that mirror as its
+    state, so a dump carries the items twice -- as dict items and as state -- with the state's keys memo-shared with the
+    item keys.  Here nothing is mirrored: attributes ARE the items, and `__getstate__` hands pickle a plain dict built from
+    the items' own key objects, which yields the very same byte stream (tests/golden/model_ref.bin) whatever instances
+    existed before.  Only what model files need lives here: dicts handed to the constructor become Options (as in the
+    reference), attribute reads of missing keys give None; the option *validation* of buffalo's front is not product code."""
+
+    def __init__(self, *sources, **items):
+        super().__init__()
+        for src in sources + (items,):
+            for key, value in dict(src).items():
+                self[key] = Option(value) if isinstance(value, dict) and not isinstance(value, Option) else value
+
+    def __getattr__(self, name):
+        if name.startswith("__"):           # pickle / copy probe for dunder hooks: those are not options
+            raise AttributeError(name)
+        return self.get(name)
+
+    def __setattr__(self, name, value):
+        self[name] = value
+
+    def __delattr__(self, name):
+        del self[name]
+
+    def __getstate__(self):
+        return dict(self)
+
+    def __setstate__(self, state):
+        self.update(state)
+
 
 _REF_MODULE = "buffalo.misc._aux"
 _lock = threading.Lock()
@@ -70,7 +103,7 @@ def dump_objects(path, data):
 
 class _Unpickler(pickle.Unpickler):
     def find_class(self, module, name):
-        if name == "Option" and module in (_REF_MODULE, "buffalo.misc.aux", "buffalo_amd.misc"):
+        if name == "Option" and module in (_REF_MODULE, "buffalo.misc.aux", "buffalo_amd.misc", "buffalo_amd.serialize"):
             try:
                 return super().find_class(module, name)
             except (ImportError, AttributeError):

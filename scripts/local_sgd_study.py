@@ -30,17 +30,18 @@ def top10(P, Q, Qb):
     return np.argsort(-(P[users] @ Q.T + Qb.reshape(1, -1)), axis=1)[:, :10]
 
 
-K0 = float(os.environ.get("K0", "0.25"))
+K0 = float(os.environ.get("K0", "0.25"))          # stiffness of the bias dynamics (curvature of the logistic loss)
+KQ = float(os.environ.get("KQ", os.environ.get("K0", "0.25")))   # stiffness assumed for the factor rows
 item_cnt = np.bincount(csr.keys, minlength=I).astype(np.float64)
 
 
-def weights(world, exchanges, lr_now):
+def weights(world, exchanges, lr_now, k0=None):
     """Saturation-aware combination (csrc/sgd_base.hip exchange weights): a row that receives m updates per rank and
     interval contracts by exp(-x), x = lr * k0 * m, towards its local equilibrium; N such deltas from the same start
     combine like ONE run of N m updates when scaled by (1 - exp(-N x)) / (N (1 - exp(-x))): 1 (sum) for cold rows,
     1/N (mean) for saturated ones."""
     m = (item_cnt + nnz / I) / (world * exchanges)          # positive + expected negative updates per rank and interval
-    x = np.maximum(lr_now * K0 * m, 1e-12)
+    x = np.maximum(lr_now * (K0 if k0 is None else k0) * m, 1e-12)
     return ((1.0 - np.exp(-world * x)) / (world * (1.0 - np.exp(-x)))).astype(np.float32)[:, None]
 
 
@@ -82,8 +83,8 @@ def run(world, exchanges, pipelined, sat=False):
             R, Rb = sum(S), sum(Sb)
             if sat:
                 frac = (e + (x + 0.5) / exchanges) / epochs
-                w = weights(world, exchanges, max(min_lr, lr - (lr - min_lr) * frac))
-                R, Rb = R * w, Rb * w
+                lr_now = max(min_lr, lr - (lr - min_lr) * frac)
+                R, Rb = R * weights(world, exchanges, lr_now, KQ), Rb * weights(world, exchanges, lr_now, K0)
             if pipelined:
                 pend = (S, Sb, R, Rb)
             else:
@@ -120,7 +121,7 @@ if os.environ.get("CONFIGS"):      # e.g. CONFIGS="2,1,1;8,1,1" = (exchanges, pi
 for exchanges, pipelined, sat in CONFIGS:
     m, t = run(world, exchanges, pipelined, sat)
     m["top10_overlap_vs_single"] = float(np.mean([len(set(a) & set(b)) / 10 for a, b in zip(t, tb)]))
-    name = "world%d_%dx_%s%s" % (world, exchanges, "pipelined" if pipelined else "blocking", "_saturation_weights_k%g" % K0 if sat else "")
+    name = "world%d_%dx_%s%s" % (world, exchanges, "pipelined" if pipelined else "blocking", "_saturation_weights_kb%g_kq%g" % (K0, KQ) if sat else "")
     out["runs"][name] = m
     print(name, m, "%.0f s" % (time.time() - t0), flush=True)
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)

@@ -8,6 +8,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+HARNESS = os.path.join(ROOT, "tests", "front_harness")     # buffalo_front: the stand-in for buffalo's own Python front
+if HARNESS not in sys.path:
+    sys.path.insert(0, HARNESS)
 
 
 def pytest_configure(config):

@@ -5,7 +5,7 @@ import time
 import numpy as np
 
 from .. import data as bdata
-from ..backend import CyALS
+from buffalo_amd.backend import CyALS
 from ..data import BufferedDataMatrix, Data
 from .base import Algo, Evaluable, get_logger
 from .options import ALSOption

@@ -58,7 +58,7 @@ class Algo:
 
     def get_topk(self, scores, k, sorted=True, num_threads=4):
         """evaluate/base.py:31-42 (Evaluable.get_topk): column indices of the k best scores per row, on the GPU."""
-        from ..parallel import quickselect
+        from buffalo_amd.parallel import quickselect
         scores = np.ascontiguousarray(scores, dtype=np.float32)
         many = scores.ndim == 2
         if not many:
@@ -73,7 +73,7 @@ class Algo:
         """TopK engine that admits every score -- what numpy scores + quickselect give in algo/base.py:40-55."""
         eng = getattr(self, "_topk_engine", None)
         if eng is None:
-            from ..parallel import TopK
+            from buffalo_amd.parallel import TopK
             eng = self._topk_engine = TopK()
             eng.set_mode("flt_min_rule", 0)
         return eng
@@ -113,7 +113,7 @@ class Algo:
 
     # -- Serializable (base.py:271-318): files are byte-compatible with stock buffalo, see buffalo_amd/serialize.py
     def save(self, path=None, with_itemid_map=True, with_userid_map=True, data_fields=()):
-        from ..serialize import dump_objects
+        from buffalo_amd.serialize import dump_objects
         if path is None:
             path = self.opt.model_path
         if with_itemid_map and not self._idmanager.itemid_mapped and getattr(self, "data", None) is not None:
@@ -126,7 +126,7 @@ class Algo:
         dump_objects(path, data)
 
     def load(self, path, data_fields=()):
-        from ..serialize import load_objects
+        from buffalo_amd.serialize import load_objects
         for name, obj in load_objects(path, data_fields):
             setattr(self, name, obj)
 
@@ -178,8 +178,21 @@ class Evaluable:
         NDCG = AP = HIT = AUC = N = 0.0
         idcgs = np.cumsum(1.0 / np.log2(np.arange(2, topk + 2)))
         dcgs = 1.0 / np.log2(np.arange(2, topk + 2))
+        # the ranking asks for topk + (seen items of the batch's heaviest user) candidates; the GPU selection sorts up to
+        # TOPK_LIMIT per row, so users whose history would not fit are ranked from dense scores on the host instead
+        TOPK_LIMIT = 16384
         for index in range(0, len(rows), batch_size):
-            recs = self._get_topk_recommendation(rows[index:index + batch_size], topk=topk + max_seen)
+            batch = rows[index:index + batch_size]
+            light = [r for r in batch if topk + len(validation_seen.get(int(r), ())) <= TOPK_LIMIT]
+            heavy = [r for r in batch if topk + len(validation_seen.get(int(r), ())) > TOPK_LIMIT]
+            need = topk + max((len(validation_seen.get(int(r), ())) for r in light), default=0)
+            recs = self._get_topk_recommendation(np.array(light, dtype=np.int32), topk=min(need, num_items)) if light else []
+            for r in heavy:
+                d = self.opt.d
+                sc = self.Q[:, :d] @ self.P[int(r), :d]
+                if getattr(self.opt, "use_bias", False) and getattr(self, "Qb", None) is not None:
+                    sc = sc + np.asarray(self.Qb).reshape(-1)
+                recs.append((int(r), np.argsort(-sc, kind="stable")))
             for row, cand in recs:
                 seen = validation_seen.get(row, set())
                 if len(seen) == 0:

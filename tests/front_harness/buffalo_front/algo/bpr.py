@@ -1,7 +1,7 @@
 """BPRMF front (mirror of /root/reference/buffalo/algo/bpr.py)."""
 import numpy as np
 
-from ..backend import CyBPR
+from buffalo_amd.backend import CyBPR
 from ._sgd_front import SgdFront
 from .options import BPRMFOption
 

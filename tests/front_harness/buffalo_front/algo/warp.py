@@ -2,7 +2,7 @@
 accelerator=True at warp.py:31-32 -- this package provides that backend)."""
 import numpy as np
 
-from ..backend import CyWARP
+from buffalo_amd.backend import CyWARP
 from ._sgd_front import SgdFront
 from .options import WARPOption
 

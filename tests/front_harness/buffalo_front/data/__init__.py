@@ -65,7 +65,7 @@ class StreamOptions(DataOption):
 
 def _group(num_rows, num_cols, rows, cols, vals):
     """(row, col)-sorted CSR group in the reference layout (fileio.hpp:263-420), built on the device."""
-    from ..ingest import coo_to_csr
+    from buffalo_amd.ingest import coo_to_csr
     return coo_to_csr(rows, cols, vals, num_rows, num_cols)
 
 
@@ -189,8 +189,9 @@ class Stream(Data):
                 rows.append(u), cols.append(int(c)), vals.append(float(cnt))
             for c, cnt in zip(*np.unique(held, return_counts=True)) if held else ():
                 vr.append(u), vc.append(int(c)), vv.append(float(cnt))
-        limit = int(v.get("max_samples", 500)) if v else 0
-        vali = (vr[:limit], vc[:limit], vv[:limit]) if vr else None
+        # every held-out entry is a validation sample (the reference holds out for all users and keeps them all,
+        # stream.py:100-118, 222-230: vali_limit is the sum over the users) -- nothing leaves train without entering vali
+        vali = (vr, vc, vv) if vr else None
         return self._finish(U, len(names), rows, cols, vals, vali)
 
 

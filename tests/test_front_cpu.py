@@ -5,9 +5,9 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
-from buffalo_amd.algo.options import ALSOption, BPRMFOption, WARPOption
-from buffalo_amd.data import BufferedDataMatrix, MatrixMarket, MatrixMarketOptions, Stream, StreamOptions, load
-from buffalo_amd.misc import Option
+from buffalo_front.algo.options import ALSOption, BPRMFOption, WARPOption
+from buffalo_front.data import BufferedDataMatrix, MatrixMarket, MatrixMarketOptions, Stream, StreamOptions, load
+from buffalo_front.misc import Option
 
 
 @pytest.fixture(autouse=True)
@@ -16,7 +16,7 @@ def _oracle_builds_the_groups(monkeypatch, oracle):
     this suite, so the CPU oracle's restatement of the same step stands in for it.  What is under test here
     is the host logic around it (parsing, hold-out, chunking); tests/test_ingest_gpu.py runs the same loader
     checks against the real device path."""
-    import buffalo_amd.data as D
+    import buffalo_front.data as D
     monkeypatch.setattr(D, "_group", lambda nr, nc, r, c, v: oracle.coo_to_csr(r, c, v, nr, nc))
 
 
@@ -87,7 +87,7 @@ def test_stream_loader(tmp_path):
     (tmp_path / "iid").write_text("a\nb\nc\nd\n")
     opt = StreamOptions().get_default_option()
     opt.input.main, opt.input.uid, opt.input.iid = str(tmp_path / "main"), str(tmp_path / "uid"), str(tmp_path / "iid")
-    opt.data.validation = {"name": "newest", "n": 1, "max_samples": 10}
+    opt.data.validation = {"name": "newest", "n": 1, "max_samples": 1}   # every held-out entry is kept (stream.py:100-118): 2 > max_samples
     d = Stream(opt)
     d.create()
     rw = d.get_group("rowwise")

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 def _data(seed=3):
     from buffalo_amd import synth
-    from buffalo_amd.data import MatrixMarketOptions
+    from buffalo_front.data import MatrixMarketOptions
     csr, vali = synth.planted(500, 300, d_true=6, density=0.06, seed=seed)
     M = sp.csr_matrix((csr.vals, csr.keys, np.concatenate([[0], csr.indptr])), shape=(500, 300)).tolil()
     for u, i in vali:                      # put the held-out interactions back: the loader splits them off itself
@@ -23,7 +23,7 @@ def _data(seed=3):
 
 @pytest.mark.parametrize("algo", ["ALS", "BPRMF", "WARP"])
 def test_train_and_validate(algo):
-    import buffalo_amd.algo as A
+    import buffalo_front.algo as A
     np.random.seed(7)
     data_opt = _data()
     if algo == "ALS":
@@ -54,7 +54,7 @@ def test_train_and_validate(algo):
 
 
 def test_accelerator_false_is_refused():
-    import buffalo_amd.algo as A
+    import buffalo_front.algo as A
     opt = A.BPRMFOption().get_default_option()
     opt.accelerator = False
     with pytest.raises(NotImplementedError):
@@ -62,7 +62,7 @@ def test_accelerator_false_is_refused():
 
 
 def test_save_load_roundtrip(tmp_path):
-    import buffalo_amd.algo as A
+    import buffalo_front.algo as A
     np.random.seed(3)
     opt = A.ALSOption().get_default_option()
     opt.update(d=8, num_iters=1)

@@ -37,7 +37,7 @@ def test_empty_and_invalid_inputs(oracle):
 def test_loaders_build_their_groups_on_the_device(tmp_path, oracle):
     """The MatrixMarket loader checks of tests/test_front_cpu.py, with the real device path underneath."""
     import scipy.io
-    from buffalo_amd.data import MatrixMarketOptions, load
+    from buffalo_front.data import MatrixMarketOptions, load
     M = sp.random(40, 30, density=0.2, format="coo", random_state=3)
     M.data[:] = np.random.default_rng(0).integers(1, 5, size=M.nnz)
     scipy.io.mmwrite(str(tmp_path / "main.mtx"), M)

@@ -1,0 +1,112 @@
+"""The reference's call pattern at speed (/root/reference/buffalo/algo/bpr.py:170-217, cuda/_bpr.pyx:60-74): keys are handed
+over on every call and the model is copied back after every epoch.  auto_resident keeps a chunk it has seen in HBM (same row
+range, same length, same sampled checksum of the host buffer), lazy_sync defers the per-epoch copy-back."""
+import numpy as np
+import pytest
+
+from conftest import bpr_opt, tiny_csr
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+DET = dict(sampler="counter", pos_order="csr", inline=True)
+
+
+def _setup(csr, opt, modes):
+    from buffalo_amd.backend import CyBPR
+    d, vdim = opt["d"], ((opt["d"] + 31) // 32) * 32
+    rng = np.random.default_rng(1)
+    P = H.pad(rng.normal(scale=0.3, size=(csr.num_users, d)).astype(np.float32), vdim)
+    Q = H.pad(rng.normal(scale=0.3, size=(csr.num_items, d)).astype(np.float32), vdim)
+    Qb = rng.normal(scale=0.1, size=(csr.num_items, 1)).astype(np.float32)
+    obj = CyBPR()
+    assert obj.init(H.write_opt(dict(opt, accelerator=True)))
+    for k, v in modes.items():
+        obj.set_mode(k, v)
+    obj.initialize_model(P, Q, Qb, csr.nnz)
+    obj.set_cumulative_table(H.cum_table(csr, opt), csr.num_items)
+    obj.set_placeholder(csr.indptr, csr.nnz + 1)
+    obj.initialize_model(P, Q, Qb, csr.nnz, True)
+    obj.set_cumulative_table(H.cum_table(csr, opt), csr.num_items)
+    return obj, P, Q, Qb
+
+
+@pytest.mark.parametrize("modes", [dict(sequential=1), dict(hogwild_atomic=3, im_single_wave=1, im_force_queues=4)])
+def test_chunks_are_uploaded_once_and_again_when_their_content_changes(oracle, modes):
+    csr = tiny_csr(U=80, I=120, density=0.1, seed=9)
+    other = tiny_csr(U=80, I=120, density=0.1, seed=10)
+    # same shape and row lengths, different items: what a caller gets who swaps the data under the same buffers
+    other_keys = np.ascontiguousarray(np.concatenate([np.sort((csr.row(u)[0] + 7) % 120) for u in range(80)]).astype(np.int32))
+    opt = bpr_opt(d=32, lr=0.05, min_lr=0.05, num_iters=4, random_seed=3)
+    obj, P, Q, Qb = _setup(csr, opt, modes)
+    chunks = H.chunks_of(csr, 2)
+    uploads = []
+    for epoch in range(4):
+        keys_all = csr.keys if epoch < 3 else other_keys
+        for a, b in chunks:
+            beg, end = (0 if a == 0 else int(csr.indptr[a - 1])), int(csr.indptr[b - 1])
+            obj.add_jobs(a, b, csr.indptr, np.ascontiguousarray(keys_all[beg:end]))
+        obj.update_parameters()
+        uploads.append(obj.stats()["h2d_bytes"])
+    key_bytes = csr.nnz * 4
+    assert uploads[1] == uploads[0] and uploads[2] == uploads[0]          # epochs 2, 3: nothing re-sent
+    assert uploads[3] - uploads[2] == key_bytes                           # epoch 4: new content under the same ranges -> re-uploaded
+    # ... and the result is the oracle's on the same sequence of matrices
+    if "sequential" in modes:
+        rng = np.random.default_rng(1)
+        Po = rng.normal(scale=0.3, size=(80, 32)).astype(np.float32)
+        Qo = rng.normal(scale=0.3, size=(120, 32)).astype(np.float32)
+        Qbo = rng.normal(scale=0.1, size=(120, 1)).astype(np.float32)
+        o = oracle.OracleBPRMF()
+        assert o.init(H.write_opt(opt))
+        o.initialize_model(Po, Qo, Qbo, csr.nnz)
+        o.set_cumulative_table(H.cum_table(csr, opt), csr.num_items)
+        o.set_modes(**DET)
+        o.launch_workers()
+        for epoch in range(4):
+            keys_all = csr.keys if epoch < 3 else other_keys
+            for a, b in chunks:
+                beg, end = (0 if a == 0 else int(csr.indptr[a - 1])), int(csr.indptr[b - 1])
+                o.add_jobs(a, b, csr.indptr, np.ascontiguousarray(keys_all[beg:end]))
+            o.update_parameters()
+        o.join()
+        assert H.relerr(P[:, :32], Po) < 1e-5 and H.relerr(Q[:, :32], Qo) < 1e-5 and H.relerr(Qb, Qbo) < 1e-5
+
+
+def test_auto_resident_off_resends_every_call():
+    csr = tiny_csr(U=40, I=60, density=0.2, seed=13)
+    opt = bpr_opt(d=32, lr=0.05, min_lr=0.05, num_iters=2, random_seed=3)
+    obj, *_ = _setup(csr, opt, dict(sequential=1, auto_resident=0))
+    before = obj.stats()["h2d_bytes"]
+    for _ in range(2):
+        obj.add_jobs(0, csr.num_users, csr.indptr, csr.keys)
+        obj.update_parameters()
+    assert obj.stats()["h2d_bytes"] - before == 2 * csr.nnz * 4
+
+
+def test_lazy_sync_defers_the_copy_back():
+    csr = tiny_csr(U=40, I=60, density=0.2, seed=13)
+    opt = bpr_opt(d=32, lr=0.05, min_lr=0.05, num_iters=2, random_seed=3)
+    obj, P, Q, Qb = _setup(csr, opt, dict(sequential=1, lazy_sync=1))
+    P0, Q0 = P.copy(), Q.copy()
+    obj.add_jobs(0, csr.num_users, csr.indptr, csr.keys)
+    obj.update_parameters()                       # the mirror's per-epoch synchronize(True) (cuda/_bpr.pyx:59-61): deferred
+    np.testing.assert_array_equal(P, P0)
+    np.testing.assert_array_equal(Q, Q0)
+    assert obj.stats()["d2h_bytes"] == 0
+    obj.flush_host()
+    assert not np.array_equal(P, P0) and not np.array_equal(Q, Q0)
+    # reference behaviour (default): the arrays follow every epoch
+    ref, Pr, Qr, Qbr = _setup(csr, opt, dict(sequential=1))
+    ref.add_jobs(0, csr.num_users, csr.indptr, csr.keys)
+    ref.update_parameters()
+    np.testing.assert_array_equal(Pr, P)
+    np.testing.assert_array_equal(Qr, Q)
+    # a deferred copy is paid at the latest when the object goes away
+    obj2, P2, Q2, _ = _setup(csr, opt, dict(sequential=1, lazy_sync=1))
+    obj2.add_jobs(0, csr.num_users, csr.indptr, csr.keys)
+    obj2.update_parameters()
+    del obj2
+    import gc
+    gc.collect()
+    np.testing.assert_array_equal(P2, P)

@@ -14,7 +14,7 @@ GOLDEN = os.path.join(HERE, "golden", "model_ref.bin")
 
 
 def test_reads_a_file_written_by_the_reference_classes():
-    from buffalo_amd.misc import Option
+    from buffalo_amd.serialize import Option
     from buffalo_amd.serialize import load_objects
     objs = dict(load_objects(GOLDEN))
     assert list(objs) == ["_idmanager", "opt", "Q", "Qb", "P"]
@@ -29,18 +29,18 @@ def test_reads_a_file_written_by_the_reference_classes():
 
 def test_writes_the_same_bytes_as_the_reference(tmp_path):
     import make_model_fixture as mk
-    from buffalo_amd.misc import Option
+    from buffalo_amd.serialize import Option
     from buffalo_amd.serialize import dump_objects
     out = tmp_path / "ours.bin"
     dump_objects(str(out), mk.content(Option))
     assert out.read_bytes() == open(GOLDEN, "rb").read()
-    assert Option.__module__ == "buffalo_amd.misc" and "buffalo.misc._aux" not in sys.modules   # the alias does not leak
+    assert Option.__module__ == "buffalo_amd.serialize" and "buffalo.misc._aux" not in sys.modules   # the alias does not leak
 
 
 def test_algo_save_load_roundtrip_through_the_reference_format(tmp_path):
     import make_model_fixture as mk
-    from buffalo_amd.algo.base import Algo
-    from buffalo_amd.misc import Option
+    from buffalo_front.algo.base import Algo
+    from buffalo_amd.serialize import Option
 
     class Model(Algo):
         def _get_data(self):
