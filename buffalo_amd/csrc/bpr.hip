@@ -800,12 +800,19 @@ class BprHandle : public SgdHandle {
         // the staleness budgets are stated for lr = 0.05 and scale with 1 / lr: what matters is how far a row moves
         int64_t sync_updates = xcd_sync_updates_ > 0 ? xcd_sync_updates_ : int64_t(1) << 23;
         if (comm_) {
-            // multi-GPU: every merge segment is an exchange point, and the exchange of a segment travels behind the NEXT
-            // segment's walk -- one segment late.  A late delta costs more the longer the interval and the larger lr: at
-            // BASELINE scale and the reference's default lr, 8 ranks with ONE delayed exchange per epoch leave the popular
-            // items' biases 40 % off the single-process run, two 14 %, four 1.5 % (profiles/r02_local_sgd_study_*.json), so a
-            // call is cut into at least 4 exchange segments, more at large lr; "comm_segments" pins it
-            const int64_t segs = comm_segments_ > 0 ? comm_segments_ : std::min<int64_t>(8, std::max<int64_t>(4, static_cast<int64_t>(std::ceil(c.lr * 80.0))));
+            // multi-GPU: every merge segment is an exchange point.  Two regimes (profiles/r02_local_sgd_study_*, r02_shard_times.txt):
+            //  * long calls: the exchange of a segment travels behind the NEXT segment's walk -- one segment late.  A late delta
+            //    costs more the longer the interval and the larger lr (8 ranks, BASELINE scale, lr 0.002: the popular items'
+            //    biases end 40 % off the single-process run with ONE delayed exchange per epoch, 14 % with two, 1.5 % with
+            //    four), so pipelining needs at least 4 exchange segments per call, more at large lr;
+            //  * short calls: a segment costs ~0.1 ms of merge / drain / launch work on top of its walk, which a 2.5 M-triple
+            //    shard (8 ranks on ML-20M) cannot amortise -- 1.7 -> 2.4 ms per epoch with four.  Below 2^21 triples per
+            //    segment the call is ONE segment and its exchange is finished before it returns (blocking: 6 % on the
+            //    biases, everything else within 3 %).
+            // "comm_segments" pins the number, "comm_overlap" = 0 always blocks.
+            int64_t segs = comm_segments_ > 0 ? comm_segments_ : std::min<int64_t>(8, std::max<int64_t>(4, static_cast<int64_t>(std::ceil(c.lr * 80.0))));
+            if (comm_segments_ <= 0 && c.total / segs < (int64_t(1) << 21)) segs = 1;
+            comm_blocking_call_ = segs == 1;
             sync_updates = std::min<int64_t>(sync_updates, std::max<int64_t>(1, (c.total + segs - 1) / segs));
         }
         int64_t q_entries[kImMaxQueues] = {0};
@@ -1061,7 +1068,7 @@ class BprHandle : public SgdHandle {
                 exchange_begin();
             }
         }
-        if (comm_ && !comm_overlap_) exchange_finish();
+        if (comm_ && (!comm_overlap_ || comm_blocking_call_)) exchange_finish();
         if (compute_loss_) BFH_HIP(hipMemcpyAsync(loss_sum, scratch_.get(), sizeof(double), hipMemcpyDeviceToHost, stream));
         sync_stream();
         im_check_done();

@@ -377,7 +377,8 @@ void SgdHandle::acc_gather(const SgdParams& p, int num_neg, bool do_pos, bool do
     g.gradQb = with_bias ? p.gradQb : nullptr;
     g.cntQ = pcn_ ? p.cntQ : nullptr;
     g.num_neg = num_neg; g.vdim = vdim_; g.Q_rows = Q_rows_;
-    const int64_t waves = static_cast<int64_t>(num_cus_) * (waves_per_cu_ > 0 ? waves_per_cu_ : 16);
+    // a streaming gather: 26-67 VGPRs leave room for 8 waves per SIMD, and latency hiding is all this kernel needs
+    const int64_t waves = static_cast<int64_t>(num_cus_) * (gather_waves_per_cu_ > 0 ? gather_waves_per_cu_ : 32);
     if (do_pos) {
         g.inc_key = acc_pkey_.get(); g.inc_idx = acc_pidx_.get(); g.n = n; g.pos_list = 1;
         g.sign = sab_pos[0]; g.a = sab_pos[1]; g.b = sab_pos[2];
@@ -599,6 +600,7 @@ static uint64_t sample_signature(const int32_t* keys, int64_t n) {
 
 void SgdHandle::unpin_host() {
     for (auto& p : pinned_) (void)hipHostUnregister(p.first);
+    if (!pinned_.empty()) (void)hipGetLastError();   // an array that was freed while pinned must not leave a sticky error behind
     pinned_.clear();
 }
 
@@ -938,6 +940,7 @@ void SgdHandle::set_mode(const std::string& name, int64_t v) {
     else if (name == "xcd_v4") xcd_v4_ = v != 0;
     else if (name == "xcd_hot_tau") { BFH_REQUIRE(v >= 0, "xcd_hot_tau is a permille value >= 0"); xcd_hot_tau_ = static_cast<int>(v); }
     else if (name == "accum_two_pass") accum_two_pass_ = v != 0;
+    else if (name == "gather_waves_per_cu") gather_waves_per_cu_ = static_cast<int>(v);
     else if (name == "auto_resident") auto_resident_ = v != 0;
     else if (name == "lazy_sync") lazy_sync_ = v != 0;
     else if (name == "pin_host") pin_host_ = v != 0;

@@ -156,6 +156,7 @@ class SgdHandle : public HandleBase {
     std::map<std::pair<int, int>, ChunkSig> chunks_;
     std::vector<std::pair<void*, size_t>> pinned_;
     void unpin_host();
+    int gather_waves_per_cu_ = 0;  // grad_gather_kernel grid (0: 32 waves per CU)
     int accum_two_pass_ = 1;       // adam / adagrad / WARP: item-side gradients by the sorted gather (0: one atomic row add per triple)
     int64_t csr_generation_ = 0;   // bumped by set_resident_csr
     bool chunk_set_ = false;
@@ -186,7 +187,8 @@ class SgdHandle : public HandleBase {
 
     Comm* comm_ = nullptr;          // not owned
     int comm_overlap_ = 1;          // leave the last exchange of a call in flight (finished by the next exchange point / reader)
-    int comm_segments_ = 0;         // exchange segments per partial_update call (0: from the learning rate)
+    int comm_segments_ = 0;         // exchange segments per partial_update call (0: from the learning rate and the call's size)
+    bool comm_blocking_call_ = false;   // this call is one segment: its exchange is finished before it returns
     bool x_inited_ = false, x_pending_ = false;
     DevBuf<float> xZ_, xS_, xR_;    // [Q_rows * vdim + ceil4(Q_rows)]: state at the last exchange, own delta, summed deltas
     DevBuf<float> xW_, xWb_;        // [Q_rows] combination weight of every factor row / bias for the exchange in flight (sum .. mean)

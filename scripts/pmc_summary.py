@@ -12,15 +12,18 @@ meta = {}
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "bpr_item_major_kernel" not in k and "bpr_update_kernel" not in k:
+        if not any(t in k for t in ("bpr_item_major_kernel", "bpr_update_kernel", "grad_gather_kernel", "warp_update_kernel", "als_gram_kernel",
+                                    "xcd_merge_kernel", "bpr_presample_kernel")):
             continue
         per[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         meta[k] = {"vgpr": r.get("VGPR_Count"), "sgpr": r.get("SGPR_Count"), "grid": r.get("Grid_Size"), "wg": r.get("Workgroup_Size")}
 # the dominant kernel = the one with the largest total FETCH_SIZE (the drain instantiation finds nothing to do)
-dom = max(per, key=lambda k: sum(per[k].get("FETCH_SIZE", [0.0])))
+bpr = [k for k in per if "bpr_item_major_kernel" in k or "bpr_update_kernel" in k]
+dom = max(bpr, key=lambda k: sum(per[k].get("FETCH_SIZE", [0.0])))
 c = {n: sum(v) / len(v) for n, v in per[dom].items()}
 out = {
-    "command": "rocprofv3 --kernel-trace --pmc <COUNTER> --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline",
+    "command": "rocprofv3 --kernel-trace --pmc <COUNTER> --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra "
+               "(scripts/gpu_profile.sh; the MFMA-utilisation pass keeps the extras)",
     "kernel": dom, "launches_seen": {n: len(v) for n, v in per[dom].items()}, "counters_per_launch": c, **meta[dom],
     "fetch_bytes_raw": c.get("FETCH_SIZE", 0.0) * 1024, "fetch_bytes_corrected_x2": c.get("FETCH_SIZE", 0.0) * 2048,
     "write_bytes": c.get("WRITE_SIZE", 0.0) * 1024,
@@ -31,6 +34,11 @@ out = {
              "under 'others'.",
     "others": {k[:90]: {n: sum(v) / len(v) for n, v in d.items()} for k, d in per.items() if k != dom},
 }
+als = [k for k in per if "als_gram_kernel" in k and "SQ_VALU_MFMA_BUSY_CYCLES" in per[k]]
+if als:   # MFMA utilisation of the ALS Gramian/solve kernel: busy cycles over (active cycles x 1024 SIMDs)
+    a = {n: sum(v) / len(v) for n, v in per[als[0]].items()}
+    out["als_gram_kernel"] = {"counters_per_launch": a, **meta[als[0]],
+                              "mfma_busy_frac": a["SQ_VALU_MFMA_BUSY_CYCLES"] / (a.get("GRBM_GUI_ACTIVE", 0.0) * 1024) if a.get("GRBM_GUI_ACTIVE") else None}
 if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
     out["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
 json.dump(out, open(out_path, "w"), indent=1)

@@ -95,8 +95,10 @@ def test_half_epochs_match_oracle(oracle, d, kw, shape, design):
     oracle's after each comparison), so differences are the kernels' own.  Truncated fp32 CG is
     sensitive to summation order (cond(A) ~ 1e3..1e4): the HIP result has to sit inside the oracle's
     OWN rounding envelope, measured against a float64 evaluation of the same recurrence:
-        err(hip, f64) <= max(5 * err(oracle, f64), 5e-5)   and   err(hip, oracle) <= 4 * max(...)
-    (factor 10 instead of 5 for 128 < vdim <= 256)."""
+        err(hip, f64) <= max(2.5 * err(oracle, f64), 5e-5)   and   err(hip, oracle) <= 4 * max(...)
+    (factor 10 instead of 2.5 for 128 < vdim <= 256).  Measured over all cases below (profiles/r02_als_error_ratios.txt):
+    the ratio err(hip, f64) / err(oracle, f64) is 0.04 .. 2.2 above the 5e-5 floor at vdim <= 128 (median 0.8: the MFMA
+    Gramian is as often MORE accurate than the reference's per-nnz recurrence as less), up to 9 for the wide kernel."""
     import ref_numpy as rn
     from buffalo_amd import synth
     if design == "scratch" and not (d == 128 and kw.get("block_size", 32) == 32):
@@ -133,8 +135,10 @@ def test_half_epochs_match_oracle(oracle, d, kw, shape, design):
             e_or, e_hip, e_pair = H.relerr(Xo, truth), H.relerr(X[:, :d], truth_hip), H.relerr(X[:, :d], Xo)
             # the explicit Gramian adds the rounding of an n-term fp32 sum per entry of M to what the matrix-free
             # reference recurrence sees; CG amplifies it with the conditioning of the 32x32 blocks, which grows
-            # with d: the envelope is 5x the oracle's own error up to vdim 128 and 10x for the wide kernel
-            env = max((5 if _vdim(d) <= 128 else 10) * e_or, 5e-5)
+            # with d: the envelope is 2.5x the oracle's own error up to vdim 128 and 10x for the wide kernel
+            env = max((2.5 if _vdim(d) <= 128 else 10) * e_or, 5e-5)
+            print("\nALS d=%d %s %s/%s it %d axis %d: err(hip,f64) %.3e  err(oracle,f64) %.3e  ratio %.2f  hip~oracle %.3e"
+                  % (d, kw, shape, design, it, axis, e_hip, e_or, e_hip / max(e_or, 1e-30), e_pair))
             assert e_hip <= env, (it, axis, e_hip, e_or)
             gap = H.relerr(truth_hip, truth)     # what the two Gramians' roundings alone do to the exact recurrence
             assert e_pair <= 4 * env + 2 * gap, (it, axis, e_pair, e_or, gap)
@@ -220,6 +224,84 @@ def test_identical_topk_after_training(oracle, optimizer):
     info = (optimizer, exact, len(users), worst, H.relerr(P[:, :d], Po), H.relerr(Q[:, :d], Qo))
     assert worst <= tie, info
     assert exact >= (0.97 if optimizer == "llt" else 0.5) * len(users), info
+
+
+def test_identical_topk_after_training_d128_ialspp(oracle):
+    """The same question for BASELINE config #3's path: d = 128 -> iALS++ (Q-13), ML-100K shape, 3 free-running epochs from
+    the reference's initialisation.  The 32x32 block systems are solved by 3 CG steps in fp32 on both sides, so agreement is
+    limited by conditioning, not by logic: the lists must be identical for most users and nowhere reach further below the
+    oracle's own 10th score than 2 % of the score range."""
+    from buffalo_amd import synth
+    csr = synth.generate(*synth.SHAPES["ml100k"], seed=7, vals="counts")
+    d = 128
+    opt = als_opt(d=d, num_iters=3, compute_loss_on_training=True, optimizer="manual_cg")
+    np.random.seed(7)
+    o, obj, (P, Q), (Po, Qo) = _setup(oracle, csr, d, opt, seed=7, scale=1.0 / d)
+    for _ in range(3):
+        lo, lg = _epoch(o, obj, csr)
+    assert abs(lg[0] / lg[1] - lo[0] / lo[1]) < 5e-3 * abs(lo[0] / lo[1])
+    so, sg = Po @ Qo.T, P[:, :d] @ Q[:, :d].T
+    exact, overlap, worst, users = 0, 0.0, 0.0, range(0, csr.num_users, 3)
+    for u in users:
+        to, tg = np.argsort(-so[u])[:10], np.argsort(-sg[u])[:10]
+        exact += int(list(to) == list(tg))
+        overlap += len(set(to) & set(tg)) / 10.0
+        worst = max(worst, float((so[u][to[-1]] - so[u][tg].min()) / (np.abs(so[u]).max() + 1e-30)))
+    info = (exact, len(users), overlap / len(users), worst, H.relerr(P[:, :d], Po), H.relerr(Q[:, :d], Qo))
+    print("\nALS d=128 iALS++ ML-100K shape, 3 epochs: identical top-10 for %d of %d users, mean overlap %.3f, worst reach %.2e, "
+          "factor distance P %.2e Q %.2e" % info)
+    assert worst <= 2e-2, info
+    assert overlap / len(users) >= 0.95, info
+    assert exact >= 0.8 * len(users), info
+
+
+def test_config3_size_spot_parity(oracle):
+    """BASELINE config #3 at full size (138,493 x 27,278, 20,000,263 nnz, d=128, iALS++): one epoch on the GPU from the
+    reference's initialisation, and the oracle on four sampled 500-row stretches of each side, started from the same inputs
+    (the user stretches from the initial factors; the item stretches from the GPU's updated user factors)."""
+    from buffalo_amd import synth
+    from buffalo_amd.backend import CyALS
+    import bench
+    from buffalo_amd import ingest
+    U, I, nnz = synth.SHAPES["ml20m"]
+    base = bench.load_matrix("ml20m", 7)           # the bench matrix (cached on the box), values 1 + Poisson(1) like bench.py's ALS leg
+    vals = (1 + np.random.default_rng(7).poisson(1.0, size=nnz)).astype(np.float32)
+    csr = synth.CSR(U, I, base.indptr, base.keys, vals)
+    col = ingest.coo_to_csr(csr.keys, csr.rows(), vals, I, U)
+    t = synth.CSR(I, U, col["indptr"], col["key"], col["val"])
+    d = 128
+    opt = als_opt(d=d, num_iters=1)
+    P, Q, _ = synth.init_factors(U, I, d, seed=7)
+    P0 = P.copy()
+    obj = CyALS()
+    assert obj.init(H.write_opt(dict(opt, accelerator=True)))
+    obj.initialize_model(P, Q)
+    obj.set_resident_csr(0, csr.indptr, csr.keys, csr.vals)
+    obj.set_resident_csr(1, t.indptr, t.keys, t.vals)
+    obj.set_mode("als_writeback", 0)
+    worst = {}
+    for axis, mat, rows in ((0, csr, U), (1, t, I)):
+        # the oracle's inputs for this half-epoch: the side being solved as it is now, the other side as the GPU sees it
+        obj.synchronize(True)
+        Xo, Yo = (P.copy(), Q.copy()) if axis == 0 else (Q.copy(), P.copy())
+        o = oracle.OracleALS()
+        assert o.init(H.write_opt(dict(opt, num_workers=16)))
+        o.initialize_model(*((Xo, Yo) if axis == 0 else (Yo, Xo)))
+        o.precompute(axis)
+        obj.precompute(axis)
+        obj.partial_update(0, rows, mat.indptr, None, None, axis)
+        obj.synchronize(True)
+        X = P if axis == 0 else Q
+        errs = []
+        for a in np.linspace(0, rows - 500, 4).astype(int):
+            b = int(a) + 500
+            keys, vals = H.chunk_arrays(mat, int(a), b)
+            o.partial_update(int(a), b, mat.indptr, keys, vals, axis)
+            errs.append(H.relerr(X[int(a):b], Xo[int(a):b]))
+        worst[axis] = max(errs)
+        print("\nconfig #3 spot parity axis %d: 4 x 500 rows, relative error vs the oracle %s" % (axis, ["%.2e" % e for e in errs]))
+    assert not np.array_equal(P, P0)
+    assert worst[0] < 2e-3 and worst[1] < 2e-3, worst
 
 
 def test_full_size_properties():
