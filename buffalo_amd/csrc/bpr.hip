@@ -810,14 +810,19 @@ class BprHandle : public SgdHandle {
             //    segment the call is ONE segment and its exchange is finished before it returns (blocking: 6 % on the
             //    biases, everything else within 3 %).
             // "comm_segments" pins the number, "comm_overlap" = 0 always blocks.
-            int64_t segs = comm_segments_ > 0 ? comm_segments_ : std::min<int64_t>(8, std::max<int64_t>(4, static_cast<int64_t>(std::ceil(c.lr * 80.0))));
-            if (comm_segments_ <= 0 && c.total / segs < (int64_t(1) << 21)) segs = 1;
+            // Every rank must run the SAME number of exchange points per call (each is a collective), so the decision uses only
+            // what all ranks share: the learning rate and the average shard size num_nnz / world (one call per epoch assumed).
+            int64_t segs = comm_segments_ > 0 ? comm_segments_ : std::min<int64_t>(8, std::max<int64_t>(4, static_cast<int64_t>(std::ceil(static_cast<double>(c.lr) * 80.0 - 1e-6))));
+            const int64_t avg_call = num_nnz_ * num_neg_ / std::max(1, comm_->size());
+            if (comm_segments_ <= 0 && avg_call / segs < (int64_t(1) << 21)) segs = 1;
             comm_blocking_call_ = segs == 1;
+            comm_forced_segments_ = segs;
             sync_updates = std::min<int64_t>(sync_updates, std::max<int64_t>(1, (c.total + segs - 1) / segs));
         }
         int64_t q_entries[kImMaxQueues] = {0};
         for (int x = 0; x < nq; ++x) q_entries[x] = im_qbeg_[x + 1] - im_qbeg_[x];
-        const ImPlan plan = im_make_plan(nq, q_entries, num_neg_, sync_updates);
+        ImPlan plan = im_make_plan(nq, q_entries, num_neg_, sync_updates);
+        if (comm_) plan.segments = comm_forced_segments_;   // not left to the rounding of local sizes
         const int64_t segments = plan.segments;
         const double lr_scale = c.lr > 0.f ? 0.05 / static_cast<double>(c.lr) : 1e9;
         const double max_stale = std::min(1e9, static_cast<double>(im_max_stale_) * lr_scale);

@@ -189,6 +189,7 @@ class SgdHandle : public HandleBase {
     int comm_overlap_ = 1;          // leave the last exchange of a call in flight (finished by the next exchange point / reader)
     int comm_segments_ = 0;         // exchange segments per partial_update call (0: from the learning rate and the call's size)
     bool comm_blocking_call_ = false;   // this call is one segment: its exchange is finished before it returns
+    int64_t comm_forced_segments_ = 1;  // exchange segments of the current call (identical on every rank)
     bool x_inited_ = false, x_pending_ = false;
     DevBuf<float> xZ_, xS_, xR_;    // [Q_rows * vdim + ceil4(Q_rows)]: state at the last exchange, own delta, summed deltas
     DevBuf<float> xW_, xWb_;        // [Q_rows] combination weight of every factor row / bias for the exchange in flight (sum .. mean)

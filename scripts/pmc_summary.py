@@ -35,10 +35,12 @@ out = {
     "others": {k[:90]: {n: sum(v) / len(v) for n, v in d.items()} for k, d in per.items() if k != dom},
 }
 als = [k for k in per if "als_gram_kernel" in k and "SQ_VALU_MFMA_BUSY_CYCLES" in per[k]]
-if als:   # MFMA utilisation of the ALS Gramian/solve kernel: busy cycles over (active cycles x 1024 SIMDs)
+if als:   # MFMA utilisation of the ALS Gramian/solve kernel: matrix-pipe busy cycles over (kernel cycles x 1024 SIMDs).
+    # GRBM_GUI_ACTIVE is reported summed over the 8 XCDs (71.4 M for a 3.9 ms launch at ~2.3 GHz), hence the / 8.
     a = {n: sum(v) / len(v) for n, v in per[als[0]].items()}
     out["als_gram_kernel"] = {"counters_per_launch": a, **meta[als[0]],
-                              "mfma_busy_frac": a["SQ_VALU_MFMA_BUSY_CYCLES"] / (a.get("GRBM_GUI_ACTIVE", 0.0) * 1024) if a.get("GRBM_GUI_ACTIVE") else None}
+                              "mfma_busy_frac": a["SQ_VALU_MFMA_BUSY_CYCLES"] / (a.get("GRBM_GUI_ACTIVE", 0.0) / 8 * 1024) if a.get("GRBM_GUI_ACTIVE") else None,
+                              "mfma_instructions_per_launch": a["SQ_VALU_MFMA_BUSY_CYCLES"] / 64.0}
 if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
     out["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
 json.dump(out, open(out_path, "w"), indent=1)

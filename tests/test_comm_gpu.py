@@ -51,10 +51,11 @@ def _run(cls, opt, csr, P, Q, Qb, epochs, comm, modes, n_chunks=1):
 @pytest.mark.parametrize("modes,n_chunks", [
     (dict(sequential=1), 1),                                   # user-major walk: exchange after every call
     (dict(sequential=1, comm_overlap=0), 2),
-    # item-major: several merge segments = exchange points per call (comm_segments=1: the communicator does not add any, so the
-    # schedule is the one of the run without it)
-    (dict(hogwild_atomic=3, im_single_wave=1, im_force_queues=4, xcd_sync_updates=200, comm_segments=1), 1),
-    (dict(hogwild_atomic=3, im_single_wave=1, im_force_queues=4, xcd_sync_updates=150, comm_segments=1, comm_overlap=0), 2),
+    # item-major: one merge segment = one exchange point per call, left in flight / finished before the call returns
+    (dict(hogwild_atomic=3, im_single_wave=1, im_force_queues=4, comm_segments=1), 1),
+    (dict(hogwild_atomic=3, im_single_wave=1, im_force_queues=4, comm_segments=1, comm_overlap=0), 2),
+    # three exchange segments per call; the run without a communicator is given the merge interval that cuts the call the same way
+    (dict(hogwild_atomic=3, im_single_wave=1, im_force_queues=4, comm_segments=3, xcd_sync_updates="nnz/3"), 1),
 ])
 def test_sgd_one_rank_world_equals_no_comm(comm, modes, n_chunks):
     """Deterministic walks: with one rank R == S, so folding "the other ranks' part" in adds exactly zero and a flush
@@ -63,6 +64,9 @@ def test_sgd_one_rank_world_equals_no_comm(comm, modes, n_chunks):
     csr = tiny_csr(U=60, I=80, density=0.15, seed=4)
     d, vdim = 40, 64
     opt = bpr_opt(d=d, lr=0.05, min_lr=0.01, num_iters=3, random_seed=5)
+    modes = dict(modes)
+    if modes.get("xcd_sync_updates") == "nnz/3":
+        modes["xcd_sync_updates"] = (csr.nnz + 2) // 3
     ref = _factors(csr, d, vdim)
     got = tuple(a.copy() for a in ref)
     _run(CyBPR, opt, csr, *ref, 3, None, modes, n_chunks)
