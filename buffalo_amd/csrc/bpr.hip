@@ -813,7 +813,7 @@ class BprHandle : public SgdHandle {
             // Every rank must run the SAME number of exchange points per call (each is a collective), so the decision uses only
             // what all ranks share: the learning rate and the average shard size num_nnz / world (one call per epoch assumed).
             int64_t segs = comm_segments_ > 0 ? comm_segments_ : std::min<int64_t>(8, std::max<int64_t>(4, static_cast<int64_t>(std::ceil(static_cast<double>(c.lr) * 80.0 - 1e-6))));
-            const int64_t avg_call = num_nnz_ * num_neg_ / std::max(1, comm_->size());
+            const int64_t avg_call = num_nnz_ * num_neg_ / std::max(1, std::max(comm_->size(), num_shards_));
             if (comm_segments_ <= 0 && avg_call / segs < (int64_t(1) << 21)) segs = 1;
             comm_blocking_call_ = segs == 1;
             comm_forced_segments_ = segs;

@@ -252,17 +252,20 @@ def test_identical_topk_after_training_d128_ialspp(oracle):
           "factor distance P %.2e Q %.2e" % info)
     assert worst <= 2e-2, info
     assert overlap / len(users) >= 0.95, info
-    assert exact >= 0.8 * len(users), info
+    assert exact >= 0.9 * len(users), info
 
 
 def test_config3_size_spot_parity(oracle):
     """BASELINE config #3 at full size (138,493 x 27,278, 20,000,263 nnz, d=128, iALS++): one epoch on the GPU from the
-    reference's initialisation, and the oracle on four sampled 500-row stretches of each side, started from the same inputs
-    (the user stretches from the initial factors; the item stretches from the GPU's updated user factors)."""
-    from buffalo_amd import synth
-    from buffalo_amd.backend import CyALS
+    reference's initialisation, and -- on four sampled 500-row stretches of each side, started from the same inputs (the
+    user stretches from the initial factors; the item stretches from the GPU's updated user factors) -- the oracle and a
+    float64 evaluation of the same recurrence.  Same envelope as the small cases: err(hip, f64) <= max(2.5 err(oracle, f64),
+    5e-5).  (The item stretches contain rows of up to 1.3e5 entries, where the oracle's left-to-right fp32 sums are the
+    inaccurate side: comparing the two fp32 results directly there measures the oracle, not the kernel.)"""
     import bench
-    from buffalo_amd import ingest
+    import ref_numpy as rn
+    from buffalo_amd import ingest, synth
+    from buffalo_amd.backend import CyALS
     U, I, nnz = synth.SHAPES["ml20m"]
     base = bench.load_matrix("ml20m", 7)           # the bench matrix (cached on the box), values 1 + Poisson(1) like bench.py's ALS leg
     vals = (1 + np.random.default_rng(7).poisson(1.0, size=nnz)).astype(np.float32)
@@ -279,29 +282,40 @@ def test_config3_size_spot_parity(oracle):
     obj.set_resident_csr(0, csr.indptr, csr.keys, csr.vals)
     obj.set_resident_csr(1, t.indptr, t.keys, t.vals)
     obj.set_mode("als_writeback", 0)
-    worst = {}
     for axis, mat, rows in ((0, csr, U), (1, t, I)):
-        # the oracle's inputs for this half-epoch: the side being solved as it is now, the other side as the GPU sees it
+        # the inputs of this half-epoch: the side being solved as it is now, the other side as the GPU sees it
         obj.synchronize(True)
-        Xo, Yo = (P.copy(), Q.copy()) if axis == 0 else (Q.copy(), P.copy())
+        Xin, Yin = (P.copy(), Q.copy()) if axis == 0 else (Q.copy(), P.copy())
+        Xo = Xin.copy()
         o = oracle.OracleALS()
         assert o.init(H.write_opt(dict(opt, num_workers=16)))
-        o.initialize_model(*((Xo, Yo) if axis == 0 else (Yo, Xo)))
+        o.initialize_model(*((Xo, Yin) if axis == 0 else (Yin, Xo)))
         o.precompute(axis)
         obj.precompute(axis)
+        ff_or = o.get_ff(d)
+        ff_hip = obj.device_tensor("FF", (d, d)).cpu().numpy().copy()
         obj.partial_update(0, rows, mat.indptr, None, None, axis)
         obj.synchronize(True)
         X = P if axis == 0 else Q
-        errs = []
+        reg = opt["reg_u"] if axis == 0 else opt["reg_i"]
         for a in np.linspace(0, rows - 500, 4).astype(int):
-            b = int(a) + 500
-            keys, vals = H.chunk_arrays(mat, int(a), b)
-            o.partial_update(int(a), b, mat.indptr, keys, vals, axis)
-            errs.append(H.relerr(X[int(a):b], Xo[int(a):b]))
-        worst[axis] = max(errs)
-        print("\nconfig #3 spot parity axis %d: 4 x 500 rows, relative error vs the oracle %s" % (axis, ["%.2e" % e for e in errs]))
+            a, b = int(a), int(a) + 500
+            keys, vals_c = H.chunk_arrays(mat, a, b)
+            o.partial_update(a, b, mat.indptr, keys, vals_c, axis)
+            t_or, t_hip = Xin[a:b].astype(np.float64), Xin[a:b].astype(np.float64)
+            longest = 0
+            for r in range(a, b):
+                k, v = mat.row(r)
+                longest = max(longest, len(k))
+                if len(k):   # the float64 recurrence on compacted inputs (the row itself, the rows of the other side it touches)
+                    sub = Yin[k]
+                    t_or[r - a] = rn.ialspp_row_f64_fast(Xin[r], sub, ff_or, v, opt["alpha"], reg, opt["block_size"])
+                    t_hip[r - a] = rn.ialspp_row_f64_fast(Xin[r], sub, ff_hip, v, opt["alpha"], reg, opt["block_size"])
+            e_or, e_hip, e_pair = H.relerr(Xo[a:b], t_or), H.relerr(X[a:b], t_hip), H.relerr(X[a:b], Xo[a:b])
+            print("\nconfig #3 spot parity axis %d rows [%d, %d) (longest %d entries): err(hip,f64) %.2e  err(oracle,f64) %.2e  ratio %.2f  "
+                  "hip~oracle %.2e" % (axis, a, b, longest, e_hip, e_or, e_hip / max(e_or, 1e-30), e_pair))
+            assert e_hip <= max(2.5 * e_or, 5e-5), (axis, a, e_hip, e_or)
     assert not np.array_equal(P, P0)
-    assert worst[0] < 2e-3 and worst[1] < 2e-3, worst
 
 
 def test_full_size_properties():

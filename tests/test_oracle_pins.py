@@ -558,3 +558,20 @@ def test_eals_descends_the_float64_objective_and_keeps_its_cache(oracle, opt_fil
     vh, _ = o.caches(0, csr.nnz)
     assert np.abs(vh - (P[rows] * Q[csr.keys]).sum(1)).max() < 1e-5
     assert abs(rmse - np.sqrt(((csr.vals - vh) ** 2).mean())) < 1e-5
+
+
+def test_ialspp_f64_fast_equals_loop_version():
+    """tests/ref_numpy.py: the matrix-product form of the float64 iALS++ row recurrence (used at config #3 size) against the
+    per-entry loop form the oracle is pinned on."""
+    import ref_numpy as R
+    rng = np.random.default_rng(3)
+    D, n = 96, 57
+    P = rng.normal(scale=0.2, size=(3, D)).astype(np.float32)
+    Q = rng.normal(scale=0.2, size=(40, D)).astype(np.float32)
+    FF = (Q.astype(np.float64).T @ Q.astype(np.float64)).astype(np.float32)
+    keys = rng.integers(0, 40, n)
+    vals = (1 + rng.poisson(1.0, n)).astype(np.float32)
+    for bs in (32, 7):
+        a = R.ialspp_row_f64(P, Q, FF, 1, keys, vals, 4.0, 0.3, bs)
+        b = R.ialspp_row_f64_fast(P[1], Q[keys], FF, vals, 4.0, 0.3, bs)
+        assert np.abs(a - b).max() < 1e-12 * max(1.0, np.abs(a).max())
