@@ -583,6 +583,14 @@ namespace bfh {
 class BprHandle : public SgdHandle {
  public:
     BprHandle() : SgdHandle(0) { hogwild_atomic_ = 3; }   // sgd default: the item-major walk (bpr_item_major.hpp)
+    ~BprHandle() override {
+        if (pre_stream_) {
+            (void)hipStreamSynchronize(pre_stream_);
+            (void)hipStreamDestroy(pre_stream_);
+            (void)hipEventDestroy(pre_done_);
+            (void)hipEventDestroy(pre_ready_);
+        }
+    }
     void parse_specific() override {
         num_neg_ = opt_.integer("num_negative_samples");
         BFH_REQUIRE(num_neg_ >= 1 && num_neg_ <= 255, "num_negative_samples must be in [1,255]");
@@ -800,21 +808,17 @@ class BprHandle : public SgdHandle {
         // the staleness budgets are stated for lr = 0.05 and scale with 1 / lr: what matters is how far a row moves
         int64_t sync_updates = xcd_sync_updates_ > 0 ? xcd_sync_updates_ : int64_t(1) << 23;
         if (comm_) {
-            // multi-GPU: every merge segment is an exchange point.  Two regimes (profiles/r02_local_sgd_study_*, r02_shard_times.txt):
-            //  * long calls: the exchange of a segment travels behind the NEXT segment's walk -- one segment late.  A late delta
-            //    costs more the longer the interval and the larger lr (8 ranks, BASELINE scale, lr 0.002: the popular items'
-            //    biases end 40 % off the single-process run with ONE delayed exchange per epoch, 14 % with two, 1.5 % with
-            //    four), so pipelining needs at least 4 exchange segments per call, more at large lr;
-            //  * short calls: a segment costs ~0.1 ms of merge / drain / launch work on top of its walk, which a 2.5 M-triple
-            //    shard (8 ranks on ML-20M) cannot amortise -- 1.7 -> 2.4 ms per epoch with four.  Below 2^21 triples per
-            //    segment the call is ONE segment and its exchange is finished before it returns (blocking: 6 % on the
-            //    biases, everything else within 3 %).
-            // "comm_segments" pins the number, "comm_overlap" = 0 always blocks.
-            // Every rank must run the SAME number of exchange points per call (each is a collective), so the decision uses only
-            // what all ranks share: the learning rate and the average shard size num_nnz / world (one call per epoch assumed).
-            int64_t segs = comm_segments_ > 0 ? comm_segments_ : std::min<int64_t>(8, std::max<int64_t>(4, static_cast<int64_t>(std::ceil(static_cast<double>(c.lr) * 80.0 - 1e-6))));
-            const int64_t avg_call = num_nnz_ * num_neg_ / std::max(1, std::max(comm_->size(), num_shards_));
-            if (comm_segments_ <= 0 && avg_call / segs < (int64_t(1) << 21)) segs = 1;
+            // multi-GPU: every merge segment is an exchange point.  By default a call is ONE segment whose exchange is finished
+            // before it returns (blocking).  "comm_segments" = k cuts the call into k segments whose exchanges travel behind the
+            // NEXT segment's walk (one segment late; the last one stays in flight until the next exchange point or reader).
+            // Measured / simulated (profiles/r02_shard_times_*, r02_local_sgd_study_*): a segment costs ~0.2 ms of merge / drain /
+            // launch-tail work on top of its walk -- as much as the 14 MB all-reduce it hides -- so on ML-20M pipelining loses at
+            // every N (N = 2: 5.1 ms per epoch with four segments against 4.2 + ~0.2 blocking); and a delta that lands one
+            // interval late needs >= 4 exchange points per epoch to match the blocking exchange's statistics (8 ranks, lr 0.002:
+            // the popular items' biases end 40 % off with one delayed exchange, 14 % with two, 1.5 % with four; blocking: 6 %).
+            // It pays only where a walk is long against the fixed cost (large d, WARP-sized shards).
+            // Every rank must run the SAME number of exchange points per call (each is a collective): the knob, not local sizes.
+            const int64_t segs = comm_segments_ > 0 ? comm_segments_ : 1;
             comm_blocking_call_ = segs == 1;
             comm_forced_segments_ = segs;
             sync_updates = std::min<int64_t>(sync_updates, std::max<int64_t>(1, (c.total + segs - 1) / segs));
@@ -856,10 +860,45 @@ class BprHandle : public SgdHandle {
         q.trace = (im_single_wave_ && im_trace_.size() >= static_cast<size_t>(c.total)) ? im_trace_.get() : nullptr;
         q.done = reinterpret_cast<unsigned long long*>(scratch_.get() + 1);
         if (im_presample_) {
-            im_neg_.resize(static_cast<size_t>(c.total));
-            hipLaunchKernelGGL(bpr_presample_kernel, dim3(static_cast<unsigned>((c.total + 255) / 256)), dim3(256), 0, stream, p, c, im_neg_.get());
-            BFH_HIP(hipGetLastError());
-            q.neg_pre = im_neg_.get();
+            // A draw is a pure function of (seed, nnz position, slot, epoch, attempt) -- not of the model -- so the negatives of
+            // the NEXT epoch over this same chunk can be drawn on a side stream while this epoch's walk runs (0.35 ms per
+            // ML-20M epoch off the critical path).  The speculation is keyed on everything the draws depend on; a call it does
+            // not match (another chunk, the same epoch again, changed keys) draws its own on the main stream as before.
+            const dim3 pgrid(static_cast<unsigned>((c.total + 255) / 256)), pblock(256);
+            const PreKey want{static_cast<int64_t>(p.epoch), start_x, next_x, c.total, csr_generation_, p.nnz_offset, p.shift, static_cast<int64_t>(p.seed),
+                              (c.uniform ? 1 : 0) | (c.verify_neg ? 2 : 0) | (c.num_neg << 2), c.cum_total};
+            int buf = 0;
+            if (pre_valid_ && pre_key_ == want) {
+                buf = pre_buf_;
+                BFH_HIP(hipStreamWaitEvent(stream, pre_done_, 0));
+            } else {
+                if (pre_valid_) BFH_HIP(hipStreamSynchronize(pre_stream_));   // a stale speculation may still be writing the other buffer
+                if (im_neg_[0].size() < static_cast<size_t>(c.total)) im_neg_[0].resize(static_cast<size_t>(c.total));
+                hipLaunchKernelGGL(bpr_presample_kernel, pgrid, pblock, 0, stream, p, c, im_neg_[0].get());
+                BFH_HIP(hipGetLastError());
+            }
+            pre_valid_ = false;
+            q.neg_pre = im_neg_[buf].get();
+            if (im_presample_ahead_ && keeps && !im_single_wave_) {
+                if (!pre_stream_) {
+                    BFH_HIP(hipStreamCreateWithFlags(&pre_stream_, hipStreamNonBlocking));
+                    BFH_HIP(hipEventCreateWithFlags(&pre_done_, hipEventDisableTiming));
+                    BFH_HIP(hipEventCreateWithFlags(&pre_ready_, hipEventDisableTiming));
+                }
+                const int other = 1 - buf;
+                if (im_neg_[other].size() < static_cast<size_t>(c.total)) im_neg_[other].resize(static_cast<size_t>(c.total));
+                SgdParams p2 = p;
+                p2.epoch = p.epoch + 1;
+                BFH_HIP(hipEventRecord(pre_ready_, stream));                   // the staged chunk (keys, row ids) is in place behind this point
+                BFH_HIP(hipStreamWaitEvent(pre_stream_, pre_ready_, 0));
+                hipLaunchKernelGGL(bpr_presample_kernel, pgrid, pblock, 0, pre_stream_, p2, c, im_neg_[other].get());
+                BFH_HIP(hipGetLastError());
+                BFH_HIP(hipEventRecord(pre_done_, pre_stream_));
+                pre_key_ = want;
+                pre_key_.epoch = static_cast<int64_t>(p.epoch) + 1;
+                pre_buf_ = other;
+                pre_valid_ = true;
+            }
         }
         BFH_HIP(hipMemsetAsync(scratch_.get() + 1, 0, sizeof(double), stream));
         q.slice_len = plan.slice_len;
@@ -1145,7 +1184,23 @@ class BprHandle : public SgdHandle {
     DevBuf<int64_t> im_qbeg_dev_;
     DevBuf<uint8_t> im_flush_, im_hot_user_;
     DevBuf<int> im_tickets_;
-    DevBuf<int32_t> im_neg_;
+    DevBuf<int32_t> im_neg_[2];    // pre-drawn negatives: this call's, and the speculation for the next epoch
+    struct PreKey {
+        int64_t epoch;
+        int start_x, next_x;
+        int64_t total, gen, nnz_offset, shift, seed;
+        int flags;
+        int64_t cum_total;
+        bool operator==(const PreKey& o) const {
+            return epoch == o.epoch && start_x == o.start_x && next_x == o.next_x && total == o.total && gen == o.gen && nnz_offset == o.nnz_offset &&
+                   shift == o.shift && seed == o.seed && flags == o.flags && cum_total == o.cum_total;
+        }
+    };
+    PreKey pre_key_{};
+    bool pre_valid_ = false;
+    int pre_buf_ = 0;
+    hipStream_t pre_stream_ = nullptr;
+    hipEvent_t pre_done_ = nullptr, pre_ready_ = nullptr;
     int64_t im_qbeg_[kImMaxQueues + 1] = {0};
     int64_t im_gen_ = -1, im_n_ = -1, im_expect_done_ = -1, im_built_blocks_ = -1;
     int im_built_nq_ = -1;

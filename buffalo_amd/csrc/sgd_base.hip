@@ -932,6 +932,7 @@ void SgdHandle::set_mode(const std::string& name, int64_t v) {
     else if (name == "im_drift_budget") { BFH_REQUIRE(v >= 0, "im_drift_budget is a permille value >= 0"); im_drift_budget_milli_ = static_cast<int>(v); }
     else if (name == "im_blocks") { BFH_REQUIRE(v >= 0 && v <= 64, "im_blocks must be in [0,64] (0 = choose from the learning rate)"); im_blocks_ = static_cast<int>(v); }
     else if (name == "im_presample") im_presample_ = v != 0;
+    else if (name == "im_presample_ahead") im_presample_ahead_ = v != 0;
     else if (name == "im_drain_only") im_drain_only_ = v != 0;
     else if (name == "im_single_wave") im_single_wave_ = v != 0;
     else if (name == "im_trace") { BFH_REQUIRE(v >= 0, "im_trace is a capacity in triples"); im_trace_.resize(static_cast<size_t>(v), true, stream); sync_stream(); }
@@ -947,7 +948,7 @@ void SgdHandle::set_mode(const std::string& name, int64_t v) {
     else if (name == "comm_overlap") comm_overlap_ = v != 0;
     else if (name == "comm_stiffness") { BFH_REQUIRE(v >= 0, "comm_stiffness is a permille value >= 0 (0: plain sum of the deltas)"); comm_stiffness_milli_ = static_cast<int>(v); }
     else if (name == "comm_stiffness_q") { BFH_REQUIRE(v >= 0, "comm_stiffness_q is a permille value >= 0"); comm_stiffness_q_milli_ = static_cast<int>(v); }
-    else if (name == "comm_segments") { BFH_REQUIRE(v >= 0 && v <= 64, "comm_segments must be in [0,64] (0 = from the learning rate)"); comm_segments_ = static_cast<int>(v); }
+    else if (name == "comm_segments") { BFH_REQUIRE(v >= 0 && v <= 64, "comm_segments must be in [0,64] (0 = one blocking exchange per call)"); comm_segments_ = static_cast<int>(v); }
     else if (name == "prefetch") prefetch_ = static_cast<int>(v);
     else if (name == "waves_per_cu") waves_per_cu_ = static_cast<int>(v);
     else if (name == "chunk") { BFH_REQUIRE(v >= 64 && v % 64 == 0, "chunk must be a positive multiple of 64"); chunk_ = static_cast<int>(v); chunk_set_ = true; }

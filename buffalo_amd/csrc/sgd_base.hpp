@@ -141,6 +141,7 @@ class SgdHandle : public HandleBase {
     DevBuf<int32_t> im_trace_;     // test hook ("im_trace" = capacity): table index of every triple of a single-wave call
     int im_drift_budget_milli_ = 1000;  // policy 3: lr-weighted positive steps of a row per merge interval above which its negatives go chip-wide
     int im_presample_ = 1;         // policy 3: draw the call's negatives in CSR order before the walk
+    int im_presample_ahead_ = 1;   // ... and the next epoch's on a side stream while this epoch's walk runs
     int im_blocks_ = 0;            // policy 3: runs an item's entries are cut into inside a queue (0 = from the learning rate)
     int im_max_stale_ = 64;        // policy 3: updates of one item row that may be in flight unseen by the other waves
     int xcd_fresh_ = -1, xcd_v4_ = 0;  // re-read before store; float4-per-lane rows (hot-row atomics then cost 4x the line operations)
@@ -187,7 +188,7 @@ class SgdHandle : public HandleBase {
 
     Comm* comm_ = nullptr;          // not owned
     int comm_overlap_ = 1;          // leave the last exchange of a call in flight (finished by the next exchange point / reader)
-    int comm_segments_ = 0;         // exchange segments per partial_update call (0: from the learning rate and the call's size)
+    int comm_segments_ = 0;         // exchange segments per partial_update call (0 = 1: one blocking exchange; k > 1: pipelined)
     bool comm_blocking_call_ = false;   // this call is one segment: its exchange is finished before it returns
     int64_t comm_forced_segments_ = 1;  // exchange segments of the current call (identical on every rank)
     bool x_inited_ = false, x_pending_ = false;

@@ -210,10 +210,13 @@ void* bfh_als_stream(void* h);
  *   rank 0:      bfh_comm_unique_id(id, 128)  -> hand the 128 bytes to every rank (MPI / a file / torch's store)
  *   every rank:  comm = bfh_comm_create(world, rank, id, device);  bfh_{bpr,warp,als}_set_comm(h, comm)
  * and from then on the handle exchanges by itself over RCCL / xGMI:
- *   BPRMF sgd  -- users (P rows + their CSR rows) sharded, Q / Qb replicated: every exchange point (a merge segment of
- *                 partial_update) sums what the ranks changed, Q <- Q_sync + sum_r (Q_r - Q_sync), with ONE ncclAllReduce of
- *                 Q | Qb on the communicator's stream, pipelined one deep: the delta travels while the next walk runs and is
- *                 folded in at the next exchange point ("comm_overlap" = 0: before partial_update returns);
+ *   BPRMF sgd  -- users (P rows + their CSR rows) sharded, Q / Qb replicated: at every exchange point ONE ncclAllReduce of
+ *                 Q | Qb sums what the ranks changed since the state Z they agree on, and every rank advances
+ *                 Z <- Z + w R with a per-row weight w between 1 (cold rows: the deltas are independent steps, SUM) and
+ *                 1/world (rows every rank drove to its local equilibrium: MEAN) -- see exchange_weight_kernel.  Default: one
+ *                 exchange per partial_update, finished before it returns.  "comm_segments" = k > 1 cuts a call into k
+ *                 segments whose exchanges travel on the communicator's stream behind the next segment's walk, the last one
+ *                 staying in flight until the next exchange point ("comm_overlap" = 0: until the call returns);
  *                 bfh_*_comm_flush / synchronize / compute_loss finish what is in flight;
  *   adam / adagrad / WARP -- update_parameters sums gradQ | gradQb (| counts) over the ranks before the (then identical)
  *                 optimizer step: exactly the single-GPU result up to summation order (lib/algo.cc:382);

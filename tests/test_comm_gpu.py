@@ -77,7 +77,7 @@ def test_sgd_one_rank_world_equals_no_comm(comm, modes, n_chunks):
 
 
 @pytest.mark.parametrize("modes,lo,hi", [
-    ({}, 30, 30),                                 # a 14 K-triple call is one segment, its exchange blocking
+    ({}, 30, 30),                                 # default: a call is one segment, its exchange blocking
     (dict(comm_segments=4), 30 * 4, 30 * 5),      # pinned: 4 pipelined exchange segments per call (5 when the plan rounds up)
 ])
 def test_item_major_default_with_comm_runs_and_learns(comm, modes, lo, hi):
