@@ -1645,6 +1645,7 @@ __global__ __launch_bounds__(256) void als_solve_kernel(AlsParams p, const AlsHe
 class AlsHandle : public HandleBase {
  public:
     ~AlsHandle() override {
+        unpin_host();
         if (stream) (void)hipStreamDestroy(stream);
     }
 
@@ -1694,6 +1695,13 @@ class AlsHandle : public HandleBase {
         BFH_REQUIRE(P && Q && P_rows > 0 && Q_rows > 0, "initialize_model: null factors or empty shapes");
         hostP_ = P; hostQ_ = Q; P_rows_ = P_rows; Q_rows_ = Q_rows;
         const size_t np = static_cast<size_t>(P_rows) * vdim_, nq = static_cast<size_t>(Q_rows) * vdim_;
+        unpin_host();
+        if (pin_host_) {   // the updated rows go back into these arrays after every partial_update (als.cu:403): page-lock them
+            for (auto pr : {std::make_pair(static_cast<void*>(P), np * sizeof(float)), std::make_pair(static_cast<void*>(Q), nq * sizeof(float))}) {
+                if (hipHostRegister(pr.first, pr.second, hipHostRegisterDefault) == hipSuccess) pinned_.push_back(pr.first);
+                else (void)hipGetLastError();
+            }
+        }
         P_.resize(np); Q_.resize(nq);
         BFH_HIP(hipMemcpyAsync(P_.get(), P, np * sizeof(float), hipMemcpyHostToDevice, stream));
         BFH_HIP(hipMemcpyAsync(Q_.get(), Q, nq * sizeof(float), hipMemcpyHostToDevice, stream));
@@ -1715,6 +1723,8 @@ class AlsHandle : public HandleBase {
         keys_.resize(batch_size);
         vals_.resize(batch_size);
         yui_.resize(batch_size);
+        ax_[0].chunks.clear();
+        ax_[1].chunks.clear();
         BFH_HIP(hipStreamSynchronize(stream));
         work_cache_.clear();
         placeholder_ = true;
@@ -1806,6 +1816,30 @@ class AlsHandle : public HandleBase {
         p.out_scale = 1.0f;
         p.ff_scale = 1.0f;
         if (A.resident) {
+            p.keys = A.keys.get() + beg;
+            p.vals = A.vals.get() + beg;
+            p.yui = yui_.get();
+        } else if (auto_resident_ && keys && vals && !A.indptr_host.empty()) {
+            // the reference hands keys / vals over on every call (cuda/_als.pyx:52-67): a chunk seen before -- same row range,
+            // same length, same sampled checksum of both host buffers -- is served from its place in a full-size device copy
+            const int64_t total = A.indptr_host.back();
+            BFH_REQUIRE(end <= total, "partial_update: indptr disagrees with the placeholder's");
+            if (A.keys.size() < static_cast<size_t>(total)) {
+                A.keys.resize(static_cast<size_t>(total));
+                A.vals.resize(static_cast<size_t>(total));
+                A.chunks.clear();
+            }
+            if (yui_.size() < static_cast<size_t>(n)) yui_.resize(static_cast<size_t>(n));
+            const uint64_t sig = sample_signature(keys, n) * 31u + sample_signature(reinterpret_cast<const int32_t*>(vals), n);
+            auto it = A.chunks.find({start_x, next_x});
+            if (it == A.chunks.end() || it->second.first != n || it->second.second != sig) {
+                if (n) {
+                    BFH_HIP(hipMemcpyAsync(A.keys.get() + beg, keys, n * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+                    BFH_HIP(hipMemcpyAsync(A.vals.get() + beg, vals, n * sizeof(float), hipMemcpyHostToDevice, stream));
+                    stats.h2d_bytes += static_cast<double>(n * 8);
+                }
+                A.chunks[{start_x, next_x}] = {n, sig};
+            }
             p.keys = A.keys.get() + beg;
             p.vals = A.vals.get() + beg;
             p.yui = yui_.get();
@@ -2080,6 +2114,8 @@ class AlsHandle : public HandleBase {
 
     void set_mode(const std::string& name, int64_t v) {
         if (name == "als_writeback") writeback_ = v != 0;
+        else if (name == "auto_resident") auto_resident_ = v != 0;
+        else if (name == "pin_host") pin_host_ = v != 0;
         else if (name == "als_v1") force_v1_ = v != 0;
         else if (name == "als_debug") debug_ = static_cast<int>(v);
         else if (name == "als_inreg") no_inreg_ = v == 0;                 // 0: iALS++ rows go through the scratch + solve kernel instead of the in-register solve
@@ -2100,7 +2136,15 @@ class AlsHandle : public HandleBase {
         DevBuf<int32_t> keys;
         DevBuf<float> vals;
         bool resident = false;
+        std::map<std::pair<int, int>, std::pair<int64_t, uint64_t>> chunks;   // auto-residency: row range -> (length, checksum)
     };
+    void unpin_host() {
+        for (void* q : pinned_) (void)hipHostUnregister(q);
+        if (!pinned_.empty()) (void)hipGetLastError();
+        pinned_.clear();
+    }
+    std::vector<void*> pinned_;
+    bool auto_resident_ = true, pin_host_ = true;
 
     Options opt_;
     bool inited_ = false, model_ = false, placeholder_ = false, writeback_ = true;

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -177,6 +178,26 @@ class EventTimer {
 };
 
 static inline int vdim_of(int d) { return ((d + 31) / 32) * 32; }  // bpr.cu:266-267, als.cu:251-252
+
+// Auto-residency of chunks the caller hands over on every call (the reference's call pattern, cuda/_bpr.pyx:60-74, _als.pyx:52-67):
+// 64-bit mix of ~2K sampled keys + both ends + the length: cheap enough to run on every call, and a chunk whose content
+// changed under the same row range is caught unless it agrees with the old one at every sampled position
+static inline uint64_t sample_signature(const int32_t* keys, int64_t n) {
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ static_cast<uint64_t>(n);
+    auto mix = [&](uint64_t v) {
+        h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+        h *= 0xff51afd7ed558ccdull;
+        h ^= h >> 33;
+    };
+    const int64_t edge = std::min<int64_t>(n, 64);
+    for (int64_t i = 0; i < edge; ++i) mix(static_cast<uint32_t>(keys[i]));
+    for (int64_t i = n - edge; i < n; ++i) mix(static_cast<uint32_t>(keys[i]));
+    const int64_t samples = 2048, stride = std::max<int64_t>(1, n / samples);
+    for (int64_t i = stride / 2; i < n; i += stride) mix((static_cast<uint64_t>(i) << 32) | static_cast<uint32_t>(keys[i]));
+    return h;
+}
+
+
 
 // Stable LSD radix sort of (uint32 key, int32 value) pairs over the low `bits` key bits, on `s`
 // (rocprim::radix_sort_pairs; implemented in ingest.hip so only that file pays for the headers).

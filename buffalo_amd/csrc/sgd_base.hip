@@ -581,23 +581,6 @@ void SgdHandle::exchange_gradients() {
 }
 
 // ------------------------------------------------------------------------------------------------
-// 64-bit mix of ~2K sampled keys + both ends + the length: cheap enough to run on every call, and a chunk whose content
-// changed under the same row range is caught unless it agrees with the old one at every sampled position
-static uint64_t sample_signature(const int32_t* keys, int64_t n) {
-    uint64_t h = 0x9E3779B97F4A7C15ull ^ static_cast<uint64_t>(n);
-    auto mix = [&](uint64_t v) {
-        h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
-        h *= 0xff51afd7ed558ccdull;
-        h ^= h >> 33;
-    };
-    const int64_t edge = std::min<int64_t>(n, 64);
-    for (int64_t i = 0; i < edge; ++i) mix(static_cast<uint32_t>(keys[i]));
-    for (int64_t i = n - edge; i < n; ++i) mix(static_cast<uint32_t>(keys[i]));
-    const int64_t samples = 2048, stride = std::max<int64_t>(1, n / samples);
-    for (int64_t i = stride / 2; i < n; i += stride) mix((static_cast<uint64_t>(i) << 32) | static_cast<uint32_t>(keys[i]));
-    return h;
-}
-
 void SgdHandle::unpin_host() {
     for (auto& p : pinned_) (void)hipHostUnregister(p.first);
     if (!pinned_.empty()) (void)hipGetLastError();   // an array that was freed while pinned must not leave a sticky error behind

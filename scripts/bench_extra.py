@@ -136,6 +136,35 @@ if "bpr_pcie" in which:
                                            "note": "80 MB keys H2D (pageable numpy) + fill_rows + kernel + 85 MB D2H per epoch"}
     print("bpr_pcie", out["bpr_host_buffers_every_epoch"], flush=True)
 
+if "als_pcie" in which:
+    # the reference's call pattern for ALS: keys / vals handed over on every partial_update, updated rows written back every call
+    rng = np.random.default_rng(7)
+    vals = (1 + rng.poisson(1.0, size=nnz)).astype(np.float32)
+    from buffalo_amd import ingest
+    col = ingest.coo_to_csr(csr.keys, csr.rows(), vals, I, U)
+    from bench import ALS_OPT
+    for auto in (1, 0):
+        P, Q, _ = synth.init_factors(U, I, 128, seed=7)
+        g = CyALS()
+        assert g.init(write_opt(ALS_OPT))
+        g.set_mode("auto_resident", auto)
+        g.initialize_model(P, Q)
+        g.set_placeholder(csr.indptr, col["indptr"], nnz + 1)
+
+        def epoch():
+            g.precompute(0)
+            g.partial_update(0, U, csr.indptr, csr.keys, vals, 0)
+            g.precompute(1)
+            g.partial_update(0, I, col["indptr"], col["key"], col["val"], 1)
+        epoch()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            epoch()
+        dt = (time.perf_counter() - t0) / 3
+        out["als_host_buffers_auto_resident_%d" % auto] = {"epoch_ms": dt * 1e3, "interactions_per_s": 2 * nnz / dt,
+                                                           "note": "keys + vals handed over every call, updated rows copied back every call (als.cu:403)"}
+        print("als_pcie auto_resident=%d" % auto, out["als_host_buffers_auto_resident_%d" % auto], flush=True)
+
 if "eals" in which:
     from buffalo_amd.backend import CyEALS
     rng = np.random.default_rng(7)

@@ -110,3 +110,40 @@ def test_lazy_sync_defers_the_copy_back():
     import gc
     gc.collect()
     np.testing.assert_array_equal(P2, P)
+
+
+def test_als_chunks_are_uploaded_once(oracle):
+    """ALS through the reference's call pattern (keys / vals handed over on every partial_update, cuda/_als.pyx:52-67):
+    a chunk is uploaded the first time and when its content changes; results equal the resident run's bit for bit."""
+    from conftest import als_opt
+    from buffalo_amd.backend import CyALS
+    csr = tiny_csr(U=90, I=70, density=0.15, seed=4, counts=True)
+    t = csr.transpose()
+    opt = als_opt(d=32, num_iters=3, accelerator=True)
+    rng = np.random.default_rng(2)
+    P0 = np.abs(rng.normal(scale=0.2, size=(90, 32))).astype(np.float32)
+    Q0 = np.abs(rng.normal(scale=0.2, size=(70, 32))).astype(np.float32)
+    outs, uploads = [], []
+    for resident in (True, False):
+        P, Q = P0.copy(), Q0.copy()
+        g = CyALS()
+        assert g.init(H.write_opt(opt))
+        g.initialize_model(P, Q)
+        g.set_placeholder(csr.indptr, t.indptr, csr.nnz + 1)
+        if resident:
+            g.set_resident_csr(0, csr.indptr, csr.keys, csr.vals)
+            g.set_resident_csr(1, t.indptr, t.keys, t.vals)
+        per_epoch = []
+        for _ in range(3):
+            before = g.stats()["h2d_bytes"]
+            for axis, m in ((0, csr), (1, t)):
+                g.precompute(axis)
+                for a, b in H.chunks_of(m, 2):
+                    keys, vals = H.chunk_arrays(m, a, b)
+                    g.partial_update(a, b, m.indptr, None if resident else keys, None if resident else vals, axis)
+            per_epoch.append(g.stats()["h2d_bytes"] - before)
+        outs.append((P, Q))
+        uploads.append(per_epoch)
+    assert uploads[1][0] == 2 * csr.nnz * 8 and uploads[1][1] == 0 and uploads[1][2] == 0    # both orientations once, then nothing
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
