@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbuffalo_hip.so")
-SOURCES = ["common.hip", "comm.hip", "sgd_base.hip", "bpr.hip", "warp.hip", "als.hip", "topk.hip", "ingest.hip"]
+SOURCES = ["common.hip", "comm.hip", "sgd_base.hip", "bpr.hip", "warp.hip", "als.hip", "topk.hip", "ingest.hip", "sppmi.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall",
          "-Wno-unused-function", "-Wno-unused-result"]

@@ -113,6 +113,11 @@ SIGNATURES = {
     "bfh_cfr_get_stats": (_i32, [_vp, C.POINTER(Stats)]),
     "bfh_cfr_reset_stats": (_i32, [_vp]),
     "bfh_coo_to_csr": (_i32, [_pi32, _pi32, _pf, _i64, _i32, _i32, C.POINTER(_i64), _pi32, _pf, C.POINTER(Stats)]),
+    "bfh_sppmi_create": (_vp, []),
+    "bfh_sppmi_destroy": (None, [_vp]),
+    "bfh_sppmi_build": (_i32, [_vp, _pi64, _pi32, _i32, _i32, _i32, _i32, _pi64, _pi64]),
+    "bfh_sppmi_fetch": (_i32, [_vp, _pi64, _pi32, _pf]),
+    "bfh_sppmi_get_stats": (_i32, [_vp, C.POINTER(Stats)]),
     "bfh_topk_create": (_vp, []),
     "bfh_topk_destroy": (None, [_vp]),
     "bfh_topk_set_device": (_i32, [_vp, _i32]),

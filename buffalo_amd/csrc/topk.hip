@@ -51,15 +51,40 @@ __global__ __launch_bounds__(256) void topk_pack_kernel(const float* __restrict_
 //   A row of query b: P + (qidx ? qidx[q0+b] : q0+b) * ld.  W = min(128, d_pad - kc), W % 8 == 0.
 // grid.x = item-tile groups, grid.y = query blocks of 128; block = 256 threads.
 // ------------------------------------------------------------------------------------------------
+// The fused form (FILTER): the tile's scores never reach HBM.  Every query row carries a threshold -- the kk-th best
+// admissible score of a SAMPLE of the columns (the first C0), i.e. a lower bound of the final kk-th best -- and the
+// epilogue appends the (column, score) pairs at or above it to the row's candidate segment of this tile group: a few
+// hundred of 27 K columns.  Slots come from a per-wave LDS counter (one wave owns a row within a tile group, so no
+// global atomics); a segment that overflows is noticed by the select kernel, which sends the row to the dense path.
+struct FilterArgs {
+    const float* thr;       // [nq] batch-local thresholds on score (+ bias)
+    const float* Qb;        // nullable: added to every score before the comparison (as topk_select_kernel does)
+    const uint32_t* pool;   // nullable bitmap over columns: columns outside it are never candidates
+    uint2* cand;            // [(b * gridDim.x + blockIdx.x) * cap_seg + slot] = (column, bits of the raw score)
+    int* cand_cnt;          // [b * gridDim.x + blockIdx.x] candidates seen (> cap_seg: overflow)
+    int cap_seg;
+};
+
 // FULL: the K-chunk is a whole 128 columns (nv == 16): no per-float4 guards, straight-line MFMA stream
-template <bool FULL>
+template <bool FULL, bool FILTER>
 __global__ __launch_bounds__(256, 3) void topk_scores_kernel(const float* __restrict__ P, const int32_t* __restrict__ qidx, int q0, int nq,
                                                              const float4* __restrict__ Qp, int q_rows, int ld, int kc, int W, float* __restrict__ S,
-                                                             size_t ld_s, int tiles_per_block, int accumulate) {
+                                                             size_t ld_s, int tiles_per_block, int accumulate, FilterArgs f) {
+    __shared__ int s_cnt[FILTER ? 4 : 1][32];
+    __shared__ float s_thr[FILTER ? 4 : 1][32];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int half = lane >> 5, col = lane & 31;
     const int b0q = (blockIdx.y * 4 + wv) * 32;   // first query (batch-local) of this wave
     if (b0q >= nq) return;
+    if constexpr (FILTER) {
+        if (lane < 32) {
+            s_cnt[wv][lane] = 0;
+            s_thr[wv][lane] = b0q + lane < nq ? f.thr[b0q + lane] : __builtin_inff();
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
     const int nv = W / 8;                        // float4s per lane and row
     const int koff = kc + half * (W / 2);
     // A operands: query row b0 + col, this half's columns
@@ -92,11 +117,12 @@ __global__ __launch_bounds__(256, 3) void topk_scores_kernel(const float* __rest
         for (int v = 0; v < 8; ++v)
             if (FULL || 8 + v < nv) b1[v] = bp[(8 + v) * 64];
         f32x16 acc;
-        float* Sl = S + static_cast<size_t>(b0q + 4 * half) * ld_s + t * 32 + col;   // C layout: row (e&3)+8(e>>2)+4half, col lane&31
+        float* Sl = FILTER ? nullptr : S + static_cast<size_t>(b0q + 4 * half) * ld_s + t * 32 + col;   // C layout: row (e&3)+8(e>>2)+4half, col lane&31
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int r = (e & 3) + 8 * (e >> 2);
-            acc[e] = (accumulate && jok && b0q + 4 * half + r < nq) ? Sl[static_cast<size_t>(r) * ld_s] : 0.f;
+            if constexpr (FILTER) acc[e] = 0.f;
+            else acc[e] = (accumulate && jok && b0q + 4 * half + r < nq) ? Sl[static_cast<size_t>(r) * ld_s] : 0.f;
         }
 #pragma unroll
         for (int v = 0; v < 8; ++v)
@@ -120,7 +146,23 @@ __global__ __launch_bounds__(256, 3) void topk_scores_kernel(const float* __rest
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[8 + v].z, b1[v].z, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[8 + v].w, b1[v].w, acc, 0, 0, 0);
             }
-        if (jok) {
+        if constexpr (FILTER) {
+            const int j = t * 32 + col;
+            bool colok = jok;
+            if (f.pool && jok) colok = ((f.pool[j >> 5] >> (j & 31)) & 1u) != 0u;
+            const float qb = (f.Qb && jok) ? f.Qb[j] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rr = 4 * half + (e & 3) + 8 * (e >> 2);
+                const float sc = f.Qb ? acc[e] + qb : acc[e];   // the very sum the select kernel forms
+                if (colok && sc >= s_thr[wv][rr]) {           // rows beyond nq carry +inf
+                    const int slot = atomicAdd(&s_cnt[wv][rr], 1);
+                    if (slot < f.cap_seg)
+                        f.cand[(static_cast<size_t>(b0q + rr) * gridDim.x + blockIdx.x) * f.cap_seg + slot] =
+                            make_uint2(static_cast<uint32_t>(j), __builtin_bit_cast(uint32_t, acc[e]));
+                }
+            }
+        } else if (jok) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int r = (e & 3) + 8 * (e >> 2);
@@ -128,6 +170,22 @@ __global__ __launch_bounds__(256, 3) void topk_scores_kernel(const float* __rest
             }
         }
     }
+    if constexpr (FILTER) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < 32 && b0q + lane < nq) f.cand_cnt[static_cast<size_t>(b0q + lane) * gridDim.x + blockIdx.x] = s_cnt[wv][lane];
+    }
+}
+
+// thr[b] = the kk-th best admissible score of the sampled columns (row q0 + b of the select output), or "everything":
+// with the admission rule only scores > FLT_MIN can be listed, so FLT_MIN itself is a valid bound then
+__global__ void topk_thr_kernel(const int32_t* __restrict__ keys, const float* __restrict__ scores, int q0, int nb, int k, int kk, int rule_flt_min,
+                                float* __restrict__ thr) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    const size_t at = static_cast<size_t>(q0 + b) * k + (kk - 1);
+    thr[b] = (kk > 0 && keys[at] >= 0) ? scores[at] : (rule_flt_min ? FLT_MIN : -__builtin_inff());
 }
 
 // order-preserving map: smaller key <=> larger score (-0 and +0 coincide)
@@ -156,6 +214,14 @@ struct SelectArgs {
     float* out_scores;       // nullable (quickselect)
     int p2;                  // power of two >= kk: sort buffer entries
     int cand_cap;            // entries of the candidate buffer behind the sort buffer (0: multi-pass path only)
+    const int32_t* out_row;  // nullable: output row of S row b (else q0 + b); self_idx is then indexed by b
+    // list mode (the fused path): the row is not a dense score row but the candidate segments topk_scores_kernel<.., FILTER>
+    // wrote -- every admissible column at or above a lower bound of the kk-th best score, in no particular order
+    const uint2* cand;       // nullable: [(b * n_seg + g) * cap_seg + slot] = (column, bits of the raw score)
+    const int* cand_cnt;     // [b * n_seg + g]
+    int n_seg, cap_seg;
+    int list_cap;            // entries of the LDS list behind the candidate buffer
+    int* redo;               // [0]: rows sent to the dense path (a segment or the list overflowed), [1 + i]: their b
 };
 
 __global__ __launch_bounds__(256) void topk_select_kernel(SelectArgs a) {
@@ -165,12 +231,52 @@ __global__ __launch_bounds__(256) void topk_select_kernel(SelectArgs a) {
     __shared__ int s_misc[8];   // 0: chosen bin, 1: remaining, 2: n_gt slots, 3: run_eq, 4..7: wave eq counts / fast-path counters
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int b = blockIdx.x;
-    const float* row = a.S + static_cast<size_t>(b) * a.ld_s;
-    const int self = a.self_idx ? a.self_idx[a.q0 + b] : -1;
-    auto key_of = [&](int j, uint32_t& key) -> bool {
+    const bool list = a.cand != nullptr;
+    const float* row = list ? nullptr : a.S + static_cast<size_t>(b) * a.ld_s;
+    const int orow = a.out_row ? a.out_row[b] : a.q0 + b;
+    const int self = a.self_idx ? a.self_idx[a.out_row ? b : a.q0 + b] : -1;
+    uint2* lst = reinterpret_cast<uint2*>(sel + a.p2 + a.cand_cap);
+    int cols = a.cols;   // positions the passes run over: columns of the dense row, or entries of the list
+    if (list) {
+        // gather the segments into one LDS list; a row whose segments or list overflowed is redone densely by the host
+        if (tid == 0) {
+            int tot = 0, over = 0;
+            for (int g = 0; g < a.n_seg; ++g) {
+                const int c = a.cand_cnt[static_cast<size_t>(b) * a.n_seg + g];
+                over |= c > a.cap_seg;
+                tot += c;
+            }
+            s_misc[6] = tot;
+            s_misc[7] = (over || tot > a.list_cap) ? 1 : 0;
+        }
+        __syncthreads();
+        cols = s_misc[6];
+        if (s_misc[7]) {   // block-uniform
+            if (tid == 0) a.redo[1 + atomicAdd(a.redo, 1)] = b;
+            return;
+        }
+        int off = 0;
+        for (int g = 0; g < a.n_seg; ++g) {
+            const int c = a.cand_cnt[static_cast<size_t>(b) * a.n_seg + g];
+            const uint2* seg = a.cand + (static_cast<size_t>(b) * a.n_seg + g) * a.cap_seg;
+            for (int i = tid; i < c; i += 256) lst[off + i] = seg[i];
+            off += c;
+        }
+        __syncthreads();
+    }
+    // position i -> (admissible?, key, column j)
+    auto key_of = [&](int i, uint32_t& key, int& j) -> bool {
+        float s;
+        if (list) {
+            const uint2 c = lst[i];
+            j = static_cast<int>(c.x);
+            s = __builtin_bit_cast(float, c.y);
+        } else {
+            j = i;
+            s = row[i];
+        }
         if (j == self) return false;
         if (a.pool && !((a.pool[j >> 5] >> (j & 31)) & 1u)) return false;
-        float s = row[j];
         if (a.Qb) s += a.Qb[j];
         if (a.rule_flt_min && !(s > FLT_MIN)) return false;
         key = desc_key(s);
@@ -214,9 +320,10 @@ __global__ __launch_bounds__(256) void topk_select_kernel(SelectArgs a) {
         for (int i = tid; i < 4096; i += 256) hist[i] = 0;
         for (int i = tid; i < a.p2; i += 256) sel[i] = ~0ull;
         __syncthreads();
-        for (int j = tid; j < a.cols; j += 256) {
+        for (int i = tid; i < cols; i += 256) {
             uint32_t key;
-            if (key_of(j, key)) atomicAdd(&hist[key >> 20], 1);
+            int j;
+            if (key_of(i, key, j)) atomicAdd(&hist[key >> 20], 1);
         }
         __syncthreads();
         find_bin(4096, a.kk);
@@ -225,9 +332,10 @@ __global__ __launch_bounds__(256) void topk_select_kernel(SelectArgs a) {
         if (tid == 0) { s_misc[4] = 0; s_misc[5] = 0; }
         __syncthreads();
         const bool all1 = bin1 < 0;
-        for (int j = tid; j < a.cols; j += 256) {
+        for (int i = tid; i < cols; i += 256) {
             uint32_t key;
-            if (!key_of(j, key)) continue;
+            int j;
+            if (!key_of(i, key, j)) continue;
             const int top = static_cast<int>(key >> 20);
             if (all1 || top < bin1) sel[atomicAdd(&s_misc[4], 1)] = pack(key, j);
             else if (top == bin1) {
@@ -278,9 +386,10 @@ __global__ __launch_bounds__(256) void topk_select_kernel(SelectArgs a) {
             const int shift = 24 - 8 * pass;
             hist[tid] = 0;
             __syncthreads();
-            for (int j = tid; j < a.cols; j += 256) {
+            for (int i = tid; i < cols; i += 256) {
                 uint32_t key;
-                if (key_of(j, key) && (key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1);
+                int j;
+                if (key_of(i, key, j) && (key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1);
             }
             __syncthreads();
             if (tid == 0) {
@@ -324,9 +433,10 @@ __global__ __launch_bounds__(256) void topk_select_kernel(SelectArgs a) {
         // the `remaining` members of A with the HIGHEST indices.
         const bool ordered = !take_all && remaining < eq_total;
         if (kk_eff > 0) {
-            for (int j = tid; j < a.cols; j += 256) {
+            for (int i = tid; i < cols; i += 256) {
                 uint32_t key = 0;
-                if (!key_of(j, key)) continue;
+                int j;
+                if (!key_of(i, key, j)) continue;
                 if (take_all || key < prefix) sel[atomicAdd(&s_misc[2], 1)] = pack(key, j);
                 else if (!ordered && key == prefix) sel[n_gt + atomicAdd(&s_misc[3], 1)] = pack(key, j);   // all eq_total == remaining of them
             }
@@ -334,6 +444,26 @@ __global__ __launch_bounds__(256) void topk_select_kernel(SelectArgs a) {
         if (ordered) {
             __shared__ int s_run[4];    // 0: candidates >= t so far, 1: candidates == t so far, 2: |A|, 3: done
             __shared__ int s_wave[8];   // per-wave counts of the current 256-column step: [0..3] >= t, [4..7] == t
+            if (list) {
+                // the tie rule walks the candidates in COLUMN order; the list is in arrival order: sort it by column
+                // (every column at or above the k-th score is in the list, so the walk sees what the dense walk sees)
+                int n2 = 2;
+                while (n2 < cols) n2 <<= 1;
+                __syncthreads();
+                for (int i = cols + tid; i < n2; i += 256) lst[i] = make_uint2(0xFFFFFFFFu, 0u);
+                __syncthreads();
+                for (int size = 2; size <= n2; size <<= 1)
+                    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                        for (int t = tid; t < (n2 >> 1); t += 256) {
+                            const int lo = ((t & ~(stride - 1)) << 1) | (t & (stride - 1));
+                            const int hi = lo | stride;
+                            const bool up = (lo & size) == 0;
+                            const uint2 x = lst[lo], y = lst[hi];
+                            if ((x.x > y.x) == up) { lst[lo] = y; lst[hi] = x; }
+                        }
+                        __syncthreads();
+                    }
+            }
             if (tid < 4) s_run[tid] = 0;
             __syncthreads();
             for (int phase = 0; phase < 2; ++phase) {
@@ -342,10 +472,11 @@ __global__ __launch_bounds__(256) void topk_select_kernel(SelectArgs a) {
                 __syncthreads();
                 if (tid < 2) s_run[tid] = 0;
                 __syncthreads();
-                for (int base = 0; base < a.cols; base += 256) {
-                    const int j = base + tid;
+                for (int base = 0; base < cols; base += 256) {
+                    const int i = base + tid;
                     uint32_t key = 0;
-                    const bool ok = j < a.cols && key_of(j, key);
+                    int j = 0;
+                    const bool ok = i < cols && key_of(i, key, j);
                     const bool ge = ok && key <= prefix, eq = ok && key == prefix;
                     const unsigned long long bge = __ballot(ge), beq = __ballot(eq);
                     const unsigned long long below = (1ull << lane) - 1ull;
@@ -384,8 +515,8 @@ __global__ __launch_bounds__(256) void topk_select_kernel(SelectArgs a) {
             }
             __syncthreads();
         }
-    int32_t* ok = a.out_keys + static_cast<size_t>(a.q0 + b) * a.k;
-    float* os = a.out_scores ? a.out_scores + static_cast<size_t>(a.q0 + b) * a.k : nullptr;
+    int32_t* ok = a.out_keys + static_cast<size_t>(orow) * a.k;
+    float* os = a.out_scores ? a.out_scores + static_cast<size_t>(orow) * a.k : nullptr;
     for (int r = tid; r < a.k; r += 256) {
         if (r < kk_eff) {
             const unsigned long long c = sel[r];
@@ -425,6 +556,62 @@ class TopkHandle : public HandleBase {
         return p;
     }
 
+    // ---- launch helpers ----
+    // dense scores of `nb` queries (rows qidx ? qidx[q0 + b] : q0 + b of dP) against the first `cols` candidates -> S_ [nb, ld_s]
+    void launch_scores(const float* dP, const int32_t* qidx, int q0, int nb, int cols, int ld, int d_pad, size_t ld_s, size_t tiles_all) {
+        const int n_tiles = (cols + 31) / 32;
+        const int qblocks = (nb + 127) / 128;
+        int tpb = static_cast<int>((static_cast<int64_t>(n_tiles) * qblocks + num_cus_ * 8 - 1) / (num_cus_ * 8));
+        if (tpb < 1) tpb = 1;
+        const dim3 grid((n_tiles + tpb - 1) / tpb, qblocks);
+        for (int kc = 0; kc < d_pad; kc += 128) {
+            const int W = std::min(128, d_pad - kc);
+            const float4* qp = Qp_.get() + static_cast<size_t>(kc / 128) * tiles_all * 16 * 64;
+            if (W == 128)
+                hipLaunchKernelGGL((topk_scores_kernel<true, false>), grid, dim3(256), 0, stream, dP, qidx, q0, nb, qp, cols, ld, kc, W, S_.get(), ld_s,
+                                   tpb, kc > 0 ? 1 : 0, FilterArgs{});
+            else
+                hipLaunchKernelGGL((topk_scores_kernel<false, false>), grid, dim3(256), 0, stream, dP, qidx, q0, nb, qp, cols, ld, kc, W, S_.get(), ld_s,
+                                   tpb, kc > 0 ? 1 : 0, FilterArgs{});
+            BFH_HIP(hipGetLastError());
+        }
+    }
+    void launch_select(const SelectArgs& a, int rows, size_t lds) {
+        hipLaunchKernelGGL(topk_select_kernel, dim3(rows), dim3(256), lds, stream, a);
+        BFH_HIP(hipGetLastError());
+    }
+
+    // The fused path's shape for a call, or `on = false`: the dense path.  C0 = sampled columns (the thresholds' source):
+    // the filter is expected to pass kk * q_rows / C0 columns per query, which must sit well inside the LDS list.
+    struct FusedPlan {
+        bool on = false;
+        int c0 = 0, n_seg = 1, tpb = 1, cap_seg = 0;
+    };
+    static constexpr int kListCap = 2048;
+    FusedPlan fused_plan(int nq, int q_rows, int d_pad, int kk) const {
+        FusedPlan fp;
+        if (fused_ == 0 || d_pad > 128) return fp;   // two K-chunks accumulate through the score buffer
+        const bool force = fused_ > 0;
+        if (!force && (nq < 8192 || q_rows < 8192)) return fp;   // small sweeps: the dense path's item-tile parallelism matters more
+        const int n_tiles = (q_rows + 31) / 32;
+        int64_t need = (static_cast<int64_t>(kk) * q_rows + kListCap / 3 - 1) / (kListCap / 3);
+        int c0 = force && fused_c0_ > 0 ? fused_c0_ : (force ? 32 : 2048);
+        while (c0 < need) c0 <<= 1;
+        c0 = (c0 + 31) / 32 * 32;
+        if (force) c0 = std::min(c0, n_tiles * 32);   // tests: any shape goes through (overflowing rows take the dense path)
+        else if (c0 > q_rows / 4) return fp;
+        if (c0 >= q_rows + 32) return fp;
+        fp.c0 = std::min(c0, q_rows);
+        const int qblocks = (nq + 127) / 128;
+        int tpb = static_cast<int>((static_cast<int64_t>(n_tiles) * qblocks + num_cus_ * 8 - 1) / (num_cus_ * 8));
+        tpb = std::max(tpb, (n_tiles + 7) / 8);       // at most 8 segments per query
+        fp.tpb = std::max(1, tpb);
+        fp.n_seg = (n_tiles + fp.tpb - 1) / fp.tpb;
+        fp.cap_seg = static_cast<int>(std::min<int64_t>(static_cast<int64_t>(fp.tpb) * 32, std::max(64, 2 * kListCap / fp.n_seg)));
+        fp.on = true;
+        return fp;
+    }
+
     // core: factor matrices in HBM, [rows, ld], ld % 8 == 0, columns [d, ld) zero
     void run_device(const int32_t* indexes, int nq, const float* dP, bool gather, const float* dQ, int q_rows, int d, int ld, const float* dQb,
                     bool same, int32_t* out_keys, float* out_scores, const int32_t* pool, int pool_size, int k) {
@@ -455,15 +642,22 @@ class TopkHandle : public HandleBase {
         d_keys_.resize(std::max(d_keys_.size(), static_cast<size_t>(nq) * k));
         d_scores_.resize(std::max(d_scores_.size(), static_cast<size_t>(nq) * k));
         const size_t ld_s = (static_cast<size_t>(q_rows) + 31) / 32 * 32;
-        // query batch: score buffer <= 2 GiB, multiple of 128 rows
-        int batch = static_cast<int>(std::min<size_t>(nq, std::max<size_t>(128, ((size_t(1) << 31) / (ld_s * 4)) / 128 * 128)));
-        S_.resize(std::max(S_.size(), static_cast<size_t>(batch) * ld_s));
         const int d_pad = (d + 7) / 8 * 8;
         const int n_tiles = (q_rows + 31) / 32;
         const int p2 = pow2_at_least(kk);
         const int cand_cap = cand_capacity(p2);
-        const size_t lds = static_cast<size_t>(p2 + cand_cap) * 8;
-        BFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(topk_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        const FusedPlan fp = fused_plan(nq, q_rows, d_pad, kk);
+        // query batch, multiple of 128 rows: dense -- score buffer <= 2 GiB; fused -- sample scores + candidate segments <= 2 GiB,
+        // and room in the score buffer for 128 dense rows (the rows the fused path hands back)
+        const size_t per_query = fp.on ? static_cast<size_t>(fp.c0) * 4 + static_cast<size_t>(fp.n_seg) * fp.cap_seg * 8 : ld_s * 4;
+        const int batch = static_cast<int>(std::min<size_t>(nq, std::max<size_t>(128, ((size_t(1) << 31) / per_query) / 128 * 128)));
+        const int redo_rows = fp.on ? static_cast<int>(std::max<size_t>(128, std::min<size_t>(batch, (size_t(1) << 28) / ld_s) / 128 * 128)) : 0;
+        S_.resize(std::max(S_.size(), fp.on ? std::max(static_cast<size_t>(batch) * fp.c0, static_cast<size_t>(redo_rows) * ld_s)
+                                             : static_cast<size_t>(batch) * ld_s));
+        const size_t lds_dense = static_cast<size_t>(p2 + cand_cap) * 8;
+        const size_t lds_list = lds_dense + static_cast<size_t>(kListCap) * 8;
+        BFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(topk_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    static_cast<int>(fp.on ? lds_list : lds_dense)));
         {   // candidate matrix in operand order, one slab per K-chunk
             const int n_chunks = (d_pad + 127) / 128;
             const size_t per = static_cast<size_t>(n_tiles) * 16 * 64;
@@ -477,35 +671,88 @@ class TopkHandle : public HandleBase {
             }
             t_aux_.end(slot, stream);
         }
+        SelectArgs base{};
+        base.Qb = dQb; base.pool = d_pool; base.rule_flt_min = flt_min_rule_ ? 1 : 0; base.k = k; base.kk = kk;
+        base.out_keys = d_keys_.get(); base.out_scores = d_scores_.get(); base.p2 = p2; base.cand_cap = fast_select_ ? cand_cap : 0;
+        const int32_t* qidx = gather ? d_idx_.get() : nullptr;
+        if (fp.on) {
+            thr_.resize(std::max(thr_.size(), static_cast<size_t>(batch)));
+            cand_.resize(std::max(cand_.size(), static_cast<size_t>(batch) * fp.n_seg * fp.cap_seg));
+            cnt_.resize(std::max(cnt_.size(), static_cast<size_t>(batch) * fp.n_seg));
+            redo_.resize(std::max(redo_.size(), static_cast<size_t>(batch) + 1));
+        }
         for (int q0 = 0; q0 < nq; q0 += batch) {
             const int nb = std::min(batch, nq - q0);
-            const int qblocks = (nb + 127) / 128;
-            int tpb = static_cast<int>((static_cast<int64_t>(n_tiles) * qblocks + num_cus_ * 8 - 1) / (num_cus_ * 8));
-            if (tpb < 1) tpb = 1;
-            const int slot = t_main_.begin(stream);
-            for (int kc = 0; kc < d_pad; kc += 128) {
-                const int W = std::min(128, d_pad - kc);
-                if (W == 128)
-                    hipLaunchKernelGGL(topk_scores_kernel<true>, dim3((n_tiles + tpb - 1) / tpb, qblocks), dim3(256), 0, stream, dP,
-                                       gather ? d_idx_.get() : nullptr, q0, nb, Qp_.get() + static_cast<size_t>(kc / 128) * n_tiles * 16 * 64, q_rows, ld,
-                                       kc, W, S_.get(), ld_s, tpb, kc > 0 ? 1 : 0);
-                else
-                    hipLaunchKernelGGL(topk_scores_kernel<false>, dim3((n_tiles + tpb - 1) / tpb, qblocks), dim3(256), 0, stream, dP,
-                                       gather ? d_idx_.get() : nullptr, q0, nb, Qp_.get() + static_cast<size_t>(kc / 128) * n_tiles * 16 * 64, q_rows, ld,
-                                       kc, W, S_.get(), ld_s, tpb, kc > 0 ? 1 : 0);
-                BFH_HIP(hipGetLastError());
+            if (!fp.on) {
+                int slot = t_main_.begin(stream);
+                launch_scores(dP, qidx, q0, nb, q_rows, ld, d_pad, ld_s, n_tiles);
+                t_main_.end(slot, stream);
+                SelectArgs a = base;
+                a.S = S_.get(); a.ld_s = ld_s; a.cols = q_rows; a.self_idx = same ? d_idx_.get() : nullptr; a.q0 = q0;
+                slot = t_aux_.begin(stream);
+                launch_select(a, nb, lds_dense);
+                t_aux_.end(slot, stream);
+                continue;   // the scores kernel of the next batch reuses S_: the stream orders it after this select
             }
+            // ---- fused: (1) thresholds from the first c0 columns, (2) filtered sweep, (3) selection over the candidate lists ----
+            int slot = t_main_.begin(stream);
+            launch_scores(dP, qidx, q0, nb, fp.c0, ld, d_pad, static_cast<size_t>(fp.c0), n_tiles);
             t_main_.end(slot, stream);
-            SelectArgs a{};
-            a.S = S_.get(); a.ld_s = ld_s; a.cols = q_rows; a.Qb = dQb; a.pool = d_pool;
-            a.self_idx = same ? d_idx_.get() : nullptr;
-            a.q0 = q0; a.rule_flt_min = flt_min_rule_ ? 1 : 0; a.k = k; a.kk = kk;
-            a.out_keys = d_keys_.get(); a.out_scores = d_scores_.get(); a.p2 = p2; a.cand_cap = fast_select_ ? cand_cap : 0;
-            const int slot2 = t_aux_.begin(stream);
-            hipLaunchKernelGGL(topk_select_kernel, dim3(nb), dim3(256), lds, stream, a);
+            slot = t_aux_.begin(stream);
+            SelectArgs a = base;
+            a.S = S_.get(); a.ld_s = static_cast<size_t>(fp.c0); a.cols = fp.c0; a.self_idx = same ? d_idx_.get() : nullptr; a.q0 = q0;
+            launch_select(a, nb, lds_dense);
+            hipLaunchKernelGGL(topk_thr_kernel, dim3((nb + 255) / 256), dim3(256), 0, stream, d_keys_.get(), d_scores_.get(), q0, nb, k, kk,
+                               flt_min_rule_ ? 1 : 0, thr_.get());
             BFH_HIP(hipGetLastError());
-            t_aux_.end(slot2, stream);
-            // the scores kernel of the next batch reuses S_: the stream orders it after this select
+            BFH_HIP(hipMemsetAsync(redo_.get(), 0, sizeof(int), stream));
+            t_aux_.end(slot, stream);
+            FilterArgs f{thr_.get(), dQb, d_pool, cand_.get(), cnt_.get(), fp.cap_seg};
+            slot = t_main_.begin(stream);
+            if (d_pad == 128)
+                hipLaunchKernelGGL((topk_scores_kernel<true, true>), dim3(fp.n_seg, (nb + 127) / 128), dim3(256), 0, stream, dP, qidx, q0, nb, Qp_.get(),
+                                   q_rows, ld, 0, d_pad, static_cast<float*>(nullptr), size_t(0), fp.tpb, 0, f);
+            else
+                hipLaunchKernelGGL((topk_scores_kernel<false, true>), dim3(fp.n_seg, (nb + 127) / 128), dim3(256), 0, stream, dP, qidx, q0, nb, Qp_.get(),
+                                   q_rows, ld, 0, d_pad, static_cast<float*>(nullptr), size_t(0), fp.tpb, 0, f);
+            BFH_HIP(hipGetLastError());
+            t_main_.end(slot, stream);
+            slot = t_aux_.begin(stream);
+            a.S = nullptr; a.cand = cand_.get(); a.cand_cnt = cnt_.get(); a.n_seg = fp.n_seg; a.cap_seg = fp.cap_seg; a.list_cap = kListCap;
+            a.redo = redo_.get();
+            launch_select(a, nb, lds_list);
+            t_aux_.end(slot, stream);
+            int n_redo = 0;
+            BFH_HIP(hipMemcpyAsync(&n_redo, redo_.get(), sizeof(int), hipMemcpyDeviceToHost, stream));
+            BFH_HIP(hipStreamSynchronize(stream));
+            stats.merges += n_redo;   // top-k: rows the fused path handed back to the dense path
+            if (n_redo == 0) continue;
+            // ---- rows whose candidates did not fit (ties at the threshold, all-inadmissible rows, tiny pools): dense path ----
+            std::vector<int32_t> rows(static_cast<size_t>(n_redo));
+            BFH_HIP(hipMemcpy(rows.data(), redo_.get() + 1, sizeof(int32_t) * n_redo, hipMemcpyDeviceToHost));
+            std::sort(rows.begin(), rows.end());
+            std::vector<int32_t> side(static_cast<size_t>(n_redo) * 3);   // row of dP | original index (self exclusion) | output row
+            for (int i = 0; i < n_redo; ++i) {
+                const int q = q0 + rows[i];
+                side[i] = gather ? indexes[q] : q;
+                side[n_redo + i] = indexes[q];
+                side[2 * static_cast<size_t>(n_redo) + i] = q;
+            }
+            redo_side_.resize(std::max(redo_side_.size(), side.size()));
+            BFH_HIP(hipMemcpy(redo_side_.get(), side.data(), side.size() * 4, hipMemcpyHostToDevice));
+            for (int r0 = 0; r0 < n_redo; r0 += redo_rows) {
+                const int nr = std::min(redo_rows, n_redo - r0);
+                slot = t_main_.begin(stream);
+                launch_scores(dP, redo_side_.get() + r0, 0, nr, q_rows, ld, d_pad, ld_s, n_tiles);
+                t_main_.end(slot, stream);
+                SelectArgs r = base;
+                r.S = S_.get(); r.ld_s = ld_s; r.cols = q_rows; r.q0 = 0;
+                r.self_idx = same ? redo_side_.get() + n_redo + r0 : nullptr;
+                r.out_row = redo_side_.get() + 2 * static_cast<size_t>(n_redo) + r0;
+                slot = t_aux_.begin(stream);
+                launch_select(r, nr, lds_dense);
+                t_aux_.end(slot, stream);
+            }
         }
         BFH_HIP(hipMemcpyAsync(out_keys, d_keys_.get(), sizeof(int32_t) * nq * k, hipMemcpyDeviceToHost, stream));
         BFH_HIP(hipMemcpyAsync(out_scores, d_scores_.get(), sizeof(float) * nq * k, hipMemcpyDeviceToHost, stream));
@@ -589,6 +836,8 @@ class TopkHandle : public HandleBase {
     void set_mode(const std::string& name, int64_t v) {
         if (name == "flt_min_rule") flt_min_rule_ = v != 0;
         else if (name == "fast_select") fast_select_ = v != 0;   // 0: multi-pass radix select only (debug / comparison)
+        else if (name == "fused") fused_ = static_cast<int>(v);      // -1: by size (default), 0: dense path only, 1: whenever d <= 128 (tests)
+        else if (name == "fused_c0") fused_c0_ = static_cast<int>(v);   // with fused = 1: columns sampled for the thresholds (0: by rule)
         else if (name == "timing") timing = v != 0;
         else throw Error(BFH_ERR_INVALID, "unknown mode '" + name + "'");
     }
@@ -596,11 +845,17 @@ class TopkHandle : public HandleBase {
  private:
     int num_cus_ = 256;
     bool fast_select_ = true;
+    int fused_ = -1, fused_c0_ = 0;
     bool flt_min_rule_ = true;   // _core.hpp:26,115: the running list starts at FLT_MIN, so scores <= FLT_MIN are never admitted
     DevBuf<int32_t> d_idx_, d_keys_;
     DevBuf<uint32_t> d_pool_;
     DevBuf<float> d_scores_, S_, hP_, hQ_, hQb_;
     DevBuf<float4> Qp_;   // candidate matrix in MFMA operand order (topk_pack_kernel)
+    // fused path: per-query thresholds, candidate segments + counts, rows handed back to the dense path
+    DevBuf<float> thr_;
+    DevBuf<uint2> cand_;
+    DevBuf<int> cnt_, redo_;
+    DevBuf<int32_t> redo_side_;
     EventTimer t_main_, t_aux_;
 };
 

@@ -1,6 +1,7 @@
 """COO -> compressed rows on the GPU (`bfh_coo_to_csr`): the device-side replacement of the sort + binarization
 step of buffalo's data creation (/root/reference/buffalo/data/fileio.hpp:263-420, called per orientation from
-data/base.py:399-451).  No CPU fallback."""
+data/base.py:399-451), and the SPPMI matrix of a stream (`bfh_sppmi_*`: stream.py:257-267 + fileio.hpp:109-254 +
+stream.py:169-195).  No CPU fallback."""
 import ctypes as C
 
 import numpy as np
@@ -30,4 +31,38 @@ def coo_to_csr(major, minor, vals, num_major, num_minor, with_stats=False):
     if rc < 0:
         raise BuffaloHipError((L.bfh_last_error(None) or b"bfh_coo_to_csr failed").decode())
     g = {"indptr": indptr, "key": key, "val": val}
+    return (g, st.as_dict()) if with_stats else g
+
+
+def build_sppmi(indptr, items, num_items, windows, k, with_stats=False):
+    """SPPMI group of a stream: `indptr` = END offsets [num_users] over the 0-based `items` of the users' sequences,
+    `windows` / `k` = the reference's data.sppmi options (stream.py:34-36).  Returns {"indptr": int64 END offsets
+    [num_items], "key": int32 [nnz], "val": float32 [nnz], "total_lines": D} -- the layout of the reference's `sppmi`
+    HDF5 group (stream.py:183-188), which CFR reads as its context matrix."""
+    indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+    items = np.ascontiguousarray(items, dtype=np.int32)
+    if indptr.ndim != 1 or items.ndim != 1 or indptr.shape[0] == 0 or int(indptr[-1]) != items.shape[0]:
+        raise ValueError("indptr must be 1-d END offsets whose last entry is len(items)")
+    L = lib()
+    h = L.bfh_sppmi_create()
+    if not h:
+        raise BuffaloHipError((L.bfh_last_error(None) or b"bfh_sppmi_create failed").decode())
+    try:
+        nnz, lines = C.c_int64(0), C.c_int64(0)
+        rc = L.bfh_sppmi_build(h, indptr.ctypes.data_as(C.POINTER(C.c_int64)), items.ctypes.data_as(C.POINTER(C.c_int32)), indptr.shape[0],
+                               int(num_items), int(windows), int(k), C.byref(nnz), C.byref(lines))
+        if rc < 0:
+            raise BuffaloHipError((L.bfh_last_error(h) or b"bfh_sppmi_build failed").decode())
+        out_indptr = np.empty(int(num_items), dtype=np.int64)
+        key = np.empty(nnz.value, dtype=np.int32)
+        val = np.empty(nnz.value, dtype=np.float32)
+        rc = L.bfh_sppmi_fetch(h, out_indptr.ctypes.data_as(C.POINTER(C.c_int64)), key.ctypes.data_as(C.POINTER(C.c_int32)),
+                               val.ctypes.data_as(C.POINTER(C.c_float)))
+        if rc < 0:
+            raise BuffaloHipError((L.bfh_last_error(h) or b"bfh_sppmi_fetch failed").decode())
+        st = Stats()
+        L.bfh_sppmi_get_stats(h, C.byref(st))
+    finally:
+        L.bfh_sppmi_destroy(h)
+    g = {"indptr": out_indptr, "key": key, "val": val, "total_lines": lines.value}
     return (g, st.as_dict()) if with_stats else g

@@ -339,6 +339,25 @@ int bfh_eals_estimate_loss(void* h, int nnz, const int64_t* indptr, const int32_
 int bfh_eals_get_stats(void* h, bfh_stats* out);
 int bfh_eals_reset_stats(void* h);
 
+/* ------------------------------------------------------------------------------------------------
+ * SPPMI matrix of a stream   (CoFactor's context input)
+ * Replaces, in HBM and without text files: the pair lines of buffalo/data/stream.py:257-267 (every event with the
+ * `windows` events after it in its user's sequence, both orientations), _parallel_build_sppmi
+ * (buffalo/data/fileio.hpp:109-254: appearances, pmi = log(cnt) + log(D) - log(app[probe]) - log(app[c]), shift
+ * log(k), entries with sppmi > 0, values carried with the six significant digits of the reference's text output)
+ * and the sort + compression of its output (stream.py:169-195).
+ * bfh_sppmi_build: `indptr` are END offsets [num_users] over the 0-based `items` of the stream; reports the number of
+ * entries and D (sppmi_total_lines).  bfh_sppmi_fetch copies the group out: indptr_out[num_items] (END offsets),
+ * keys_out[nnz], vals_out[nnz], rows ascending, columns ascending inside a row, a pair (p, p) listed twice as the
+ * reference lists it.
+ * ---------------------------------------------------------------------------------------------- */
+void* bfh_sppmi_create(void);
+void bfh_sppmi_destroy(void* h);
+int bfh_sppmi_build(void* h, const int64_t* indptr, const int32_t* items, int num_users, int num_items, int windows, int k,
+                    int64_t* nnz, int64_t* total_lines);
+int bfh_sppmi_fetch(void* h, int64_t* indptr_out, int32_t* keys_out, float* vals_out);
+int bfh_sppmi_get_stats(void* h, bfh_stats* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,6 +32,7 @@
 #include <cmath>
 #include <condition_variable>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <deque>
 #include <limits>
@@ -1773,6 +1774,67 @@ void orc_coo_to_csr(const int32_t* major, const int32_t* minor, const float* val
         out_minor[i] = minor[order[i]];
         out_vals[i] = vals[order[i]];
     }
+}
+
+// SPPMI matrix of a stream (the context input of CoFactor / CFR).  Three reference steps, restated in memory:
+//   * pair lines, buffalo/data/stream.py:257-267: for every user's (training) sequence, each item and the `windows` items
+//     after it are written as the two lines "w c" and "c w" (1-based ids); sppmi_total_lines counts the lines;
+//   * the lines are sorted by their first id (stream.py:173, aux.psort key=1) and _parallel_build_sppmi
+//     (buffalo/data/fileio.hpp:109-254) walks the groups: appearances[id] = lines starting with id (:137-160); for a group
+//     `probe` and every distinct second id c <= probe (:207-208), cnt = lines "probe c" of the group,
+//     pmi = log(cnt) + log(D) - log(app[probe]) - log(app[c]) (double, in this order, :210-212), sppmi = pmi - log(k);
+//     when sppmi > 0 the TEXT lines "probe c sppmi" and "c probe sppmi" are written (:215-221; c == probe gives the same
+//     line twice) -- `fout << double` prints six significant digits, and that is what the next step parses;
+//   * the output is sorted and compressed like any matrix (stream.py:181-195 -> fileio.hpp:263-420: "%d %d %f", ids made
+//     0-based, stable sort by (row, col), END-offset indptr).
+// Returns nnz; fills the outputs only when cap >= nnz.
+int64_t orc_build_sppmi(const int64_t* indptr, const int32_t* items, int num_users, int num_items, int windows, int k, int64_t cap,
+                        int64_t* out_indptr, int32_t* out_key, float* out_val, int64_t* total_lines_out) {
+    std::vector<std::pair<int, int>> lines;
+    for (int u = 0; u < num_users; ++u) {
+        const int64_t beg = u ? indptr[u - 1] : 0, sz = indptr[u] - beg;
+        for (int64_t i = 0; i < sz; ++i)
+            for (int64_t j = i + 1; j < i + windows + 1 && j < sz; ++j) {
+                const int w = items[beg + i] + 1, c = items[beg + j] + 1;
+                lines.emplace_back(w, c);
+                lines.emplace_back(c, w);
+            }
+    }
+    const int64_t total_lines = (int64_t)lines.size();
+    if (total_lines_out) *total_lines_out = total_lines;
+    std::stable_sort(lines.begin(), lines.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first < b.first; });
+    const double log_d = std::log((double)total_lines), log_k = std::log((double)k);
+    std::vector<int64_t> appearances(num_items, 0);
+    for (const auto& l : lines) appearances[l.first - 1] += 1;
+    std::vector<int32_t> rr, cc;
+    std::vector<float> vv;
+    size_t g0 = 0;
+    while (g0 < lines.size()) {
+        size_t g1 = g0;
+        const int probe_id = lines[g0].first;
+        std::vector<int> chunk;
+        while (g1 < lines.size() && lines[g1].first == probe_id) chunk.push_back(lines[g1++].second);
+        std::unordered_set<int> chunk_set(chunk.begin(), chunk.end());
+        for (const int _c : chunk_set) {
+            if (probe_id < _c) continue;
+            const int64_t cnt = std::count(chunk.begin(), chunk.end(), _c);
+            const double pmi = std::log((double)cnt) + log_d - std::log((double)appearances[probe_id - 1]) - std::log((double)appearances[_c - 1]);
+            const double sppmi = pmi - log_k;
+            if (sppmi > 0) {
+                char buf[64];
+                std::snprintf(buf, sizeof(buf), "%g", sppmi);   // operator<<(double): precision 6, general format
+                float v = 0.f;
+                std::sscanf(buf, "%f", &v);
+                rr.push_back(probe_id - 1); cc.push_back(_c - 1); vv.push_back(v);
+                rr.push_back(_c - 1); cc.push_back(probe_id - 1); vv.push_back(v);
+            }
+        }
+        g0 = g1;
+    }
+    const int64_t nnz = (int64_t)rr.size();
+    if (cap >= nnz && nnz > 0) orc_coo_to_csr(rr.data(), cc.data(), vv.data(), nnz, num_items, out_indptr, out_key, out_val);
+    else if (cap >= nnz) std::fill(out_indptr, out_indptr + num_items, (int64_t)0);
+    return nnz;
 }
 
 }  // extern "C"

@@ -78,6 +78,7 @@ def lib():
         "orc_dot_topn": (None, [pi32, i32, pf, i32, i32, pf, i32, i32, pf, i32, pi32, pf, pi32, i32, i32, i32]),
         "orc_quickselect": (None, [pf, i32, i32, pi32, i32, i32]),
         "orc_coo_to_csr": (None, [pi32, pi32, pf, i64, i32, pi64, pi32, pf]),
+        "orc_build_sppmi": (i64, [pi64, pi32, i32, i32, i32, i32, i64, pi64, pi32, pf, pi64]),
         "orc_eals_initialize_model": (None, [vp, pf, pf, pf, i32, i32]),
         "orc_eals_precompute_cache": (None, [vp, i32, pi64, pi32, i32]),
         "orc_eals_update": (i32, [vp, pi64, pi32, pf, i32]),
@@ -369,3 +370,19 @@ def coo_to_csr(major, minor, vals, num_major, num_minor=None):
     lib().orc_coo_to_csr(_p(major, C.c_int32), _p(minor, C.c_int32), _p(vals, C.c_float), nnz, int(num_major),
                          _p(indptr, C.c_int64), _p(key, C.c_int32), _p(val, C.c_float))
     return {"indptr": indptr, "key": key, "val": val}
+
+
+def build_sppmi(indptr, items, num_items, windows, k):
+    """stream.py:257-267 + fileio.hpp:109-254 + stream.py:169-195 on the oracle: the SPPMI group (indptr, key, val) of a stream
+    given as END-offset `indptr` [num_users] over 0-based `items`; same return layout as buffalo_amd.ingest.build_sppmi."""
+    indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+    items = np.ascontiguousarray(items, dtype=np.int32)
+    tl = np.zeros(1, dtype=np.int64)
+    out_indptr = np.zeros(int(num_items), dtype=np.int64)
+    nnz = lib().orc_build_sppmi(_p(indptr, C.c_int64), _p(items, C.c_int32), indptr.shape[0], int(num_items), int(windows), int(k), 0,
+                                _p(out_indptr, C.c_int64), None, None, _p(tl, C.c_int64))
+    key = np.empty(max(nnz, 1), dtype=np.int32)
+    val = np.empty(max(nnz, 1), dtype=np.float32)
+    lib().orc_build_sppmi(_p(indptr, C.c_int64), _p(items, C.c_int32), indptr.shape[0], int(num_items), int(windows), int(k), max(nnz, 1),
+                          _p(out_indptr, C.c_int64), _p(key, C.c_int32), _p(val, C.c_float), _p(tl, C.c_int64))
+    return {"indptr": out_indptr, "key": key[:nnz], "val": val[:nnz], "total_lines": int(tl[0])}

@@ -254,7 +254,9 @@ if "topk" in which:
     eng = par.TopK()
     nob, nop = np.array([[]], np.float32), np.array([], np.int32)
     res = {}
-    for nq in (128, 4096, U):
+    for nq, fused in ((128, -1), (4096, -1), (U, 0), (U, -1)):
+        # fused = 0: dense score buffer + select; -1: the size rule (fused threshold filter from 8192 queries x 8192 items up)
+        eng.set_mode("fused", fused)
         idx = np.arange(nq, dtype=np.int32)
         ok, osc = np.empty((nq, k), np.int32), np.empty((nq, k), np.float32)
         eng.dot_topn(idx, P, Q, nob, ok, osc, nop, k)
@@ -263,9 +265,14 @@ if "topk" in which:
         eng.dot_topn(idx, P, Q, nob, ok, osc, nop, k)
         dt = time.perf_counter() - t0
         st = eng.stats()
-        res["nq%d" % nq] = {"wall_ms_host_arrays": dt * 1e3, "scores_kernel_ms": st["kernel_ms"], "select_kernel_ms": st["aux_ms"],
-                            "scores_TFLOPs": 2.0 * nq * I * d / (st["kernel_ms"] * 1e-3) / 1e12, "queries_per_s": nq / dt}
-        print("topk", nq, res["nq%d" % nq], flush=True)
+        name = "nq%d%s" % (nq, "_dense" if (fused == 0) else "")
+        res[name] = {"wall_ms_host_arrays": dt * 1e3, "scores_kernel_ms": st["kernel_ms"], "select_and_aux_kernel_ms": st["aux_ms"],
+                     "scores_TFLOPs": 2.0 * nq * I * d / (st["kernel_ms"] * 1e-3) / 1e12, "queries_per_s": nq / dt,
+                     "rows_redone_densely": st["merges"]}
+        if nq == U:
+            res[name]["keys_checksum"] = int(ok.astype(np.int64).sum())
+        print("topk", name, res[name], flush=True)
+    assert res["nq%d" % U]["keys_checksum"] == res["nq%d_dense" % U]["keys_checksum"]
     from oracle import oracle as orc     # CPU restatement of parallel::dot_topn, all host cores (OpenMP), bounded sample
     nq = 4096
     idx = np.arange(nq, dtype=np.int32)

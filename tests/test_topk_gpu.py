@@ -14,6 +14,20 @@ import topk_cases as tc
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["auto", "fused-c0-32", "fused-c0-rule"], autouse=True)
+def fused_mode(request):
+    """Every case runs three ways: the size rule (these shapes: the dense score buffer + select), the fused path forced
+    with one sampled tile (loose thresholds: long candidate lists, overflowing rows handed back to the dense path) and
+    forced with the rule's sample size.  The fused path must be bit-identical to the dense one."""
+    from buffalo_amd import parallel as par
+    eng = par._engine()
+    eng.set_mode("fused", -1 if request.param == "auto" else 1)
+    eng.set_mode("fused_c0", 32 if request.param == "fused-c0-32" else 0)
+    yield request.param
+    eng.set_mode("fused", -1)
+    eng.set_mode("fused_c0", 0)
+
+
 def _check_float_case(oracle, par, indexes, P, Q, Qb, pool, k):
     gk, gs = tc.run(par.dot_topn, indexes, P, Q, Qb, pool, k)
     ok, os_ = tc.run(oracle.dot_topn, indexes, P, Q, Qb, pool, k)
@@ -82,6 +96,44 @@ def test_float_factors_match_oracle(oracle, d, q_rows, nq, k):
     idx2 = idx[idx < q_rows]
     if len(idx2):
         _check_float_case(oracle, par, idx2, Q, Q, tc.NO_BIAS, tc.EMPTY_POOL, min(k, 64))   # most_similar: self excluded
+
+
+@pytest.mark.parametrize("same,bias,pool_n,k,flt", [(False, False, 0, 10, 1), (False, True, 0, 100, 1), (True, False, 0, 25, 1),
+                                                    (False, True, 700, 30, 1), (False, False, 0, 64, 0), (True, True, 40, 50, 0)])
+def test_fused_path_is_bit_identical_to_dense(fused_mode, same, bias, pool_n, k, flt):
+    """Own engine: 6,000 candidates x 300 queries, d=96: float factors with duplicated rows (exact ties at every rank),
+    a constant block (hundreds of equal scores: ties straddling the k-th place and overflowing candidate lists) and an
+    all-negative user (nothing admissible under the FLT_MIN rule)."""
+    if fused_mode == "auto":
+        pytest.skip("comparison of the two forced paths")
+    from buffalo_amd import parallel as par
+    rng = np.random.default_rng(k + pool_n)
+    Q = rng.normal(scale=0.3, size=(6000, 96)).astype(np.float32)
+    Q[1000:1400] = Q[2000:2400]                      # exact duplicates
+    Q[3000:3300] = Q[3000]                           # one row 300 times
+    P = Q if same else rng.normal(scale=0.3, size=(300, 96)).astype(np.float32)
+    if not same:
+        P[7] = -np.abs(P[7])
+        Q[:, :48] = np.abs(Q[:, :48])                 # ... so that user 7's scores lean negative
+        P[7, 48:] = 0.0
+        P[9] = 4.0 * Q[3000]                          # the constant block is this user's best score
+    Qb = rng.normal(scale=0.1, size=(6000, 1)).astype(np.float32) if bias else tc.NO_BIAS
+    pool = rng.permutation(6000)[:pool_n].astype(np.int32) if pool_n else tc.EMPTY_POOL
+    idx = np.arange(300, dtype=np.int32)
+    out = {}
+    for name, fused, c0 in (("dense", 0, 0), ("fused", 1, 0), ("fused32", 1, 32), ("fused1024", 1, 1024)):
+        eng = par.TopK()
+        eng.set_mode("fused", fused)
+        eng.set_mode("fused_c0", c0)
+        eng.set_mode("flt_min_rule", flt)
+        out[name] = tc.run(lambda *a: eng.dot_topn(*a[:8]), idx, P, Q, Qb, pool, k)
+        out[name + "_redo"] = eng.stats()["merges"]
+    assert out["dense_redo"] == 0
+    print("rows handed back to the dense path: c0 rule %d, c0=32 %d, c0=1024 %d of 300" % (out["fused_redo"], out["fused32_redo"], out["fused1024_redo"]))
+    for name in ("fused", "fused32", "fused1024"):
+        assert np.array_equal(out[name][0], out["dense"][0]), name
+        assert np.array_equal(out[name][1], out["dense"][1]), name
+    assert out["fused1024_redo"] < 300     # the fused path itself produced rows
 
 
 def test_quickselect_matches_oracle(oracle):
