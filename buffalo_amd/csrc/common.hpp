@@ -203,6 +203,9 @@ static inline uint64_t sample_signature(const int32_t* keys, int64_t n) {
 // (rocprim::radix_sort_pairs; implemented in ingest.hip so only that file pays for the headers).
 void device_sort_pairs_u32(const uint32_t* keys_in, uint32_t* keys_out, const int32_t* vals_in, int32_t* vals_out, int64_t n, int bits,
                            DevBuf<char>& tmp, hipStream_t s);
+// (ingest.hip) the same over 64-bit keys with 64-bit payloads (eALS: position of every entry in the other orientation)
+void device_sort_pairs_u64(const uint64_t* keys_in, uint64_t* keys_out, const int64_t* vals_in, int64_t* vals_out, int64_t n, int bits,
+                           DevBuf<char>& tmp, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
 // Device helpers (wave64)

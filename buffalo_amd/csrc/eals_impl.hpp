@@ -210,6 +210,20 @@ __global__ __launch_bounds__(1024) void eals_update_heavy_kernel(EalsParams p) {
     }
 }
 
+// entry `ind` of a compressed side -> sort key (other id << 32 | own id); the payload is the entry's position
+__global__ __launch_bounds__(256) void eals_coord_kernel(const int64_t* __restrict__ indptr, const int32_t* __restrict__ keys, int rows, int64_t nnz,
+                                                         uint64_t* __restrict__ key_out, int64_t* __restrict__ pos_out) {
+    const int64_t ind = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (ind >= nnz) return;
+    const uint64_t x = static_cast<uint64_t>(lower_bound_dev<int64_t>(indptr, rows, ind + 1));   // first row whose END offset is > ind
+    key_out[ind] = (static_cast<uint64_t>(static_cast<uint32_t>(keys[ind])) << 32) | x;
+    pos_out[ind] = ind;
+}
+__global__ __launch_bounds__(256) void eals_rank_kernel(const int64_t* __restrict__ sorted_pos, int64_t nnz, int64_t* __restrict__ map) {
+    const int64_t r = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (r < nnz) map[sorted_pos[r]] = r;
+}
+
 // vhat[ind] = X[row(ind)] . Y[key(ind)]   (eals.cc:72-78); one wave per row
 __global__ __launch_bounds__(256) void eals_cache_kernel(const float* __restrict__ X, const float* __restrict__ Y, int vdim, int rows,
                                                          const int64_t* __restrict__ indptr, const int32_t* __restrict__ keys, float* __restrict__ vhat) {
@@ -346,16 +360,6 @@ class EalsHandle : public AlsHandle {
         s.map.resize(std::max(nnz, 1));
         BFH_HIP(hipMemcpyAsync(s.indptr.get(), indptr, sizeof(int64_t) * rows, hipMemcpyHostToDevice, stream));
         if (nnz) BFH_HIP(hipMemcpyAsync(s.keys.get(), keys, sizeof(int32_t) * nnz, hipMemcpyHostToDevice, stream));
-        // rank of every entry in (other id, own id) order = its position in the other orientation (eals.cc:81-99)
-        std::vector<std::pair<uint64_t, int64_t>> coord(nnz);
-        {
-            int64_t prev = 0;
-            for (int x = 0; x < rows; ++x) {
-                for (int64_t ind = prev; ind < indptr[x]; ++ind)
-                    coord[ind] = {(static_cast<uint64_t>(static_cast<uint32_t>(keys[ind])) << 32) | static_cast<uint32_t>(x), ind};
-                prev = indptr[x];
-            }
-        }
         {
             std::vector<int32_t> li, hv;
             int64_t prev = 0;
@@ -374,17 +378,31 @@ class EalsHandle : public AlsHandle {
             if (!hv.empty()) BFH_HIP(hipMemcpyAsync(s.heavy.get(), hv.data(), hv.size() * 4, hipMemcpyHostToDevice, stream));
             BFH_HIP(hipStreamSynchronize(stream));   // li / hv are locals
         }
-        std::sort(coord.begin(), coord.end());
-        std::vector<int64_t> map(nnz);
-        for (int64_t r = 0; r < nnz; ++r) map[coord[r].second] = r;
-        if (nnz) BFH_HIP(hipMemcpyAsync(s.map.get(), map.data(), sizeof(int64_t) * nnz, hipMemcpyHostToDevice, stream));
         const int slot = t_aux_.begin(stream);
+        if (nnz) {
+            // rank of every entry in (other id, own id) order = its position in the other orientation (eals.cc:81-99): one
+            // radix sort of (other id << 32 | own id) with the entry's position as payload, then map[payload[r]] = r
+            DevBuf<uint64_t> ka, kb;
+            DevBuf<int64_t> va, vb;
+            DevBuf<char> tmp;
+            ka.resize(nnz); kb.resize(nnz); va.resize(nnz); vb.resize(nnz);
+            const unsigned blocks = static_cast<unsigned>((static_cast<int64_t>(nnz) + 255) / 256);
+            hipLaunchKernelGGL(eals_coord_kernel, dim3(blocks), dim3(256), 0, stream, s.indptr.get(), s.keys.get(), rows, static_cast<int64_t>(nnz), ka.get(),
+                               va.get());
+            BFH_HIP(hipGetLastError());
+            int bits = 33;
+            while (bits < 64 && (uint64_t(1) << (bits - 32)) < static_cast<uint64_t>(axis == 0 ? Q_rows_ : P_rows_)) ++bits;
+            device_sort_pairs_u64(ka.get(), kb.get(), va.get(), vb.get(), nnz, bits, tmp, stream);
+            hipLaunchKernelGGL(eals_rank_kernel, dim3(blocks), dim3(256), 0, stream, vb.get(), static_cast<int64_t>(nnz), s.map.get());
+            BFH_HIP(hipGetLastError());
+            BFH_HIP(hipStreamSynchronize(stream));   // the sort buffers are locals
+        }
         hipLaunchKernelGGL(eals_cache_kernel, dim3(static_cast<unsigned>((rows + 3) / 4)), dim3(256), 0, stream, axis == 0 ? P_.get() : Q_.get(),
                            axis == 0 ? Q_.get() : P_.get(), vdim_, rows, s.indptr.get(), s.keys.get(), s.vhat.get());
         BFH_HIP(hipGetLastError());
         t_aux_.end(slot, stream);
-        BFH_HIP(hipStreamSynchronize(stream));   // map is a local
-        stats.h2d_bytes += 8.0 * rows + 12.0 * nnz;
+        BFH_HIP(hipStreamSynchronize(stream));
+        stats.h2d_bytes += 8.0 * rows + 4.0 * nnz;
         stats.aux_ms += t_aux_.drain();
         cached_[axis] = true;
     }

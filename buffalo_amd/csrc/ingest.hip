@@ -57,6 +57,17 @@ void device_sort_pairs_u32(const uint32_t* keys_in, uint32_t* keys_out, const in
     BFH_HIP(rocprim::radix_sort_pairs(tmp.get(), bytes, keys_in, keys_out, vals_in, vals_out, count, 0u, end_bit, s));
 }
 
+void device_sort_pairs_u64(const uint64_t* keys_in, uint64_t* keys_out, const int64_t* vals_in, int64_t* vals_out, int64_t n, int bits,
+                           DevBuf<char>& tmp, hipStream_t s) {
+    size_t bytes = 0;
+    const size_t count = static_cast<size_t>(n);
+    const unsigned end_bit = static_cast<unsigned>(bits);
+    BFH_HIP(rocprim::radix_sort_pairs(nullptr, bytes, keys_in, keys_out, vals_in, vals_out, count, 0u, end_bit, s));
+    if (tmp.size() < bytes) tmp.resize(bytes ? bytes : 1);
+    bytes = tmp.size();
+    BFH_HIP(rocprim::radix_sort_pairs(tmp.get(), bytes, keys_in, keys_out, vals_in, vals_out, count, 0u, end_bit, s));
+}
+
 static void coo_to_csr(const int32_t* major, const int32_t* minor, const float* vals, int64_t nnz, int num_major, int num_minor, int64_t* indptr,
                        int32_t* out_minor, float* out_vals, bfh_stats* stats) {
     BFH_REQUIRE(nnz >= 0 && num_major > 0 && num_minor > 0, "coo_to_csr: empty shape");

@@ -157,9 +157,10 @@ __global__ __launch_bounds__(256, 3) void topk_scores_kernel(const float* __rest
                 const float sc = f.Qb ? acc[e] + qb : acc[e];   // the very sum the select kernel forms
                 if (colok && sc >= s_thr[wv][rr]) {           // rows beyond nq carry +inf
                     const int slot = atomicAdd(&s_cnt[wv][rr], 1);
+                    const float raw = acc[e];   // (a bit_cast applied to the vector element itself reads element 0)
                     if (slot < f.cap_seg)
                         f.cand[(static_cast<size_t>(b0q + rr) * gridDim.x + blockIdx.x) * f.cap_seg + slot] =
-                            make_uint2(static_cast<uint32_t>(j), __builtin_bit_cast(uint32_t, acc[e]));
+                            make_uint2(static_cast<uint32_t>(j), __float_as_uint(raw));
                 }
             }
         } else if (jok) {
@@ -222,6 +223,9 @@ struct SelectArgs {
     int n_seg, cap_seg;
     int list_cap;            // entries of the LDS list behind the candidate buffer
     int* redo;               // [0]: rows sent to the dense path (a segment or the list overflowed), [1 + i]: their b
+    const int* row_list;     // nullable: block x works on row row_list[x] (the rows topk_list_wave_kernel passed on)
+    int* general;            // topk_list_wave_kernel: [0] rows passed on to topk_select_kernel (ties at the k-th place), [1 + i]: their b
+    float* thr;              // topk_thr_wave_kernel: [b] the kk-th best admissible score of the row, or "everything"
 };
 
 __global__ __launch_bounds__(256) void topk_select_kernel(SelectArgs a) {
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(256) void topk_select_kernel(SelectArgs a) {
     __shared__ int part[256];
     __shared__ int s_misc[8];   // 0: chosen bin, 1: remaining, 2: n_gt slots, 3: run_eq, 4..7: wave eq counts / fast-path counters
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int b = blockIdx.x;
+    const int b = a.row_list ? a.row_list[blockIdx.x] : blockIdx.x;
     const bool list = a.cand != nullptr;
     const float* row = list ? nullptr : a.S + static_cast<size_t>(b) * a.ld_s;
     const int orow = a.out_row ? a.out_row[b] : a.q0 + b;
@@ -529,6 +533,177 @@ __global__ __launch_bounds__(256) void topk_select_kernel(SelectArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// One WAVE per row, for rows that fit in registers: no block barriers, no LDS histograms.  The k-th smallest key of the
+// row is found bit by bit (32 rounds of "how many live keys have a 0 here", one DPP wave sum each) over the keys the
+// lanes hold; a 256-thread block per row spends most of its time in the fixed cost of its barriers when the row has a
+// few hundred entries, as the candidate lists of the fused path do.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_sum_i32(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false);   // row_ror:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xf, 0xf, false);   // row_ror:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x122, 0xf, 0xf, false);   // row_ror:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x121, 0xf, 0xf, false);   // row_ror:1
+    return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) + (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
+}
+
+// key[s], s < SLOTS, live where bit s of `valid` is set.  Returns the number of live keys m; when m >= kk: kth = the kk-th
+// smallest, need_eq = how many of the keys == kth belong to the kk smallest, eq_total = how many there are.
+template <int SLOTS>
+__device__ __forceinline__ int wave_kth_key(const uint32_t (&key)[SLOTS], uint64_t valid, int kk, uint32_t& kth, int& need_eq, int& eq_total) {
+    const int m = wave_sum_i32(__popcll(valid));
+    kth = 0u; need_eq = 0; eq_total = 0;
+    if (m < kk) return m;
+    uint32_t prefix = 0u;
+    int remaining = kk;
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t hi = bit == 31 ? 0u : (0xFFFFFFFFu << (bit + 1));
+        int c = 0;
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl) {
+            const uint32_t k = key[sl];
+            c += (((valid >> sl) & 1ull) && (k & hi) == prefix && !((k >> bit) & 1u)) ? 1 : 0;
+        }
+        c = wave_sum_i32(c);
+        if (c < remaining) { remaining -= c; prefix |= 1u << bit; }
+    }
+    int e = 0;
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) e += (((valid >> sl) & 1ull) && key[sl] == prefix) ? 1 : 0;
+    kth = prefix; need_eq = remaining; eq_total = wave_sum_i32(e);
+    return m;
+}
+
+// admission rules of topk_select_kernel::key_of for column j with raw score s
+__device__ __forceinline__ bool topk_admit(const SelectArgs& a, int j, int self, float s, uint32_t& key) {
+    if (j == self) return false;
+    if (a.pool && !((a.pool[j >> 5] >> (j & 31)) & 1u)) return false;
+    if (a.Qb) s += a.Qb[j];
+    if (a.rule_flt_min && !(s > FLT_MIN)) return false;
+    key = desc_key(s);
+    return true;
+}
+
+// thresholds of the fused path from the dense scores of the sampled columns (a.cols <= 4096: 64 keys per lane):
+// thr[b] = the kk-th best admissible score, or -- with fewer than kk of them -- "everything" (with the admission rule only
+// scores > FLT_MIN can be listed, so FLT_MIN is a valid bound then).  grid: ceil(rows / 4) blocks of 4 waves.
+__global__ __launch_bounds__(256) void topk_thr_wave_kernel(SelectArgs a, int rows) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= rows) return;
+    const float* row = a.S + static_cast<size_t>(b) * a.ld_s;
+    const int self = a.self_idx ? a.self_idx[a.q0 + b] : -1;
+    uint32_t key[64];
+    uint64_t valid = 0ull;
+#pragma unroll
+    for (int sl = 0; sl < 64; ++sl) {
+        const int j = sl * 64 + lane;
+        key[sl] = 0u;
+        if (j < a.cols) {
+            uint32_t k = 0u;
+            if (topk_admit(a, j, self, row[j], k)) { key[sl] = k; valid |= 1ull << sl; }
+        }
+    }
+    uint32_t kth; int need_eq, eq_total;
+    const int m = wave_kth_key<64>(key, valid, a.kk, kth, need_eq, eq_total);
+    if (lane == 0) a.thr[b] = m >= a.kk ? key_score(kth) : (a.rule_flt_min ? FLT_MIN : -__builtin_inff());
+}
+
+// selection over the candidate lists of the fused path, one wave per row (lists of <= 2048 entries: 32 per lane).
+// A row whose segments or list overflowed goes to `redo` (dense path); a row with ties straddling the k-th place goes to
+// `general` (topk_select_kernel's list mode, which walks the ties in column order).  Dynamic LDS: 4 * p2 * 8 bytes.
+__global__ __launch_bounds__(256) void topk_list_wave_kernel(SelectArgs a, int rows) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long wsel[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wv;
+    if (b >= rows) return;
+    unsigned long long* sel = wsel + static_cast<size_t>(wv) * a.p2;
+    const int self = a.self_idx ? a.self_idx[a.q0 + b] : -1;
+    // segment ends (n_seg <= 8): e[g] = entries of the segments 0..g
+    int seg_end[8];
+    int over = 0, tot = 0;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        int c = 0;
+        if (g < a.n_seg) {
+            c = a.cand_cnt[static_cast<size_t>(b) * a.n_seg + g];
+            over |= c > a.cap_seg;
+        }
+        tot += c;
+        seg_end[g] = tot;
+    }
+    if (over || tot > a.list_cap) {
+        if (lane == 0) a.redo[1 + atomicAdd(a.redo, 1)] = b;
+        return;
+    }
+    uint32_t key[32], col[32];
+    uint64_t valid = 0ull;
+#pragma unroll
+    for (int sl = 0; sl < 32; ++sl) {
+        const int i = sl * 64 + lane;
+        key[sl] = 0u; col[sl] = 0u;
+        if (i < tot) {
+            int g = 0, beg = 0;
+#pragma unroll
+            for (int q = 0; q < 7; ++q)
+                if (i >= seg_end[q]) { g = q + 1; beg = seg_end[q]; }
+            const uint2 c = a.cand[(static_cast<size_t>(b) * a.n_seg + g) * a.cap_seg + (i - beg)];
+            uint32_t k = 0u;
+            if (topk_admit(a, static_cast<int>(c.x), self, __uint_as_float(c.y), k)) { key[sl] = k; col[sl] = c.x; valid |= 1ull << sl; }
+        }
+    }
+    uint32_t kth; int need_eq, eq_total;
+    const int m = wave_kth_key<32>(key, valid, a.kk, kth, need_eq, eq_total);
+    const bool take_all = m < a.kk;
+    if (!take_all && need_eq < eq_total) {   // ties straddle the k-th place: the reference's rule needs column order
+        if (lane == 0) a.general[1 + atomicAdd(a.general, 1)] = b;
+        return;
+    }
+    const int kk_eff = take_all ? m : a.kk;
+    for (int i = lane; i < a.p2; i += 64) sel[i] = ~0ull;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    int base = 0;
+#pragma unroll
+    for (int sl = 0; sl < 32; ++sl) {
+        const bool win = ((valid >> sl) & 1ull) && (take_all || key[sl] <= kth);
+        const unsigned long long mask = __ballot(win);
+        if (win) sel[base + __popcll(mask & ((1ull << lane) - 1ull))] = (static_cast<unsigned long long>(key[sl]) << 32) | (0xFFFFFFFFu - col[sl]);
+        base += __popcll(mask);
+    }
+    // bitonic sort of the wave's p2 entries, ascending composite = (score desc, column desc)
+    for (int size = 2; size <= a.p2; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int t = lane; t < (a.p2 >> 1); t += 64) {
+                const int lo = ((t & ~(stride - 1)) << 1) | (t & (stride - 1));
+                const int hi = lo | stride;
+                const bool up = (lo & size) == 0;
+                const unsigned long long x = sel[lo], y = sel[hi];
+                if ((x > y) == up) { sel[lo] = y; sel[hi] = x; }
+            }
+        }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int orow = a.q0 + b;
+    int32_t* ok = a.out_keys + static_cast<size_t>(orow) * a.k;
+    float* os = a.out_scores ? a.out_scores + static_cast<size_t>(orow) * a.k : nullptr;
+    for (int r = lane; r < a.k; r += 64) {
+        if (r < kk_eff) {
+            const unsigned long long c = sel[r];
+            ok[r] = static_cast<int32_t>(0xFFFFFFFFu - static_cast<uint32_t>(c & 0xFFFFFFFFull));
+            if (os) os[r] = key_score(static_cast<uint32_t>(c >> 32));
+        } else {
+            ok[r] = -1;
+            if (os) os[r] = r < a.kk ? FLT_MIN : 0.0f;   // _core.hpp:26 / :134-137
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 class TopkHandle : public HandleBase {
  public:
@@ -680,6 +855,7 @@ class TopkHandle : public HandleBase {
             cand_.resize(std::max(cand_.size(), static_cast<size_t>(batch) * fp.n_seg * fp.cap_seg));
             cnt_.resize(std::max(cnt_.size(), static_cast<size_t>(batch) * fp.n_seg));
             redo_.resize(std::max(redo_.size(), static_cast<size_t>(batch) + 1));
+            general_.resize(std::max(general_.size(), static_cast<size_t>(batch) + 1));
         }
         for (int q0 = 0; q0 < nq; q0 += batch) {
             const int nb = std::min(batch, nq - q0);
@@ -701,11 +877,17 @@ class TopkHandle : public HandleBase {
             slot = t_aux_.begin(stream);
             SelectArgs a = base;
             a.S = S_.get(); a.ld_s = static_cast<size_t>(fp.c0); a.cols = fp.c0; a.self_idx = same ? d_idx_.get() : nullptr; a.q0 = q0;
-            launch_select(a, nb, lds_dense);
-            hipLaunchKernelGGL(topk_thr_kernel, dim3((nb + 255) / 256), dim3(256), 0, stream, d_keys_.get(), d_scores_.get(), q0, nb, k, kk,
-                               flt_min_rule_ ? 1 : 0, thr_.get());
+            if (wave_select_ && fp.c0 <= 4096) {
+                a.thr = thr_.get();
+                hipLaunchKernelGGL(topk_thr_wave_kernel, dim3((nb + 3) / 4), dim3(256), 0, stream, a, nb);
+            } else {
+                launch_select(a, nb, lds_dense);
+                hipLaunchKernelGGL(topk_thr_kernel, dim3((nb + 255) / 256), dim3(256), 0, stream, d_keys_.get(), d_scores_.get(), q0, nb, k, kk,
+                                   flt_min_rule_ ? 1 : 0, thr_.get());
+            }
             BFH_HIP(hipGetLastError());
             BFH_HIP(hipMemsetAsync(redo_.get(), 0, sizeof(int), stream));
+            BFH_HIP(hipMemsetAsync(general_.get(), 0, sizeof(int), stream));
             t_aux_.end(slot, stream);
             FilterArgs f{thr_.get(), dQb, d_pool, cand_.get(), cnt_.get(), fp.cap_seg};
             slot = t_main_.begin(stream);
@@ -719,13 +901,28 @@ class TopkHandle : public HandleBase {
             t_main_.end(slot, stream);
             slot = t_aux_.begin(stream);
             a.S = nullptr; a.cand = cand_.get(); a.cand_cnt = cnt_.get(); a.n_seg = fp.n_seg; a.cap_seg = fp.cap_seg; a.list_cap = kListCap;
-            a.redo = redo_.get();
-            launch_select(a, nb, lds_list);
+            a.redo = redo_.get(); a.general = general_.get(); a.thr = nullptr;
+            const bool wave_list = wave_select_ && p2 <= 1024;
+            if (wave_list) {
+                hipLaunchKernelGGL(topk_list_wave_kernel, dim3((nb + 3) / 4), dim3(256), static_cast<size_t>(4) * p2 * 8, stream, a, nb);
+                BFH_HIP(hipGetLastError());
+            } else {
+                launch_select(a, nb, lds_list);
+            }
             t_aux_.end(slot, stream);
-            int n_redo = 0;
+            int n_redo = 0, n_general = 0;
             BFH_HIP(hipMemcpyAsync(&n_redo, redo_.get(), sizeof(int), hipMemcpyDeviceToHost, stream));
+            BFH_HIP(hipMemcpyAsync(&n_general, general_.get(), sizeof(int), hipMemcpyDeviceToHost, stream));
             BFH_HIP(hipStreamSynchronize(stream));
-            stats.merges += n_redo;   // top-k: rows the fused path handed back to the dense path
+            stats.merges += n_redo;      // top-k: rows the fused path handed back to the dense path
+            stats.exchanges += n_general;   // top-k: rows with ties at the k-th place (block-level list selection)
+            if (n_general > 0) {
+                slot = t_aux_.begin(stream);
+                a.row_list = general_.get() + 1;
+                launch_select(a, n_general, lds_list);
+                a.row_list = nullptr;
+                t_aux_.end(slot, stream);
+            }
             if (n_redo == 0) continue;
             // ---- rows whose candidates did not fit (ties at the threshold, all-inadmissible rows, tiny pools): dense path ----
             std::vector<int32_t> rows(static_cast<size_t>(n_redo));
@@ -837,6 +1034,7 @@ class TopkHandle : public HandleBase {
         if (name == "flt_min_rule") flt_min_rule_ = v != 0;
         else if (name == "fast_select") fast_select_ = v != 0;   // 0: multi-pass radix select only (debug / comparison)
         else if (name == "fused") fused_ = static_cast<int>(v);      // -1: by size (default), 0: dense path only, 1: whenever d <= 128 (tests)
+        else if (name == "wave_select") wave_select_ = v != 0;       // 0: block-per-row selection everywhere (comparison)
         else if (name == "fused_c0") fused_c0_ = static_cast<int>(v);   // with fused = 1: columns sampled for the thresholds (0: by rule)
         else if (name == "timing") timing = v != 0;
         else throw Error(BFH_ERR_INVALID, "unknown mode '" + name + "'");
@@ -846,6 +1044,7 @@ class TopkHandle : public HandleBase {
     int num_cus_ = 256;
     bool fast_select_ = true;
     int fused_ = -1, fused_c0_ = 0;
+    bool wave_select_ = true;
     bool flt_min_rule_ = true;   // _core.hpp:26,115: the running list starts at FLT_MIN, so scores <= FLT_MIN are never admitted
     DevBuf<int32_t> d_idx_, d_keys_;
     DevBuf<uint32_t> d_pool_;
@@ -854,7 +1053,7 @@ class TopkHandle : public HandleBase {
     // fused path: per-query thresholds, candidate segments + counts, rows handed back to the dense path
     DevBuf<float> thr_;
     DevBuf<uint2> cand_;
-    DevBuf<int> cnt_, redo_;
+    DevBuf<int> cnt_, redo_, general_;
     DevBuf<int32_t> redo_side_;
     EventTimer t_main_, t_aux_;
 };

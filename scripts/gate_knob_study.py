@@ -1,0 +1,36 @@
+"""GPU side of the lr-0.05 gate study: the item-major walk under several knob settings (and the all-atomic user-major walk),
+three runs each, against the stored oracle reference (scripts/gate_oracle_ref.py).  Prints one line per run."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import bench  # noqa: E402
+import test_bpr_gate_gpu as G  # noqa: E402
+
+ref = np.load(os.path.join(ROOT, "scripts", "data", "gate_lr005_oracle.npz"))
+users = ref["users"]
+csr = G._csr()
+eu, ep, en = G._eval_set(csr)
+epochs = int(os.environ.get("EPOCHS", "24"))
+opt = bench.bpr_options(epochs, lr=0.05, min_lr=0.05)
+print("oracle a", ref["metrics_a"], "b", ref["metrics_b"], "a~b overlap %.3f" % G._overlap(ref["top_a"], ref["top_b"]), flush=True)
+SETTINGS = [{}, {"im_max_stale": 16}, {"im_max_stale": 4}, {"xcd_sync_updates": 1 << 21}, {"xcd_sync_updates": 1 << 20, "im_max_stale": 16},
+            {"im_blocks": 16}, {"im_blocks": 2}, {"xcd_hot_tau": 30}, {"im_drift_budget": 250}, {"hogwild_atomic": 1}]
+rows = []
+for modes in SETTINGS:
+    for rep in range(3):
+        obj, P, Q, Qb = G._run_hip(csr, opt, epochs, modes)
+        top = G._top10(P, Q, Qb, users)
+        m = G._metrics(lambda: obj.compute_loss(eu, ep, en), P, Q, Qb)
+        m["prec10"] = G._precision10(csr, top, users)
+        m["overlap"] = 0.5 * (G._overlap(top, ref["top_a"]) + G._overlap(top, ref["top_b"]))
+        m["modes"] = modes
+        rows.append(m)
+        print(json.dumps(m), flush=True)
+        del obj
+json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "gate_knob_study.json"), "w"), indent=1)
