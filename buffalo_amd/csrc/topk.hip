@@ -548,30 +548,68 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
     return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) + (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
 }
 
+__device__ __forceinline__ void wave_lds_sync() {   // LDS traffic of ONE wave: program order is enough, keep the compiler from moving it
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ int wave_incl_scan_i32(int v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __builtin_amdgcn_ds_bpermute(((lane - d) & 63) << 2, v);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+constexpr int kWaveHistBins = 4096;   // uint32 per wave
+
 // key[s], s < SLOTS, live where bit s of `valid` is set.  Returns the number of live keys m; when m >= kk: kth = the kk-th
 // smallest, need_eq = how many of the keys == kth belong to the kk smallest, eq_total = how many there are.
+// Three histogram levels over the key's bits 31..20, 19..8, 7..0 in the wave's own LDS histogram `hist` (kWaveHistBins
+// words): the live keys that match the prefix found so far are counted by their next digit (LDS atomics), the digit
+// holding the kk-th key is located with two wave scans (row totals of the [rows][64] bin matrix, then inside the row).
 template <int SLOTS>
-__device__ __forceinline__ int wave_kth_key(const uint32_t (&key)[SLOTS], uint64_t valid, int kk, uint32_t& kth, int& need_eq, int& eq_total) {
+__device__ __forceinline__ int wave_kth_key(const uint32_t (&key)[SLOTS], uint64_t valid, int kk, uint32_t* hist, int lane, uint32_t& kth, int& need_eq,
+                                            int& eq_total) {
     const int m = wave_sum_i32(__popcll(valid));
     kth = 0u; need_eq = 0; eq_total = 0;
     if (m < kk) return m;
-    uint32_t prefix = 0u;
-    int remaining = kk;
-    for (int bit = 31; bit >= 0; --bit) {
-        const uint32_t hi = bit == 31 ? 0u : (0xFFFFFFFFu << (bit + 1));
-        int c = 0;
+    uint32_t prefix = 0u, mask = 0u;
+    int remaining = kk, bin_count = 0;
+#pragma unroll
+    for (int level = 0; level < 3; ++level) {
+        const int shift = level == 0 ? 20 : (level == 1 ? 8 : 0);
+        const int nb = level == 2 ? 256 : 4096;
+        const int rows = nb / 64;
+        uint4* h4 = reinterpret_cast<uint4*>(hist);
+        for (int i = lane; i < nb / 4; i += 64) h4[i] = make_uint4(0u, 0u, 0u, 0u);
+        wave_lds_sync();
 #pragma unroll
         for (int sl = 0; sl < SLOTS; ++sl) {
             const uint32_t k = key[sl];
-            c += (((valid >> sl) & 1ull) && (k & hi) == prefix && !((k >> bit) & 1u)) ? 1 : 0;
+            if (((valid >> sl) & 1ull) && (k & mask) == prefix) atomicAdd(&hist[(k >> shift) & static_cast<uint32_t>(nb - 1)], 1u);
         }
-        c = wave_sum_i32(c);
-        if (c < remaining) { remaining -= c; prefix |= 1u << bit; }
+        wave_lds_sync();
+        // row totals: lane r < rows sums bins [64 r, 64 r + 64), read skewed so that the lanes spread over the banks
+        int rt = 0;
+        if (lane < rows)
+            for (int j = 0; j < 64; ++j) rt += static_cast<int>(hist[lane * 64 + ((j + lane) & 63)]);
+        const int rincl = wave_incl_scan_i32(rt, lane);
+        const unsigned long long rb = __ballot(lane < rows && rincl >= remaining);
+        const int r = __builtin_ctzll(rb);   // rb != 0: the matching keys number at least `remaining`
+        remaining -= __builtin_amdgcn_readlane(rincl - rt, r);
+        const int bv = static_cast<int>(hist[r * 64 + lane]);
+        const int bincl = wave_incl_scan_i32(bv, lane);
+        const unsigned long long bb = __ballot(bincl >= remaining);
+        const int c = __builtin_ctzll(bb);
+        remaining -= __builtin_amdgcn_readlane(bincl - bv, c);
+        bin_count = __builtin_amdgcn_readlane(bv, c);
+        prefix |= static_cast<uint32_t>(r * 64 + c) << shift;
+        mask |= static_cast<uint32_t>(nb - 1) << shift;
+        wave_lds_sync();
     }
-    int e = 0;
-#pragma unroll
-    for (int sl = 0; sl < SLOTS; ++sl) e += (((valid >> sl) & 1ull) && key[sl] == prefix) ? 1 : 0;
-    kth = prefix; need_eq = remaining; eq_total = wave_sum_i32(e);
+    kth = prefix; need_eq = remaining; eq_total = bin_count;
     return m;
 }
 
@@ -589,6 +627,7 @@ __device__ __forceinline__ bool topk_admit(const SelectArgs& a, int j, int self,
 // thr[b] = the kk-th best admissible score, or -- with fewer than kk of them -- "everything" (with the admission rule only
 // scores > FLT_MIN can be listed, so FLT_MIN is a valid bound then).  grid: ceil(rows / 4) blocks of 4 waves.
 __global__ __launch_bounds__(256) void topk_thr_wave_kernel(SelectArgs a, int rows) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t whist_dyn[];   // 4 * kWaveHistBins words
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= rows) return;
@@ -606,19 +645,20 @@ __global__ __launch_bounds__(256) void topk_thr_wave_kernel(SelectArgs a, int ro
         }
     }
     uint32_t kth; int need_eq, eq_total;
-    const int m = wave_kth_key<64>(key, valid, a.kk, kth, need_eq, eq_total);
+    const int m = wave_kth_key<64>(key, valid, a.kk, whist_dyn + (threadIdx.x >> 6) * kWaveHistBins, lane, kth, need_eq, eq_total);
     if (lane == 0) a.thr[b] = m >= a.kk ? key_score(kth) : (a.rule_flt_min ? FLT_MIN : -__builtin_inff());
 }
 
 // selection over the candidate lists of the fused path, one wave per row (lists of <= 2048 entries: 32 per lane).
 // A row whose segments or list overflowed goes to `redo` (dense path); a row with ties straddling the k-th place goes to
-// `general` (topk_select_kernel's list mode, which walks the ties in column order).  Dynamic LDS: 4 * p2 * 8 bytes.
+// `general` (topk_select_kernel's list mode, which walks the ties in column order).  Dynamic LDS: 4 histograms + 4 * p2 * 8 bytes.
 __global__ __launch_bounds__(256) void topk_list_wave_kernel(SelectArgs a, int rows) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long wsel[];
+    extern __shared__ __attribute__((aligned(16))) unsigned long long wsel[];   // 4 histograms (kWaveHistBins words each), then 4 * p2 sort entries
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int b = blockIdx.x * 4 + wv;
     if (b >= rows) return;
-    unsigned long long* sel = wsel + static_cast<size_t>(wv) * a.p2;
+    uint32_t* whist = reinterpret_cast<uint32_t*>(wsel) + static_cast<size_t>(wv) * kWaveHistBins;
+    unsigned long long* sel = wsel + (4 * kWaveHistBins) / 2 + static_cast<size_t>(wv) * a.p2;
     const int self = a.self_idx ? a.self_idx[a.q0 + b] : -1;
     // segment ends (n_seg <= 8): e[g] = entries of the segments 0..g
     int seg_end[8];
@@ -654,7 +694,7 @@ __global__ __launch_bounds__(256) void topk_list_wave_kernel(SelectArgs a, int r
         }
     }
     uint32_t kth; int need_eq, eq_total;
-    const int m = wave_kth_key<32>(key, valid, a.kk, kth, need_eq, eq_total);
+    const int m = wave_kth_key<32>(key, valid, a.kk, whist, lane, kth, need_eq, eq_total);
     const bool take_all = m < a.kk;
     if (!take_all && need_eq < eq_total) {   // ties straddle the k-th place: the reference's rule needs column order
         if (lane == 0) a.general[1 + atomicAdd(a.general, 1)] = b;
@@ -833,6 +873,13 @@ class TopkHandle : public HandleBase {
         const size_t lds_list = lds_dense + static_cast<size_t>(kListCap) * 8;
         BFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(topk_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     static_cast<int>(fp.on ? lds_list : lds_dense)));
+        const size_t kWaveLds = static_cast<size_t>(4) * kWaveHistBins * 4;   // the wave kernels' four histograms
+        if (fp.on && wave_select_) {
+            BFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(topk_thr_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        static_cast<int>(kWaveLds)));
+            BFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(topk_list_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        static_cast<int>(kWaveLds + static_cast<size_t>(4) * std::min(p2, 1024) * 8)));
+        }
         {   // candidate matrix in operand order, one slab per K-chunk
             const int n_chunks = (d_pad + 127) / 128;
             const size_t per = static_cast<size_t>(n_tiles) * 16 * 64;
@@ -879,7 +926,7 @@ class TopkHandle : public HandleBase {
             a.S = S_.get(); a.ld_s = static_cast<size_t>(fp.c0); a.cols = fp.c0; a.self_idx = same ? d_idx_.get() : nullptr; a.q0 = q0;
             if (wave_select_ && fp.c0 <= 4096) {
                 a.thr = thr_.get();
-                hipLaunchKernelGGL(topk_thr_wave_kernel, dim3((nb + 3) / 4), dim3(256), 0, stream, a, nb);
+                hipLaunchKernelGGL(topk_thr_wave_kernel, dim3((nb + 3) / 4), dim3(256), kWaveLds, stream, a, nb);
             } else {
                 launch_select(a, nb, lds_dense);
                 hipLaunchKernelGGL(topk_thr_kernel, dim3((nb + 255) / 256), dim3(256), 0, stream, d_keys_.get(), d_scores_.get(), q0, nb, k, kk,
@@ -904,7 +951,7 @@ class TopkHandle : public HandleBase {
             a.redo = redo_.get(); a.general = general_.get(); a.thr = nullptr;
             const bool wave_list = wave_select_ && p2 <= 1024;
             if (wave_list) {
-                hipLaunchKernelGGL(topk_list_wave_kernel, dim3((nb + 3) / 4), dim3(256), static_cast<size_t>(4) * p2 * 8, stream, a, nb);
+                hipLaunchKernelGGL(topk_list_wave_kernel, dim3((nb + 3) / 4), dim3(256), kWaveLds + static_cast<size_t>(4) * p2 * 8, stream, a, nb);
                 BFH_HIP(hipGetLastError());
             } else {
                 launch_select(a, nb, lds_list);

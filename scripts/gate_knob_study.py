@@ -1,4 +1,4 @@
-"""GPU side of the lr-0.05 gate study: the item-major walk under several knob settings (and the all-atomic user-major walk),
+"""GPU side of the gate study (env CASE = "lr0.05" | "bench", SETTINGS = JSON list of knob dicts, EPOCHS): the item-major walk under several knob settings (and the all-atomic user-major walk),
 three runs each, against the stored oracle reference (scripts/gate_oracle_ref.py).  Prints one line per run."""
 import json
 import os
@@ -12,14 +12,16 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import bench  # noqa: E402
 import test_bpr_gate_gpu as G  # noqa: E402
 
-ref = np.load(os.path.join(ROOT, "scripts", "data", "gate_lr005_oracle.npz"))
+case = os.environ.get("CASE", "lr0.05")
+kw, default_epochs = {"lr0.05": (dict(lr=0.05, min_lr=0.05), 24), "bench": (dict(lr=0.002, min_lr=0.0001), 3)}[case]
+ref = np.load(os.path.join(ROOT, "scripts", "data", "gate_%s_oracle.npz" % case.replace(".", "")))
 users = ref["users"]
 csr = G._csr()
 eu, ep, en = G._eval_set(csr)
-epochs = int(os.environ.get("EPOCHS", "24"))
-opt = bench.bpr_options(epochs, lr=0.05, min_lr=0.05)
+epochs = int(os.environ.get("EPOCHS", str(default_epochs)))
+opt = bench.bpr_options(epochs, **kw)
 print("oracle a", ref["metrics_a"], "b", ref["metrics_b"], "a~b overlap %.3f" % G._overlap(ref["top_a"], ref["top_b"]), flush=True)
-SETTINGS = [{}, {"im_max_stale": 16}, {"im_max_stale": 4}, {"xcd_sync_updates": 1 << 21}, {"xcd_sync_updates": 1 << 20, "im_max_stale": 16},
+SETTINGS = json.loads(os.environ["SETTINGS"]) if "SETTINGS" in os.environ else [{}, {"im_max_stale": 16}, {"im_max_stale": 4}, {"xcd_sync_updates": 1 << 21}, {"xcd_sync_updates": 1 << 20, "im_max_stale": 16},
             {"im_blocks": 16}, {"im_blocks": 2}, {"xcd_hot_tau": 30}, {"im_drift_budget": 250}, {"hogwild_atomic": 1}]
 rows = []
 for modes in SETTINGS:
@@ -33,4 +35,4 @@ for modes in SETTINGS:
         rows.append(m)
         print(json.dumps(m), flush=True)
         del obj
-json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "gate_knob_study.json"), "w"), indent=1)
+json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "gate_knob_study_%s.json" % case), "w"), indent=1)
