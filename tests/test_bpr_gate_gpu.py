@@ -13,13 +13,8 @@ of it:
 * Frobenius norms of P, Q, Qb,
 * precision@10 of the top-10 lists of 2,000 sampled users against the matrix itself (what the lists are for; an average,
   so it does not hinge on near-ties),
-* overlap of those lists (the oracle-vs-oracle overlap is the yardstick: at these learning rates the ranking is
-  carried by the popularity biases plus small factors, and two oracle runs agree on far fewer than 10 of 10).
-  At lr 0.05 the identity of the ten items is a noisy statistic on BOTH sides: five oracle pairs (8 / 16 workers, two
-  seeds; this container and the GPU box) gave 0.35, 0.37, 0.39, 0.40, 0.41, 0.48; the HIP run against the oracles gave
-  0.36 and 0.21 on two boxes (profiles/r02_gate_*.txt) -- its biases relax a few epochs behind (|Qb| 96 vs 91.5), which
-  reorders near-ties among the popular items.  So that case carries a wide overlap slack and the precision bound does
-  the gating (oracle pairs: 0.627 / 0.637).
+* overlap of those lists (the oracle-vs-oracle overlap is the yardstick: the ranking is carried by the popularity biases
+  plus small factors, and two oracle runs agree on fewer than 10 of 10).
 
 Case "bench": lr 0.002 -> 0.0001 over 3 epochs (the reference's BPRMFOption defaults = bench.py's options).
 Case "lr0.05": constant lr 0.05 towards convergence (24 epochs; oracle workers 8 and 16 -- the 64-worker pool is
@@ -28,9 +23,19 @@ queue-bound at 7 s per epoch).  At this lr the factors of the reference path gro
 37.4, 66.9 ... 430 on the oracle); during that transient a fixed-epoch comparison amplifies any difference in the
 update schedule exponentially (the oracle's own 1-thread and 8-thread runs agree to 0.4 % because they share the
 schedule; every parallel GPU schedule -- atomics included -- grows ~1.85x per epoch), so the gate compares the
-state both reach, not a point on the way.  Measured at epoch 24 (profiles/r02_gate_*.txt): |P| 424 vs 430, |Q| 111 vs
-108, |Qb| 96.6 vs 91.6 -- the biases are still relaxing on both sides (oracle: 184 -> 91.5, -1.1 % per epoch at the end)
+state both reach, not a point on the way.  Measured at epoch 24 (profiles/r02_gate_*.txt, `im_max_stale` 64): |P| 424 vs 430,
+|Q| 111 vs 108, |Qb| 96.6 vs 91.6 -- the biases are still relaxing on both sides (oracle: 184 -> 91.5, -1.1 % per epoch at the end)
 and the parallel schedule trails by the epoch it lost in the transient, hence the wider Qb bound.
+
+What the lr-0.05 bounds are calibrated on (scripts/gate_oracle_ref.py + scripts/gate_knob_study.py, profiles/r02_gate_study_*):
+the state after 24 epochs at a constant lr of 0.05 is a noisy stationary point for the REFERENCE path itself.  Seven oracle
+pairs (8 / 16 workers, two seeds, this container and three GPU boxes): sampled loss 0.1696 .. 0.1773, precision@10
+0.58 .. 0.685, top-10 overlap between two oracle runs 0.17 .. 0.50.  Thirty HIP runs over three boxes: loss 0.1715 .. 0.185
+(three runs inside one process agree to 0.001, runs on different boxes differ by 0.01), precision@10 0.52 .. 0.63, overlap
+with the oracles 0.15 .. 0.38, |P| 430.1 (oracle 430.4 .. 430.6; 425.7 with the former `im_max_stale` = 64, which is why the
+default is 16), |Q| 110.9 vs 108.2, |Qb| 94.9 vs 91.5.  The norms are the sharp part of this case; loss, precision and
+overlap carry bounds as wide as the reference's own scatter.  The "bench" case (the reference's default lr) is tight on
+everything: thirty-odd HIP runs all gave loss 0.20718 .. 0.20723 against 0.2073 .. 0.2098 for the oracles.
 """
 import time
 
@@ -140,8 +145,8 @@ CASES = {
     #        overlap slack)
     "bench": (dict(lr=0.002, min_lr=0.0001), 3, (8, 64), {"loss": (0.01, 3.0), "P": (0.02, 3.0), "Q": (0.02, 3.0), "Qb": (0.02, 3.0),
                                                            "prec10": (0.03, 3.0)}, 0.10),
-    "lr0.05": (dict(lr=0.05, min_lr=0.05), 24, (8, 16), {"loss": (0.06, 3.0), "P": (0.05, 3.0), "Q": (0.05, 3.0), "Qb": (0.08, 3.0),
-                                                          "prec10": (0.05, 3.0)}, 0.25),
+    "lr0.05": (dict(lr=0.05, min_lr=0.05), 24, (8, 16), {"loss": (0.09, 3.0), "P": (0.02, 3.0), "Q": (0.05, 3.0), "Qb": (0.07, 3.0),
+                                                          "prec10": (0.25, 3.0)}, 0.40),
 }
 
 
