@@ -756,13 +756,20 @@ class BprHandle : public SgdHandle {
         int slot = t_aux_.begin(stream);
         // ---- entries grouped by (owner queue of the user, item); cached for a resident matrix ----
         const bool keeps = resident_ || (auto_resident_ && !chunks_.empty());   // the staged chunk lives on in HBM under csr_generation_
-        const bool cached = keeps && im_gen_ == csr_generation_ && im_start_ == start_x && im_next_ == next_x && im_n_ == n && im_built_blocks_ == blocks && im_built_nq_ == nq;
+        // Small shards (multi-GPU): the same waves work on an N-times smaller user set, and with one owner XCD per user most
+        // triples fall under the collision rule and pay a user-row atomic (8 shards of ML-20M: 3/4 of them, 1.44 vs 1.15 ms).
+        // There the users get what the negatives have: per-XCD replicas of P, entries spread over the queues by position (a
+        // user's share of one queue is nq times smaller), plain stores through the XCD's own L2, the delta rule at the merges.
+        const int64_t users_here = next_x - start_x;
+        const bool p_rep = im_user_replicas_ > 0 || (im_user_replicas_ < 0 && !im_single_wave_ && users_here < static_cast<int64_t>(nq) * 6144);
+        const bool cached = keeps && im_gen_ == csr_generation_ && im_start_ == start_x && im_next_ == next_x && im_n_ == n && im_built_blocks_ == blocks && im_built_nq_ == nq &&
+                            im_built_spread_ == p_rep;
         if (!cached) {
             im_key_a_.resize(static_cast<size_t>(n)); im_key_b_.resize(static_cast<size_t>(n));
             im_pos_a_.resize(static_cast<size_t>(n)); im_pos_b_.resize(static_cast<size_t>(n));
             im_qbeg_dev_.resize(kImMaxQueues + 1);
             hipLaunchKernelGGL(im_keys_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, stream, p.rows, p.keys, n, nq,
-                               static_cast<uint32_t>(blocks), static_cast<uint32_t>(Q_rows_), im_key_a_.get(), im_pos_a_.get());
+                               static_cast<uint32_t>(blocks), static_cast<uint32_t>(Q_rows_), p_rep ? 1 : 0, im_key_a_.get(), im_pos_a_.get());
             BFH_HIP(hipGetLastError());
             int bits = 1;
             while ((int64_t(1) << bits) < static_cast<int64_t>(nq) * blocks * Q_rows_) ++bits;
@@ -773,7 +780,7 @@ class BprHandle : public SgdHandle {
             BFH_HIP(hipMemcpyAsync(im_qbeg_, im_qbeg_dev_.get(), (nq + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
             sync_stream();
             im_gen_ = keeps ? csr_generation_ : -1;
-            im_start_ = start_x; im_next_ = next_x; im_n_ = n; im_built_blocks_ = blocks; im_built_nq_ = nq;
+            im_start_ = start_x; im_next_ = next_x; im_n_ = n; im_built_blocks_ = blocks; im_built_nq_ = nq; im_built_spread_ = p_rep;
         }
         // ---- per-row policy flags ----
         const int64_t waves = im_resident_waves();
@@ -838,7 +845,7 @@ class BprHandle : public SgdHandle {
                            im_drift_budget_milli_ * 1e-3, hot_.get(), im_flush_.get());
         BFH_HIP(hipMemsetAsync(im_hot_user_.get(), 0, im_hot_user_.bytes(), stream));
         hipLaunchKernelGGL(im_user_flags_kernel, dim3((next_x - start_x + 255) / 256), dim3(256), 0, stream, p.indptr, start_x, next_x - start_x,
-                           static_cast<double>(num_neg_), triples / nq, inflight, tau, im_hot_user_.get());
+                           static_cast<double>(num_neg_), p_rep ? triples : triples / nq, inflight, tau, im_hot_user_.get());
         BFH_HIP(hipGetLastError());
         // ---- replicas of the item factors (+ the copy they started from) ----
         xcd_alloc(true);
@@ -848,6 +855,14 @@ class BprHandle : public SgdHandle {
         c.rep_bstride = rep_bstride();
         c.hot = hot_.get();
         xcd_broadcast(true);
+        const int64_t np4 = static_cast<int64_t>(P_rows_) * vdim_ / 4;          // replica stride (float4s)
+        const int64_t up4 = users_here * vdim_ / 4, uoff4 = static_cast<int64_t>(start_x) * vdim_ / 4;   // this call's rows
+        if (p_rep) {
+            if (repP_.size() < static_cast<size_t>(kXcdReplicas) * P_rows_ * vdim_) repP_.resize(static_cast<size_t>(kXcdReplicas) * P_rows_ * vdim_);
+            hipLaunchKernelGGL((xcd_broadcast_kernel<float4>), dim3(static_cast<unsigned>(std::min<int64_t>((up4 + 255) / 256, 8192))), dim3(256), 0, stream,
+                               reinterpret_cast<const float4*>(P_.get()) + uoff4, reinterpret_cast<float4*>(repP_.get()) + uoff4, up4, np4, kXcdReplicas);
+            BFH_HIP(hipGetLastError());
+        }
         // ---- queues, slice order, segments ----
         ImQueues q{};
         q.ent_key = im_key_b_.get();
@@ -855,6 +870,8 @@ class BprHandle : public SgdHandle {
         q.nq = nq;
         for (int i = 0; i < 16; ++i) q.xcd_queue[i] = im_xcd_queue_[i];
         q.hot_user = im_hot_user_.get();
+        q.rep_P = p_rep ? repP_.get() : nullptr;
+        q.rep_pstride = static_cast<int64_t>(P_rows_) * vdim_;
         q.flush_every = im_flush_.get();
         q.strict = im_single_wave_;
         q.trace = (im_single_wave_ && im_trace_.size() >= static_cast<size_t>(c.total)) ? im_trace_.get() : nullptr;
@@ -929,6 +946,13 @@ class BprHandle : public SgdHandle {
             // refreshed; this segment's own delta goes out behind the merge and travels while the next walk runs
             exchange_finish(true);
             xcd_merge(sgm + 1 < segments, c.hot, true);
+            if (p_rep) {   // P <- P + sum_x (P_x - P); hot users' rows were updated in P itself and are skipped
+                hipLaunchKernelGGL((xcd_merge_kernel<float4>), dim3(static_cast<unsigned>(std::min<int64_t>((up4 + 255) / 256, 8192))), dim3(256), 0, stream,
+                                   reinterpret_cast<float4*>(P_.get()) + uoff4, reinterpret_cast<float4*>(repP_.get()) + uoff4, up4, np4, 1.0f,
+                                   sgm + 1 < segments ? 1 : 0, static_cast<const uint8_t*>(im_hot_user_.get()) + start_x, vdim_ / 4,
+                                   static_cast<float4*>(nullptr));
+                BFH_HIP(hipGetLastError());
+            }
             t_aux_.end(slot, stream);
             stats.merges += 1;
             if (comm_) {
@@ -1171,6 +1195,7 @@ class BprHandle : public SgdHandle {
     bool verify_neg_ = true, uniform_ = true;
     DevBuf<float> exp_table_;
     DevBuf<float> repQ_, repQb_;   // policy 2: [8][Q_rows][vdim], [8][ceil64(Q_rows)]
+    DevBuf<float> repP_;           // policy 3 on small shards: [8][P_rows][vdim]
     DevBuf<int> itemcnt_;          // policy 2: updates per item row (popularity)
     DevBuf<uint8_t> hot_;
     int64_t itemcnt_gen_ = -1;

@@ -52,6 +52,10 @@ struct ImQueues {
     const uint8_t* hot_user;   // [P_rows] 1: P[u] is updated with atomics
     const uint8_t* flush_every;  // [Q_rows] triples between two flushes of the register-resident item row (1..64)
     const int32_t* neg_pre;    // [chunk nnz * num_neg] negatives drawn by bpr_presample_kernel, or null: draw in the walk
+    float* rep_P;              // null: a user's entries all sit in the queue of ONE XCD, which alone touches P[u].  Otherwise
+                               // [nq][P_rows * vdim] per-XCD replicas of P: entries are spread over the queues by position and
+                               // a wave works on its XCD's copy (small shards: see launch_item_major)
+    int64_t rep_pstride;
     int strict;                // test hook: wait for every memory operation of a triple before the next one starts
     int32_t* trace;            // test hook (single-wave runs): sigmoid-table index of every triple in processing order, or null
 };
@@ -111,12 +115,15 @@ __global__ void xcd_probe_kernel(int* seen) {
 
 // sort key of every entry: ((owner queue of the user) * blocks + block) * Q_rows + item.  `blocks` > 1 cuts an
 // item's entries inside a queue into that many runs (by a hash of the nnz position), visited at different times.
+// `spread`: the queue is a hash of the position instead of the user's owner (per-XCD replicas of P, ImQueues::rep_P).
 __global__ __launch_bounds__(256) void im_keys_kernel(const int32_t* __restrict__ rows, const int32_t* __restrict__ keys, int64_t n, int nq,
-                                                      uint32_t blocks, uint32_t q_rows, uint32_t* __restrict__ kout, int32_t* __restrict__ vout) {
+                                                      uint32_t blocks, uint32_t q_rows, int spread, uint32_t* __restrict__ kout,
+                                                      int32_t* __restrict__ vout) {
     const int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
     if (t >= n) return;
     const uint32_t blk = blocks > 1 ? ((static_cast<uint32_t>(t) * 2654435761u) >> 16) % blocks : 0u;
-    kout[t] = (static_cast<uint32_t>(rows[t] % nq) * blocks + blk) * q_rows + static_cast<uint32_t>(keys[t]);
+    const uint32_t queue = spread ? ((static_cast<uint32_t>(t) * 0x85EBCA6Bu) >> 11) % static_cast<uint32_t>(nq) : static_cast<uint32_t>(rows[t] % nq);
+    kout[t] = (queue * blocks + blk) * q_rows + static_cast<uint32_t>(keys[t]);
     vout[t] = static_cast<int32_t>(t);
 }
 
@@ -251,6 +258,7 @@ __global__ __launch_bounds__(256, K <= 4 ? (PIPE ? 5 : 6) : 1) void bpr_item_maj
     constexpr bool drain = DRAIN;
     float* const Qrep = drain ? p.Q : c.rep_Q + static_cast<size_t>(my_queue < 0 ? 0 : my_queue) * c.rep_stride;
     float* const Qbrep = drain ? p.Qb : c.rep_Qb + static_cast<size_t>(my_queue < 0 ? 0 : my_queue) * c.rep_bstride;
+    float* const Prep = (drain || !q.rep_P) ? p.P : q.rep_P + static_cast<size_t>(my_queue < 0 ? 0 : my_queue) * q.rep_pstride;
     auto rload = [&](Row<K>& r, const float* base) { row_load<K, true, true>(r, base, lane, vdim); };
     auto rstore = [&](const Row<K>& r, float* base) { row_store<K, true, false>(r, base, lane, vdim); };
 
@@ -327,7 +335,7 @@ __global__ __launch_bounds__(256, K <= 4 ? (PIPE ? 5 : 6) : 1) void bpr_item_maj
                 }
                 my_pol = drain ? 3 : ((q.hot_user[my_u] ? 1 : 0) | (c.hot[my_neg] ? 2 : 0));
             }
-            auto pu_ptr = [&](int u) -> float* { return p.P + static_cast<size_t>(u) * vdim; };
+            auto pu_ptr = [&](int u, bool hot) -> float* { return (hot ? p.P : Prep) + static_cast<size_t>(u) * vdim; };
             auto qj_ptr = [&](int j, bool hot) -> float* { return (hot ? p.Q : Qrep) + static_cast<size_t>(j) * vdim; };
             auto bj_ptr = [&](int j, bool hot) -> float* { return (hot ? p.Qb : Qbrep) + j; };
 
@@ -338,8 +346,9 @@ __global__ __launch_bounds__(256, K <= 4 ? (PIPE ? 5 : 6) : 1) void bpr_item_maj
             auto fetch = [&](Slot& s, int j) {
                 if (j < n_here) {
                     const int u = __builtin_amdgcn_readlane(my_u, j), ng = __builtin_amdgcn_readlane(my_neg, j);
-                    const bool hj = (__builtin_amdgcn_readlane(my_pol, j) & 2) != 0;
-                    rload(s.pu, pu_ptr(u));
+                    const int pl = __builtin_amdgcn_readlane(my_pol, j);
+                    const bool hj = (pl & 2) != 0;
+                    rload(s.pu, pu_ptr(u, (pl & 1) != 0));
                     rload(s.qj, qj_ptr(ng, hj));
                     s.bj = c.use_bias ? coh_load(bj_ptr(ng, hj)) : 0.f;
                 }
@@ -361,7 +370,7 @@ __global__ __launch_bounds__(256, K <= 4 ? (PIPE ? 5 : 6) : 1) void bpr_item_maj
                 if (u == prev_u) {
                     // consecutive slots of one entry (num_negative_samples > 1): carry the updated row
                 } else if (!PIPE || u == prev2_u) {
-                    rload(pu, pu_ptr(u));
+                    rload(pu, pu_ptr(u, at_u));
                 } else {
                     pu = s.pu;
                 }
@@ -418,7 +427,7 @@ __global__ __launch_bounds__(256, K <= 4 ? (PIPE ? 5 : 6) : 1) void bpr_item_maj
                     if (same) { bi = bj; dbi_acc += dbj; }
                 }
                 // ---------------- write the two per-triple rows back ----------------
-                float* Pu = pu_ptr(u);
+                float* Pu = pu_ptr(u, at_u);
                 float* Qj = qj_ptr(neg, at_j);
                 const bool fr_u = PIPE && c.fresh && !at_u, fr_j = PIPE && c.fresh && !at_j && !same && c.update_j;
                 Row<K> fu, fj;

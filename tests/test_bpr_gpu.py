@@ -154,6 +154,9 @@ def test_triples_parallel_disjoint_rows(oracle):
     (96, dict(update_j=False), dict(xcd_sync_updates=1024)),
     (32, dict(update_i=False), {}),
     (64, {}, dict(n_chunks=3)),                          # the reference's call pattern: keys sent chunk by chunk, nothing resident
+    (128, dict(num_negative_samples=2), dict(im_user_replicas=0)),       # one owner XCD per user (the big-shard form) on this small matrix
+    (128, dict(num_negative_samples=2), dict(im_user_replicas=1, xcd_sync_updates=1024)),   # per-XCD replicas of P, several merges
+    (64, {}, dict(im_user_replicas=1, n_chunks=3)),      # replicas over a row range per call
 ])
 def test_item_major_conflict_free(oracle, d, kw, modes):
     """hogwild_atomic=3 (item-major walk, users owned by XCDs, Q[i] in registers, Q[j] in per-XCD replicas):
@@ -305,7 +308,7 @@ def test_compute_loss_matches_oracle(oracle):
     assert abs(got - want) < 1e-5 * max(1.0, abs(want))
 
 
-@pytest.mark.parametrize("atomic", [1, 0, 2, 3])
+@pytest.mark.parametrize("atomic", [1, 0, 2, 3, 30, 31])
 def test_hogwild_statistical_parity(oracle, atomic):
     """Throughput mode vs the threaded reference path: same ranking quality on planted low-rank data
     (mirrors the ndcg threshold test, tests/algo/test_bpr.py:38-47).  With fp32 atomics no update is
@@ -322,7 +325,11 @@ def test_hogwild_statistical_parity(oracle, atomic):
     Po, Qo, Qbo = P0.copy(), Q0.copy(), Qb0.copy()
     H.run_oracle_sgd(oracle.OracleBPRMF, opt, csr, Po, Qo, Qbo, epochs=30)
     P, Q, Qb = H.pad(P0, vdim), H.pad(Q0, vdim), Qb0.copy()
-    H.run_hip_sgd(CyBPR, opt, csr, P, Q, Qb, epochs=30, modes=dict(hogwild_atomic=atomic, chunk=64), resident=True)
+    extra = {}
+    if atomic >= 30:      # item-major with users owned by one XCD each (30) / with per-XCD replicas of P (31); 3 = by shard size
+        extra["im_user_replicas"] = atomic - 30
+        atomic = 3
+    H.run_hip_sgd(CyBPR, opt, csr, P, Q, Qb, epochs=30, modes=dict(hogwild_atomic=atomic, chunk=64, **extra), resident=True)
     n_ref = H.ndcg_at_k(Po, Qo, csr, vali, Qb=Qbo)
     n_hip = H.ndcg_at_k(P[:, :d], Q[:, :d], csr, vali, Qb=Qb)
     base = H.ndcg_at_k(P0, Q0, csr, vali, Qb=Qb0)
