@@ -761,7 +761,13 @@ class BprHandle : public SgdHandle {
         // There the users get what the negatives have: per-XCD replicas of P, entries spread over the queues by position (a
         // user's share of one queue is nq times smaller), plain stores through the XCD's own L2, the delta rule at the merges.
         const int64_t users_here = next_x - start_x;
-        const bool p_rep = im_user_replicas_ > 0 || (im_user_replicas_ < 0 && !im_single_wave_ && users_here < static_cast<int64_t>(nq) * 6144);
+        // Measured (profiles/r02_shard_times_user_replicas.txt, ML-20M / d=128, per-rank epoch): 8 shards 1.73 -> 1.31 ms (walk 1.52 -> 1.07);
+        // 4 shards 2.43 -> 2.65, 2 shards 4.32 -> 5.45, whole matrix 9.2 -> 10.2: eight copies of a big P fall out of the Infinity Cache,
+        // so the rule is "fewer than 3072 users per queue".  Statistics (profiles/r02_gate_study_user_replicas.txt, whole matrix, 8 copies):
+        // at the reference's lr the gate metrics stay inside the oracle pair's spread; at lr 0.05 the sum of eight deltas of a heavy
+        // user overshoots (|P| 390 vs 430, one run in three diverging), so above lr 0.01 the owner form stays.
+        const bool p_rep = im_user_replicas_ > 0 ||
+                           (im_user_replicas_ < 0 && !im_single_wave_ && users_here < static_cast<int64_t>(nq) * 3072 && c.lr <= 0.01f);
         const bool cached = keeps && im_gen_ == csr_generation_ && im_start_ == start_x && im_next_ == next_x && im_n_ == n && im_built_blocks_ == blocks && im_built_nq_ == nq &&
                             im_built_spread_ == p_rep;
         if (!cached) {
@@ -858,9 +864,10 @@ class BprHandle : public SgdHandle {
         const int64_t np4 = static_cast<int64_t>(P_rows_) * vdim_ / 4;          // replica stride (float4s)
         const int64_t up4 = users_here * vdim_ / 4, uoff4 = static_cast<int64_t>(start_x) * vdim_ / 4;   // this call's rows
         if (p_rep) {
-            if (repP_.size() < static_cast<size_t>(kXcdReplicas) * P_rows_ * vdim_) repP_.resize(static_cast<size_t>(kXcdReplicas) * P_rows_ * vdim_);
+            // eight replicas + the copy they started from (P itself receives the hot users' atomics and whatever the drain launch does)
+            if (repP_.size() < static_cast<size_t>(kXcdReplicas + 1) * P_rows_ * vdim_) repP_.resize(static_cast<size_t>(kXcdReplicas + 1) * P_rows_ * vdim_);
             hipLaunchKernelGGL((xcd_broadcast_kernel<float4>), dim3(static_cast<unsigned>(std::min<int64_t>((up4 + 255) / 256, 8192))), dim3(256), 0, stream,
-                               reinterpret_cast<const float4*>(P_.get()) + uoff4, reinterpret_cast<float4*>(repP_.get()) + uoff4, up4, np4, kXcdReplicas);
+                               reinterpret_cast<const float4*>(P_.get()) + uoff4, reinterpret_cast<float4*>(repP_.get()) + uoff4, up4, np4, kXcdReplicas + 1);
             BFH_HIP(hipGetLastError());
         }
         // ---- queues, slice order, segments ----
@@ -946,11 +953,11 @@ class BprHandle : public SgdHandle {
             // refreshed; this segment's own delta goes out behind the merge and travels while the next walk runs
             exchange_finish(true);
             xcd_merge(sgm + 1 < segments, c.hot, true);
-            if (p_rep) {   // P <- P + sum_x (P_x - P); hot users' rows were updated in P itself and are skipped
+            if (p_rep) {   // P <- P + sum_x (P_x - B); hot users' rows were updated in P itself and are skipped
                 hipLaunchKernelGGL((xcd_merge_kernel<float4>), dim3(static_cast<unsigned>(std::min<int64_t>((up4 + 255) / 256, 8192))), dim3(256), 0, stream,
                                    reinterpret_cast<float4*>(P_.get()) + uoff4, reinterpret_cast<float4*>(repP_.get()) + uoff4, up4, np4, 1.0f,
                                    sgm + 1 < segments ? 1 : 0, static_cast<const uint8_t*>(im_hot_user_.get()) + start_x, vdim_ / 4,
-                                   static_cast<float4*>(nullptr));
+                                   reinterpret_cast<float4*>(repP_.get()) + kXcdReplicas * np4 + uoff4);
                 BFH_HIP(hipGetLastError());
             }
             t_aux_.end(slot, stream);
@@ -1195,7 +1202,7 @@ class BprHandle : public SgdHandle {
     bool verify_neg_ = true, uniform_ = true;
     DevBuf<float> exp_table_;
     DevBuf<float> repQ_, repQb_;   // policy 2: [8][Q_rows][vdim], [8][ceil64(Q_rows)]
-    DevBuf<float> repP_;           // policy 3 on small shards: [8][P_rows][vdim]
+    DevBuf<float> repP_;           // policy 3 on small shards: [8 + 1][P_rows][vdim]
     DevBuf<int> itemcnt_;          // policy 2: updates per item row (popularity)
     DevBuf<uint8_t> hot_;
     int64_t itemcnt_gen_ = -1;

@@ -165,8 +165,8 @@ int bfh_als_synchronize(void* h, int device_to_host);
  *                      probability of a plainly stored row, above it the row is updated with atomics;
  *   "im_max_stale"     (3) updates of one item row in flight unseen by the other waves, stated at lr 0.05 (scales 1/lr; default 16);
  *   "im_user_replicas" (3) 1 = per-XCD replicas of P (entries spread over the queues by position, delta rule at the merges)
- *                      instead of one owner XCD per user; -1 (default) = when a call has fewer than 6144 users per queue
- *                      (the shards of a 4- or 8-GPU run), 0 = never;
+ *                      instead of one owner XCD per user; -1 (default) = when a call has fewer than 3072 users per queue
+ *                      (the shards of an 8-GPU ML-20M run) and lr <= 0.01, 0 = never;
  *   "im_drift_budget"  (3, permille) lr-weighted positive steps of a row per merge interval above which its negative
  *                      updates also go to the chip-wide copy;  "im_blocks" runs an item's entries are cut into per queue (0 = ceil(160 lr));
  *   "im_presample"     (3) 1 = draw the call's negatives in CSR order before the walk;  "xcd_fresh" re-read a row right
