@@ -63,6 +63,7 @@ struct FilterArgs {
     uint2* cand;            // [(b * gridDim.x + blockIdx.x) * cap_seg + slot] = (column, bits of the raw score)
     int* cand_cnt;          // [b * gridDim.x + blockIdx.x] candidates seen (> cap_seg: overflow)
     int cap_seg;
+    int t_first;            // first tile of the sweep: the sampled columns in front of it reach the selection from their dense scores
 };
 
 // FULL: the K-chunk is a whole 128 columns (nv == 16): no per-float4 guards, straight-line MFMA stream
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256, 3) void topk_scores_kernel(const float* __rest
     for (int v = 0; v < 16; ++v) a[v] = (FULL || v < nv) ? ap[v] : make_float4(0.f, 0.f, 0.f, 0.f);
 
     const int n_tiles = (q_rows + 31) / 32;
-    const int t_begin = blockIdx.x * tiles_per_block;
+    const int t_begin = (FILTER ? f.t_first : 0) + blockIdx.x * tiles_per_block;
     int t_end = t_begin + tiles_per_block;
     if (t_end > n_tiles) t_end = n_tiles;
     // B operands of a tile in two halves of 8 float4s: the second half of tile t and the first half of tile t+1 are in
@@ -265,6 +266,26 @@ __global__ __launch_bounds__(256) void topk_select_kernel(SelectArgs a) {
             const uint2* seg = a.cand + (static_cast<size_t>(b) * a.n_seg + g) * a.cap_seg;
             for (int i = tid; i < c; i += 256) lst[off + i] = seg[i];
             off += c;
+        }
+        if (a.S) {   // the sampled columns [0, a.cols): their dense scores are still there; the same test the filtered sweep applies
+            if (tid == 0) s_misc[5] = off;
+            __syncthreads();
+            const float* srow = a.S + static_cast<size_t>(b) * a.ld_s;
+            const float thr = a.thr[b];
+            for (int j = tid; j < a.cols; j += 256) {
+                const float raw = srow[j];
+                const float sc = a.Qb ? raw + a.Qb[j] : raw;
+                if (sc >= thr) {
+                    const int at = atomicAdd(&s_misc[5], 1);
+                    if (at < a.list_cap) lst[at] = make_uint2(static_cast<uint32_t>(j), __float_as_uint(raw));
+                }
+            }
+            __syncthreads();
+            cols = s_misc[5];
+            if (cols > a.list_cap) {   // block-uniform
+                if (tid == 0) a.redo[1 + atomicAdd(a.redo, 1)] = b;
+                return;
+            }
         }
         __syncthreads();
     }
@@ -563,6 +584,7 @@ __device__ __forceinline__ int wave_incl_scan_i32(int v, int lane) {
 }
 
 constexpr int kWaveHistBins = 4096;   // uint32 per wave
+constexpr int kWaveSampleCap = 512;   // sampled columns at or above the threshold a wave takes over (normally kk plus ties)
 
 // key[s], s < SLOTS, live where bit s of `valid` is set.  Returns the number of live keys m; when m >= kk: kth = the kk-th
 // smallest, need_eq = how many of the keys == kth belong to the kk smallest, eq_total = how many there are.
@@ -653,12 +675,13 @@ __global__ __launch_bounds__(256) void topk_thr_wave_kernel(SelectArgs a, int ro
 // A row whose segments or list overflowed goes to `redo` (dense path); a row with ties straddling the k-th place goes to
 // `general` (topk_select_kernel's list mode, which walks the ties in column order).  Dynamic LDS: 4 histograms + 4 * p2 * 8 bytes.
 __global__ __launch_bounds__(256) void topk_list_wave_kernel(SelectArgs a, int rows) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long wsel[];   // 4 histograms (kWaveHistBins words each), then 4 * p2 sort entries
+    extern __shared__ __attribute__((aligned(16))) unsigned long long wsel[];   // 4 histograms (kWaveHistBins words), 4 sample lists, 4 * p2 sort entries
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int b = blockIdx.x * 4 + wv;
     if (b >= rows) return;
     uint32_t* whist = reinterpret_cast<uint32_t*>(wsel) + static_cast<size_t>(wv) * kWaveHistBins;
-    unsigned long long* sel = wsel + (4 * kWaveHistBins) / 2 + static_cast<size_t>(wv) * a.p2;
+    uint2* s0 = reinterpret_cast<uint2*>(wsel + (4 * kWaveHistBins) / 2) + static_cast<size_t>(wv) * kWaveSampleCap;
+    unsigned long long* sel = wsel + (4 * kWaveHistBins) / 2 + 4 * kWaveSampleCap + static_cast<size_t>(wv) * a.p2;
     const int self = a.self_idx ? a.self_idx[a.q0 + b] : -1;
     // segment ends (n_seg <= 8): e[g] = entries of the segments 0..g
     int seg_end[8];
@@ -673,7 +696,27 @@ __global__ __launch_bounds__(256) void topk_list_wave_kernel(SelectArgs a, int r
         tot += c;
         seg_end[g] = tot;
     }
-    if (over || tot > a.list_cap) {
+    // the sampled columns [0, a.cols) come from their dense scores (the sweep starts behind them): the same test as the sweep's
+    int n0 = 0;
+    if (a.S) {
+        const float* srow = a.S + static_cast<size_t>(b) * a.ld_s;
+        const float thr = a.thr[b];
+        for (int base = 0; base < a.cols; base += 64) {
+            const int j = base + lane;
+            float raw = 0.f;
+            bool pass = false;
+            if (j < a.cols) {
+                raw = srow[j];
+                pass = (a.Qb ? raw + a.Qb[j] : raw) >= thr;
+            }
+            const unsigned long long mask = __ballot(pass);
+            const int at = n0 + __popcll(mask & ((1ull << lane) - 1ull));
+            if (pass && at < kWaveSampleCap) s0[at] = make_uint2(static_cast<uint32_t>(j), __float_as_uint(raw));
+            n0 += __popcll(mask);
+        }
+        wave_lds_sync();
+    }
+    if (over || n0 > kWaveSampleCap || tot + n0 > a.list_cap) {
         if (lane == 0) a.redo[1 + atomicAdd(a.redo, 1)] = b;
         return;
     }
@@ -683,12 +726,12 @@ __global__ __launch_bounds__(256) void topk_list_wave_kernel(SelectArgs a, int r
     for (int sl = 0; sl < 32; ++sl) {
         const int i = sl * 64 + lane;
         key[sl] = 0u; col[sl] = 0u;
-        if (i < tot) {
+        if (i < tot + n0) {
             int g = 0, beg = 0;
 #pragma unroll
             for (int q = 0; q < 7; ++q)
                 if (i >= seg_end[q]) { g = q + 1; beg = seg_end[q]; }
-            const uint2 c = a.cand[(static_cast<size_t>(b) * a.n_seg + g) * a.cap_seg + (i - beg)];
+            const uint2 c = i < tot ? a.cand[(static_cast<size_t>(b) * a.n_seg + g) * a.cap_seg + (i - beg)] : s0[i - tot];
             uint32_t k = 0u;
             if (topk_admit(a, static_cast<int>(c.x), self, __uint_as_float(c.y), k)) { key[sl] = k; col[sl] = c.x; valid |= 1ull << sl; }
         }
@@ -800,7 +843,7 @@ class TopkHandle : public HandleBase {
     // the filter is expected to pass kk * q_rows / C0 columns per query, which must sit well inside the LDS list.
     struct FusedPlan {
         bool on = false;
-        int c0 = 0, n_seg = 1, tpb = 1, cap_seg = 0;
+        int c0 = 0, c0_tiles = 0, n_seg = 1, tpb = 1, cap_seg = 0;
     };
     static constexpr int kListCap = 2048;
     FusedPlan fused_plan(int nq, int q_rows, int d_pad, int kk) const {
@@ -817,11 +860,13 @@ class TopkHandle : public HandleBase {
         else if (c0 > q_rows / 4) return fp;
         if (c0 >= q_rows + 32) return fp;
         fp.c0 = std::min(c0, q_rows);
+        fp.c0_tiles = (fp.c0 + 31) / 32;              // c0 is a multiple of 32 or the whole matrix
+        const int sweep_tiles = n_tiles - fp.c0_tiles;   // the filtered sweep starts behind the sample
         const int qblocks = (nq + 127) / 128;
-        int tpb = static_cast<int>((static_cast<int64_t>(n_tiles) * qblocks + num_cus_ * 8 - 1) / (num_cus_ * 8));
-        tpb = std::max(tpb, (n_tiles + 7) / 8);       // at most 8 segments per query
+        int tpb = static_cast<int>((static_cast<int64_t>(sweep_tiles) * qblocks + num_cus_ * 8 - 1) / (num_cus_ * 8));
+        tpb = std::max(tpb, (sweep_tiles + 7) / 8);   // at most 8 segments per query
         fp.tpb = std::max(1, tpb);
-        fp.n_seg = (n_tiles + fp.tpb - 1) / fp.tpb;
+        fp.n_seg = std::max(1, (sweep_tiles + fp.tpb - 1) / fp.tpb);
         fp.cap_seg = static_cast<int>(std::min<int64_t>(static_cast<int64_t>(fp.tpb) * 32, std::max(64, 2 * kListCap / fp.n_seg)));
         fp.on = true;
         return fp;
@@ -874,11 +919,12 @@ class TopkHandle : public HandleBase {
         BFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(topk_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     static_cast<int>(fp.on ? lds_list : lds_dense)));
         const size_t kWaveLds = static_cast<size_t>(4) * kWaveHistBins * 4;   // the wave kernels' four histograms
+        const size_t kListLds = kWaveLds + static_cast<size_t>(4) * kWaveSampleCap * 8;   // + the list kernel's four sample lists
         if (fp.on && wave_select_) {
             BFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(topk_thr_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         static_cast<int>(kWaveLds)));
             BFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(topk_list_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        static_cast<int>(kWaveLds + static_cast<size_t>(4) * std::min(p2, 1024) * 8)));
+                                        static_cast<int>(kListLds + static_cast<size_t>(4) * std::min(p2, 1024) * 8)));
         }
         {   // candidate matrix in operand order, one slab per K-chunk
             const int n_chunks = (d_pad + 127) / 128;
@@ -936,7 +982,7 @@ class TopkHandle : public HandleBase {
             BFH_HIP(hipMemsetAsync(redo_.get(), 0, sizeof(int), stream));
             BFH_HIP(hipMemsetAsync(general_.get(), 0, sizeof(int), stream));
             t_aux_.end(slot, stream);
-            FilterArgs f{thr_.get(), dQb, d_pool, cand_.get(), cnt_.get(), fp.cap_seg};
+            FilterArgs f{thr_.get(), dQb, d_pool, cand_.get(), cnt_.get(), fp.cap_seg, fp.c0_tiles};
             slot = t_main_.begin(stream);
             if (d_pad == 128)
                 hipLaunchKernelGGL((topk_scores_kernel<true, true>), dim3(fp.n_seg, (nb + 127) / 128), dim3(256), 0, stream, dP, qidx, q0, nb, Qp_.get(),
@@ -947,11 +993,12 @@ class TopkHandle : public HandleBase {
             BFH_HIP(hipGetLastError());
             t_main_.end(slot, stream);
             slot = t_aux_.begin(stream);
-            a.S = nullptr; a.cand = cand_.get(); a.cand_cnt = cnt_.get(); a.n_seg = fp.n_seg; a.cap_seg = fp.cap_seg; a.list_cap = kListCap;
-            a.redo = redo_.get(); a.general = general_.get(); a.thr = nullptr;
+            // a.S / ld_s / cols stay on the sample scores: the selection takes the sampled columns from there
+            a.cand = cand_.get(); a.cand_cnt = cnt_.get(); a.n_seg = fp.n_seg; a.cap_seg = fp.cap_seg; a.list_cap = kListCap;
+            a.redo = redo_.get(); a.general = general_.get(); a.thr = thr_.get();
             const bool wave_list = wave_select_ && p2 <= 1024;
             if (wave_list) {
-                hipLaunchKernelGGL(topk_list_wave_kernel, dim3((nb + 3) / 4), dim3(256), kWaveLds + static_cast<size_t>(4) * p2 * 8, stream, a, nb);
+                hipLaunchKernelGGL(topk_list_wave_kernel, dim3((nb + 3) / 4), dim3(256), kListLds + static_cast<size_t>(4) * p2 * 8, stream, a, nb);
                 BFH_HIP(hipGetLastError());
             } else {
                 launch_select(a, nb, lds_list);

@@ -379,10 +379,11 @@ def build_sppmi(indptr, items, num_items, windows, k):
     items = np.ascontiguousarray(items, dtype=np.int32)
     tl = np.zeros(1, dtype=np.int64)
     out_indptr = np.zeros(int(num_items), dtype=np.int64)
-    nnz = lib().orc_build_sppmi(_p(indptr, C.c_int64), _p(items, C.c_int32), indptr.shape[0], int(num_items), int(windows), int(k), 0,
-                                _p(out_indptr, C.c_int64), None, None, _p(tl, C.c_int64))
-    key = np.empty(max(nnz, 1), dtype=np.int32)
-    val = np.empty(max(nnz, 1), dtype=np.float32)
-    lib().orc_build_sppmi(_p(indptr, C.c_int64), _p(items, C.c_int32), indptr.shape[0], int(num_items), int(windows), int(k), max(nnz, 1),
-                          _p(out_indptr, C.c_int64), _p(key, C.c_int32), _p(val, C.c_float), _p(tl, C.c_int64))
+    lens = np.diff(np.concatenate([[0], indptr]))
+    w = int(windows)
+    cap = max(1, int(2 * np.where(lens <= w + 1, lens * (lens - 1) // 2, (lens - w) * w + w * (w - 1) // 2).sum()))   # entries <= lines
+    key = np.empty(cap, dtype=np.int32)
+    val = np.empty(cap, dtype=np.float32)
+    nnz = lib().orc_build_sppmi(_p(indptr, C.c_int64), _p(items, C.c_int32), indptr.shape[0], int(num_items), w, int(k), cap,
+                                _p(out_indptr, C.c_int64), _p(key, C.c_int32), _p(val, C.c_float), _p(tl, C.c_int64))
     return {"indptr": out_indptr, "key": key[:nnz], "val": val[:nnz], "total_lines": int(tl[0])}
