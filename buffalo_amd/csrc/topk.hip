@@ -227,6 +227,11 @@ struct SelectArgs {
     const int* row_list;     // nullable: block x works on row row_list[x] (the rows topk_list_wave_kernel passed on)
     int* general;            // topk_list_wave_kernel: [0] rows passed on to topk_select_kernel (ties at the k-th place), [1 + i]: their b
     float* thr;              // topk_thr_wave_kernel: [b] the kk-th best admissible score of the row, or "everything"
+    // the sampled columns' own candidates (written by topk_thr_wave_kernel from the dense sample scores; the filtered sweep
+    // then starts behind the sample): one more segment per row for the list selection.  Null: the sweep covered every column.
+    uint2* s0_cand;          // [b * s0_cap + slot]
+    int* s0_cnt;             // [b] (> s0_cap: overflow)
+    int s0_cap;
 };
 
 __global__ __launch_bounds__(256) void topk_select_kernel(SelectArgs a) {
@@ -251,6 +256,11 @@ __global__ __launch_bounds__(256) void topk_select_kernel(SelectArgs a) {
                 over |= c > a.cap_seg;
                 tot += c;
             }
+            if (a.s0_cand) {
+                const int c = a.s0_cnt[b];
+                over |= c > a.s0_cap;
+                tot += c;
+            }
             s_misc[6] = tot;
             s_misc[7] = (over || tot > a.list_cap) ? 1 : 0;
         }
@@ -267,34 +277,21 @@ __global__ __launch_bounds__(256) void topk_select_kernel(SelectArgs a) {
             for (int i = tid; i < c; i += 256) lst[off + i] = seg[i];
             off += c;
         }
-        if (a.S) {   // the sampled columns [0, a.cols): their dense scores are still there; the same test the filtered sweep applies
-            if (tid == 0) s_misc[5] = off;
-            __syncthreads();
-            const float* srow = a.S + static_cast<size_t>(b) * a.ld_s;
-            const float thr = a.thr[b];
-            for (int j = tid; j < a.cols; j += 256) {
-                const float raw = srow[j];
-                const float sc = a.Qb ? raw + a.Qb[j] : raw;
-                if (sc >= thr) {
-                    const int at = atomicAdd(&s_misc[5], 1);
-                    if (at < a.list_cap) lst[at] = make_uint2(static_cast<uint32_t>(j), __float_as_uint(raw));
-                }
-            }
-            __syncthreads();
-            cols = s_misc[5];
-            if (cols > a.list_cap) {   // block-uniform
-                if (tid == 0) a.redo[1 + atomicAdd(a.redo, 1)] = b;
-                return;
-            }
+        if (a.s0_cand) {
+            const int c = a.s0_cnt[b];
+            const uint2* seg = a.s0_cand + static_cast<size_t>(b) * a.s0_cap;
+            for (int i = tid; i < c; i += 256) lst[off + i] = seg[i];
         }
         __syncthreads();
     }
     // position i -> (admissible?, key, column j)
     auto key_of = [&](int i, uint32_t& key, int& j) -> bool {
         float s;
+        bool biased = false;   // sample-segment entries carry the bias already (bit 31 of the column)
         if (list) {
             const uint2 c = lst[i];
-            j = static_cast<int>(c.x);
+            j = static_cast<int>(c.x & 0x7FFFFFFFu);
+            biased = (c.x >> 31) != 0u;
             s = __builtin_bit_cast(float, c.y);
         } else {
             j = i;
@@ -302,7 +299,7 @@ __global__ __launch_bounds__(256) void topk_select_kernel(SelectArgs a) {
         }
         if (j == self) return false;
         if (a.pool && !((a.pool[j >> 5] >> (j & 31)) & 1u)) return false;
-        if (a.Qb) s += a.Qb[j];
+        if (a.Qb && !biased) s += a.Qb[j];
         if (a.rule_flt_min && !(s > FLT_MIN)) return false;
         key = desc_key(s);
         return true;
@@ -484,7 +481,7 @@ __global__ __launch_bounds__(256) void topk_select_kernel(SelectArgs a) {
                             const int hi = lo | stride;
                             const bool up = (lo & size) == 0;
                             const uint2 x = lst[lo], y = lst[hi];
-                            if ((x.x > y.x) == up) { lst[lo] = y; lst[hi] = x; }
+                            if (((x.x & 0x7FFFFFFFu) > (y.x & 0x7FFFFFFFu)) == up) { lst[lo] = y; lst[hi] = x; }   // (bit 31: bias flag)
                         }
                         __syncthreads();
                     }
@@ -584,7 +581,7 @@ __device__ __forceinline__ int wave_incl_scan_i32(int v, int lane) {
 }
 
 constexpr int kWaveHistBins = 4096;   // uint32 per wave
-constexpr int kWaveSampleCap = 512;   // sampled columns at or above the threshold a wave takes over (normally kk plus ties)
+constexpr int kSampleCap = 512;      // entries of a row's sample segment (normally kk plus the ties at the threshold)
 
 // key[s], s < SLOTS, live where bit s of `valid` is set.  Returns the number of live keys m; when m >= kk: kth = the kk-th
 // smallest, need_eq = how many of the keys == kth belong to the kk smallest, eq_total = how many there are.
@@ -645,10 +642,16 @@ __device__ __forceinline__ bool topk_admit(const SelectArgs& a, int j, int self,
     return true;
 }
 
+// Both wave kernels fetch a row's entries in straight-line groups of 16 loads per lane: a load that sits behind the
+// admission branches of the previous entry is not issued before that entry is done, and 64 serialised round trips per row
+// made the first version of these kernels 10x slower than their arithmetic.
+
 // thresholds of the fused path from the dense scores of the sampled columns (a.cols <= 4096: 64 keys per lane):
 // thr[b] = the kk-th best admissible score, or -- with fewer than kk of them -- "everything" (with the admission rule only
-// scores > FLT_MIN can be listed, so FLT_MIN is a valid bound then).  grid: ceil(rows / 4) blocks of 4 waves.
-__global__ __launch_bounds__(256) void topk_thr_wave_kernel(SelectArgs a, int rows) {
+// scores > FLT_MIN can be listed, so FLT_MIN is a valid bound then).  The sampled columns that reach the threshold are
+// written out as the row's sample segment (s0_cand), so that the filtered sweep can start behind the sample.
+// grid: ceil(rows / 4) blocks of 4 waves; dynamic LDS: 4 histograms.
+__global__ __launch_bounds__(256, 2) void topk_thr_wave_kernel(SelectArgs a, int rows) {
     extern __shared__ __attribute__((aligned(16))) uint32_t whist_dyn[];   // 4 * kWaveHistBins words
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -658,33 +661,75 @@ __global__ __launch_bounds__(256) void topk_thr_wave_kernel(SelectArgs a, int ro
     uint32_t key[64];
     uint64_t valid = 0ull;
 #pragma unroll
-    for (int sl = 0; sl < 64; ++sl) {
-        const int j = sl * 64 + lane;
-        key[sl] = 0u;
-        if (j < a.cols) {
-            uint32_t k = 0u;
-            if (topk_admit(a, j, self, row[j], k)) { key[sl] = k; valid |= 1ull << sl; }
+    for (int c = 0; c < 4; ++c) {
+        float rawv[16], qb[16];
+        uint32_t pw[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int j = (c * 16 + t) * 64 + lane;
+            rawv[t] = row[j < a.cols ? j : a.cols - 1];
         }
+        if (a.Qb) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int j = (c * 16 + t) * 64 + lane;
+                qb[t] = a.Qb[j < a.cols ? j : a.cols - 1];
+            }
+        }
+        if (a.pool) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int j = (c * 16 + t) * 64 + lane;
+                pw[t] = a.pool[(j < a.cols ? j : a.cols - 1) >> 5];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int sl = c * 16 + t;
+            const int j = sl * 64 + lane;
+            float sc = rawv[t];
+            if (a.Qb) sc += qb[t];
+            bool ok = j < a.cols && j != self;
+            if (a.pool) ok = ok && ((pw[t] >> (j & 31)) & 1u);
+            if (a.rule_flt_min) ok = ok && sc > FLT_MIN;
+            key[sl] = ok ? desc_key(sc) : 0u;
+            valid |= static_cast<uint64_t>(ok ? 1 : 0) << sl;
+        }
+        __builtin_amdgcn_sched_barrier(0);   // one group's loads in flight at a time: 64 keys + 48 group registers, not 256
     }
     uint32_t kth; int need_eq, eq_total;
     const int m = wave_kth_key<64>(key, valid, a.kk, whist_dyn + (threadIdx.x >> 6) * kWaveHistBins, lane, kth, need_eq, eq_total);
     if (lane == 0) a.thr[b] = m >= a.kk ? key_score(kth) : (a.rule_flt_min ? FLT_MIN : -__builtin_inff());
+    if (a.s0_cand) {   // the admissible sampled columns at or above the threshold: the kk best plus the ties at the k-th place
+        uint2* out = a.s0_cand + static_cast<size_t>(b) * a.s0_cap;
+        int n0 = 0;
+#pragma unroll
+        for (int sl = 0; sl < 64; ++sl) {
+            const bool win = ((valid >> sl) & 1ull) && (m < a.kk || key[sl] <= kth);
+            const unsigned long long mask = __ballot(win);
+            const int at = n0 + __popcll(mask & ((1ull << lane) - 1ull));
+            // bit 31 of the column: the score already carries the bias (key -> score is exact, so the selection sees the same key)
+            if (win && at < a.s0_cap) out[at] = make_uint2(static_cast<uint32_t>(sl * 64 + lane) | 0x80000000u, __float_as_uint(key_score(key[sl])));
+            n0 += __popcll(mask);
+            if ((sl & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // keep the 64 ballots from being formed all at once (SGPR spills)
+        }
+        if (lane == 0) a.s0_cnt[b] = n0;
+    }
 }
 
 // selection over the candidate lists of the fused path, one wave per row (lists of <= 2048 entries: 32 per lane).
 // A row whose segments or list overflowed goes to `redo` (dense path); a row with ties straddling the k-th place goes to
 // `general` (topk_select_kernel's list mode, which walks the ties in column order).  Dynamic LDS: 4 histograms + 4 * p2 * 8 bytes.
 __global__ __launch_bounds__(256) void topk_list_wave_kernel(SelectArgs a, int rows) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long wsel[];   // 4 histograms (kWaveHistBins words), 4 sample lists, 4 * p2 sort entries
+    extern __shared__ __attribute__((aligned(16))) unsigned long long wsel[];   // 4 histograms (kWaveHistBins words), then 4 * p2 sort entries
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int b = blockIdx.x * 4 + wv;
     if (b >= rows) return;
     uint32_t* whist = reinterpret_cast<uint32_t*>(wsel) + static_cast<size_t>(wv) * kWaveHistBins;
-    uint2* s0 = reinterpret_cast<uint2*>(wsel + (4 * kWaveHistBins) / 2) + static_cast<size_t>(wv) * kWaveSampleCap;
-    unsigned long long* sel = wsel + (4 * kWaveHistBins) / 2 + 4 * kWaveSampleCap + static_cast<size_t>(wv) * a.p2;
+    unsigned long long* sel = wsel + (4 * kWaveHistBins) / 2 + static_cast<size_t>(wv) * a.p2;
     const int self = a.self_idx ? a.self_idx[a.q0 + b] : -1;
-    // segment ends (n_seg <= 8): e[g] = entries of the segments 0..g
-    int seg_end[8];
+    // segment ends (n_seg <= 8 sweep segments, then the sample segment): seg_end[g] = entries of the segments 0..g
+    int seg_end[9];
     int over = 0, tot = 0;
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
@@ -696,45 +741,60 @@ __global__ __launch_bounds__(256) void topk_list_wave_kernel(SelectArgs a, int r
         tot += c;
         seg_end[g] = tot;
     }
-    // the sampled columns [0, a.cols) come from their dense scores (the sweep starts behind them): the same test as the sweep's
-    int n0 = 0;
-    if (a.S) {
-        const float* srow = a.S + static_cast<size_t>(b) * a.ld_s;
-        const float thr = a.thr[b];
-        for (int base = 0; base < a.cols; base += 64) {
-            const int j = base + lane;
-            float raw = 0.f;
-            bool pass = false;
-            if (j < a.cols) {
-                raw = srow[j];
-                pass = (a.Qb ? raw + a.Qb[j] : raw) >= thr;
-            }
-            const unsigned long long mask = __ballot(pass);
-            const int at = n0 + __popcll(mask & ((1ull << lane) - 1ull));
-            if (pass && at < kWaveSampleCap) s0[at] = make_uint2(static_cast<uint32_t>(j), __float_as_uint(raw));
-            n0 += __popcll(mask);
+    {
+        int c = 0;
+        if (a.s0_cand) {
+            c = a.s0_cnt[b];
+            over |= c > a.s0_cap;
         }
-        wave_lds_sync();
+        tot += c;
+        seg_end[8] = tot;
     }
-    if (over || n0 > kWaveSampleCap || tot + n0 > a.list_cap) {
+    if (over || tot > a.list_cap) {
         if (lane == 0) a.redo[1 + atomicAdd(a.redo, 1)] = b;
         return;
     }
     uint32_t key[32], col[32];
     uint64_t valid = 0ull;
 #pragma unroll
-    for (int sl = 0; sl < 32; ++sl) {
-        const int i = sl * 64 + lane;
-        key[sl] = 0u; col[sl] = 0u;
-        if (i < tot + n0) {
+    for (int c = 0; c < 2; ++c) {
+        uint2 cv[16];
+        float qb[16];
+        uint32_t pw[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            int i = (c * 16 + t) * 64 + lane;
+            if (i >= tot) i = tot > 0 ? tot - 1 : 0;
             int g = 0, beg = 0;
 #pragma unroll
-            for (int q = 0; q < 7; ++q)
+            for (int q = 0; q < 8; ++q)
                 if (i >= seg_end[q]) { g = q + 1; beg = seg_end[q]; }
-            const uint2 c = i < tot ? a.cand[(static_cast<size_t>(b) * a.n_seg + g) * a.cap_seg + (i - beg)] : s0[i - tot];
-            uint32_t k = 0u;
-            if (topk_admit(a, static_cast<int>(c.x), self, __uint_as_float(c.y), k)) { key[sl] = k; col[sl] = c.x; valid |= 1ull << sl; }
+            const uint2* src = g < 8 ? a.cand + (static_cast<size_t>(b) * a.n_seg + g) * a.cap_seg : a.s0_cand + static_cast<size_t>(b) * a.s0_cap;
+            cv[t] = tot > 0 ? src[i - beg] : make_uint2(0u, 0u);
         }
+        if (a.Qb) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) qb[t] = a.Qb[cv[t].x & 0x7FFFFFFFu];
+        }
+        if (a.pool) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) pw[t] = a.pool[(cv[t].x & 0x7FFFFFFFu) >> 5];
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int sl = c * 16 + t;
+            const int i = sl * 64 + lane;
+            const int j = static_cast<int>(cv[t].x & 0x7FFFFFFFu);
+            float sc = __uint_as_float(cv[t].y);
+            if (a.Qb && !(cv[t].x >> 31)) sc += qb[t];   // sample-segment entries carry the bias already
+            bool ok = i < tot && j != self;
+            if (a.pool) ok = ok && ((pw[t] >> (j & 31)) & 1u);
+            if (a.rule_flt_min) ok = ok && sc > FLT_MIN;
+            key[sl] = ok ? desc_key(sc) : 0u;
+            col[sl] = static_cast<uint32_t>(j);
+            valid |= static_cast<uint64_t>(ok ? 1 : 0) << sl;
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
     uint32_t kth; int need_eq, eq_total;
     const int m = wave_kth_key<32>(key, valid, a.kk, whist, lane, kth, need_eq, eq_total);
@@ -745,8 +805,7 @@ __global__ __launch_bounds__(256) void topk_list_wave_kernel(SelectArgs a, int r
     }
     const int kk_eff = take_all ? m : a.kk;
     for (int i = lane; i < a.p2; i += 64) sel[i] = ~0ull;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_sync();
     int base = 0;
 #pragma unroll
     for (int sl = 0; sl < 32; ++sl) {
@@ -758,9 +817,7 @@ __global__ __launch_bounds__(256) void topk_list_wave_kernel(SelectArgs a, int r
     // bitonic sort of the wave's p2 entries, ascending composite = (score desc, column desc)
     for (int size = 2; size <= a.p2; size <<= 1)
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            wave_lds_sync();
             for (int t = lane; t < (a.p2 >> 1); t += 64) {
                 const int lo = ((t & ~(stride - 1)) << 1) | (t & (stride - 1));
                 const int hi = lo | stride;
@@ -769,9 +826,7 @@ __global__ __launch_bounds__(256) void topk_list_wave_kernel(SelectArgs a, int r
                 if ((x > y) == up) { sel[lo] = y; sel[hi] = x; }
             }
         }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    wave_lds_sync();
     const int orow = a.q0 + b;
     int32_t* ok = a.out_keys + static_cast<size_t>(orow) * a.k;
     float* os = a.out_scores ? a.out_scores + static_cast<size_t>(orow) * a.k : nullptr;
@@ -844,6 +899,7 @@ class TopkHandle : public HandleBase {
     struct FusedPlan {
         bool on = false;
         int c0 = 0, c0_tiles = 0, n_seg = 1, tpb = 1, cap_seg = 0;
+        bool sample_seg = false;
     };
     static constexpr int kListCap = 2048;
     FusedPlan fused_plan(int nq, int q_rows, int d_pad, int kk) const {
@@ -853,15 +909,17 @@ class TopkHandle : public HandleBase {
         if (!force && (nq < 8192 || q_rows < 8192)) return fp;   // small sweeps: the dense path's item-tile parallelism matters more
         const int n_tiles = (q_rows + 31) / 32;
         int64_t need = (static_cast<int64_t>(kk) * q_rows + kListCap / 3 - 1) / (kListCap / 3);
-        int c0 = force && fused_c0_ > 0 ? fused_c0_ : (force ? 32 : 2048);
+        int c0 = force ? 32 : 2048;
         while (c0 < need) c0 <<= 1;
+        if (force && fused_c0_ > 0) c0 = fused_c0_;   // tests: exactly this sample (too small a sample overflows the lists: the dense redo path)
         c0 = (c0 + 31) / 32 * 32;
         if (force) c0 = std::min(c0, n_tiles * 32);   // tests: any shape goes through (overflowing rows take the dense path)
         else if (c0 > q_rows / 4) return fp;
         if (c0 >= q_rows + 32) return fp;
         fp.c0 = std::min(c0, q_rows);
         fp.c0_tiles = (fp.c0 + 31) / 32;              // c0 is a multiple of 32 or the whole matrix
-        const int sweep_tiles = n_tiles - fp.c0_tiles;   // the filtered sweep starts behind the sample
+        fp.sample_seg = wave_select_ && fp.c0 <= 4096;   // topk_thr_wave_kernel writes the sample's own candidates ...
+        const int sweep_tiles = n_tiles - (fp.sample_seg ? fp.c0_tiles : 0);   // ... and the filtered sweep starts behind the sample
         const int qblocks = (nq + 127) / 128;
         int tpb = static_cast<int>((static_cast<int64_t>(sweep_tiles) * qblocks + num_cus_ * 8 - 1) / (num_cus_ * 8));
         tpb = std::max(tpb, (sweep_tiles + 7) / 8);   // at most 8 segments per query
@@ -919,7 +977,7 @@ class TopkHandle : public HandleBase {
         BFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(topk_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     static_cast<int>(fp.on ? lds_list : lds_dense)));
         const size_t kWaveLds = static_cast<size_t>(4) * kWaveHistBins * 4;   // the wave kernels' four histograms
-        const size_t kListLds = kWaveLds + static_cast<size_t>(4) * kWaveSampleCap * 8;   // + the list kernel's four sample lists
+        const size_t kListLds = kWaveLds;
         if (fp.on && wave_select_) {
             BFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(topk_thr_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         static_cast<int>(kWaveLds)));
@@ -949,6 +1007,8 @@ class TopkHandle : public HandleBase {
             cnt_.resize(std::max(cnt_.size(), static_cast<size_t>(batch) * fp.n_seg));
             redo_.resize(std::max(redo_.size(), static_cast<size_t>(batch) + 1));
             general_.resize(std::max(general_.size(), static_cast<size_t>(batch) + 1));
+            s0_cand_.resize(std::max(s0_cand_.size(), static_cast<size_t>(batch) * kSampleCap));
+            s0_cnt_.resize(std::max(s0_cnt_.size(), static_cast<size_t>(batch)));
         }
         for (int q0 = 0; q0 < nq; q0 += batch) {
             const int nb = std::min(batch, nq - q0);
@@ -970,8 +1030,12 @@ class TopkHandle : public HandleBase {
             slot = t_aux_.begin(stream);
             SelectArgs a = base;
             a.S = S_.get(); a.ld_s = static_cast<size_t>(fp.c0); a.cols = fp.c0; a.self_idx = same ? d_idx_.get() : nullptr; a.q0 = q0;
-            if (wave_select_ && fp.c0 <= 4096) {
+            // the wave kernel also writes the sample's own candidates, and the sweep then starts behind the sample; the block-level
+            // route (samples beyond 4096 columns) only yields thresholds, and the sweep covers every column
+            const bool sample_seg = fp.sample_seg;
+            if (sample_seg) {
                 a.thr = thr_.get();
+                a.s0_cand = s0_cand_.get(); a.s0_cnt = s0_cnt_.get(); a.s0_cap = kSampleCap;
                 hipLaunchKernelGGL(topk_thr_wave_kernel, dim3((nb + 3) / 4), dim3(256), kWaveLds, stream, a, nb);
             } else {
                 launch_select(a, nb, lds_dense);
@@ -982,7 +1046,7 @@ class TopkHandle : public HandleBase {
             BFH_HIP(hipMemsetAsync(redo_.get(), 0, sizeof(int), stream));
             BFH_HIP(hipMemsetAsync(general_.get(), 0, sizeof(int), stream));
             t_aux_.end(slot, stream);
-            FilterArgs f{thr_.get(), dQb, d_pool, cand_.get(), cnt_.get(), fp.cap_seg, fp.c0_tiles};
+            FilterArgs f{thr_.get(), dQb, d_pool, cand_.get(), cnt_.get(), fp.cap_seg, sample_seg ? fp.c0_tiles : 0};
             slot = t_main_.begin(stream);
             if (d_pad == 128)
                 hipLaunchKernelGGL((topk_scores_kernel<true, true>), dim3(fp.n_seg, (nb + 127) / 128), dim3(256), 0, stream, dP, qidx, q0, nb, Qp_.get(),
@@ -993,9 +1057,8 @@ class TopkHandle : public HandleBase {
             BFH_HIP(hipGetLastError());
             t_main_.end(slot, stream);
             slot = t_aux_.begin(stream);
-            // a.S / ld_s / cols stay on the sample scores: the selection takes the sampled columns from there
-            a.cand = cand_.get(); a.cand_cnt = cnt_.get(); a.n_seg = fp.n_seg; a.cap_seg = fp.cap_seg; a.list_cap = kListCap;
-            a.redo = redo_.get(); a.general = general_.get(); a.thr = thr_.get();
+            a.S = nullptr; a.cand = cand_.get(); a.cand_cnt = cnt_.get(); a.n_seg = fp.n_seg; a.cap_seg = fp.cap_seg; a.list_cap = kListCap;
+            a.redo = redo_.get(); a.general = general_.get(); a.thr = nullptr;   // (a.s0_* stay: the sample segment, if there is one)
             const bool wave_list = wave_select_ && p2 <= 1024;
             if (wave_list) {
                 hipLaunchKernelGGL(topk_list_wave_kernel, dim3((nb + 3) / 4), dim3(256), kListLds + static_cast<size_t>(4) * p2 * 8, stream, a, nb);
@@ -1146,8 +1209,8 @@ class TopkHandle : public HandleBase {
     DevBuf<float4> Qp_;   // candidate matrix in MFMA operand order (topk_pack_kernel)
     // fused path: per-query thresholds, candidate segments + counts, rows handed back to the dense path
     DevBuf<float> thr_;
-    DevBuf<uint2> cand_;
-    DevBuf<int> cnt_, redo_, general_;
+    DevBuf<uint2> cand_, s0_cand_;
+    DevBuf<int> cnt_, redo_, general_, s0_cnt_;
     DevBuf<int32_t> redo_side_;
     EventTimer t_main_, t_aux_;
 };

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(params=["auto", "fused-c0-32", "fused-c0-rule"], autouse=True)
 def fused_mode(request):
     """Every case runs three ways: the size rule (these shapes: the dense score buffer + select), the fused path forced
-    with one sampled tile (loose thresholds: long candidate lists, overflowing rows handed back to the dense path) and
+    with exactly one sampled tile (loose thresholds: long candidate lists, overflowing rows handed back to the dense path) and
     forced with the rule's sample size.  The fused path must be bit-identical to the dense one."""
     from buffalo_amd import parallel as par
     eng = par._engine()
@@ -133,7 +133,9 @@ def test_fused_path_is_bit_identical_to_dense(fused_mode, same, bias, pool_n, k,
     for name in ("fused", "fused32", "fused1024"):
         assert np.array_equal(out[name][0], out["dense"][0]), name
         assert np.array_equal(out[name][1], out["dense"][1]), name
-    assert out["fused1024_redo"] < 300     # the fused path itself produced rows
+    if pool_n == 0:
+        assert out["fused1024_redo"] < 300 and out["fused_redo"] < 300     # the fused path itself produced rows ...
+        assert out["fused32_redo"] > 0                                      # ... and a one-tile sample overflows lists: the dense redo path ran
 
 
 def test_quickselect_matches_oracle(oracle):
