@@ -116,6 +116,51 @@ def test_rows_without_entries_are_left_alone(oracle):
     assert B["item_bias"][1, 0] == 0.0 == A["item_bias"][1, 0]
 
 
+def test_stream_to_sppmi_to_cfr_epoch(oracle):
+    """The whole data path of CoFactor on the device: a stream of user sequences -> rowwise matrix (bfh_coo_to_csr) and SPPMI
+    context matrix (bfh_sppmi_*, windows 3) -> one CFR epoch (bfh_cfr_*), against the same chain on the oracle
+    (stream.py:240-267 + fileio.hpp:109-254 -> cfr.cc)."""
+    from collections import Counter
+    from buffalo_amd import ingest
+    from buffalo_amd.backend import CyCFR
+    from buffalo_amd.synth import CSR
+    Uu, Ii, d = 400, 120, 24
+    rng = np.random.default_rng(12)
+    lens = rng.integers(2, 40, size=Uu)
+    indptr = np.cumsum(lens).astype(np.int64)
+    pop = 1.0 / np.arange(1, Ii + 1)
+    items = rng.choice(Ii, size=int(indptr[-1]), p=pop / pop.sum()).astype(np.int32)
+    # internal_data_type "matrix": per-user counts of the sequence (stream.py:252-255)
+    rows, cols, vals = [], [], []
+    beg = 0
+    for u, end in enumerate(indptr):
+        for c, v in sorted(Counter(items[beg:end].tolist()).items()):
+            rows.append(u), cols.append(c), vals.append(float(v))
+        beg = int(end)
+    rows, cols, vals = np.array(rows, np.int32), np.array(cols, np.int32), np.array(vals, np.float32)
+    g_row = ingest.coo_to_csr(rows, cols, vals, Uu, Ii)
+    o_row = oracle.coo_to_csr(rows, cols, vals, Uu, Ii)
+    g_sp = ingest.build_sppmi(indptr, items, Ii, 3, 1)
+    o_sp = oracle.build_sppmi(indptr, items, Ii, 3, 1)
+    for k in ("indptr", "key"):
+        assert np.array_equal(g_row[k], o_row[k]) and np.array_equal(g_sp[k], o_sp[k])
+    assert np.array_equal(g_sp["val"].view(np.int32), o_sp["val"].view(np.int32)) and len(g_sp["key"]) > Ii
+    opt = _opt(d=d, optimizer="llt")
+    A, B = _arrays(Uu, Ii, d, seed=4), _arrays(Uu, Ii, d, seed=4)
+    o, g = oracle.OracleCFR(), CyCFR()
+    assert o.init(H.write_opt(opt)) and g.init(H.write_opt(opt))
+    _bind(o, A), _bind(g, B)
+    mk = lambda grp, r, c: CSR(r, c, grp["indptr"], grp["key"], grp["val"])     # noqa: E731
+    csr_o, ctx_o = mk(o_row, Uu, Ii), mk(o_sp, Ii, Ii)
+    csr_g, ctx_g = mk(g_row, Uu, Ii), mk(g_sp, Ii, Ii)
+    lo = _epoch(o, csr_o, csr_o.transpose(), ctx_o)
+    lg = _epoch(g, csr_g, csr_g.transpose(), ctx_g)
+    for name in A:
+        assert H.relerr(B[name], A[name]) < 2e-4, (name, H.relerr(B[name], A[name]))
+    for a, b in zip(lo, lg):
+        assert abs(a - b) <= 1e-4 * max(1.0, abs(a)), (lo, lg)
+
+
 def test_unsupported_options_fail_loudly():
     from buffalo_amd._lib import BuffaloHipError
     from buffalo_amd.backend import CyCFR
