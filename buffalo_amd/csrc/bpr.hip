@@ -197,6 +197,28 @@ __device__ __forceinline__ void row_atomic_add(const Row<K>& r, float* __restric
         atomic_add_row<K>(r, base, lane, vdim);
     }
 }
+// float4 rows with the non-temporal hint on top (aux bit 1): load past the L1 (sc1) as row_load<.., COH>, store plain
+template <int K>
+__device__ __forceinline__ void row_load_nt(Row<K>& r, const float* __restrict__ base, int lane, int vdim) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, vdim * 4, 0x00020000);
+#pragma unroll
+    for (int kv = 0; kv < K / 4; ++kv) {
+        const f32q v = __builtin_bit_cast(f32q, __builtin_amdgcn_raw_buffer_load_b128(rs, (kv * 64 + lane) * 16, 0, 18));
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) r.v[kv * 4 + c4] = v.v[c4];
+    }
+}
+template <int K>
+__device__ __forceinline__ void row_store_nt(const Row<K>& r, float* __restrict__ base, int lane, int vdim) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, vdim * 4, 0x00020000);
+#pragma unroll
+    for (int kv = 0; kv < K / 4; ++kv) {
+        f32q v;
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) v.v[c4] = r.v[kv * 4 + c4];
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(b128_t, v), rs, (kv * 64 + lane) * 16, 0, 2);
+    }
+}
 // device-coherent scalar (bias) access for the write-through policy
 __device__ __forceinline__ float coh_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void coh_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -876,6 +898,7 @@ class BprHandle : public SgdHandle {
         q.ent_pos = im_pos_b_.get();
         q.nq = nq;
         for (int i = 0; i < 16; ++i) q.xcd_queue[i] = im_xcd_queue_[i];
+        q.p_nt = im_p_nt_;
         q.hot_user = im_hot_user_.get();
         q.rep_P = p_rep ? repP_.get() : nullptr;
         q.rep_pstride = static_cast<int64_t>(P_rows_) * vdim_;

@@ -56,6 +56,7 @@ struct ImQueues {
                                // [nq][P_rows * vdim] per-XCD replicas of P: entries are spread over the queues by position and
                                // a wave works on its XCD's copy (small shards: see launch_item_major)
     int64_t rep_pstride;
+    int p_nt;                  // P rows are read / written with the non-temporal hint (they are streamed once per triple; study knob)
     int strict;                // test hook: wait for every memory operation of a triple before the next one starts
     int32_t* trace;            // test hook (single-wave runs): sigmoid-table index of every triple in processing order, or null
 };
@@ -261,6 +262,14 @@ __global__ __launch_bounds__(256, K <= 4 ? (PIPE ? 5 : 6) : 1) void bpr_item_maj
     float* const Prep = (drain || !q.rep_P) ? p.P : q.rep_P + static_cast<size_t>(my_queue < 0 ? 0 : my_queue) * q.rep_pstride;
     auto rload = [&](Row<K>& r, const float* base) { row_load<K, true, true>(r, base, lane, vdim); };
     auto rstore = [&](const Row<K>& r, float* base) { row_store<K, true, false>(r, base, lane, vdim); };
+    auto pload = [&](Row<K>& r, const float* base) {
+        if (q.p_nt) row_load_nt<K>(r, base, lane, vdim);
+        else row_load<K, true, true>(r, base, lane, vdim);
+    };
+    auto pstore = [&](const Row<K>& r, float* base) {
+        if (q.p_nt) row_store_nt<K>(r, base, lane, vdim);
+        else row_store<K, true, false>(r, base, lane, vdim);
+    };
 
     int cur_i = -1, since_flush = 0, flush_n = 64;
     Row<K> qi, dqi, qi_re;   // the slice's item row, its step since the last flush, the row as re-read after a flush
@@ -348,7 +357,7 @@ __global__ __launch_bounds__(256, K <= 4 ? (PIPE ? 5 : 6) : 1) void bpr_item_maj
                     const int u = __builtin_amdgcn_readlane(my_u, j), ng = __builtin_amdgcn_readlane(my_neg, j);
                     const int pl = __builtin_amdgcn_readlane(my_pol, j);
                     const bool hj = (pl & 2) != 0;
-                    rload(s.pu, pu_ptr(u, (pl & 1) != 0));
+                    pload(s.pu, pu_ptr(u, (pl & 1) != 0));
                     rload(s.qj, qj_ptr(ng, hj));
                     s.bj = c.use_bias ? coh_load(bj_ptr(ng, hj)) : 0.f;
                 }
@@ -370,7 +379,7 @@ __global__ __launch_bounds__(256, K <= 4 ? (PIPE ? 5 : 6) : 1) void bpr_item_maj
                 if (u == prev_u) {
                     // consecutive slots of one entry (num_negative_samples > 1): carry the updated row
                 } else if (!PIPE || u == prev2_u) {
-                    rload(pu, pu_ptr(u, at_u));
+                    pload(pu, pu_ptr(u, at_u));
                 } else {
                     pu = s.pu;
                 }
@@ -431,16 +440,16 @@ __global__ __launch_bounds__(256, K <= 4 ? (PIPE ? 5 : 6) : 1) void bpr_item_maj
                 float* Qj = qj_ptr(neg, at_j);
                 const bool fr_u = PIPE && c.fresh && !at_u, fr_j = PIPE && c.fresh && !at_j && !same && c.update_j;
                 Row<K> fu, fj;
-                if (fr_u) rload(fu, Pu);
+                if (fr_u) pload(fu, Pu);
                 if (fr_j) rload(fj, Qj);
                 if (at_u) {
                     row_atomic_add_full_lines<K>(dpu, Pu, lane, vdim);
                 } else if (fr_u) {
 #pragma unroll
                     for (int k = 0; k < K; ++k) fu.v[k] += dpu.v[k];
-                    rstore(fu, Pu);
+                    pstore(fu, Pu);
                 } else {
-                    rstore(pu, Pu);
+                    pstore(pu, Pu);
                 }
                 if (c.update_j && !same) {
                     if (at_j) {

@@ -12,6 +12,7 @@ import numpy as np
 SHAPES = {
     "ml100k": (943, 1682, 80000),
     "ml20m": (138493, 27278, 20000263),
+    "ml20m_i3410": (138493, 3410, 20000263),    # study shape: an item table of 1.75 MB (fits an XCD's L2); heavy users saturate it
 }
 
 
