@@ -51,6 +51,7 @@ struct BprConsts {
     const float* exp_table;
     double* loss_out;
     int chunk;
+    int neg_limit;        // study knob: uniform negatives are folded into [0, neg_limit) (0: off) -- what the walk does when the negatives' rows fit an L2
     // injected triples (bfh_bpr_update_triples)
     const int32_t* inj_u;
     const int32_t* inj_p;
@@ -94,6 +95,7 @@ __device__ __forceinline__ int bpr_sample_negative(const SgdParams& p, const Bpr
         counter_draw(p.seed, 0u, gpos, slot, p.epoch, attempt, o0, o1);
         if (c.uniform) {
             neg = static_cast<int>((static_cast<uint64_t>(o0) * static_cast<uint32_t>(p.Q_rows)) >> 32);
+            if (c.neg_limit > 0) neg %= c.neg_limit;
         } else {
             const uint64_t r64 = (static_cast<uint64_t>(o1) << 32) | o0;
             const int64_t r = static_cast<int64_t>(__umul64hi(r64, static_cast<uint64_t>(c.cum_total)));
@@ -634,7 +636,7 @@ class BprHandle : public SgdHandle {
         c.lr = static_cast<float>(lr);
         c.reg_u = reg_u_; c.reg_i = reg_i_; c.reg_j = reg_j_; c.reg_b = reg_b_;
         c.use_bias = use_bias_; c.update_i = update_i_; c.update_j = update_j_;
-        c.verify_neg = verify_neg_; c.uniform = uniform_; c.num_neg = num_neg_;
+        c.verify_neg = verify_neg_; c.uniform = uniform_; c.num_neg = num_neg_; c.neg_limit = im_neg_limit_;
         c.pcn = pcn_; c.compute_loss = compute_loss_;
         c.atomic = hogwild_atomic_; c.sequential = sequential_;
         c.cum_total = cum_total_;
