@@ -334,9 +334,13 @@ def extra_sppmi(csr, seed, cpu=True):
                      % (csr.num_users, csr.nnz, csr.num_items),
            "pair_lines": lines, "distinct_pairs": st["launches"], "nnz": int(len(g["key"])), "device_ms": st["kernel_ms"], "wall_ms": dt * 1e3,
            "lines_per_s_device": lines / (st["kernel_ms"] * 1e-3),
-           "hbm": {"algorithmic_bytes": 16 * lines * 6, "note": "8-byte keys written, radix-sorted (5 passes over 35 bits: read + write), run-length "
-                   "encoded: ~6 x 16 B per line", "achieved_GBps": 16 * lines * 6 / (st["kernel_ms"] * 1e-3) / 1e9,
-                   "frac": 16 * lines * 6 / (st["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+           }
+    kb = 4 if csr.num_items ** 2 <= 2 ** 32 else 8
+    passes = -(-max(1, int(np.ceil(np.log2(float(csr.num_items) ** 2)))) // 8)
+    alg = lines * kb * (2 + 2 * passes)
+    out["hbm"] = {"algorithmic_bytes": alg, "note": "%d-byte keys: written once, %d radix passes (read + write), read once by the run-length encode"
+                                                    % (kb, passes),
+                  "achieved_GBps": alg / (st["kernel_ms"] * 1e-3) / 1e9, "frac": alg / (st["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
     if cpu:
         from oracle import oracle as orc
         orc.build()

@@ -12,7 +12,8 @@
 //
 // Device formulation -- no text, no files, one pass each:
 //   1. pairs per user in closed form, exclusive scan -> where each user's lines start;
-//   2. one thread per event writes its <= 2 * windows lines as 64-bit keys  first * num_items + second;
+//   2. one thread per event writes its <= 2 * windows lines as keys  first * num_items + second  (32-bit while num_items^2 fits,
+//      which halves the bytes of steps 2-3; 64-bit beyond 65,536 items);
 //   3. radix sort of the keys over the bits they use (rocprim::radix_sort_keys), run-length encode (distinct pairs + cnt);
 //   4. appearances by two binary searches per item in the sorted keys (no atomics on popular items);
 //   5. one thread per distinct pair: the reference's double arithmetic, the six-digit decimal rounding of the text
@@ -20,7 +21,7 @@
 //   6. exclusive scan of the emit counts, scatter.  The distinct pairs are already in (row, col) order and the lines
 //      are symmetric (cnt(a, b) == cnt(b, a)), so entry (a, b) is produced from its own run with probe = max(a, b) --
 //      the output needs no second sort; indptr comes from the row changes.
-// HBM-bound integer work: 16 B per line and radix pass; the log / rounding step touches only the distinct pairs.
+// HBM-bound integer work: 8 (16) B per line and radix pass; the log / rounding step touches only the distinct pairs.
 #include <cmath>
 #include <cstring>
 
@@ -54,9 +55,11 @@ __global__ __launch_bounds__(256) void sppmi_count_kernel(const int64_t* __restr
 }
 
 // one thread per event: its pairs with the `windows` events after it, both orientations
+// KeyT: uint32_t when num_items^2 fits 32 bits (half the bytes through the sort), else uint64_t
+template <typename KeyT>
 __global__ __launch_bounds__(256) void sppmi_lines_kernel(const int64_t* __restrict__ indptr, const int32_t* __restrict__ items, int num_users,
                                                           int64_t num_events, int windows, uint64_t num_items, const int64_t* __restrict__ pair_off,
-                                                          uint64_t* __restrict__ keys) {
+                                                          KeyT* __restrict__ keys) {
     const int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
     if (e >= num_events) return;
     const int u = static_cast<int>(lower_bound_dev<int64_t>(indptr, num_users, e + 1));   // first user whose END offset is > e
@@ -65,16 +68,19 @@ __global__ __launch_bounds__(256) void sppmi_lines_kernel(const int64_t* __restr
     const uint64_t w = static_cast<uint32_t>(items[e]);
     for (int64_t j = i + 1; j < i + windows + 1 && j < L; ++j) {
         const uint64_t c = static_cast<uint32_t>(items[beg + j]);
-        keys[at++] = w * num_items + c;
-        keys[at++] = c * num_items + w;
+        keys[at++] = static_cast<KeyT>(w * num_items + c);
+        keys[at++] = static_cast<KeyT>(c * num_items + w);
     }
 }
 
-__global__ __launch_bounds__(256) void sppmi_appear_kernel(const uint64_t* __restrict__ sorted, int64_t n, int num_items, int64_t* __restrict__ app) {
+template <typename KeyT>
+__global__ __launch_bounds__(256) void sppmi_appear_kernel(const KeyT* __restrict__ sorted, int64_t n, int num_items, int64_t* __restrict__ app) {
     const int x = blockIdx.x * 256 + threadIdx.x;
     if (x >= num_items) return;
     const uint64_t ni = static_cast<uint64_t>(num_items);
-    app[x] = lower_bound_dev<uint64_t>(sorted, n, (static_cast<uint64_t>(x) + 1) * ni) - lower_bound_dev<uint64_t>(sorted, n, static_cast<uint64_t>(x) * ni);
+    // (x + 1) * ni can be one past the key type's range for the last item: its run ends at n
+    const int64_t end = x + 1 < num_items ? lower_bound_dev<KeyT>(sorted, n, static_cast<KeyT>((static_cast<uint64_t>(x) + 1) * ni)) : n;
+    app[x] = end - lower_bound_dev<KeyT>(sorted, n, static_cast<KeyT>(static_cast<uint64_t>(x) * ni));
 }
 
 __host__ __device__ __forceinline__ double sppmi_pow10(int m) {   // exact for 0 <= m <= 22
@@ -100,12 +106,13 @@ __host__ __device__ __forceinline__ float sppmi_text_round_trip(double x) {
 }
 
 // one thread per distinct (a, b): value + number of output entries (0: sppmi <= 0, 2: a == b -- the reference writes that line twice)
-__global__ __launch_bounds__(256) void sppmi_value_kernel(const uint64_t* __restrict__ uniq, const unsigned int* __restrict__ cnt, int64_t runs,
+template <typename KeyT>
+__global__ __launch_bounds__(256) void sppmi_value_kernel(const KeyT* __restrict__ uniq, const unsigned int* __restrict__ cnt, int64_t runs,
                                                           uint64_t num_items, const int64_t* __restrict__ app, double log_d, double log_k,
                                                           float* __restrict__ val, int64_t* __restrict__ emit) {
     const int64_t r = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
     if (r >= runs) return;
-    const uint64_t key = uniq[r];
+    const uint64_t key = static_cast<uint64_t>(uniq[r]);
     const uint64_t a = key / num_items, b = key % num_items;
     const uint64_t probe = a > b ? a : b, c = a > b ? b : a;   // fileio.hpp:207-208: the group of the larger id does the pair
     const double pmi = log(static_cast<double>(cnt[r])) + log_d - log(static_cast<double>(app[probe])) - log(static_cast<double>(app[c]));
@@ -115,13 +122,14 @@ __global__ __launch_bounds__(256) void sppmi_value_kernel(const uint64_t* __rest
     emit[r] = keep ? (a == b ? 2 : 1) : 0;
 }
 
-__global__ __launch_bounds__(256) void sppmi_scatter_kernel(const uint64_t* __restrict__ uniq, const float* __restrict__ val,
+template <typename KeyT>
+__global__ __launch_bounds__(256) void sppmi_scatter_kernel(const KeyT* __restrict__ uniq, const float* __restrict__ val,
                                                             const int64_t* __restrict__ emit_off, int64_t runs, int64_t nnz, uint64_t num_items,
                                                             int32_t* __restrict__ out_row, int32_t* __restrict__ out_key, float* __restrict__ out_val) {
     const int64_t r = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
     if (r >= runs) return;
     const int64_t at = emit_off[r], end = r + 1 < runs ? emit_off[r + 1] : nnz;
-    const uint64_t key = uniq[r];
+    const uint64_t key = static_cast<uint64_t>(uniq[r]);
     for (int64_t p = at; p < end; ++p) {
         out_row[p] = static_cast<int32_t>(key / num_items);
         out_key[p] = static_cast<int32_t>(key % num_items);
@@ -150,6 +158,13 @@ class SppmiHandle : public HandleBase {
     }
 
     void build(const int64_t* indptr, const int32_t* items, int num_users, int num_items, int windows, int k, int64_t* nnz_out, int64_t* lines_out) {
+        if (static_cast<uint64_t>(num_items) * static_cast<uint64_t>(num_items) <= (uint64_t(1) << 32))
+            build_with<uint32_t>(indptr, items, num_users, num_items, windows, k, nnz_out, lines_out);
+        else
+            build_with<uint64_t>(indptr, items, num_users, num_items, windows, k, nnz_out, lines_out);
+    }
+    template <typename KeyT>
+    void build_with(const int64_t* indptr, const int32_t* items, int num_users, int num_items, int windows, int k, int64_t* nnz_out, int64_t* lines_out) {
         BFH_REQUIRE(num_users > 0 && num_items > 0 && windows > 0 && k > 0, "sppmi: num_users, num_items, windows and k must be positive");
         ensure();
         const int64_t events = indptr[num_users - 1];
@@ -176,7 +191,7 @@ class SppmiHandle : public HandleBase {
         }
         DevBuf<int64_t> d_indptr, d_pairs, d_off, d_app, d_emit, d_emit_off, d_runs;
         DevBuf<int32_t> d_items, d_rows;
-        DevBuf<uint64_t> d_keys, d_sorted, d_uniq;
+        DevBuf<KeyT> d_keys, d_sorted, d_uniq;
         DevBuf<unsigned int> d_cnt;
         DevBuf<float> d_val;
         DevBuf<char> d_tmp;
@@ -197,15 +212,15 @@ class SppmiHandle : public HandleBase {
         with_tmp([&](void* t, size_t& b) {
             return rocprim::exclusive_scan(t, b, d_pairs.get(), d_off.get(), int64_t(0), static_cast<size_t>(num_users), rocprim::plus<int64_t>(), stream);
         });
-        hipLaunchKernelGGL(sppmi_lines_kernel, dim3(static_cast<unsigned>((events + 255) / 256)), dim3(256), 0, stream, d_indptr.get(), d_items.get(),
+        hipLaunchKernelGGL((sppmi_lines_kernel<KeyT>), dim3(static_cast<unsigned>((events + 255) / 256)), dim3(256), 0, stream, d_indptr.get(), d_items.get(),
                            num_users, events, windows, static_cast<uint64_t>(num_items), d_off.get(), d_keys.get());
         BFH_HIP(hipGetLastError());
         int bits = 1;
-        while (bits < 64 && (uint64_t(1) << bits) < static_cast<uint64_t>(num_items) * static_cast<uint64_t>(num_items)) ++bits;
+        while (bits < static_cast<int>(sizeof(KeyT)) * 8 && (uint64_t(1) << bits) < static_cast<uint64_t>(num_items) * static_cast<uint64_t>(num_items)) ++bits;
         with_tmp([&](void* t, size_t& b) {
             return rocprim::radix_sort_keys(t, b, d_keys.get(), d_sorted.get(), static_cast<size_t>(lines), 0u, static_cast<unsigned>(bits), stream);
         });
-        hipLaunchKernelGGL(sppmi_appear_kernel, dim3((num_items + 255) / 256), dim3(256), 0, stream, d_sorted.get(), lines, num_items, d_app.get());
+        hipLaunchKernelGGL((sppmi_appear_kernel<KeyT>), dim3((num_items + 255) / 256), dim3(256), 0, stream, d_sorted.get(), lines, num_items, d_app.get());
         BFH_HIP(hipGetLastError());
         // distinct pairs: at most `lines`; the key buffer is free again and holds them
         d_uniq.resize(static_cast<size_t>(lines)); d_cnt.resize(static_cast<size_t>(lines)); d_runs.resize(1);
@@ -217,7 +232,7 @@ class SppmiHandle : public HandleBase {
         BFH_HIP(hipStreamSynchronize(stream));
         d_val.resize(static_cast<size_t>(runs)); d_emit.resize(static_cast<size_t>(runs)); d_emit_off.resize(static_cast<size_t>(runs));
         const unsigned rblocks = static_cast<unsigned>((runs + 255) / 256);
-        hipLaunchKernelGGL(sppmi_value_kernel, dim3(rblocks), dim3(256), 0, stream, d_uniq.get(), d_cnt.get(), runs, static_cast<uint64_t>(num_items),
+        hipLaunchKernelGGL((sppmi_value_kernel<KeyT>), dim3(rblocks), dim3(256), 0, stream, d_uniq.get(), d_cnt.get(), runs, static_cast<uint64_t>(num_items),
                            d_app.get(), std::log(static_cast<double>(lines)), std::log(static_cast<double>(k)), d_val.get(), d_emit.get());
         BFH_HIP(hipGetLastError());
         with_tmp([&](void* t, size_t& b) {
@@ -230,7 +245,7 @@ class SppmiHandle : public HandleBase {
         nnz_ = last_off + last_emit;
         if (nnz_ > 0) {
             d_rows.resize(static_cast<size_t>(nnz_)); d_key_out_.resize(static_cast<size_t>(nnz_)); d_val_out_.resize(static_cast<size_t>(nnz_));
-            hipLaunchKernelGGL(sppmi_scatter_kernel, dim3(rblocks), dim3(256), 0, stream, d_uniq.get(), d_val.get(), d_emit_off.get(), runs, nnz_,
+            hipLaunchKernelGGL((sppmi_scatter_kernel<KeyT>), dim3(rblocks), dim3(256), 0, stream, d_uniq.get(), d_val.get(), d_emit_off.get(), runs, nnz_,
                                static_cast<uint64_t>(num_items), d_rows.get(), d_key_out_.get(), d_val_out_.get());
             hipLaunchKernelGGL(sppmi_indptr_kernel, dim3(static_cast<unsigned>((nnz_ + 255) / 256)), dim3(256), 0, stream, d_rows.get(), nnz_, num_items,
                                d_indptr_out_.get());

@@ -98,7 +98,8 @@ def test_oracle_edge_cases(oracle):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("num_users,num_items,max_len,windows,k,seed", [(60, 25, 14, 3, 1, 0), (200, 90, 30, 5, 2, 1), (40, 7, 9, 2, 1, 2),
-                                                                       (5, 300, 40, 50, 1, 3), (3000, 1500, 60, 5, 1, 4), (1, 10, 12, 3, 1, 5)])
+                                                                       (5, 300, 40, 50, 1, 3), (3000, 1500, 60, 5, 1, 4), (1, 10, 12, 3, 1, 5),
+                                                                       (800, 70000, 25, 4, 1, 6)])     # > 65,536 items: 64-bit keys
 def test_device_matches_oracle(oracle, num_users, num_items, max_len, windows, k, seed):
     from buffalo_amd import ingest
     indptr, items = _stream(num_users, num_items, max_len, seed)
