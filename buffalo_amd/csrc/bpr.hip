@@ -731,7 +731,14 @@ class BprHandle : public SgdHandle {
         else hipLaunchKernelGGL((bpr_item_major_kernel<K, false, false>), grid, block, 0, stream, p, c, q);
         BFH_HIP(hipGetLastError());
     }
+    // two triples per wave (bpr_item_major_dual_kernel): vdim <= 128, rows read where they are used, not a test-hook run
+    bool im_dual() const { return im_dual_ > 0 && vdim_ <= 128 && !im_prefetch() && !im_single_wave_ && !im_drain_only_; }
     void im_launch(const SgdParams& p, const BprConsts& c, const ImQueues& q, int64_t waves, bool drain) {
+        if (!drain && im_dual()) {
+            hipLaunchKernelGGL(bpr_item_major_dual_kernel, dim3(static_cast<unsigned>((waves + 3) / 4)), dim3(256), 0, stream, p, c, q);
+            BFH_HIP(hipGetLastError());
+            return;
+        }
         const int KV = (vdim_ + 255) / 256;
         if (KV <= 1) im_launch_k<4>(p, c, q, waves, drain);
         else if (KV <= 2) im_launch_k<8>(p, c, q, waves, drain);
@@ -741,7 +748,9 @@ class BprHandle : public SgdHandle {
         if (waves_per_cu_ > 0) return static_cast<int64_t>(num_cus_) * waves_per_cu_;
         const int KV = (vdim_ + 255) / 256;
         const void* fn = nullptr;
-        if (im_prefetch())
+        if (im_dual())
+            fn = reinterpret_cast<const void*>(bpr_item_major_dual_kernel);
+        else if (im_prefetch())
             fn = KV <= 1 ? reinterpret_cast<const void*>(bpr_item_major_kernel<4, true, false>)
                          : (KV <= 2 ? reinterpret_cast<const void*>(bpr_item_major_kernel<8, true, false>)
                                     : reinterpret_cast<const void*>(bpr_item_major_kernel<16, true, false>));
@@ -840,7 +849,7 @@ class BprHandle : public SgdHandle {
         const double queue_waves = static_cast<double>(waves) / nq;
         // rows a queue's waves hold between the load and the store of one update: the current and the prefetched
         // triple's, or -- when the row is re-read right before the store -- one L2 round trip out of a triple's time
-        const double inflight = (!im_prefetch() ? 0.25 : (c.fresh ? 0.5 : 2.0)) * queue_waves;
+        const double inflight = (!im_prefetch() ? 0.25 : (c.fresh ? 0.5 : 2.0)) * queue_waves * (im_dual() ? 2.0 : 1.0);
         const double tau = xcd_hot_tau_ * 1e-3;
         // the staleness budgets are stated for lr = 0.05 and scale with 1 / lr: what matters is how far a row moves
         int64_t sync_updates = xcd_sync_updates_ > 0 ? xcd_sync_updates_ : int64_t(1) << 23;

@@ -501,4 +501,240 @@ __global__ __launch_bounds__(256, K <= 4 ? (PIPE ? 5 : 6) : 1) void bpr_item_maj
     if (c.compute_loss && lane == 0 && loss != 0.0) atomicAdd(c.loss_out, loss);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Two triples per wave (vdim <= 128).  The walk above keeps one triple in flight per wave and spends ~2.5 us on each
+// (a dependent chain of one fabric round trip, a wave reduction, a table lookup and the stores) with half of the lanes
+// idle at d = 128.  Here the two half-waves walk two different slices side by side: a row is one dword per lane of the
+// half (element k * 32 + lane32, k < 4: every load / store / atomic instruction covers one full 128-B line per half, so
+// the flush needs no lane permutation), everything that is wave-uniform above becomes half-uniform (held per lane), the
+// control flow diverges by half where the two slices differ (new item, hot row, flush), and the only cross-lane steps --
+// the dot product's reduction and the metadata broadcast -- run for both halves at once.  Same schedule, same flush /
+// replica / hot-row rules, same sampler; the drain launch and the test hooks stay with the kernel above.
+// ------------------------------------------------------------------------------------------------
+struct HRow { float v[4]; };
+
+__device__ __forceinline__ float half_sum(float v, int half) {   // sum over the 32 lanes of each half; every lane gets its half's total
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));  // row_ror:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));  // row_ror:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));  // row_ror:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));  // row_ror:1
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return half ? (r2 + r3) : (r0 + r1);
+}
+__device__ __forceinline__ void hrow_load(HRow& r, const float* rp, int nk) {   // rp = row + lane32; past the L1 (sc1)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r.v[k] = k < nk ? __hip_atomic_load(rp + k * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+}
+__device__ __forceinline__ void hrow_store(const HRow& r, float* rp, int nk) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (k < nk) rp[k * 32] = r.v[k];
+}
+__device__ __forceinline__ void hrow_atomic_add(const HRow& r, float* rp, int nk) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (k < nk) atomic_add_f32(rp + k * 32, r.v[k]);
+}
+
+__global__ __launch_bounds__(256, 6) void bpr_item_major_dual_kernel(SgdParams p, BprConsts c, ImQueues q) {
+    const int lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31;
+    const int vdim = p.vdim;
+    // elements this lane holds: k * 32 + l32 < vdim
+    const int nk = l32 < vdim ? (vdim - l32 + 31) / 32 : 0;
+    const int qq = q.xcd_queue[xcc_id_raw()];
+    if (qq < 0) return;   // a workgroup on an XCD the probe did not see: the drain launch covers whatever is left
+    float* const Qrep = c.rep_Q + static_cast<size_t>(qq) * c.rep_stride;
+    float* const Qbrep = c.rep_Qb + static_cast<size_t>(qq) * c.rep_bstride;
+    float* const Prep = q.rep_P ? q.rep_P + static_cast<size_t>(qq) * q.rep_pstride : p.P;
+    const int64_t n_tickets = q.t_end[qq] - q.t_beg[qq];
+    if (n_tickets <= 0) return;
+
+    // per half (the same value in its 32 lanes)
+    int cur_i = -1, since_flush = 0, flush_n = 64;
+    HRow qi, dqi, qi_re, pu, qj;
+    float bi = 0.f, dbi_acc = 0.f, bi_re = 0.f, bj = 0.f;
+    bool re_pending = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { qi.v[k] = 0.f; dqi.v[k] = 0.f; qi_re.v[k] = 0.f; pu.v[k] = 0.f; qj.v[k] = 0.f; }
+    double loss = 0.0;
+    unsigned long long processed = 0;
+
+    auto flush_item = [&](bool reload) {   // see bpr_item_major_kernel: one atomic row add, `reload` = the add returns the row
+        if (cur_i < 0) return;
+        float* Qi = p.Q + static_cast<size_t>(cur_i) * vdim + l32;
+        re_pending = false;
+        if (reload && c.update_i) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                qi_re.v[k] = k < nk ? __hip_atomic_fetch_add(Qi + k * 32, dqi.v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + dqi.v[k] : 0.f;
+            if (c.use_bias) {
+                // lane32 0 adds; every lane of the half needs the result: all of them read the row's bias after the add is
+                // issued would race with it, so the adding lane's value is spread with a half-wide readlane below
+                float now = 0.f;
+                if (l32 == 0) now = __hip_atomic_fetch_add(p.Qb + cur_i, dbi_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + dbi_acc;
+                bi_re = now;   // valid in lane32 0 only; broadcast by the caller (uniform control flow)
+            }
+            re_pending = true;
+        } else if (c.update_i) {
+            hrow_atomic_add(dqi, Qi, nk);
+            if (c.use_bias && l32 == 0) atomic_add_f32(p.Qb + cur_i, dbi_acc);
+        } else if (reload) {   // frozen positives: nothing to push, just refresh the row
+            hrow_load(qi_re, Qi, nk);
+            if (c.use_bias) bi_re = coh_load(p.Qb + cur_i);
+            re_pending = true;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dqi.v[k] = 0.f;
+        dbi_acc = 0.f;
+        since_flush = 0;
+    };
+
+    for (;;) {
+        // ---- two tickets: slice A for half 0, slice B for half 1 ----
+        int64_t tk = 0;
+        if (lane == 0) tk = static_cast<int64_t>(atomicAdd(q.tickets + qq, 2));
+        tk = __builtin_amdgcn_readfirstlane(static_cast<int>(tk));
+        if (tk >= n_tickets) break;
+        int n_sl[2];
+        int it_[2], u_[2], ng_[2], pl_[2];   // metadata of triple `lane` of slice A / B
+#pragma unroll
+        for (int sidx = 0; sidx < 2; ++sidx) {
+            it_[sidx] = -1; u_[sidx] = -1; ng_[sidx] = -1; pl_[sidx] = 0;
+            n_sl[sidx] = 0;
+            if (tk + sidx >= n_tickets) continue;
+            const int64_t slice = static_cast<int64_t>((static_cast<unsigned long long>(q.t_beg[qq] + tk + sidx) * static_cast<unsigned long long>(q.q_stride[qq])) %
+                                                       static_cast<unsigned long long>(q.q_slices[qq]));
+            const int64_t t0 = slice * q.slice_len;
+            const int n_here = static_cast<int>((q.q_triples[qq] - t0) < q.slice_len ? (q.q_triples[qq] - t0) : q.slice_len);
+            n_sl[sidx] = n_here;
+            if (lane < n_here) {
+                const int64_t t = t0 + lane;
+                const int64_t e = q.q_beg[qq] + t / c.num_neg;
+                const uint32_t slot = static_cast<uint32_t>(t % c.num_neg);
+                it_[sidx] = static_cast<int>(q.ent_key[e] % static_cast<uint32_t>(p.Q_rows));
+                const int64_t pos_idx = q.ent_pos[e];
+                u_[sidx] = p.rows[pos_idx];
+                if (q.neg_pre) {
+                    ng_[sidx] = q.neg_pre[pos_idx * c.num_neg + slot];
+                } else {
+                    const int64_t ubeg = (u_[sidx] == 0 ? 0 : p.indptr[u_[sidx] - 1]) - p.shift;
+                    const int64_t uend = p.indptr[u_[sidx]] - p.shift;
+                    ng_[sidx] = bpr_sample_negative(p, c, static_cast<uint64_t>(p.nnz_offset + p.shift + pos_idx), slot, ubeg, uend);
+                }
+                pl_[sidx] = (q.hot_user[u_[sidx]] ? 1 : 0) | (c.hot[ng_[sidx]] ? 2 : 0);
+            }
+        }
+        const int n_mine = half ? n_sl[1] : n_sl[0];
+        const int n_max = n_sl[0] > n_sl[1] ? n_sl[0] : n_sl[1];
+        int prev_u = -1, prev_neg = -1;
+        bool prev_hj = false;
+
+        for (int j = 0; j < n_max; ++j) {
+            // half-uniform metadata of this step (readlanes for both halves, one select)
+            const int item = half ? __builtin_amdgcn_readlane(it_[1], j) : __builtin_amdgcn_readlane(it_[0], j);
+            const int u = half ? __builtin_amdgcn_readlane(u_[1], j) : __builtin_amdgcn_readlane(u_[0], j);
+            const int neg = half ? __builtin_amdgcn_readlane(ng_[1], j) : __builtin_amdgcn_readlane(ng_[0], j);
+            const int pol = half ? __builtin_amdgcn_readlane(pl_[1], j) : __builtin_amdgcn_readlane(pl_[0], j);
+            const int jn = j + 1 < 64 ? j + 1 : 63;
+            const int item_next = half ? __builtin_amdgcn_readlane(it_[1], jn) : __builtin_amdgcn_readlane(it_[0], jn);
+            const bool act = j < n_mine;
+            const bool at_u = (pol & 1) != 0, at_j = (pol & 2) != 0;
+            const bool same = item == neg;
+            float* const Pu = (at_u ? p.P : Prep) + static_cast<size_t>(act ? u : 0) * vdim + l32;
+            float* const Qj = (at_j ? p.Q : Qrep) + static_cast<size_t>(act ? neg : 0) * vdim + l32;
+            float* const Bj = (at_j ? p.Qb : Qbrep) + (act ? neg : 0);
+            if (act) {
+                if (u != prev_u) hrow_load(pu, Pu, nk);                       // else: consecutive slots of one entry carry the row
+                if (!(neg == prev_neg && at_j == prev_hj)) {
+                    hrow_load(qj, Qj, nk);
+                    if (c.use_bias) bj = coh_load(Bj);
+                }
+                if (item != cur_i) {
+                    flush_item(false);
+                    cur_i = item;
+                    flush_n = q.flush_every[item];
+                    hrow_load(qi, p.Q + static_cast<size_t>(item) * vdim + l32, nk);
+                    if (c.use_bias) bi = coh_load(p.Qb + item);
+                }
+            }
+            // ---- score + sigmoid table (bpr.cc:119-131) ----
+            float part = 0.f;
+            if (act) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) part += pu.v[k] * (qi.v[k] - qj.v[k]);
+            }
+            float x = half_sum(part, half);
+            if (c.use_bias) x += (bi - bj);
+            float logit = 0.f;
+            if (act) {
+                if (6.0f < x) logit = 0.0f;
+                else if (x < -6.0f) logit = 1.0f;
+                else logit = c.exp_table[static_cast<int>((x + 6.0f) * 83.0f)];
+                if (c.compute_loss) loss += static_cast<double>(log1pf(__expf(-fminf(fmaxf(x, -6.f), 6.f))));
+            }
+            bool want_flush = false;
+            if (act) {
+                // ---- bpr.cc:157-171 (Q-1: the user step sees the updated item rows) ----
+                HRow dj, dpu;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float idv = logit * pu.v[k];
+                    const float di = c.update_i ? c.lr * (idv - c.reg_i * qi.v[k]) : 0.f;
+                    qi.v[k] += di;
+                    dqi.v[k] += di;
+                    if (same) qj.v[k] = qi.v[k];
+                    dj.v[k] = c.update_j ? c.lr * (-idv - c.reg_j * qj.v[k]) : 0.f;
+                    qj.v[k] += dj.v[k];
+                    if (same) { qi.v[k] = qj.v[k]; dqi.v[k] += dj.v[k]; }
+                    dpu.v[k] = c.lr * (logit * (qi.v[k] - qj.v[k]) - c.reg_u * pu.v[k]);
+                    pu.v[k] += dpu.v[k];
+                }
+                float dbj = 0.f;
+                if (c.use_bias) {
+                    const float dbi = c.update_i ? c.lr * (logit - c.reg_b * bi) : 0.f;
+                    bi += dbi;
+                    dbi_acc += dbi;
+                    if (same) bj = bi;
+                    dbj = c.update_j ? c.lr * (-logit - c.reg_b * bj) : 0.f;
+                    bj += dbj;
+                    if (same) { bi = bj; dbi_acc += dbj; }
+                }
+                // ---- write the two per-triple rows back ----
+                if (at_u) hrow_atomic_add(dpu, Pu, nk);
+                else hrow_store(pu, Pu, nk);
+                if (c.update_j && !same) {
+                    if (at_j) hrow_atomic_add(dj, Qj, nk);
+                    else hrow_store(qj, Qj, nk);
+                    if (c.use_bias && l32 == 0) {
+                        if (at_j) atomic_add_f32(Bj, dbj);
+                        else *Bj = bj;
+                    }
+                }
+                processed += 1;
+                since_flush += 1;
+                prev_u = u; prev_neg = neg; prev_hj = at_j;
+                want_flush = since_flush >= flush_n && j + 1 < n_mine && item_next == item;
+            }
+            // a row re-read behind the previous flush has arrived by now: it carries the other waves' steps.  The bias came back
+            // in lane32 0 only: spread it (uniform control flow)
+            const float bre0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bi_re), 0));
+            const float bre1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bi_re), 32));
+            if (act && re_pending) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) qi.v[k] = qi_re.v[k] + dqi.v[k];
+                if (c.use_bias) bi = (c.update_i ? (half ? bre1 : bre0) : bi_re) + dbi_acc;
+                re_pending = false;
+            }
+            if (want_flush) flush_item(true);
+        }
+        if (n_mine > 0) flush_item(false);
+        cur_i = -1;
+    }
+    if (l32 == 0 && processed) atomicAdd(q.done, processed);
+    if (c.compute_loss && l32 == 0 && loss != 0.0) atomicAdd(c.loss_out, loss);
+}
+
 }  // namespace bfh

@@ -157,6 +157,11 @@ def test_triples_parallel_disjoint_rows(oracle):
     (128, dict(num_negative_samples=2), dict(im_user_replicas=0)),       # one owner XCD per user (the big-shard form) on this small matrix
     (128, dict(num_negative_samples=2), dict(im_user_replicas=1, xcd_sync_updates=1024)),   # per-XCD replicas of P, several merges
     (64, {}, dict(im_user_replicas=1, n_chunks=3)),      # replicas over a row range per call
+    (128, {}, dict(im_dual=1)),                          # two triples per wave (bpr_item_major_dual_kernel)
+    (96, dict(num_negative_samples=3), dict(im_dual=1, xcd_sync_updates=1024)),
+    (128, dict(num_negative_samples=2, use_bias=False), dict(im_dual=1, im_max_stale=1, xcd_hot_tau=1)),   # flush every triple, atomic rows
+    (40, dict(update_j=False), dict(im_dual=1, im_presample=0, im_user_replicas=1)),
+    (32, dict(update_i=False), dict(im_dual=1, n_chunks=3)),
 ])
 def test_item_major_conflict_free(oracle, d, kw, modes):
     """hogwild_atomic=3 (item-major walk, users owned by XCDs, Q[i] in registers, Q[j] in per-XCD replicas):
@@ -308,7 +313,7 @@ def test_compute_loss_matches_oracle(oracle):
     assert abs(got - want) < 1e-5 * max(1.0, abs(want))
 
 
-@pytest.mark.parametrize("atomic", [1, 0, 2, 3, 30, 31])
+@pytest.mark.parametrize("atomic", [1, 0, 2, 3, 30, 31, 32])
 def test_hogwild_statistical_parity(oracle, atomic):
     """Throughput mode vs the threaded reference path: same ranking quality on planted low-rank data
     (mirrors the ndcg threshold test, tests/algo/test_bpr.py:38-47).  With fp32 atomics no update is
@@ -326,7 +331,10 @@ def test_hogwild_statistical_parity(oracle, atomic):
     H.run_oracle_sgd(oracle.OracleBPRMF, opt, csr, Po, Qo, Qbo, epochs=30)
     P, Q, Qb = H.pad(P0, vdim), H.pad(Q0, vdim), Qb0.copy()
     extra = {}
-    if atomic >= 30:      # item-major with users owned by one XCD each (30) / with per-XCD replicas of P (31); 3 = by shard size
+    if atomic == 32:      # item-major, two triples per wave
+        extra["im_dual"] = 1
+        atomic = 3
+    elif atomic >= 30:    # item-major with users owned by one XCD each (30) / with per-XCD replicas of P (31); 3 = by shard size
         extra["im_user_replicas"] = atomic - 30
         atomic = 3
     H.run_hip_sgd(CyBPR, opt, csr, P, Q, Qb, epochs=30, modes=dict(hogwild_atomic=atomic, chunk=64, **extra), resident=True)
