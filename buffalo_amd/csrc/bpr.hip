@@ -732,7 +732,10 @@ class BprHandle : public SgdHandle {
         BFH_HIP(hipGetLastError());
     }
     // two triples per wave (bpr_item_major_dual_kernel): vdim <= 128, rows read where they are used, not a test-hook run
-    bool im_dual() const { return im_dual_ > 0 && vdim_ <= 128 && !im_prefetch() && !im_single_wave_ && !im_drain_only_; }
+    // Measured (profiles/r02_dual_triples_per_wave.txt, same box): 4.95 -> 4.56 ms per launch (4.20 without the hot-user atomics, whose
+    // share grows because twice as many rows are held per queue); 16, 20 and 24 waves per CU give the same time -- the walk is at the
+    // fabric's ceiling there, so the kernel is built for 5 waves per SIMD (81 VGPRs, no scratch).  "im_dual" = 0 keeps the one-triple walk.
+    bool im_dual() const { return im_dual_ != 0 && vdim_ <= 128 && !im_prefetch() && !im_single_wave_ && !im_drain_only_; }
     void im_launch(const SgdParams& p, const BprConsts& c, const ImQueues& q, int64_t waves, bool drain) {
         if (!drain && im_dual()) {
             hipLaunchKernelGGL(bpr_item_major_dual_kernel, dim3(static_cast<unsigned>((waves + 3) / 4)), dim3(256), 0, stream, p, c, q);
@@ -880,7 +883,7 @@ class BprHandle : public SgdHandle {
         const double lr_steps_per_count = static_cast<double>(num_neg_) * (triples / cnt_triples) / static_cast<double>(segments) * c.lr;
         hipLaunchKernelGGL(im_item_flags_kernel, dim3((Q_rows_ + 255) / 256), dim3(256), 0, stream, itemcnt_.get(),
                            uniform_ ? nullptr : p.cum_table, cum_total_, Q_rows_, static_cast<double>(num_neg_), cnt_triples,
-                           uniform_ ? 1.0 / Q_rows_ : 0.0, inflight, tau, static_cast<double>(waves), max_stale, lr_steps_per_count,
+                           uniform_ ? 1.0 / Q_rows_ : 0.0, inflight, tau, static_cast<double>(waves) * (im_dual() ? 2.0 : 1.0), max_stale, lr_steps_per_count,
                            im_drift_budget_milli_ * 1e-3, hot_.get(), im_flush_.get());
         BFH_HIP(hipMemsetAsync(im_hot_user_.get(), 0, im_hot_user_.bytes(), stream));
         hipLaunchKernelGGL(im_user_flags_kernel, dim3((next_x - start_x + 255) / 256), dim3(256), 0, stream, p.indptr, start_x, next_x - start_x,

@@ -539,7 +539,7 @@ __device__ __forceinline__ void hrow_atomic_add(const HRow& r, float* rp, int nk
         if (k < nk) atomic_add_f32(rp + k * 32, r.v[k]);
 }
 
-__global__ __launch_bounds__(256, 6) void bpr_item_major_dual_kernel(SgdParams p, BprConsts c, ImQueues q) {
+__global__ __launch_bounds__(256, 5) void bpr_item_major_dual_kernel(SgdParams p, BprConsts c, ImQueues q) {
     const int lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31;
     const int vdim = p.vdim;
     // elements this lane holds: k * 32 + l32 < vdim

@@ -157,6 +157,8 @@ def test_triples_parallel_disjoint_rows(oracle):
     (128, dict(num_negative_samples=2), dict(im_user_replicas=0)),       # one owner XCD per user (the big-shard form) on this small matrix
     (128, dict(num_negative_samples=2), dict(im_user_replicas=1, xcd_sync_updates=1024)),   # per-XCD replicas of P, several merges
     (64, {}, dict(im_user_replicas=1, n_chunks=3)),      # replicas over a row range per call
+    (128, {}, dict(im_dual=0)),                          # one triple per wave at vdim <= 128 (the default there is two)
+    (128, dict(num_negative_samples=2), dict(im_dual=0, xcd_hot_tau=1)),
     (128, {}, dict(im_dual=1)),                          # two triples per wave (bpr_item_major_dual_kernel)
     (96, dict(num_negative_samples=3), dict(im_dual=1, xcd_sync_updates=1024)),
     (128, dict(num_negative_samples=2, use_bias=False), dict(im_dual=1, im_max_stale=1, xcd_hot_tau=1)),   # flush every triple, atomic rows
@@ -331,8 +333,8 @@ def test_hogwild_statistical_parity(oracle, atomic):
     H.run_oracle_sgd(oracle.OracleBPRMF, opt, csr, Po, Qo, Qbo, epochs=30)
     P, Q, Qb = H.pad(P0, vdim), H.pad(Q0, vdim), Qb0.copy()
     extra = {}
-    if atomic == 32:      # item-major, two triples per wave
-        extra["im_dual"] = 1
+    if atomic == 32:      # item-major, one triple per wave (vdim 32: the default is two)
+        extra["im_dual"] = 0
         atomic = 3
     elif atomic >= 30:    # item-major with users owned by one XCD each (30) / with per-XCD replicas of P (31); 3 = by shard size
         extra["im_user_replicas"] = atomic - 30
