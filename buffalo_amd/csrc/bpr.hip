@@ -735,7 +735,13 @@ class BprHandle : public SgdHandle {
     // Measured (profiles/r02_dual_triples_per_wave.txt, same box): 4.95 -> 4.56 ms per launch (4.20 without the hot-user atomics, whose
     // share grows because twice as many rows are held per queue); 16, 20 and 24 waves per CU give the same time -- the walk is at the
     // fabric's ceiling there, so the kernel is built for 5 waves per SIMD (81 VGPRs, no scratch).  "im_dual" = 0 keeps the one-triple walk.
-    bool im_dual() const { return im_dual_ != 0 && vdim_ <= 128 && !im_prefetch() && !im_single_wave_ && !im_drain_only_; }
+    // On small shards it loses (per-rank epoch at 4 shards 2.42 -> 2.54 ms, at 8 shards 1.31 -> 1.37: twice the rows held per queue
+    // on few users turns more of them hot), so by default it is used from 6144 users per queue up (1 and 2 GPUs on ML-20M).
+    bool im_dual() const { return im_dual_call_; }
+    void im_choose_dual(int64_t users_here, int nq) {
+        im_dual_call_ = im_dual_ != 0 && vdim_ <= 128 && !im_prefetch() && !im_single_wave_ && !im_drain_only_ &&
+                        (im_dual_ > 0 || users_here >= static_cast<int64_t>(nq) * 6144);
+    }
     void im_launch(const SgdParams& p, const BprConsts& c, const ImQueues& q, int64_t waves, bool drain) {
         if (!drain && im_dual()) {
             hipLaunchKernelGGL(bpr_item_major_dual_kernel, dim3(static_cast<unsigned>((waves + 3) / 4)), dim3(256), 0, stream, p, c, q);
@@ -789,6 +795,7 @@ class BprHandle : public SgdHandle {
         const int64_t blocks = im_blocks_ > 0 ? im_blocks_ : std::min<int64_t>(16, std::max<int64_t>(1, static_cast<int64_t>(std::ceil(c.lr * 160.0))));
         BFH_REQUIRE(static_cast<int64_t>(im_nq_) * blocks * Q_rows_ < (int64_t(1) << 32), "hogwild_atomic=3: too many items for the 32-bit sort key");
         const int nq = (im_single_wave_ && im_force_queues_ > 0) ? std::min(im_force_queues_, kImMaxQueues) : im_nq_;
+        im_choose_dual(next_x - start_x, nq);
         int slot = t_aux_.begin(stream);
         // ---- entries grouped by (owner queue of the user, item); cached for a resident matrix ----
         const bool keeps = resident_ || (auto_resident_ && !chunks_.empty());   // the staged chunk lives on in HBM under csr_generation_

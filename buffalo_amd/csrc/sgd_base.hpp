@@ -143,7 +143,8 @@ class SgdHandle : public HandleBase {
     int im_presample_ = 1;         // policy 3: draw the call's negatives in CSR order before the walk
     int im_presample_ahead_ = 1;   // ... and the next epoch's on a side stream while this epoch's walk runs
     int im_blocks_ = 0;            // policy 3: runs an item's entries are cut into inside a queue (0 = from the learning rate)
-    int im_dual_ = -1;             // policy 3: two triples per wave at vdim <= 128 (bpr_item_major_dual_kernel); -1 / 1: on, 0: off
+    bool im_dual_call_ = false;    // decided per call (im_choose_dual)
+    int im_dual_ = -1;             // policy 3: two triples per wave at vdim <= 128 (bpr_item_major_dual_kernel); -1: from 6144 users per queue up, 1: always, 0: never
     int im_neg_limit_ = 0;         // policy 3 study knob: fold the uniform negatives into the first rows of Q
     int im_p_nt_ = 0;              // policy 3 study knob: non-temporal hint on the per-triple P rows
     int im_user_replicas_ = -1;    // policy 3: per-XCD replicas of P instead of one owner XCD per user (-1: for small shards, 0 / 1)

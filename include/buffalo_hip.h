@@ -164,7 +164,8 @@ int bfh_als_synchronize(void* h, int device_to_host);
  *   "xcd_merge_mean"   1 = average instead of sum the replicas' deltas;  "xcd_hot_tau" (permille) tolerated collision
  *                      probability of a plainly stored row, above it the row is updated with atomics;
  *   "im_max_stale"     (3) updates of one item row in flight unseen by the other waves, stated at lr 0.05 (scales 1/lr; default 16);
- *   "im_dual"          (3) 1 (default) = two triples per wave at vdim <= 128 (the half-waves walk two slices side by side), 0 = one;
+ *   "im_dual"          (3) two triples per wave at vdim <= 128 (the half-waves walk two slices side by side): -1 (default) = for calls
+ *                      with 6144 users per queue or more, 1 = always, 0 = never;
  *   "im_user_replicas" (3) 1 = per-XCD replicas of P (entries spread over the queues by position, delta rule at the merges)
  *                      instead of one owner XCD per user; -1 (default) = when a call has fewer than 3072 users per queue
  *                      (the shards of an 8-GPU ML-20M run) and lr <= 0.01, 0 = never;
