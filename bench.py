@@ -424,8 +424,10 @@ def main():
     os.unlink(path)
     obj.sync_every_epoch = False           # keep the model in HBM inside the timed region
     hog = "3"                               # the backend's default for sgd (bfh_bpr_set_mode "hogwild_atomic")
+    knobs = {}
     for kv in args.mode:
         k, v = kv.split("=")
+        knobs[k] = v
         obj.set_mode(k, int(v))
         if k == "hogwild_atomic":
             hog = v
@@ -503,6 +505,8 @@ def main():
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        # the library's own rule for the two-triples-per-wave walk (bfh_bpr_set_mode "im_dual"): vdim <= 128 and >= 6144 users per queue
+        dual_walk = hog == "3" and knobs.get("im_dual", "-1") != "0" and (knobs.get("im_dual", "-1") == "1" or n_local_users >= 8 * 6144)
         out = {
             "metric": "BPRMF training throughput (interactions/s), ML-20M-shaped synthetic, d=128",
             "value": updates / elapsed, "unit": "updates/s", "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -519,13 +523,15 @@ def main():
                                    "2": "per-XCD item-factor replicas (plain stores through the XCD's L2, merged by the delta rule "
                                         "%.1f times per epoch); popular rows stay chip-wide on fp32 atomics"
                                         % (st["merges"] / max(steps, 1)),
-                                   "3": "item-major walk: users owned by XCDs (plain stores through the owner's L2), the positive "
+                                   "3": "item-major walk%s: users owned by XCDs (plain stores through the owner's L2), the positive "
                                         "item row in registers with bounded-staleness atomic flushes, negatives in per-XCD replicas "
-                                        "merged by the delta rule %.1f times per epoch" % (st["merges"] / max(steps, 1))}[hog]},
+                                        "merged by the delta rule %.1f times per epoch"
+                                        % (", two triples per wave" if dual_walk else "", st["merges"] / max(steps, 1))}[hog]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": "profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)",
-                         "kernel": "bpr_item_major_kernel" if hog == "3" else "bpr_update_kernel", "kernel_ms": kernel_ms,
+                         "kernel": ("bpr_item_major_dual_kernel" if dual_walk else "bpr_item_major_kernel") if hog == "3" else "bpr_update_kernel",
+                         "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "launches_per_step": st["launches"] / max(steps, 1),
                          # the same bytes over ALL device time of a step (update launches + replica broadcast / merge kernels)

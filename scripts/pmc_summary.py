@@ -12,13 +12,13 @@ meta = {}
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if not any(t in k for t in ("bpr_item_major_kernel", "bpr_update_kernel", "grad_gather_kernel", "warp_update_kernel", "als_gram_kernel",
+        if not any(t in k for t in ("bpr_item_major_kernel", "bpr_item_major_dual_kernel", "bpr_update_kernel", "grad_gather_kernel", "warp_update_kernel", "als_gram_kernel",
                                     "xcd_merge_kernel", "bpr_presample_kernel")):
             continue
         per[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         meta[k] = {"vgpr": r.get("VGPR_Count"), "sgpr": r.get("SGPR_Count"), "grid": r.get("Grid_Size"), "wg": r.get("Workgroup_Size")}
 # the dominant kernel = the one with the largest total FETCH_SIZE (the drain instantiation finds nothing to do)
-bpr = [k for k in per if "bpr_item_major_kernel" in k or "bpr_update_kernel" in k]
+bpr = [k for k in per if "bpr_item_major_kernel" in k or "bpr_item_major_dual_kernel" in k or "bpr_update_kernel" in k]
 dom = max(bpr, key=lambda k: sum(per[k].get("FETCH_SIZE", [0.0])))
 c = {n: sum(v) / len(v) for n, v in per[dom].items()}
 out = {
