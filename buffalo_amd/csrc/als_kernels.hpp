@@ -1698,6 +1698,7 @@ class AlsHandle : public HandleBase {
         unpin_host();
         if (pin_host_) {   // the updated rows go back into these arrays after every partial_update (als.cu:403): page-lock them
             for (auto pr : {std::make_pair(static_cast<void*>(P), np * sizeof(float)), std::make_pair(static_cast<void*>(Q), nq * sizeof(float))}) {
+                if (pr.second < (size_t(1) << 20)) continue;   // small arrays share heap pages with other objects: see SgdHandle::initialize_model
                 if (hipHostRegister(pr.first, pr.second, hipHostRegisterDefault) == hipSuccess) pinned_.push_back(pr.first);
                 else (void)hipGetLastError();
             }

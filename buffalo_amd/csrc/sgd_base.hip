@@ -650,7 +650,11 @@ void SgdHandle::initialize_model(float* P, int P_rows, float* Q, float* Qb, int 
     const size_t np = static_cast<size_t>(P_rows) * vdim_, nq = static_cast<size_t>(Q_rows) * vdim_;
     unpin_host();
     if (pin_host_) {   // best effort: a refusal (already registered, exotic memory) just leaves the copies pageable
+        // only arrays of a MiB or more: those sit in pages of their own (malloc hands them out by mmap); a small array shares its
+        // pages with whatever else lives on the heap -- including arrays another handle has registered -- and overlapping
+        // registrations have aborted inside the runtime (seen once in tests/test_errors_gpu.py, on 1.5 KB factors)
         auto pin = [&](void* p, size_t bytes) {
+            if (bytes < (size_t(1) << 20)) return;
             if (hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess) pinned_.emplace_back(p, bytes);
             else (void)hipGetLastError();
         };
