@@ -164,6 +164,8 @@ int bfh_als_synchronize(void* h, int device_to_host);
  *   "xcd_merge_mean"   1 = average instead of sum the replicas' deltas;  "xcd_hot_tau" (permille) tolerated collision
  *                      probability of a plainly stored row, above it the row is updated with atomics;
  *   "im_max_stale"     (3) updates of one item row in flight unseen by the other waves, stated at lr 0.05 (scales 1/lr; default 16);
+ *   "im_p_nt", "im_neg_limit"  (3) study knobs (non-temporal hint on the P rows; uniform negatives folded into the first rows
+ *                      of Q): DESIGN.md 4.1 "what bounds it" -- not for training;
  *   "im_dual"          (3) two triples per wave at vdim <= 128 (the half-waves walk two slices side by side): -1 (default) = for calls
  *                      with 6144 users per queue or more, 1 = always, 0 = never;
  *   "im_user_replicas" (3) 1 = per-XCD replicas of P (entries spread over the queues by position, delta rule at the merges)
@@ -282,7 +284,14 @@ int bfh_topk_dot_topn_device(void* h, const int32_t* indexes, int num_queries, c
  * higher column index first (std::nth_element leaves that unspecified). */
 int bfh_topk_quickselect(void* h, const float* scores, int rows, int cols, int32_t* result, int k, int sorted);
 /* "flt_min_rule" (default 1): 0 admits every score in bfh_topk_dot_topn[_device] -- the selection the
- * validation loop gets from numpy scores + quickselect (algo/base.py:40-55 of the reference). */
+ * validation loop gets from numpy scores + quickselect (algo/base.py:40-55 of the reference).
+ * "fused" (default -1): -1 = sweeps of 8192 queries x 8192 candidates or more at d <= 128 take the fused path (thresholds
+ * from a column sample, filtered score sweep that writes only candidates, wave-per-row selection; results identical to the
+ * dense path), 0 = always the dense score buffer + select, 1 = fused whenever d <= 128; "fused_c0" (with "fused" = 1): the
+ * exact number of sampled columns (tests); "wave_select" (default 1): 0 = block-per-row selection inside the fused path;
+ * "fast_select" (default 1): 0 = the dense select's multi-pass radix path only.
+ * bfh_topk_get_stats: kernel_ms = score kernels, aux_ms = everything else; merges = rows the fused path handed back to the
+ * dense path, exchanges = rows whose ties at the k-th place went to the block-level list selection. */
 int bfh_topk_set_mode(void* h, const char* name, int64_t value);
 int bfh_topk_get_stats(void* h, bfh_stats* out);
 int bfh_topk_reset_stats(void* h);
