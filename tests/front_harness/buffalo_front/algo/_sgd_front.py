@@ -104,8 +104,7 @@ class SgdFront(Algo, Evaluable):
         self.obj.set_placeholder(indptr, batch_size)
         self.obj.initialize_model(self.P, self.Q, self.Qb, self.num_nnz, True)
 
-    def _finalize_train(self):  # bpr.py:211-217
-        self.obj.synchronize(True)
+    def _finalize_train(self):  # bpr.py:211-217 (the model came back with the last update_parameters, cuda/_bpr.pyx:59-60)
         self.P = self.P[:, :self.opt.d]
         self.Q = self.Q[:, :self.opt.d]
         return 0.0

@@ -8,7 +8,7 @@ import logging
 
 import numpy as np
 
-from ..misc import Option
+from ..misc import Option, load_option
 
 EPS = 1e-8
 
@@ -25,7 +25,7 @@ class Algo:
     def get_option(self, opt_path):  # base.py:19-26
         if isinstance(opt_path, (dict, Option)):
             opt_path = self.create_temporary_option_from_dict(opt_path)
-        opt = Option(opt_path)
+        opt = load_option(opt_path)
         self.is_valid_option(opt)
         return Option(opt), opt_path
 
@@ -110,6 +110,32 @@ class Algo:
         self._idmanager.userids = ids
         self._idmanager.userid_map = {v: idx for idx, v in enumerate(ids)}
         self._idmanager.userid_mapped = True
+
+    def get_index(self, keys, group="item"):
+        """base.py:226-250: index (or list of indices) of the given key(s) in the id map of `group`; None where a key is unknown."""
+        many = isinstance(keys, list)
+        m = self._idmanager
+        if group == "item":
+            if not m.itemid_mapped:
+                self.build_itemid_map()
+            table = m.itemid_map
+        elif group == "user":
+            if not m.userid_mapped:
+                self.build_userid_map()
+            table = m.userid_map
+        else:
+            table = None
+        found = [] if table is None else [table.get(k) for k in (keys if many else [keys])]
+        return found if many else found[0]
+
+    def get_index_pool(self, pool, group="item"):
+        """base.py:252-268: a list of keys becomes the array of the indices that exist (unknown keys are DROPPED here, which is
+        why the Par* classes' returned key list can slip against the indices); an ndarray passes through."""
+        if isinstance(pool, list):
+            return np.array([i for i in self.get_index(pool, group) if i is not None])
+        if isinstance(pool, np.ndarray):
+            return pool
+        raise ValueError("Unexpected type for pool: %s" % type(pool))
 
     # -- Serializable (base.py:271-318): files are byte-compatible with stock buffalo, see buffalo_amd/serialize.py
     def save(self, path=None, with_itemid_map=True, with_userid_map=True, data_fields=()):

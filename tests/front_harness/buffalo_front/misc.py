@@ -1,6 +1,6 @@
-"""Option plumbing shared by the algo front: same behaviour as buffalo.misc.aux
-(/root/reference/buffalo/misc/_aux.py:16-89): attribute dict, default/type validation and the
-dict -> temporary JSON file hand-off the native backends are initialised from."""
+"""Option plumbing shared by the algo front (cf. /root/reference/buffalo/misc/_aux.py:16-89): the attribute dict is the
+product's own `buffalo_amd.serialize.Option`; here are the default / type validation and the dict -> temporary JSON file
+hand-off the native backends are initialised from."""
 import abc
 import atexit
 import json
@@ -10,39 +10,15 @@ import tempfile
 _temporary_files = []
 
 
-class Option(dict):
-    def __init__(self, *args, **kwargs):
-        def read(fname):
-            with open(fname) as fin:
-                return json.load(fin)
-        args = [arg if isinstance(arg, dict) else read(arg) for arg in args]
-        super().__init__(*args, **kwargs)
-        for src in list(args) + [kwargs]:
-            for k, v in src.items():
-                self[k] = Option(v) if isinstance(v, dict) else v
+from buffalo_amd.serialize import Option   # noqa: E402,F401 -- the product's attribute dict (it pickles like buffalo.misc._aux.Option)
 
-    def __getattr__(self, attr):
-        return self.get(attr)
 
-    def __setattr__(self, key, value):
-        self.__setitem__(key, value)
-
-    def __setitem__(self, key, value):
-        super().__setitem__(key, value)
-        self.__dict__.update({key: value})
-
-    def __delattr__(self, item):
-        self.__delitem__(item)
-
-    def __delitem__(self, key):
-        super().__delitem__(key)
-        del self.__dict__[key]
-
-    def __getstate__(self):
-        return vars(self)
-
-    def __setstate__(self, state):
-        vars(self).update(state)
+def load_option(src):
+    """`Option(path)` of the reference reads the JSON file behind the path (_aux.py:17-24); a dict is taken as it is."""
+    if isinstance(src, dict):
+        return Option(src)
+    with open(src) as fin:
+        return Option(json.load(fin))
 
 
 class InputOptions(abc.ABC):
