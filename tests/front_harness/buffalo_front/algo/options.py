@@ -1,4 +1,4 @@
-"""ALSOption / BPRMFOption / WARPOption: key names, defaults and validation are part of the ABI
+"""ALSOption / BPRMFOption / WARPOption / CFROption / EALSOption: key names, defaults and validation are part of the ABI
 (the backends parse the JSON dump of these dicts) -- /root/reference/buffalo/algo/options.py:4-311.
 Only deviation: `accelerator` defaults to True because this package has no CPU backend."""
 from ..misc import InputOptions, Option
@@ -63,3 +63,31 @@ class WARPOption(AlgoOption):
             "data_opt": {},
         })
         return Option(opt)
+
+
+class EALSOption(AlgoOption):
+    def get_default_option(self):  # options.py:102-132
+        opt = super().get_default_option()
+        opt.update({
+            "save_factors": False, "d": 20, "num_iters": 10, "num_workers": 1, "reg_u": 0.1, "reg_i": 0.1, "alpha": 8.0,
+            "c0": 512.0, "exponent": 0.5, "model_path": "", "data_opt": {},
+        })
+        return Option(opt)
+
+
+class CFROption(AlgoOption):
+    def get_default_option(self):  # options.py:139-177
+        opt = super().get_default_option()
+        opt.update({
+            "save_factors": False, "d": 20, "num_iters": 10, "num_workers": 1, "num_cg_max_iters": 3, "cg_tolerance": 1e-10,
+            "eps": 1e-10, "reg_u": 0.1, "reg_i": 0.1, "reg_c": 0.1, "alpha": 8.0, "l": 1.0, "optimizer": "manual_cg",
+            "model_path": "", "data_opt": {},
+        })
+        return Option(opt)
+
+    def is_valid_option(self, opt):  # options.py:179-186
+        b = super().is_valid_option(opt)
+        possible = ["llt", "ldlt", "manual_cg", "eigen_cg", "eigen_bicg", "eigen_gmres", "eigen_dgmres", "eigen_minres"]
+        if opt.optimizer not in possible:
+            raise RuntimeError(f"optimizer ({opt.optimizer}) should be in {possible}")
+        return b

@@ -217,14 +217,42 @@ class BufferedDataMatrix:
         self.group = "rowwise"
         self.major = {"rowwise": {}, "colwise": {}}
 
+    # -- CFR's feeding (buffered_data.py:122-158): row ranges sized by the SUM of several groups' entries, chunks cut on demand
+    def fetch_batch_range(self, groups):
+        """Yield (start_x, next_x) ranges such that the entries of all `groups` inside a range fit batch_mb at 8 bytes each.
+        The last row on its own is never yielded (the reference stops once next_x + 1 reaches the row count, like Q-24)."""
+        total = sum(np.asarray(self.data.get_group(G)["indptr"], dtype=np.int64) for G in groups)
+        budget = max(int(self.data.opt.data.batch_mb * 1024 * 1024 / 8.), 64)
+        rows, start = len(total), 0
+        while True:
+            beg = int(total[start - 1]) if start else 0
+            nxt = bisect.bisect_left(total, beg + budget)
+            if nxt == start:
+                raise RuntimeError("Need more memory to load the data, cannot load data with buffer size %d that should be at "
+                                   "least %d. Increase batch_mb value to deal with this." % (budget, total[nxt] - beg))
+            yield start, nxt
+            if nxt + 1 >= rows:
+                return
+            start = nxt
+
+    def get_specific_chunk(self, group, start_x, next_x):
+        """(full END-offset indptr of `group`, its keys and values for rows [start_x, next_x))."""
+        g = self.data.get_group(group)
+        indptr = self.major[group]["indptr"] if group in self.major and self.major[group] else g["indptr"]
+        beg = int(indptr[start_x - 1]) if start_x else 0
+        end = int(indptr[next_x - 1])
+        return indptr, g["key"][beg:end], g["val"][beg:end]
+
     def get_indptrs(self):
         return (self.major["rowwise"]["indptr"], self.major["colwise"]["indptr"], self.major["rowwise"]["limit"])
 
-    def initialize(self, data):
+    def initialize(self, data, with_sppmi=False):
         self.data = data
         limit = max(int((self.data.opt.data.batch_mb * 1024 * 1024) / 16.), 64)
         need = 0
-        for G in ("rowwise", "colwise"):
+        if with_sppmi:
+            self.major["sppmi"] = {}
+        for G in ("rowwise", "colwise") + (("sppmi",) if with_sppmi else ()):
             lim = int(limit / 2)
             g, header = data.get_group(G), data.get_header()
             m = self.major[G] = {"index": 0, "limit": lim, "start_x": 0, "next_x": 0,

@@ -91,6 +91,26 @@ class Recorder:
         Recorder.trace.append({"call": "partial_update", "args": self._chunk("partial_update", start_x, next_x, indptr, keys, vals) + [int(axis)]})
         return 3.0, 4.0
 
+    def partial_update_user(self, *args):
+        self._rec("partial_update_user", args)
+        return 1.5
+
+    def partial_update_item(self, *args):
+        self._rec("partial_update_item", args)
+        return 2.5
+
+    def partial_update_context(self, *args):
+        self._rec("partial_update_context", args)
+        return 0.75
+
+    def update(self, *args):                             # CyEALS.update -> bool (eals.py:131)
+        self._rec("update", args)
+        return True
+
+    def estimate_loss(self, *args):                      # CyEALS.estimate_loss -> (rmse, total)
+        self._rec("estimate_loss", args)
+        return 0.5, 12.0
+
     def __getattr__(self, name):
         if name.startswith("_"):
             raise AttributeError(name)
@@ -202,6 +222,67 @@ def reference_trace(name):
     ret = model.train()
     shapes = {k: list(getattr(model, k).shape) for k in ("P", "Q")}
     return {"trace": Recorder.trace, "train_returned": {k: float(v) for k, v in ret.items()}, "final_shapes": shapes}
+
+
+# ------------------------------------------------------------------------------------------------
+# CFR and EALS fronts (cfr.py, eals.py): same recording stand-in where CyCFR / CyEALS stand
+# ------------------------------------------------------------------------------------------------
+MORE_CASES = {
+    # name: (algo, matrix, batch_mb, option overrides)
+    "cfr_one_range": ("cfr", (50, 30, 0.2, 5), 1024, dict(d=12, num_iters=2, random_seed=3)),
+    "cfr_ranges": ("cfr", (70, 40, 0.25, 6), 0.006, dict(d=16, num_iters=2, random_seed=4, l=0.5)),
+    "eals": ("eals", (50, 30, 0.2, 7), 1024, dict(d=12, num_iters=3, random_seed=2, c0=2.0, exponent=0.5)),
+}
+
+
+def sppmi_like(I, seed):
+    """A symmetric item x item matrix with positive values in the layout of the `sppmi` group (what the matrix holds does not
+    matter to a call trace)."""
+    rng = np.random.default_rng(seed)
+    a, b = np.nonzero(np.triu(rng.random((I, I)) < 0.2, 1))
+    rows, cols = np.concatenate([a, b]), np.concatenate([b, a])
+    v = rng.random(len(a)).astype(np.float32) + 0.1
+    vals = np.concatenate([v, v])
+    order = np.lexsort((cols, rows))
+    return {"indptr": np.cumsum(np.bincount(rows, minlength=I)).astype(np.int64), "key": cols[order].astype(np.int32),
+            "val": vals[order].astype(np.float32)}
+
+
+def reference_trace_more(name):
+    from buffalo.algo.cfr import CFR
+    from buffalo.algo.eals import EALS
+    from buffalo.algo.options import CFROption, EALSOption
+    from buffalo.data.base import Data
+    from buffalo.data.mm import MatrixMarketOptions
+    from buffalo.data.stream import StreamOptions
+    algo, shape, batch_mb, over = MORE_CASES[name]
+    U, I, rows, cols, vals = case_matrix(*shape)
+
+    class MemData(Data):
+        name = "MemData"
+
+        def create_database(self, filename, **kwargs):
+            pass
+    dopt = (StreamOptions if algo == "cfr" else MatrixMarketOptions)().get_default_option()
+    dopt.data.batch_mb = batch_mb
+    if algo == "cfr":
+        dopt.data.internal_data_type = "matrix"           # cfr.py:52: the stream loader in matrix layout
+    data = MemData(dopt)
+    data.data_type = "stream" if algo == "cfr" else "matrix"
+    groups = groups_of(U, I, rows, cols, vals)
+    attrs = {"num_nnz": len(rows), "num_users": U, "num_items": I, "completed": 1}
+    if algo == "cfr":
+        groups["sppmi"] = sppmi_like(I, shape[3])
+        attrs["sppmi_nnz"] = len(groups["sppmi"]["key"])
+    data.handle = FakeH5(groups, attrs)
+    opt = (CFROption if algo == "cfr" else EALSOption)().get_default_option()
+    opt.update(over)
+    opt.update(dict(validation={}, evaluation_on_learning=False, save_best=False))
+    Recorder.trace = []
+    model = (CFR if algo == "cfr" else EALS)(opt, data=data)
+    model.initialize()
+    ret = model.train()
+    return {"trace": Recorder.trace, "train_returned": {k: float(v) for k, v in ret.items()}}
 
 
 # ------------------------------------------------------------------------------------------------
@@ -356,6 +437,7 @@ def reference_model_files():
 def main():
     install_reference()
     out = {name: reference_trace(name) for name in CASES}
+    out.update({name: reference_trace_more(name) for name in MORE_CASES})
     out["validation_metrics"] = reference_metrics()
     out["parallel"] = reference_par()
     out["model_files"] = reference_model_files()

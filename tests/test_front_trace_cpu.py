@@ -59,6 +59,61 @@ def test_harness_front_issues_the_reference_call_sequence(name, monkeypatch):
     assert got["train_returned"] == want["train_returned"] and got["final_shapes"] == want["final_shapes"]
 
 
+@pytest.mark.parametrize("name", sorted(G.MORE_CASES))
+def test_cfr_and_eals_fronts_issue_the_reference_call_sequence(name, monkeypatch):
+    """The same for the CFR and EALS fronts (f.4): set_embedding / precompute / partial_update_{user,item,context} with the row
+    ranges of BufferedDataMatrix.fetch_batch_range, and initialize_model (negative weights) / precompute_cache / update /
+    estimate_loss."""
+    import buffalo_front.algo.cfr as hc
+    import buffalo_front.algo.eals as he
+    from buffalo_front.algo.options import CFROption, EALSOption
+    from buffalo_front.data import Data, MatrixMarketOptions, StreamOptions
+    monkeypatch.setattr(hc, "CyCFR", G.Recorder)
+    monkeypatch.setattr(he, "CyEALS", G.Recorder)
+    algo, shape, batch_mb, over = G.MORE_CASES[name]
+    U, I, rows, cols, vals = G.case_matrix(*shape)
+    dopt = (StreamOptions if algo == "cfr" else MatrixMarketOptions)().get_default_option()
+    dopt.data.batch_mb = batch_mb
+    data = Data(dopt)
+    data.data_type = "stream" if algo == "cfr" else "matrix"
+    data.groups = G.groups_of(U, I, rows, cols, vals)
+    if algo == "cfr":
+        data.groups["sppmi"] = G.sppmi_like(I, shape[3])
+    data.header = {"num_nnz": len(rows), "num_users": U, "num_items": I, "completed": 1}
+    opt = (CFROption if algo == "cfr" else EALSOption)().get_default_option()
+    opt.update(over)
+    opt.update(dict(validation={}, evaluation_on_learning=False, save_best=False))
+    G.Recorder.trace = []
+    model = (hc.CFR if algo == "cfr" else he.EALS)(opt, data=data)
+    model.initialize()
+    ret = model.train()
+    got = json.loads(json.dumps({"trace": G.Recorder.trace, "train_returned": {k: float(v) for k, v in ret.items()}}, sort_keys=True))
+    want = GOLDEN[name]
+    calls_got, calls_want = [c["call"] for c in got["trace"]], [c["call"] for c in want["trace"]]
+    assert calls_got == calls_want, "call order differs:\n got  %s\n want %s" % (" ".join(calls_got), " ".join(calls_want))
+    for i, (g, w) in enumerate(zip(got["trace"], want["trace"])):
+        assert g == w, "call %d (%s) differs:\n got  %s\n want %s" % (i, w["call"], json.dumps(g)[:2000], json.dumps(w)[:2000])
+    assert got["train_returned"] == want["train_returned"]
+
+
+def test_every_recorded_call_fits_the_ctypes_mirror():
+    """Every call stock buffalo's fronts make on their Cython classes (all recorded traces) binds to a method of the matching
+    class of buffalo_amd.backend -- the ctypes mirror of the C ABI -- with the recorded number of positional arguments."""
+    import inspect
+
+    from buffalo_amd import backend
+    mirror = {"bpr": backend.CyBPR, "als": backend.CyALS, "cfr": backend.CyCFR, "eals": backend.CyEALS}
+    seen = set()
+    for name, (algo, *_rest) in list(G.CASES.items()) + list(G.MORE_CASES.items()):
+        cls = mirror[algo]
+        for c in GOLDEN[name]["trace"]:
+            fn = getattr(cls, c["call"], None)
+            assert fn is not None, "%s has no method %s" % (cls.__name__, c["call"])
+            inspect.signature(fn).bind(None, *c["args"])       # raises TypeError when the arity does not fit
+            seen.add((algo, c["call"]))
+    assert {("bpr", "add_jobs"), ("als", "partial_update"), ("cfr", "partial_update_item"), ("eals", "estimate_loss")} <= seen
+
+
 def test_validation_metrics_match_the_reference_evaluation_code(monkeypatch):
     """NDCG / MAP / accuracy / AUC / RMSE / error computed by the reference's own Evaluable (evaluate/base.py:44-148, run by the
     generator over seeded factors and a held-out group) against the stand-in front's evaluation and the NDCG helper the GPU
