@@ -153,6 +153,11 @@ CASES = {
                                                                    sampling_power=1.0, use_bias=False)),
     "als_one_chunk": ("als", (60, 40, 0.15, 3), 1024, dict(d=20, num_iters=2, random_seed=7)),
     "als_chunked": ("als", (90, 50, 0.2, 4), 0.004, dict(d=40, num_iters=2, random_seed=9, compute_loss_on_training=False)),
+    # WARP: the reference's front refuses accelerator = True in its constructor (warp.py:30-32, "not implemented yet") but carries the
+    # same accelerator scaffold as BPRMF in _prepare_train / _finalize_train (warp.py:212-234).  The object is built with
+    # accelerator = False and switched before train(): the trace is what that scaffold would ask of a GPU WARP.
+    "warp_scaffold": ("warp", (60, 40, 0.15, 6), 1024, dict(d=24, num_iters=2, random_seed=13, compute_loss_on_training=True)),
+    "warp_scaffold_chunked": ("warp", (90, 50, 0.2, 7), 0.004, dict(d=64, num_iters=2, random_seed=14, compute_loss_on_training=False)),
 }
 
 
@@ -197,7 +202,8 @@ class FakeH5(dict):
 def reference_trace(name):
     from buffalo.algo.als import ALS
     from buffalo.algo.bpr import BPRMF
-    from buffalo.algo.options import ALSOption, BPRMFOption
+    from buffalo.algo.options import ALSOption, BPRMFOption, WARPOption
+    from buffalo.algo.warp import WARP
     from buffalo.data.base import Data
     from buffalo.data.mm import MatrixMarketOptions
     algo, shape, batch_mb, over = CASES[name]
@@ -213,12 +219,14 @@ def reference_trace(name):
     data = MemData(dopt)
     data.data_type = "matrix"
     data.handle = FakeH5(groups_of(U, I, rows, cols, vals), {"num_nnz": len(rows), "num_users": U, "num_items": I, "completed": 1})
-    opt = (BPRMFOption if algo == "bpr" else ALSOption)().get_default_option()
+    opt = {"bpr": BPRMFOption, "als": ALSOption, "warp": WARPOption}[algo]().get_default_option()
     opt.update(over)
-    opt.update(dict(accelerator=True, validation={}, evaluation_on_learning=False, save_best=False, num_workers=2))
+    opt.update(dict(accelerator=algo != "warp", validation={}, evaluation_on_learning=False, save_best=False, num_workers=2))
     Recorder.trace = []
-    model = (BPRMF if algo == "bpr" else ALS)(opt, data=data)
+    model = {"bpr": BPRMF, "als": ALS, "warp": WARP}[algo](opt, data=data)
     model.initialize()
+    if algo == "warp":
+        model.opt.accelerator = True
     ret = model.train()
     shapes = {k: list(getattr(model, k).shape) for k in ("P", "Q")}
     return {"trace": Recorder.trace, "train_returned": {k: float(v) for k, v in ret.items()}, "final_shapes": shapes}
