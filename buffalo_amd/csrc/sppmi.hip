@@ -115,9 +115,12 @@ __global__ __launch_bounds__(256) void sppmi_value_kernel(const KeyT* __restrict
     const uint64_t key = static_cast<uint64_t>(uniq[r]);
     const uint64_t a = key / num_items, b = key % num_items;
     const uint64_t probe = a > b ? a : b, c = a > b ? b : a;   // fileio.hpp:207-208: the group of the larger id does the pair
+    // fileio.hpp:182-250 writes a group when the next id's first line arrives and never flushes at end of file: the group of the
+    // largest id that has lines (the first id of the last sorted key) is never a probe, so its pairs are not in the reference's output
+    const uint64_t eof_group = static_cast<uint64_t>(uniq[runs - 1]) / num_items;
     const double pmi = log(static_cast<double>(cnt[r])) + log_d - log(static_cast<double>(app[probe])) - log(static_cast<double>(app[c]));
     const double sppmi = pmi - log_k;
-    const bool keep = sppmi > 0;
+    const bool keep = sppmi > 0 && probe != eof_group;
     val[r] = keep ? sppmi_text_round_trip(sppmi) : 0.f;
     emit[r] = keep ? (a == b ? 2 : 1) : 0;
 }

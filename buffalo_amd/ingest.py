@@ -38,7 +38,9 @@ def build_sppmi(indptr, items, num_items, windows, k, with_stats=False):
     """SPPMI group of a stream: `indptr` = END offsets [num_users] over the 0-based `items` of the users' sequences,
     `windows` / `k` = the reference's data.sppmi options (stream.py:34-36).  Returns {"indptr": int64 END offsets
     [num_items], "key": int32 [nnz], "val": float32 [nnz], "total_lines": D} -- the layout of the reference's `sppmi`
-    HDF5 group (stream.py:183-188), which CFR reads as its context matrix."""
+    HDF5 group (stream.py:183-188), which CFR reads as its context matrix.  Like the reference's builder, pairs with the
+    largest id that occurs are left out (fileio.hpp:182-250 never flushes the group at end of file); rows hold their
+    entries in column order (the reference: std::unordered_set iteration order -- same entries per row)."""
     indptr = np.ascontiguousarray(indptr, dtype=np.int64)
     items = np.ascontiguousarray(items, dtype=np.int32)
     if indptr.ndim != 1 or items.ndim != 1 or indptr.shape[0] == 0 or int(indptr[-1]) != items.shape[0]:

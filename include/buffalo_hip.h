@@ -358,12 +358,15 @@ int bfh_eals_reset_stats(void* h);
  * Replaces, in HBM and without text files: the pair lines of buffalo/data/stream.py:257-267 (every event with the
  * `windows` events after it in its user's sequence, both orientations), _parallel_build_sppmi
  * (buffalo/data/fileio.hpp:109-254: appearances, pmi = log(cnt) + log(D) - log(app[probe]) - log(app[c]), shift
- * log(k), entries with sppmi > 0, values carried with the six significant digits of the reference's text output)
- * and the sort + compression of its output (stream.py:169-195).
+ * log(k), entries with sppmi > 0, values carried with the six significant digits of the reference's text output;
+ * the group of the largest id that has lines is never written by the reference -- it flushes a group when the next id
+ * begins and not at end of file, :182-250 -- and is left out here as well) and the sort + compression of its output
+ * (stream.py:169-195).
  * bfh_sppmi_build: `indptr` are END offsets [num_users] over the 0-based `items` of the stream; reports the number of
  * entries and D (sppmi_total_lines).  bfh_sppmi_fetch copies the group out: indptr_out[num_items] (END offsets),
  * keys_out[nnz], vals_out[nnz], rows ascending, columns ascending inside a row, a pair (p, p) listed twice as the
- * reference lists it.
+ * reference lists it.  (The reference sorts its output by row only, so inside a row it keeps std::unordered_set
+ * iteration order; per row the entries here are the same multiset, bit for bit -- tests/test_oracle_ref_fileio.py.)
  * ---------------------------------------------------------------------------------------------- */
 void* bfh_sppmi_create(void);
 void bfh_sppmi_destroy(void* h);

@@ -14,7 +14,11 @@
 // The inference-side selection (dot_topn / quickselect, bottom of this file)
 // IS pinned by the reference: its own tests compare those functions with numpy
 // argsort (tests/parallel/test_base.py:38-101) and are restated as
-// test_topn_reference_test01/03/04 in tests/test_oracle_pins.py.
+// test_topn_reference_test01/03/04 in tests/test_oracle_pins.py.  The data
+// ingestion restatements (orc_coo_to_csr, orc_build_sppmi) ARE pinned by the
+// reference's own compiled code: buffalo/data/fileio.hpp builds with the
+// standard library alone (oracle/_ref, oracle/ref_fileio.cc) and
+// tests/test_oracle_ref_fileio.py holds the two functions to it bit for bit.
 //
 // All citations are relative to /root/reference/.
 // Quirk numbers (Q-n) refer to SURVEY.md section 7.4.
@@ -1784,9 +1788,16 @@ void orc_coo_to_csr(const int32_t* major, const int32_t* minor, const float* val
 //     `probe` and every distinct second id c <= probe (:207-208), cnt = lines "probe c" of the group,
 //     pmi = log(cnt) + log(D) - log(app[probe]) - log(app[c]) (double, in this order, :210-212), sppmi = pmi - log(k);
 //     when sppmi > 0 the TEXT lines "probe c sppmi" and "c probe sppmi" are written (:215-221; c == probe gives the same
-//     line twice) -- `fout << double` prints six significant digits, and that is what the next step parses;
-//   * the output is sorted and compressed like any matrix (stream.py:181-195 -> fileio.hpp:263-420: "%d %d %f", ids made
-//     0-based, stable sort by (row, col), END-offset indptr).
+//     line twice) -- `fout << double` prints six significant digits, and that is what the next step parses.  A group is
+//     written when the NEXT id's first line arrives (:204-225) and nothing flushes at end of file, so the group of the
+//     LARGEST id that has lines never acts as probe: every pair with that id is absent from the reference's output
+//     (measured on the compiled reference, oracle/_ref; with any number of splits and workers it is dropped exactly once);
+//   * the output is sorted by its row id only (stream.py:181, aux.psort: numeric + stable on the first field), split into
+//     record files (fileio.hpp:25-107: "%d %d %f", ids made 0-based) and compressed (data/base.py:354-398, END-offset indptr).
+//     Inside a row the reference therefore leaves the order its writer produced -- std::unordered_set iteration order and,
+//     with more than one worker, thread timing.  The oracle (like the device builder) gives every row in (col) order: the
+//     same multiset per row, in the one order that is reproducible.  tests/test_oracle_ref_fileio.py compares the two row
+//     by row as multisets, bit for bit.
 // Returns nnz; fills the outputs only when cap >= nnz.
 int64_t orc_build_sppmi(const int64_t* indptr, const int32_t* items, int num_users, int num_items, int windows, int k, int64_t cap,
                         int64_t* out_indptr, int32_t* out_key, float* out_val, int64_t* total_lines_out) {
@@ -1814,6 +1825,7 @@ int64_t orc_build_sppmi(const int64_t* indptr, const int32_t* items, int num_use
         const int probe_id = lines[g0].first;
         std::vector<int> chunk;
         while (g1 < lines.size() && lines[g1].first == probe_id) chunk.push_back(lines[g1++].second);
+        if (g1 == lines.size()) break;   // fileio.hpp:182-250: no flush at end of file -- the last group is never written
         std::unordered_set<int> chunk_set(chunk.begin(), chunk.end());
         for (const int _c : chunk_set) {
             if (probe_id < _c) continue;

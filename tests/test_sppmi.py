@@ -25,7 +25,8 @@ def _stream(num_users, num_items, max_len, seed, skew=1.2):
 
 def _text_level(indptr, items, num_items, windows, k):
     """The reference's flow on text lines, in Python: write the pair lines, group by first id, count, format with '%g',
-    parse, sort by (row, col)."""
+    parse, sort by (row, col).  The group of the largest id is never written (fileio.hpp:182-250 flushes a group when the next
+    id begins and not at end of file -- confirmed on the compiled reference in tests/test_oracle_ref_fileio.py)."""
     lines = []
     beg = 0
     for end in indptr:
@@ -44,7 +45,10 @@ def _text_level(indptr, items, num_items, windows, k):
     for a, c in parsed:
         groups.setdefault(a, []).append(c)
     out, exact_zero = [], set()
+    eof_group = max(groups) if groups else None
     for probe, chunk in groups.items():
+        if probe == eof_group:
+            continue
         for c, cnt in Counter(chunk).items():
             if probe < c:
                 continue
