@@ -161,12 +161,21 @@ class MatrixMarket(Data):
         return self._finish(U, I, rows[keep], cols[keep], vals[keep], vali)
 
 
+def _sppmi_group(indptr, items, num_items, windows, k):
+    """The `sppmi` group of a stream (stream.py:169-195), built on the device."""
+    from buffalo_amd.ingest import build_sppmi
+    g = build_sppmi(indptr, items, num_items, windows, k)
+    return {"indptr": g["indptr"], "key": g["key"], "val": g["val"]}
+
+
 class Stream(Data):
     name = "Stream"
+    data_type = "stream"           # stream.py:79: what CFR asks for, whatever the internal layout
 
     def create(self):
         """stream.py:273-317 with internal_data_type "matrix": every line is one user's item
-        sequence; counts become values; `newest` validation holds out the last n items."""
+        sequence; counts become values; `newest` validation holds out the last n items.  With data.sppmi = {windows, k} the
+        training part of every sequence, in its order, also feeds the `sppmi` group (stream.py:257-267, 169-195)."""
         with open(self.opt.input.main) as fin:
             lines = [l.split() for l in fin]
         U = len(lines)
@@ -181,10 +190,13 @@ class Stream(Data):
         v = self.opt.data.validation
         vali_n = int(v.get("n", 0)) if v and v.get("name") == "newest" else 0
         rows, cols, vals, vr, vc, vv = [], [], [], [], [], []
+        seq_end, seq_items = [], []
         for u, seq in enumerate(lines):
             ids = [index[w] for w in seq if w in index]
             k = min(vali_n, max(len(ids) - 1, 0))
             train, held = ids[:len(ids) - k], ids[len(ids) - k:]
+            seq_items.extend(train)
+            seq_end.append(len(seq_items))
             for c, cnt in zip(*np.unique(train, return_counts=True)) if train else ():
                 rows.append(u), cols.append(int(c)), vals.append(float(cnt))
             for c, cnt in zip(*np.unique(held, return_counts=True)) if held else ():
@@ -192,7 +204,13 @@ class Stream(Data):
         # every held-out entry is a validation sample (the reference holds out for all users and keeps them all,
         # stream.py:100-118, 222-230: vali_limit is the sum over the users) -- nothing leaves train without entering vali
         vali = (vr, vc, vv) if vr else None
-        return self._finish(U, len(names), rows, cols, vals, vali)
+        self._finish(U, len(names), rows, cols, vals, vali)
+        sp = self.opt.data.get("sppmi")
+        if sp:
+            self.groups["sppmi"] = _sppmi_group(np.asarray(seq_end, dtype=np.int64), np.asarray(seq_items, dtype=np.int32), len(names),
+                                                int(sp["windows"]), int(sp["k"]))
+            self.header["sppmi_nnz"] = int(self.groups["sppmi"]["key"].shape[0])
+        return self
 
 
 def load(opt):

@@ -75,3 +75,53 @@ def test_save_load_roundtrip(tmp_path):
     m2.load(path)
     np.testing.assert_array_equal(m.P, m2.P)
     np.testing.assert_array_equal(m.Q, m2.Q)
+
+
+def test_cfr_front_trains_on_the_device_like_on_the_oracle(tmp_path, oracle, monkeypatch):
+    """Stream file -> loader (CSR groups and the `sppmi` group built on the device) -> CFR front -> `CyCFR` on the HIP backend,
+    against the very same front run over the oracle's `OracleCFR` (tests/test_front_cfr_eals_cpu.py runs that side on the CPU).
+    Tolerances are those of the backend-level parity (tests/test_cfr_gpu.py): factors 2e-3 of the largest entry, loss 1e-3."""
+    import buffalo_front.algo.cfr as hc
+    import test_front_cfr_eals_cpu as T
+    from buffalo_front.algo.cfr import CFR
+    data, _, _ = T._stream_data(tmp_path)
+    sp_ = data.get_group("sppmi")
+    assert len(sp_["key"]) > 0 and sp_["indptr"][-1] == len(sp_["key"])
+    np.random.seed(11)
+    m = CFR(T._cfr_opt(num_iters=3), data=data)
+    m.initialize()
+    ret = m.train()
+    with monkeypatch.context() as mp:
+        mp.setattr(hc, "CyCFR", oracle.OracleCFR)
+        np.random.seed(11)
+        o = CFR(T._cfr_opt(num_iters=3), data=data)
+        o.initialize()
+        want = o.train()
+    assert abs(ret["train_loss"] - want["train_loss"]) <= 1e-3 * abs(want["train_loss"]), (ret, want)
+    for a in ("U", "I", "C"):
+        got, ref = getattr(m, a), getattr(o, a)
+        assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max(), a
+    top = m.topk_recommendation([0, 1, 2], topk=5)
+    assert len(top) == 3 and all(len(v) == 5 for v in top.values())
+
+
+def test_eals_front_trains_on_the_device_like_on_the_oracle(oracle, monkeypatch):
+    import buffalo_front.algo.eals as he
+    import test_front_cfr_eals_cpu as T
+    from buffalo_front.algo.eals import EALS
+    from buffalo_front.algo.options import EALSOption
+    data = T._mm_data()
+    opt = EALSOption().get_default_option()
+    opt.update(d=10, num_iters=4, random_seed=3, validation={}, c0=64.0, exponent=0.5)
+    np.random.seed(4)
+    m = EALS(opt, data=data)
+    m.initialize()
+    ret = m.train()
+    with monkeypatch.context() as mp:
+        mp.setattr(he, "CyEALS", oracle.OracleEALS)
+        np.random.seed(4)
+        o = EALS(opt, data=data)
+        o.initialize()
+        want = o.train()
+    assert abs(ret["train_loss"] - want["train_loss"]) <= 1e-3 * abs(want["train_loss"]), (ret, want)
+    assert np.abs(m.P - o.P).max() <= 2e-3 * np.abs(o.P).max() and np.abs(m.Q - o.Q).max() <= 2e-3 * np.abs(o.Q).max()
