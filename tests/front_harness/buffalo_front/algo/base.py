@@ -4,7 +4,9 @@ classes need (/root/reference/buffalo/algo/base.py:12-318, buffalo/evaluate/base
 Only what `train()` touches is reproduced here.  Ranking (validation, `topk_recommendation`) runs on the
 GPU through `buffalo_amd.parallel`; id maps and the pickle-framed model format
 are later rows of the scope table."""
+import json
 import logging
+import time
 
 import numpy as np
 
@@ -28,6 +30,65 @@ class Algo:
         opt = load_option(opt_path)
         self.is_valid_option(opt)
         return Option(opt), opt_path
+
+    def _open(self, name, backend_cls, opt_path, kwargs, data_types, accelerator_only=False):
+        """What every front's constructor does after its option class is set up: option dict / path -> validated Option + the
+        JSON file the backend is initialised from, the backend object, and the data (an option to load, or a Data object)."""
+        from .. import data as bdata
+        self.logger = get_logger(name)
+        self.opt, self.opt_path = self.get_option(self.get_default_option() if opt_path is None else opt_path)
+        if accelerator_only and not self.opt.accelerator:
+            raise NotImplementedError("buffalo_amd provides the accelerator (MI355X) backend only; set accelerator=True or use "
+                                      "kakao/buffalo for the CPU path")
+        self.obj = backend_cls()
+        assert self.obj.init(self.opt_path.encode("utf-8")), "cannot parse option file: %s" % opt_path
+        self.data = None
+        data_opt = kwargs.get("data_opt", self.opt.get("data_opt"))
+        if data_opt:
+            self.data = bdata.load(data_opt)
+            self.data.create()
+        elif isinstance(kwargs.get("data"), bdata.Data):
+            self.data = kwargs["data"]
+        self.logger.info("%s(%s)" % (name, json.dumps(self.opt, indent=2)))
+        assert self.data is None or self.data.data_type in data_types, "%s trains on %s data" % (name, " / ".join(data_types))
+
+    def set_data(self, data):
+        from ..data import Data
+        assert isinstance(data, Data), "Wrong instance: {}".format(type(data))
+        self.data = data
+
+    def _normalize_once(self, group, slots):
+        """normalize() of every front: `slots` maps a group name to (factor attribute, flag in opt); a group is scaled once."""
+        if group in slots:
+            attr, flag = slots[group]
+            if not self.opt.get(flag):
+                setattr(self, attr, self._normalize(getattr(self, attr)))
+                self.opt[flag] = True
+
+    def _epochs(self, one_epoch, training_callback=None, prefix="val_", report=None):
+        """The loop around every front's epoch: loss of the epoch, validation every `evaluation_period` (+ the caller's callback),
+        best-model saving, early stopping.  Returns the last epoch's loss."""
+        best, loss, self.validation_result = float("inf"), None, {}
+        for i in range(self.opt.num_iters):
+            began = time.time()
+            loss = one_epoch(i)
+            metrics = {"train_loss": loss}
+            if self.opt.validation and self.opt.evaluation_on_learning and self.periodical(self.opt.evaluation_period, i):
+                self.validation_result = self.get_validation_results()
+                metrics.update({prefix + k: v for k, v in self.validation_result.items()})
+                if callable(training_callback):
+                    training_callback(i, metrics)
+            if report:
+                self.logger.info("Iteration %d: %s %.3f Elapsed %.3f secs" % (i + 1, report, loss, time.time() - began))
+            best = self.save_best_only(loss, best, i)
+            if self.early_stopping(loss):
+                break
+        return loss
+
+    def _result(self, loss, prefix="val_"):
+        out = {"train_loss": loss}
+        out.update({prefix + k: v for k, v in self.validation_result.items()})
+        return out
 
     def _normalize(self, feat):  # base.py:28-30
         return feat / np.sqrt((feat ** 2).sum(-1) + EPS)[..., np.newaxis]

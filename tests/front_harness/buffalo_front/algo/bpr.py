@@ -1,4 +1,4 @@
-"""BPRMF front (mirror of /root/reference/buffalo/algo/bpr.py)."""
+"""BPRMF front over `CyBPR` (stock buffalo: buffalo/algo/bpr.py with accelerator = True)."""
 import numpy as np
 
 from buffalo_amd.backend import CyBPR
@@ -12,24 +12,16 @@ class BPRMF(SgdFront, BPRMFOption):
 
     def __init__(self, opt_path=None, *args, **kwargs):
         BPRMFOption.__init__(self, *args, **kwargs)
-        self._construct(opt_path, BPRMFOption, CyBPR, kwargs)
+        self._construct(opt_path, CyBPR, kwargs)
 
-    def init_factors(self):  # bpr.py:84-97 (Q-18: |N(0, 1/d^2)|)
-        header = self.data.get_header()
-        self.num_nnz = header["num_nnz"]
-        d = self.opt.d
-        self.P = np.abs(np.random.normal(scale=1.0 / (d ** 2), size=(header["num_users"], d)).astype("float32"), order="C")
-        self.Q = np.abs(np.random.normal(scale=1.0 / (d ** 2), size=(header["num_items"], d)).astype("float32"), order="C")
-        self.Qb = np.abs(np.random.normal(scale=1.0 / (d ** 2), size=(header["num_items"], 1)).astype("float32"), order="C")
-        if not self.opt.use_bias:
-            self.Qb *= 0
-        self.obj.initialize_model(self.P, self.Q, self.Qb, self.num_nnz)
-
-    def prepare_sampling(self):  # bpr.py:99-111 incl. Q-4 (`int(sampling_power)`)
-        header = self.data.get_header()
-        self.sampling_table_ = np.zeros(header["num_items"], dtype=np.int64)
+    def prepare_sampling(self):
+        """bpr.py:99-111: cumulative item-popularity table of the negative sampler (all zero = uniform); the exponent is
+        truncated to an integer as the reference truncates it (Q-4)."""
+        items = self.data.get_header()["num_items"]
+        table = np.zeros(items, dtype=np.int64)
         if self.opt.sampling_power > 0.0:
-            self.sampling_table_ += np.bincount(self.data.get_group("rowwise")["key"], minlength=header["num_items"])
-            self.sampling_table_ **= int(self.opt.sampling_power)
-            self.sampling_table_ = np.cumsum(self.sampling_table_)
-        self.obj.set_cumulative_table(self.sampling_table_, header["num_items"])
+            table += np.bincount(self.data.get_group("rowwise")["key"], minlength=items)
+            table **= int(self.opt.sampling_power)
+            table = np.cumsum(table)
+        self.sampling_table_ = table
+        self.obj.set_cumulative_table(table, items)

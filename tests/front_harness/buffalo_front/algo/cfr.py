@@ -1,13 +1,11 @@
 """CFR (CoFactor) front: what stock buffalo's `buffalo/algo/cfr.py` asks of `CyCFR`, reduced to the training loop.  Written
 against the call traces the reference's own class produces (tests/golden/make_front_traces.py, cases cfr_*) and checked
 against them call by call in tests/test_front_trace_cpu.py."""
-import json
-
 import numpy as np
 
 from buffalo_amd.backend import CyCFR
-from ..data import BufferedDataMatrix, Data
-from .base import Algo, Evaluable, get_logger
+from ..data import BufferedDataMatrix
+from .base import Algo, Evaluable
 from .options import CFROption
 
 # (attribute, embedding name handed to the backend, rows from which header field, columns)
@@ -20,23 +18,11 @@ class CFR(Algo, CFROption, Evaluable):
         Algo.__init__(self)
         CFROption.__init__(self, *args, **kwargs)
         Evaluable.__init__(self)
-        self.logger = get_logger("CFR")
-        self.opt, self.opt_path = self.get_option(CFROption().get_default_option() if opt_path is None else opt_path)
-        self.obj = CyCFR()
-        self.is_valid_option(self.opt)
-        assert self.obj.init(self.opt_path.encode("utf8")), "putting parameter to cython object failed"
+        self._open("CFR", CyCFR, opt_path, kwargs, ["stream"])     # cfr.py:52-62: a Stream in matrix layout
         self.is_initialized = False
-        data = kwargs.get("data")
-        self.data = data if isinstance(data, Data) else None
-        self.logger.info("CFR (%s)" % json.dumps(self.opt, indent=2))
-        if self.data:
-            assert self.data.data_type in ["stream"]
 
     def normalize(self, group="item"):
-        for g, attr, flag in (("user", "U", "_nrz_U"), ("item", "I", "_nrz_I"), ("context", "C", "_nrz_C")):
-            if group == g and not self.opt[flag]:
-                setattr(self, attr, self._normalize(getattr(self, attr)))
-                self.opt[flag] = True
+        self._normalize_once(group, {"user": ("U", "_nrz_U"), "item": ("I", "_nrz_I"), "context": ("C", "_nrz_C")})
 
     def initialize(self):  # cfr.py:85-103: N(0, 1/d^2) embeddings (signed, unlike ALS / BPRMF), each bound to the backend by name
         super().initialize()
@@ -83,23 +69,9 @@ class CFR(Algo, CFROption, Evaluable):
         assert self.is_initialized, "embedding matrix is not initialized"
         buf = BufferedDataMatrix()
         buf.initialize(self.data, with_sppmi=True)
-        best_loss, self.validation_result = float("inf"), {}
         scale = self.compute_scale()
-        loss = 0.0
-        for i in range(self.opt.num_iters):
-            loss = (self._sweep(buf, "user") + self._sweep(buf, "item") + self._sweep(buf, "context")) / scale
-            metrics = {"train_loss": loss}
-            if self.opt.validation and self.opt.evaluation_on_learning and self.periodical(self.opt.evaluation_period, i):
-                self.validation_result = self.get_validation_results()
-                metrics.update({"vali_%s" % k: v for k, v in self.validation_result.items()})
-                if callable(training_callback):
-                    training_callback(i, metrics)
-            best_loss = self.save_best_only(loss, best_loss, i)
-            if self.early_stopping(loss):
-                break
-        ret = {"train_loss": loss}
-        ret.update({"vali_%s" % k: v for k, v in self.validation_result.items()})
-        return ret
+        loss = self._epochs(lambda _: sum(self._sweep(buf, g) for g in ("user", "item", "context")) / scale, training_callback, prefix="vali_")
+        return self._result(0.0 if loss is None else loss, prefix="vali_")
 
     def _get_data(self):
         return super()._get_data() + [("opt", self.opt), ("I", self.I), ("U", self.U), ("C", self.C)]

@@ -1,13 +1,10 @@
 """EALS front: what stock buffalo's `buffalo/algo/eals.py` asks of `CyEALS`, reduced to the training loop.  Written against the
 call trace the reference's own class produces (tests/golden/make_front_traces.py, case eals) and checked against it call by
 call in tests/test_front_trace_cpu.py."""
-import json
-
 import numpy as np
 
 from buffalo_amd.backend import CyEALS
-from ..data import Data
-from .base import Algo, Evaluable, get_logger
+from .base import Algo, Evaluable
 from .options import EALSOption
 
 _AXIS = {"rowwise": 0, "colwise": 1}
@@ -18,21 +15,10 @@ class EALS(Algo, EALSOption, Evaluable):
         Algo.__init__(self)
         EALSOption.__init__(self, *args, **kwargs)
         Evaluable.__init__(self)
-        self.logger = get_logger("EALS")
-        self.opt, self.opt_path = self.get_option(EALSOption().get_default_option() if opt_path is None else opt_path)
-        self.obj = CyEALS()
-        assert self.obj.init(bytes(self.opt_path, "utf-8")), "cannot parse option file: %s" % opt_path
-        data = kwargs.get("data")
-        self.data = data if isinstance(data, Data) else None
-        self.logger.info("eALS(%s)" % json.dumps(self.opt, indent=2))
-        if self.data:
-            assert self.data.data_type in ["matrix"]
+        self._open("eALS", CyEALS, opt_path, kwargs, ["matrix"])
 
     def normalize(self, group="item"):
-        if group == "item" and not self.opt._nrz_Q:
-            self.Q, self.opt._nrz_Q = self._normalize(self.Q), True
-        elif group == "user" and not self.opt._nrz_P:
-            self.P, self.opt._nrz_P = self._normalize(self.P), True
+        self._normalize_once(group, {"item": ("Q", "_nrz_Q"), "user": ("P", "_nrz_P")})
 
     def initialize(self):
         super().initialize()
@@ -60,27 +46,16 @@ class EALS(Algo, EALSOption, Evaluable):
         self.C = self.negative_weights()
         self.obj.initialize_model(self.P, self.Q, self.C)
 
+    def _epoch(self, _):
+        for name in ("rowwise", "colwise"):
+            assert self.obj.update(*self._group(name), _AXIS[name])
+        return self.obj.estimate_loss(self._nnz, *self._group("rowwise"), _AXIS["rowwise"])[0]
+
     def train(self, training_callback=None):
-        best_loss, loss, self.validation_result = float("inf"), None, {}
         for name in ("rowwise", "colwise"):
             indptr, keys, _ = self._group(name)
             self.obj.precompute_cache(self._nnz, indptr, keys, _AXIS[name])
-        for i in range(self.opt.num_iters):
-            for name in ("rowwise", "colwise"):
-                assert self.obj.update(*self._group(name), _AXIS[name])
-            loss, total = self.obj.estimate_loss(self._nnz, *self._group("rowwise"), _AXIS["rowwise"])
-            metrics = {"train_loss": loss}
-            if self.opt.validation and self.opt.evaluation_on_learning and self.periodical(self.opt.evaluation_period, i):
-                self.validation_result = self.get_validation_results()
-                metrics.update({"val_%s" % k: v for k, v in self.validation_result.items()})
-                if callable(training_callback):
-                    training_callback(i, metrics)
-            best_loss = self.save_best_only(loss, best_loss, i)
-            if self.early_stopping(loss):
-                break
-        ret = {"train_loss": loss}
-        ret.update({"val_%s" % k: v for k, v in self.validation_result.items()})
-        return ret
+        return self._result(self._epochs(self._epoch, training_callback))
 
     def _get_data(self):
         return super()._get_data() + [("opt", self.opt), ("Q", self.Q), ("P", self.P)]

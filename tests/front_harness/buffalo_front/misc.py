@@ -22,32 +22,34 @@ def load_option(src):
 
 
 class InputOptions(abc.ABC):
+    """Base of every option class: defaults, a shallow type check against them, and the temporary JSON file behind a dict."""
+
     def __init__(self, *args, **kwargs):
         pass
 
     @abc.abstractmethod
     def get_default_option(self) -> dict:
-        pass
+        """The complete option dict with its default values."""
 
     def is_valid_option(self, opt) -> bool:
-        default_opt = self.get_default_option()
-        for key in default_opt:
+        for key, default in self.get_default_option().items():
             if key not in opt:
                 raise RuntimeError("{} not exists on Option".format(key))
-            if not isinstance(opt.get(key), type(default_opt[key])):
-                raise RuntimeError("Invalid type for {}, {} expected. ".format(key, type(default_opt[key])))
+            if not isinstance(opt.get(key), type(default)):
+                raise RuntimeError("Invalid type for {}, {} expected. ".format(key, type(default)))
         return True
 
     def create_temporary_option_from_dict(self, opt) -> str:
-        tmp = tempfile.NamedTemporaryFile(mode="w", dir=opt.get("tmp_dir", "/tmp/"), delete=False)
-        tmp.write(json.dumps(opt))
-        tmp.close()
-        _temporary_files.append(tmp.name)
-        return tmp.name
+        fd, path = tempfile.mkstemp(dir=opt.get("tmp_dir", "/tmp/"))
+        with os.fdopen(fd, "w") as out:
+            json.dump(opt, out)
+        _temporary_files.append(path)
+        return path
 
 
 @atexit.register
-def _cleanup_temporary_files():
-    for path in _temporary_files:
+def _remove_temporary_option_files():
+    while _temporary_files:
+        path = _temporary_files.pop()
         if os.path.isfile(path):
             os.remove(path)
