@@ -356,6 +356,34 @@ def extra_sppmi(csr, seed, cpu=True):
     return out
 
 
+def measured_stream_bandwidth(n_bytes=1 << 30, reps=20):
+    """What this box's HBM delivers to a trivial kernel ("always also report the fraction of measured
+    triad bandwidth"): STREAM triad a = b + s * c (two reads + one write per element) and a plain copy over 1 GiB fp32 arrays,
+    one fused elementwise launch each, timed with events on the stream they run on."""
+    import torch
+    n = n_bytes // 4
+    a = torch.empty(n, dtype=torch.float32, device="cuda")
+    b = torch.ones_like(a)
+    c = torch.ones_like(a)
+
+    def rate(fn, moved):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return moved * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+    out = {"triad_GBps": rate(lambda: torch.add(b, c, alpha=0.5, out=a), 3 * n_bytes), "copy_GBps": rate(lambda: a.copy_(b), 2 * n_bytes),
+           "bytes_per_array": n_bytes, "what": "a = b + 0.5 c and a = b over 1 GiB fp32 arrays, %d launches each" % reps}
+    del a, b, c
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -539,6 +567,13 @@ def main():
                                                      / 1e9 / HBM_PEAK_GBS)},
             "epoch_ms": elapsed / steps * 1e3,
         }
+        if world == 1:
+            try:   # the same box's HBM under a trivial kernel, next to the 8 TB/s the fraction is quoted against
+                m = measured_stream_bandwidth()
+                m["frac_of_triad"] = achieved / m["triad_GBps"] if m["triad_GBps"] > 0 else None
+                out["roofline"]["measured_stream"] = m
+            except Exception as e:
+                out["roofline"]["measured_stream"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(csr)
         if world == 1 and not args.no_extra:
