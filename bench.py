@@ -561,6 +561,11 @@ def main():
                          "kernel": ("bpr_item_major_dual_kernel" if dual_walk else "bpr_item_major_kernel") if hog == "3" else "bpr_update_kernel",
                          "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
+                         # SURVEY.md section 8(d)'s stricter variant, reported alongside: one side's row is read and written once per
+                         # run of its triples instead of once per triple (16 d + 20 + 8 d / mean degree bytes per update)
+                         "strict": {"bytes_per_update": 16 * D + 20 + 8 * D / (nnz / U),
+                                    "achieved": achieved * (16 * D + 20 + 8 * D / (nnz / U)) / bytes_per_update,
+                                    "frac": achieved * (16 * D + 20 + 8 * D / (nnz / U)) / bytes_per_update / HBM_PEAK_GBS},
                          "launches_per_step": st["launches"] / max(steps, 1),
                          # the same bytes over ALL device time of a step (update launches + replica broadcast / merge kernels)
                          "frac_incl_merge_kernels": (bytes_per_update * st["samples"] / max((st["kernel_ms"] + st["aux_ms"]) * 1e-3, 1e-12)
