@@ -1,10 +1,11 @@
-"""In-memory data objects feeding the training core (shim plumbing).
+"""In-memory data objects feeding the training core (stand-ins for buffalo.data's MatrixMarket / Stream / BufferedDataMatrix).
 
-The reference stages MatrixMarket / Stream inputs into an HDF5 file through a C++ sorter
-(/root/reference/buffalo/data/{base,mm,stream}.py, fileio.hpp); h5py is absent here and ingestion is
-outside the hot path, so the same *layout* is produced directly in numpy:
-rowwise / colwise groups of {indptr int64[rows] END offsets, key int32 sorted per row, val float32}
-plus a `vali` group -- exactly what `BufferedDataMatrix` and the algo classes consume.
+The reference stages its inputs into an HDF5 file through text files and a C++ sorter (/root/reference/buffalo/data/{base,mm,stream}.py,
+fileio.hpp).  Here the same GROUPS are produced in memory -- rowwise / colwise {indptr int64[rows] END offsets, key int32, val float32},
+`vali` {row, col, val}, `sppmi` -- with the sort + compression (and the SPPMI build) done on the device (`buffalo_amd.ingest`).
+What the loaders store is held, array by array, to databases built by the reference's own data package run end to end
+(tests/golden/make_data_vectors.py, tests/test_data_loaders_ref.py): same records in the same order (entries sharing a cell stay
+apart), the same np.random draws for `sample` validation, the reference's validation layout and its quirks (cited where they are).
 """
 import bisect
 
@@ -69,9 +70,9 @@ def _group(num_rows, num_cols, rows, cols, vals):
     return coo_to_csr(rows, cols, vals, num_rows, num_cols)
 
 
-def _read_ids(src, n, what):
+def _read_ids(src, n, what, first=0):
     if src is None or (isinstance(src, str) and src == ""):
-        return [str(i) for i in range(n)]
+        return [str(i) for i in range(first, n + first)]      # mm.py:143, stream.py:145: the reference names them "1".."n"
     if isinstance(src, str):
         with open(src) as fin:
             ids = [l.rstrip("\n") for l in fin]
@@ -116,48 +117,78 @@ class Data:
     def close(self):
         pass
 
-    def _finish(self, num_users, num_items, rows, cols, vals, vali):
+    def _finish(self, num_users, num_items, rows, cols, vals, vali, num_nnz=None, colwise=True):
+        """Both orientations from the training records IN THE ORDER GIVEN (the reference's sort is stable on (row, col), so records
+        that share a cell stay apart and in input order: fileio.hpp:327-341), the `vali` group, the header."""
         rows = np.asarray(rows, dtype=np.int64)
         cols = np.asarray(cols, dtype=np.int64)
         vals = np.asarray(vals, dtype=np.float32)
-        self.groups["rowwise"] = _group(num_users, num_items, rows, cols, vals)
-        self.groups["colwise"] = _group(num_items, num_users, cols, rows, vals)
+        if num_nnz is not None and rows.shape[0] > num_nnz:
+            # the header count is fixed before the split (base.py:224-226) and the sorter keeps the first `total_lines` records
+            # of the working file (fileio.hpp:313-323): what does not fit is dropped
+            rows, cols, vals = rows[:num_nnz], cols[:num_nnz], vals[:num_nnz]
+        if colwise:
+            self.groups["rowwise"] = _group(num_users, num_items, rows, cols, vals)
+            self.groups["colwise"] = _group(num_items, num_users, cols, rows, vals)
+        else:
+            # internal_data_type "stream" (stream.py:160-163, sort_key -1): the events stay in their order, so the row-wise group is the
+            # records as they come plus END offsets; the column-wise group is allocated (base.py:185-192) and never filled
+            self.groups["rowwise"] = {"indptr": np.cumsum(np.bincount(rows, minlength=num_users)).astype(np.int64),
+                                      "key": cols.astype(np.int32), "val": vals}
+            self.groups["colwise"] = {"indptr": np.zeros(num_items, np.int64), "key": np.zeros(rows.shape[0], np.int32),
+                                      "val": np.zeros(rows.shape[0], np.float32)}
         if vali is not None and len(vali[0]):
-            self.groups["vali"] = {"row": np.asarray(vali[0], dtype=np.int32), "col": np.asarray(vali[1], dtype=np.int32),
-                                   "val": np.asarray(vali[2], dtype=np.float32)}
-        self.header = {"num_nnz": int(rows.shape[0]), "num_users": int(num_users), "num_items": int(num_items),
-                       "completed": 1}
+            vr, vc, vv = (np.asarray(x) for x in vali)
+            # base.py:241-253: rows and columns in the order the samples were met, the VALUES in the order of a CSR built from
+            # them (scipy sorts by row, then column) -- the two orders differ whenever the samples are not already sorted
+            vsorted = scipy.sparse.csr_matrix((vv.astype(np.float32), (vr, vc)), (num_users, num_items)).data
+            self.groups["vali"] = {"row": vr.astype(np.int32), "col": vc.astype(np.int32), "val": vsorted.astype(np.float32)}
+        self.header = {"num_nnz": int(rows.shape[0]), "num_users": int(num_users), "num_items": int(num_items), "completed": 1}
         return self
+
+    def _sample_size(self, num_nnz):
+        """base.py:220-226: how many entries the `sample` method holds out, and which (0-based positions; the last one is never
+        drawn, the reference's reader cannot split it off)."""
+        v = self.opt.data.validation
+        if not v or v.get("name") != "sample":
+            return None
+        sz = min(int(v.get("max_samples", 500)), int(num_nnz * v.get("p", 0.01)))
+        return np.random.choice(num_nnz - 1, sz, replace=False)
 
 
 class MatrixMarket(Data):
     name = "MatrixMarket"
 
-    def create(self):
-        """mm.py:236-279: read, hold out validation samples (`sample`: a random p fraction capped at
-        max_samples, mm.py:167-234), build both orientations."""
+    def _records(self):
+        """(U, I, rows, cols, vals) in FILE order.  A matrix handed over in memory goes through scipy's writer first, as in the
+        reference (mm.py:63-80), which lists a CSR matrix row by row."""
         main = self.opt.input.main
-        if isinstance(main, str):
-            M = scipy.io.mmread(main)
-        elif scipy.sparse.issparse(main):
-            M = main
-        else:
-            M = scipy.sparse.csr_matrix(np.asarray(main))
-        M = scipy.sparse.coo_matrix(M)
-        M.sum_duplicates()
-        U, I = M.shape
-        self.userids = _read_ids(self.opt.input.uid, U, "uid")
-        self.itemids = _read_ids(self.opt.input.iid, I, "iid")
-        rows, cols, vals = M.row, M.col, M.data.astype(np.float32)
-        keep = np.ones(rows.shape[0], dtype=bool)
+        if not isinstance(main, str):
+            if isinstance(main, np.ndarray) and main.ndim == 2:
+                main = scipy.sparse.csr_matrix(main)
+            if not scipy.sparse.issparse(main):
+                raise RuntimeError("Unexpected data type for MatrixMarketOption.input.main field: %s" % type(main))
+            coo = main.tocoo()
+            return coo.shape[0], coo.shape[1], coo.row.astype(np.int64), coo.col.astype(np.int64), coo.data.astype(np.float32)
+        with open(main) as fin:
+            body = [l for l in fin if not l.lstrip().startswith("%")]
+        U, I, _ = (int(x) for x in body[0].split())
+        rec = np.array([l.split()[:3] for l in body[1:] if l.strip()], dtype=np.float64).reshape(-1, 3)
+        return U, I, rec[:, 0].astype(np.int64) - 1, rec[:, 1].astype(np.int64) - 1, rec[:, 2].astype(np.float32)
+
+    def create(self):
+        """mm.py:236-279: the coordinate lines in file order; `sample` validation takes drawn LINES out (mm.py:167-234); what is
+        left is sorted (stably) into both orientations."""
+        U, I, rows, cols, vals = self._records()
+        self.userids = _read_ids(self.opt.input.uid, U, "uid", first=1)
+        self.itemids = _read_ids(self.opt.input.iid, I, "iid", first=1)
+        picked = self._sample_size(rows.shape[0])
         vali = None
-        v = self.opt.data.validation
-        if v and v.get("name") == "sample" and rows.shape[0]:
-            n = min(int(rows.shape[0] * v.get("p", 0.01)), int(v.get("max_samples", 500)))
-            if n > 0:
-                idx = np.random.choice(rows.shape[0], size=n, replace=False)
-                keep[idx] = False
-                vali = (rows[idx], cols[idx], vals[idx])
+        keep = np.ones(rows.shape[0], dtype=bool)
+        if picked is not None and len(picked):
+            idx = np.sort(picked)                         # mm.py:186: taken out in the order the reader meets them
+            keep[idx] = False
+            vali = (rows[idx], cols[idx], vals[idx])
         return self._finish(U, I, rows[keep], cols[keep], vals[keep], vali)
 
 
@@ -168,43 +199,60 @@ def _sppmi_group(indptr, items, num_items, windows, k):
     return {"indptr": g["indptr"], "key": g["key"], "val": g["val"]}
 
 
+def _counted(seq):
+    """collections.Counter(seq).items(): distinct entries in order of first appearance, with their counts."""
+    counts = {}
+    for x in seq:
+        counts[x] = counts.get(x, 0) + 1
+    return counts.items()
+
+
 class Stream(Data):
     name = "Stream"
     data_type = "stream"           # stream.py:79: what CFR asks for, whatever the internal layout
 
     def create(self):
-        """stream.py:273-317 with internal_data_type "matrix": every line is one user's item
-        sequence; counts become values; `newest` validation holds out the last n items.  With data.sppmi = {windows, k} the
-        training part of every sequence, in its order, also feeds the `sppmi` group (stream.py:257-267, 169-195)."""
+        """stream.py:273-317.  Every line is one user's item sequence.  `newest` validation holds out the last n events of a
+        sequence (never its only one; a held-out item counts once, stream.py:222-230), `sample` validation the events at drawn
+        positions of the concatenated sequences (:231-245).  internal_data_type "matrix": a user's remaining events become
+        (item, count) records in order of first appearance; "stream": one record per event, order kept, row-wise only.  With
+        data.sppmi = {windows, k} the remaining events, in their order, also feed the `sppmi` group (:257-267, 169-195)."""
         with open(self.opt.input.main) as fin:
             lines = [l.split() for l in fin]
         U = len(lines)
-        self.userids = _read_ids(self.opt.input.uid, U, "uid")
+        self.userids = _read_ids(self.opt.input.uid, U, "uid", first=1)
         iid = self.opt.input.iid
         if iid is None or iid == "":
-            names = sorted({w for l in lines for w in l})
+            names = sorted({w for l in lines for w in l})       # the reference numbers them in set order (stream.py:122-123): arbitrary
         else:
             names = _read_ids(iid, len(open(iid).readlines()) if isinstance(iid, str) else len(iid), "iid")
         self.itemids = names
         index = {w: i for i, w in enumerate(names)}
         v = self.opt.data.validation
+        as_matrix = self.opt.data.internal_data_type == "matrix"
         vali_n = int(v.get("n", 0)) if v and v.get("name") == "newest" else 0
+        kept = [len(l) - min(vali_n, max(len(l) - 1, 0)) for l in lines]
+        # stream.py:100-120: the header count is taken before any `sample` draw -- distinct items per user in matrix layout
+        counted = sum(len(set(l[:k])) if as_matrix else k for l, k in zip(lines, kept))
+        picked = self._sample_size(counted)
+        positions = set() if picked is None else set(int(p) for p in picked)
         rows, cols, vals, vr, vc, vv = [], [], [], [], [], []
         seq_end, seq_items = [], []
-        for u, seq in enumerate(lines):
-            ids = [index[w] for w in seq if w in index]
-            k = min(vali_n, max(len(ids) - 1, 0))
-            train, held = ids[:len(ids) - k], ids[len(ids) - k:]
+        at = 0
+        for u, (seq, k) in enumerate(zip(lines, kept)):
+            held = [index[w] for w, _ in _counted(seq[k:])]
+            train = []
+            for pos, w in enumerate(seq[:k]):
+                (held if at + pos in positions else train).append(index[w])
+            at += k
             seq_items.extend(train)
             seq_end.append(len(seq_items))
-            for c, cnt in zip(*np.unique(train, return_counts=True)) if train else ():
-                rows.append(u), cols.append(int(c)), vals.append(float(cnt))
-            for c, cnt in zip(*np.unique(held, return_counts=True)) if held else ():
-                vr.append(u), vc.append(int(c)), vv.append(float(cnt))
-        # every held-out entry is a validation sample (the reference holds out for all users and keeps them all,
-        # stream.py:100-118, 222-230: vali_limit is the sum over the users) -- nothing leaves train without entering vali
+            for c, cnt in (_counted(train) if as_matrix else ((c, 1) for c in train)):
+                rows.append(u), cols.append(c), vals.append(float(cnt))
+            for c, cnt in _counted(held):
+                vr.append(u), vc.append(c), vv.append(float(cnt))
         vali = (vr, vc, vv) if vr else None
-        self._finish(U, len(names), rows, cols, vals, vali)
+        self._finish(U, len(names), rows, cols, vals, vali, num_nnz=counted - (0 if picked is None else len(picked)), colwise=as_matrix)
         sp = self.opt.data.get("sppmi")
         if sp:
             self.groups["sppmi"] = _sppmi_group(np.asarray(seq_end, dtype=np.int64), np.asarray(seq_items, dtype=np.int32), len(names),
