@@ -102,7 +102,6 @@ def test_golden_databases_are_what_the_reference_builds_now(tmp_path):
 def test_the_reference_s_own_data_tests_pass_in_this_setup():
     """tests/data/test_{mm,stream,prepro}.py of the reference, unmodified, over the same stand-ins: 19 tests with known answers about
     header counts, iteration order and id maps -- the setup the golden databases come from is one the reference itself accepts."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "golden", "make_data_vectors.py"), "--reference-tests"],
-                       capture_output=True, text=True)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "golden", "run_reference_tests.py"), "data"], capture_output=True, text=True)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert "ran 19, failures 0, errors 0" in r.stdout

@@ -1,6 +1,8 @@
 """Pins for the CPU oracle: the reference has no golden vectors for its training arithmetic
 (SURVEY.md section 4), so the C++ restatement is checked against independent numpy transliterations
 (tests/ref_numpy.py), analytic micro-cases and published known-answer vectors."""
+import os
+
 import numpy as np
 import pytest
 
@@ -366,6 +368,18 @@ def test_ialspp_matches_transliteration(oracle, opt_file, d, block):
 # own parallel tests (tests/parallel/test_base.py:38-101, numpy argsort as the known answer) and on
 # exact-arithmetic cases for the admission / tie rules of _core.hpp:37-67,115-137
 # ------------------------------------------------------------------------------------------------
+@pytest.mark.skipif(not os.path.isdir("/root/reference/tests/parallel"), reason="/root/reference is not here")
+def test_topn_the_reference_s_own_parallel_tests_pass_on_the_oracle():
+    """tests/parallel/test_base.py of the reference, UNMODIFIED (test00, 01, 03, 04; 02 is a thread-scaling timing test), with
+    `buffalo.parallel._core.dot_topn` bound to the oracle: buffalo/parallel/base.py is imported from /root/reference as it is
+    (tests/golden/run_reference_tests.py).  The three tests below restate the same cases for machines without the reference."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "golden", "run_reference_tests.py"), "parallel"], capture_output=True, text=True)
+    assert r.returncode == 0 and "ran 4, failures 0, errors 0" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
 def test_topn_reference_test01_most_similar(oracle):
     import topk_cases as tc
     Q = tc.unit_factors(128, 5, seed=1)
