@@ -80,7 +80,123 @@ def parallel_tests():
     return res
 
 
+def ml100k_shaped(root, seed=0, groups=20, affinity=40.0, skew=1.1):
+    """./ext/ml-100k/{main,uid,iid,stream} in the formats of the reference's tests/preprocess.py:12-60, with the SHAPE of MovieLens-100K
+    (943 x 1682, 100,000 ratings 1..5) and planted structure instead of its content: 20 taste groups of users and items, in-group
+    ratings likelier and higher, item popularity skewed; the three titles the tests ask most_similar about (base.py:129-139,
+    test_base.py:31-34) sit in one group and share a fan base."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    U, I, G, NNZ = 943, 1682, groups, 100000
+    trilogy = [49, 180, 171]
+    ug, ig = rng.integers(0, G, U), rng.integers(0, G, I)
+    ig[trilogy] = ig[49]
+    pop = 1.0 / np.arange(1, I + 1) ** skew
+    rng.shuffle(pop)
+    pop[trilogy] = pop.max()
+    pairs = set()
+    fans = np.nonzero(ug == ig[49])[0]
+    for u in fans:
+        if rng.random() < 0.8:
+            pairs.update((int(u), t) for t in trilogy)
+    while len(pairs) < NNZ:
+        u = rng.integers(0, U, 20000)
+        w = np.where(ig[None, :] == ug[u][:, None], affinity, 1.0) * pop[None, :]
+        i = (w.cumsum(1) / w.sum(1, keepdims=True) > rng.random((len(u), 1))).argmax(1)
+        for a, b in zip(u.tolist(), i.tolist()):
+            if len(pairs) < NNZ:
+                pairs.add((a, b))
+    pairs = sorted(pairs)
+    d = os.path.join(root, "ext", "ml-100k")
+    os.makedirs(d)
+    names = ["%d.Movie_%d" % (i, i) for i in range(I)]
+    names[49], names[180], names[171] = "49.Star_Wars_(1977)", "180.Return_of_the_Jedi_(1983)", "171.Empire_Strikes_Back,_The_(1980)"
+    with open(os.path.join(d, "main"), "w") as f:
+        f.write("%%MatrixMarket matrix coordinate integer general\n%\n%\n943 1682 100000\n")
+        for u, i in pairs:
+            v = int(np.clip(rng.normal(4.2 if ug[u] == ig[i] else 2.8, 0.9), 1, 5).round())
+            f.write("%d %d %d\n" % (u + 1, i + 1, v))
+    with open(os.path.join(d, "iid"), "w") as f:
+        f.write("\n".join(names))
+    with open(os.path.join(d, "uid"), "w") as f:
+        f.write("".join("%d\n" % (u + 1) for u in range(U)))
+    per_user = {}
+    for u, i in pairs:
+        per_user.setdefault(u, []).append(i)
+    with open(os.path.join(d, "stream"), "w") as f:
+        f.write("\n".join(" ".join(names[i] for i in rng.permutation(per_user.get(u, [0]))) for u in range(U)))
+
+
+ALGO_TESTS = {
+    # file -> the tests that need neither MovieLens-20M nor a GPU, nor compare wall-clock times (test10)
+    "test_als": ["test00_get_default_option", "test01_is_valid_option", "test02_init_with_dict", "test03_init", "test04_train",
+                 "test05_validation", "test05_1_validation_with_callback", "test06_topk", "test08_serialization",
+                 "test09_compact_serialization", "test12_train_using_ialspp", "test13_train_using_ialspp_dim_256"],
+    "test_bpr": ["test00_get_default_option", "test01_is_valid_option", "test02_init_with_dict", "test03_init", "test04_train",
+                 "test05_validation", "test05_1_validation_with_callback", "test06_topk", "test08_serialization",
+                 "test09_compact_serialization"],
+    "test_warp": ["test00_get_default_option", "test01_is_valid_option", "test02_init_with_dict", "test03_init", "test04_train",
+                  "test05_validation", "test05_1_validation_with_callback", "test06_topk", "test08_serialization",
+                  "test09_compact_serialization"],
+    "test_eals": ["test00_get_default_option", "test01_is_valid_option", "test02_init_with_dict", "test03_init", "test04_train",
+                  "test05_validation", "test05_1_validation_with_callback", "test06_topk", "test08_serialization",
+                  "test09_compact_serialization"],
+    # test_cfr.py is left out: every test from test03 on builds a Stream with data.sppmi, and stock buffalo's Stream.create() raises
+    # TypeError from its temporary-file cleanup in that case (stream.py:212, 316; see make_data_vectors.py) -- with the reference's own
+    # compiled classes as much as with these
+}
+
+
+def algo_tests(files=None):
+    """The reference's own algorithm tests with the ORACLE's classes where its compiled CyALS / CyBPRMF / CyWARP / CyCFR / CyEALS
+    stand, its fronts, data package, evaluation and serialization unmodified, on ML-100K-SHAPED synthetic data (MovieLens is not in
+    this image): thresholds on NDCG@10 / MAP@10, the training callback cadence, top-k / most_similar by item name, model files."""
+    import make_data_vectors as M
+    from oracle import oracle
+    M.install()
+    for mod, name, cls in (("_als", "CyALS", oracle.OracleALS), ("_bpr", "CyBPRMF", oracle.OracleBPRMF), ("_warp", "CyWARP", oracle.OracleWARP),
+                           ("_cfr", "CyCFR", oracle.OracleCFR), ("_eals", "CyEALS", oracle.OracleEALS)):
+        setattr(sys.modules["buffalo.algo." + mod], name, cls)
+    sys.modules["buffalo.parallel._core"].dot_topn = oracle.dot_topn
+    sys.modules["buffalo.parallel._core"].quickselect = oracle.quickselect
+    import buffalo
+    from buffalo.algo.als import ALS
+    from buffalo.algo.base import Algo
+    from buffalo.algo.bpr import BPRMF
+    from buffalo.algo.cfr import CFR
+    from buffalo.algo.eals import EALS
+    from buffalo.algo.options import ALSOption, BPRMFOption, CFROption, EALSOption, WARPOption
+    from buffalo.algo.warp import WARP
+    from buffalo.data.mm import MatrixMarketOptions
+    from buffalo.data.stream import StreamOptions
+    from buffalo.misc import aux, log
+    for k, v in dict(ALS=ALS, ALSOption=ALSOption, BPRMF=BPRMF, BPRMFOption=BPRMFOption, WARP=WARP, WARPOption=WARPOption, CFR=CFR,
+                     CFROption=CFROption, EALS=EALS, EALSOption=EALSOption, Algo=Algo, MatrixMarketOptions=MatrixMarketOptions,
+                     StreamOptions=StreamOptions, aux=aux, set_log_level=log.set_log_level, inited_CUALS=False, inited_CUBPR=False).items():
+        setattr(buffalo, k, v)
+    pkg = type(sys)("reference_tests_algo")
+    pkg.__path__ = [os.path.join(REF, "tests", "algo")]
+    sys.modules["reference_tests_algo"] = pkg
+    suite = unittest.TestSuite()
+    with tempfile.TemporaryDirectory() as d:
+        os.chdir(d)
+        ml100k_shaped(d)
+        _load("tests/algo/base.py", "reference_tests_algo.base")
+        for name, wanted in ALGO_TESTS.items():
+            if files and name not in files:
+                continue
+            mod = _load("tests/algo/%s.py" % name, "reference_tests_algo." + name)
+            case = [c for c in vars(mod).values() if isinstance(c, type) and issubclass(c, unittest.TestCase) and c.__module__ == mod.__name__][0]
+            suite.addTests(case(n) for n in wanted)
+        res = _run(suite, "algo")
+        os.chdir(ROOT)
+    return res
+
+
 if __name__ == "__main__":
     mode = sys.argv[1] if len(sys.argv) > 1 else "data"
+    if mode == "algo":
+        r = algo_tests(sys.argv[2:] or None)
+        sys.exit(0 if r.wasSuccessful() else 1)
     r = {"data": data_tests, "parallel": parallel_tests}[mode]()
     sys.exit(0 if r.wasSuccessful() else 1)
