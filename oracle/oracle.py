@@ -7,6 +7,9 @@ parity tests read like the reference's own tests:
 * ``OracleWARP``   ~ ``buffalo.algo._warp.CyWARP``   (/root/reference/buffalo/algo/_warp.pyx)
 * ``OracleALS``    ~ ``buffalo.algo._als.CyALS``     (/root/reference/buffalo/algo/_als.pyx:24-63)
 
+That surface is exercised by the reference itself: its own ``tests/algo/test_{als,bpr,warp,eals}.py`` run unmodified with these
+classes bound where its fronts import ``CyALS`` / ``CyBPRMF`` / ``CyWARP`` / ``CyEALS`` (tests/golden/run_reference_tests.py algo).
+
 Only tests/, ``__graft_entry__.smoke()`` and ``bench.py``'s cpu_baseline leg may import this.
 """
 import ctypes as C
