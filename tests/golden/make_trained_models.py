@@ -1,0 +1,106 @@
+"""Whole training runs of STOCK buffalo's Python over the oracle, as golden fixtures (TEST INFRASTRUCTURE).
+
+    python tests/golden/make_trained_models.py [--out FILE]      # needs /root/reference; default tests/golden/trained_models.npz
+
+The reference's `ALS` / `EALS` fronts (CPU mode), its MatrixMarket loader (over its compiled fileio.hpp and the in-memory h5py:
+make_data_vectors.install) and its evaluation run UNMODIFIED from /root/reference; the compiled training classes are the oracle's
+(`OracleALS` / `OracleEALS` where `buffalo.algo._als.CyALS` / `_eals.CyEALS` are imported).  From a seeded coordinate file and
+seeded np.random the whole flow is deterministic: validation draw, |N(0, 1/d^2)| factors, epochs, metrics.  Stored per case: the
+factors after training, what `train()` returned, what `get_validation_results()` says afterwards.
+
+tests/test_trained_models_ref.py rebuilds the same inputs and trains the stand-in fronts (tests/front_harness) from the same seeds:
+over the oracle on CPU -- where every number must be IDENTICAL, front for front -- and over the HIP backend on a GPU box, where
+the factors must agree within the parity tolerance of the kernels.  d is a multiple of 32 in the ALS cases so that the
+accelerator path's padded width (ceil32) draws the same random numbers as the CPU path's (als.py:81).
+"""
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+for p in (ROOT, HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+OUT = os.path.join(HERE, "trained_models.npz")
+
+CASES = {
+    # name: (algo, (U, I, seed of the file), options, np.random seed before the data is built)
+    "als_llt_d32": ("als", (150, 90, 1), dict(d=32, num_iters=3, optimizer="llt", random_seed=7, num_workers=2, validation={"topk": 10}), 5),
+    "als_manual_cg_d64": ("als", (150, 90, 2), dict(d=64, num_iters=4, optimizer="manual_cg", random_seed=9, num_workers=2, alpha=4.0,
+                                                     reg_u=0.05, reg_i=0.2, validation={"topk": 10}), 6),
+    "eals_d16": ("eals", (150, 90, 3), dict(d=16, num_iters=4, random_seed=3, num_workers=2, c0=64.0, exponent=0.5, validation={"topk": 10}), 7),
+}
+
+
+def coordinate_text(U, I, seed):
+    """A planted coordinate file: 6 taste groups, in-group cells likelier, integer values 1..5, lines in no particular order."""
+    rng = np.random.default_rng(seed)
+    ug, ig = rng.integers(0, 6, U), rng.integers(0, 6, I)
+    p = np.where(ug[:, None] == ig[None, :], 0.45, 0.04)
+    rows, cols = np.nonzero(rng.random((U, I)) < p)
+    order = rng.permutation(len(rows))
+    rows, cols = rows[order], cols[order]
+    vals = rng.integers(1, 6, len(rows))
+    return ("%%MatrixMarket matrix coordinate integer general\n%\n" + "%d %d %d\n" % (U, I, len(rows))
+            + "".join("%d %d %d\n" % (r + 1, c + 1, v) for r, c, v in zip(rows, cols, vals)))
+
+
+def data_option(opt_cls, path, work=None):
+    opt = opt_cls().get_default_option()
+    opt.input.main = path
+    opt.input.uid = None
+    opt.input.iid = None
+    opt.data.validation = {"name": "sample", "p": 0.05, "max_samples": 60}
+    if work is not None:
+        opt.data.tmp_dir = work
+        opt.data.path = os.path.join(work, "db.h5py")
+    return opt
+
+
+def reference_models():
+    import make_data_vectors as M
+    from oracle import oracle
+    M.install()
+    sys.modules["buffalo.algo._als"].CyALS = oracle.OracleALS
+    sys.modules["buffalo.algo._eals"].CyEALS = oracle.OracleEALS
+    sys.modules["buffalo.parallel._core"].dot_topn = oracle.dot_topn
+    sys.modules["buffalo.parallel._core"].quickselect = oracle.quickselect
+    from buffalo.algo.als import ALS
+    from buffalo.algo.eals import EALS
+    from buffalo.algo.options import ALSOption, EALSOption
+    from buffalo.data.mm import MatrixMarketOptions
+    from buffalo.misc import aux, log
+    log.set_log_level(1)
+    out, meta = {}, {}
+    for name, (algo, shape, over, np_seed) in CASES.items():
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "main.mtx")
+            with open(path, "w") as f:
+                f.write(coordinate_text(*shape))
+            opt = (ALSOption if algo == "als" else EALSOption)().get_default_option()
+            opt.update(over)
+            opt.validation = aux.Option(over["validation"])
+            np.random.seed(np_seed)
+            model = (ALS if algo == "als" else EALS)(opt, data_opt=aux.Option(data_option(MatrixMarketOptions, path, d)))
+            model.initialize()
+            ret = model.train()
+            vali = model.get_validation_results()
+            out[name + "/P"], out[name + "/Q"] = np.array(model.P), np.array(model.Q)
+            meta[name] = {"train": {k: float(v) for k, v in ret.items()}, "validation": {k: float(v) for k, v in vali.items()},
+                          "header": {k: int(v) for k, v in model.data.get_header().items()}}
+    out["meta"] = np.array(json.dumps(meta, sort_keys=True))
+    return out
+
+
+if __name__ == "__main__":
+    path = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else OUT
+    vec = reference_models()
+    np.savez_compressed(path, **vec)
+    meta = json.loads(str(vec["meta"]))
+    for k, v in meta.items():
+        print(k, v["train"], {a: round(b, 4) for a, b in v["validation"].items()})
+    print("wrote", path, os.path.getsize(path), "bytes")

@@ -1,0 +1,110 @@
+"""Whole training runs: stock buffalo's Python over the oracle (golden, tests/golden/make_trained_models.py) against the stand-in
+fronts from the same files and the same seeds.
+
+The golden side is the reference's own `ALS` / `EALS` front in CPU mode, its MatrixMarket loader and its evaluation, unmodified,
+with the oracle's classes as its compiled backends.  On CPU the stand-in front runs over the same oracle: validation draw, initial
+factors, every epoch and every metric must come out IDENTICAL -- the stand-in is the reference's Python, result for result.  On a
+GPU box the same front drives the HIP backend: the trained factors must agree with the golden ones within the kernels' parity
+tolerance after 3-4 free-running epochs, and the validation metrics (ranked on the device) with them."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import make_trained_models as mk  # noqa: E402
+
+GOLDEN = np.load(mk.OUT)
+META = json.loads(str(GOLDEN["meta"]))
+
+
+def _train(tmp_path, name):
+    from buffalo_front.algo import ALS, EALS, ALSOption, EALSOption
+    from buffalo_front.data import MatrixMarketOptions
+    algo, shape, over, np_seed = mk.CASES[name]
+    path = tmp_path / "main.mtx"
+    path.write_text(mk.coordinate_text(*shape))
+    opt = (ALSOption if algo == "als" else EALSOption)().get_default_option()
+    opt.update(over)
+    np.random.seed(np_seed)
+    model = (ALS if algo == "als" else EALS)(opt, data_opt=mk.data_option(MatrixMarketOptions, str(path)))
+    model.initialize()
+    ret = model.train()
+    return model, ret, model.get_validation_results()
+
+
+@pytest.mark.parametrize("name", sorted(mk.CASES))
+def test_stand_in_front_over_the_oracle_equals_stock_buffalo_over_the_oracle(tmp_path, oracle, monkeypatch, name):
+    import buffalo_front.algo.als as ha
+    import buffalo_front.algo.base as hb
+    import buffalo_front.algo.eals as he
+    import buffalo_front.data as D
+
+    class OracleBehindTheAcceleratorSurface(oracle.OracleALS):
+        """CuALS's extra calls (cuda/_als.pyx:35-67) on the CPU class: no padding, nothing to announce."""
+        def init(self, opt_path):
+            with open(opt_path) as f:
+                self._d = json.load(f)["d"]
+            return super().init(opt_path)
+
+        def get_vdim(self):
+            return self._d
+
+        def set_placeholder(self, *args):
+            pass
+
+    class OracleRanker:
+        def dot_topn(self, rows, P, Q, Qb, keys, scores, pool, k):
+            oracle.dot_topn(np.ascontiguousarray(rows, dtype=np.int32), P, Q, Qb, keys, scores, pool, k)
+    monkeypatch.setattr(D, "_group", lambda nr, nc, r, c, v: oracle.coo_to_csr(r, c, v, nr, nc))
+    monkeypatch.setattr(ha, "CyALS", OracleBehindTheAcceleratorSurface)
+    monkeypatch.setattr(he, "CyEALS", oracle.OracleEALS)
+    monkeypatch.setattr(hb.Algo, "_ranker", lambda self: OracleRanker())
+    model, ret, vali = _train(tmp_path, name)
+    want = META[name]
+    assert model.data.get_header()["num_nnz"] == want["header"]["num_nnz"]
+    assert np.array_equal(model.P, GOLDEN[name + "/P"]) and np.array_equal(model.Q, GOLDEN[name + "/Q"])
+    assert ret["train_loss"] == want["train"]["train_loss"]
+    # ranking metrics to the digit; rmse / error are float32 reductions over the held-out entries on both sides (summation order)
+    rel = lambda k: 2e-6 if k.endswith(("rmse", "error")) else 1e-9   # noqa: E731
+    for k, v in want["validation"].items():
+        assert abs(vali[k] - v) <= rel(k) * max(1.0, abs(v)), (k, vali[k], v)
+    for k, v in want["train"].items():
+        assert abs(ret[k] - v) <= rel(k) * max(1.0, abs(v)), (k, ret[k], v)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(mk.CASES))
+def test_stand_in_front_over_the_device_reaches_stock_buffalo_s_model(tmp_path, name):
+    """Same file, same seeds, the HIP backend: initial factors and validation split are identical by construction, the epochs run
+    free.  Tolerances (first run on a device at the end of round 2 -- set from the backend-level parity tests, not yet from
+    measurements of these cases): factors 5e-3 of the largest entry for the closed forms (llt, eALS), 5e-2 for the three-step CG at
+    d = 64 over 90 items (its iterates are not converged solutions and the Gramian is rank-deficient: differences between two fp32
+    implementations are carried by the regulariser), train loss 1e-3 (2e-2), rmse / error 1e-3 (2e-2), ranking metrics 0.03 (0.06):
+    with ~60 held-out entries one flipped rank moves accuracy by 0.017."""
+    model, ret, vali = _train(tmp_path, name)
+    want = META[name]
+    loose = "manual_cg" in name
+    tol = 5e-2 if loose else 5e-3
+    for f in ("P", "Q"):
+        got, ref = getattr(model, f), GOLDEN["%s/%s" % (name, f)]
+        assert got.shape == ref.shape and np.abs(got - ref).max() <= tol * np.abs(ref).max(), (f, np.abs(got - ref).max(), np.abs(ref).max())
+    assert abs(ret["train_loss"] - want["train"]["train_loss"]) <= (2e-2 if loose else 1e-3) * abs(want["train"]["train_loss"])
+    for k, v in want["validation"].items():
+        bound = (2e-2 if loose else 1e-3) * abs(v) if k in ("rmse", "error") else (0.06 if loose else 0.03)
+        assert abs(vali[k] - v) <= bound, (k, vali[k], v)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/buffalo"), reason="/root/reference is not here")
+def test_golden_models_are_what_stock_buffalo_trains_now(tmp_path):
+    import subprocess
+    out = str(tmp_path / "fresh.npz")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "golden", "make_trained_models.py"), "--out", out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    fresh = np.load(out)
+    assert sorted(fresh.files) == sorted(GOLDEN.files)
+    for k in fresh.files:
+        assert np.array_equal(fresh[k], GOLDEN[k]), k
