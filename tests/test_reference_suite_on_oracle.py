@@ -49,7 +49,17 @@ def test_the_reference_s_algorithm_tests_pass_over_the_oracle():
     private_tmp = subprocess.run(["unshare", "-m", "sh", "-c", "mount -t tmpfs tmpfs /tmp"], capture_output=True).returncode == 0
 
     def lane(names):
-        return [(n,) + _run_file(n, private_tmp) for n in names]
+        out = []
+        for n in names:
+            ok, report = _run_file(n, private_tmp)
+            if not ok:
+                # the reference's tests do not seed np.random (random_seed = 0 means "do not seed", base.py:34-35; the validation split
+                # is drawn unseeded too), so a threshold can be missed by chance: a failing file gets ONE more run, and the first
+                # failure stays visible in the test output
+                print("first run of %s failed:\n%s" % (n, "\n".join(report)))
+                ok, report = _run_file(n, private_tmp)
+            out.append((n, ok, report))
+        return out
     if private_tmp:
         with ThreadPoolExecutor(max_workers=len(LANES)) as ex:
             results = [r for part in ex.map(lane, LANES) for r in part]
