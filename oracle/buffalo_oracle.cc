@@ -19,6 +19,13 @@
 // reference's own compiled code: buffalo/data/fileio.hpp builds with the
 // standard library alone (oracle/_ref, oracle/ref_fileio.cc) and
 // tests/test_oracle_ref_fileio.py holds the two functions to it bit for bit.
+// The training classes are additionally run THROUGH the reference: 52 of its
+// own algorithm tests (tests/algo/test_{als,bpr,warp,eals}.py, unmodified:
+// NDCG / MAP thresholds, top-k by item name, serialization) pass with these
+// classes bound where its fronts import CyALS / CyBPRMF / CyWARP / CyEALS, on
+// ML-100K-shaped synthetic files (tests/test_reference_suite_on_oracle.py).
+// That bounds the learning behaviour, not the last digit: the training
+// arithmetic itself stays unpinned.
 //
 // All citations are relative to /root/reference/.
 // Quirk numbers (Q-n) refer to SURVEY.md section 7.4.
