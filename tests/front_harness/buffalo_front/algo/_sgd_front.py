@@ -55,6 +55,14 @@ class SgdFront(Algo, Evaluable):
                     picked.append((u, keys[0], next(n for n in draws if n not in seen)))
         self._sub_samples = [np.array(col, dtype=np.int32) for col in (zip(*picked) if picked else ([], [], []))]
 
+    def _get_scores(self, row, col):
+        """bpr.py:131-133 / warp.py:145-150 as they are written: `Qb[col][0]` is the bias of the FIRST validation entry's item, added
+        to every score; WARP's distance branch tests score_func == "L2" after the constructor lower-cased it (Q-23), so it is dead."""
+        d = self.opt.d
+        if self.opt.get("score_func") == "L2":
+            return 1.0 - ((self.P[row, :d] - self.Q[col, :d]) ** 2).sum(-1)
+        return (self.P[row, :d] * self.Q[col, :d]).sum(axis=1) + self.Qb[col][0]
+
     def compute_loss(self):
         return self.obj.compute_loss(*self._sub_samples) if len(self._sub_samples[0]) else 0.0
 

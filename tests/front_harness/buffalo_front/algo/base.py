@@ -309,12 +309,18 @@ class Evaluable:
             return {}
         return {"ndcg": NDCG / N, "map": AP / N, "accuracy": HIT / N, "auc": AUC / N}
 
-    def _evaluate_score_metrics(self):  # evaluate/base.py:130-148
-        g = self.data.get_group("vali")
+    def _get_scores(self, row, col):
+        """als.py:106-108 / eals.py:100-102 / cfr.py:119-121: plain dot products (the SGD fronts override this)."""
         d = self.opt.d
-        pred = np.einsum("ij,ij->i", self.P[g["row"], :d], self.Q[g["col"], :d])
-        Qb = getattr(self, "Qb", None)
-        if Qb is not None and getattr(self.opt, "use_bias", False):
-            pred = pred + Qb.reshape(-1)[g["col"]]
-        err = pred - g["val"]
-        return {"rmse": float(np.sqrt(np.mean(err * err))), "error": float(np.mean(np.abs(err)))}
+        return (self.P[row, :d] * self.Q[col, :d]).sum(axis=1)
+
+    def _evaluate_score_metrics(self):
+        """evaluate/base.py:130-148, with its running sums as they are: entry by entry, in the scores' float32."""
+        g = self.data.get_group("vali")
+        scores = self._get_scores(g["row"], g["col"])
+        error = rmse = 0.0
+        for p, v in zip(scores, g["val"]):
+            err = p - v
+            error += abs(err)
+            rmse += err * err
+        return {"rmse": (rmse / len(scores)) ** 0.5, "error": error / len(scores)}

@@ -33,7 +33,44 @@ CASES = {
     "als_manual_cg_d64": ("als", (150, 90, 2), dict(d=64, num_iters=4, optimizer="manual_cg", random_seed=9, num_workers=2, alpha=4.0,
                                                      reg_u=0.05, reg_i=0.2, validation={"topk": 10}), 6),
     "eals_d16": ("eals", (150, 90, 3), dict(d=16, num_iters=4, random_seed=3, num_workers=2, c0=64.0, exponent=0.5, validation={"topk": 10}), 7),
+    # the SGD fronts in ACCELERATOR mode (the path this repository replaces): `CuBPRMF` / the WARP scaffold's object is the oracle
+    # behind the accelerator's method surface, in its deterministic modes (counter sampler, CSR order, jobs processed inside
+    # add_jobs with the lr of completed work) -- the modes the HIP backend's `sequential` / frozen-epoch paths reproduce to 1e-5 / 1e-4
+    "bpr_sgd_d20": ("bpr", (150, 90, 4), dict(d=20, num_iters=4, lr=0.05, min_lr=0.002, random_seed=7, num_workers=1, accelerator=True,
+                                               evaluation_period=2, validation={"topk": 10}), 8),
+    "bpr_adagrad_d40": ("bpr", (150, 90, 5), dict(d=40, num_iters=3, lr=0.05, optimizer="adagrad", random_seed=11, num_workers=1,
+                                                   accelerator=True, evaluation_period=3, validation={"topk": 10}), 9),
+    "warp_d24": ("warp", (150, 90, 6), dict(d=24, num_iters=3, lr=0.05, max_trials=20, threshold=0.5, random_seed=13, num_workers=1,
+                                             evaluation_period=3, validation={"topk": 10}), 10),
 }
+DETERMINISTIC = dict(sampler="counter", pos_order="csr", inline=True)
+
+
+def accelerator_over_oracle(oracle_cls):
+    """The accelerator classes' method surface (cuda/_bpr.pyx:37-80) on an oracle class in its deterministic modes: no padding
+    (`get_vdim` = d), nothing to announce, the model is trained in place."""
+    class OracleBehindTheAcceleratorSurface(oracle_cls):
+        def init(self, opt_path):
+            path = opt_path.decode("utf-8") if isinstance(opt_path, bytes) else opt_path
+            with open(path) as f:
+                self._d = json.load(f)["d"]
+            return super().init(path)
+
+        def get_vdim(self):
+            return self._d
+
+        def set_placeholder(self, *args):
+            pass
+
+        def initialize_model(self, P, Q, Qb, num_total_samples, set_gpu=False):
+            super().initialize_model(P, Q, Qb, num_total_samples)
+            if set_gpu:                       # the hand-over right before training (bpr.py:207)
+                self.set_modes(**DETERMINISTIC)
+                self.launch_workers()         # inline mode: seeds the stream, starts no thread
+
+        def synchronize(self, *args):
+            pass
+    return OracleBehindTheAcceleratorSurface
 
 
 def coordinate_text(U, I, seed):
@@ -67,11 +104,16 @@ def reference_models():
     M.install()
     sys.modules["buffalo.algo._als"].CyALS = oracle.OracleALS
     sys.modules["buffalo.algo._eals"].CyEALS = oracle.OracleEALS
+    sys.modules["buffalo.algo.cuda._bpr"].CyBPR = accelerator_over_oracle(oracle.OracleBPRMF)     # bpr.py:19 imports it as CuBPRMF
+    sys.modules["buffalo.algo._warp"].CyWARP = accelerator_over_oracle(oracle.OracleWARP)          # warp.py has no accelerator class: see below
     sys.modules["buffalo.parallel._core"].dot_topn = oracle.dot_topn
     sys.modules["buffalo.parallel._core"].quickselect = oracle.quickselect
     from buffalo.algo.als import ALS
+    from buffalo.algo.bpr import BPRMF
     from buffalo.algo.eals import EALS
-    from buffalo.algo.options import ALSOption, EALSOption
+    from buffalo.algo.options import ALSOption, BPRMFOption, EALSOption, WARPOption
+    from buffalo.algo.warp import WARP
+    fronts = {"als": (ALS, ALSOption), "eals": (EALS, EALSOption), "bpr": (BPRMF, BPRMFOption), "warp": (WARP, WARPOption)}
     from buffalo.data.mm import MatrixMarketOptions
     from buffalo.misc import aux, log
     log.set_log_level(1)
@@ -81,15 +123,22 @@ def reference_models():
             path = os.path.join(d, "main.mtx")
             with open(path, "w") as f:
                 f.write(coordinate_text(*shape))
-            opt = (ALSOption if algo == "als" else EALSOption)().get_default_option()
+            cls, opt_cls = fronts[algo]
+            opt = opt_cls().get_default_option()
             opt.update(over)
             opt.validation = aux.Option(over["validation"])
             np.random.seed(np_seed)
-            model = (ALS if algo == "als" else EALS)(opt, data_opt=aux.Option(data_option(MatrixMarketOptions, path, d)))
+            model = cls(opt, data_opt=aux.Option(data_option(MatrixMarketOptions, path, d)))
             model.initialize()
+            if algo == "warp":
+                # warp.py:31-32 refuses accelerator = True in the constructor but carries the accelerator scaffold in _prepare_train /
+                # _finalize_train (:212-234): built without it, switched before train() (as in make_front_traces.py)
+                model.opt.accelerator = True
             ret = model.train()
             vali = model.get_validation_results()
             out[name + "/P"], out[name + "/Q"] = np.array(model.P), np.array(model.Q)
+            if hasattr(model, "Qb"):
+                out[name + "/Qb"] = np.array(model.Qb)
             meta[name] = {"train": {k: float(v) for k, v in ret.items()}, "validation": {k: float(v) for k, v in vali.items()},
                           "header": {k: int(v) for k, v in model.data.get_header().items()}}
     out["meta"] = np.array(json.dumps(meta, sort_keys=True))
