@@ -350,9 +350,26 @@ def extra_sppmi(csr, seed, cpu=True):
         t0 = time.perf_counter()
         o = orc.build_sppmi(ip, it, csr.num_items, 5, 1)
         dt = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": o["total_lines"] / dt, "unit": "pair lines/s", "cores": 1, "kind": CPU_KIND, "what": CPU_WHAT +
-                               " -- in memory: the reference additionally writes, sorts and re-reads three text files",
-                               "sample": "the first %d sequences (%d events, %d lines), one thread, %.1f s" % (n_users, int(ip[-1]), o["total_lines"], dt)}
+        port = {"value": o["total_lines"] / dt, "unit": "pair lines/s", "cores": 1, "kind": CPU_KIND, "what": CPU_WHAT +
+                " -- in memory: the reference additionally writes, sorts and re-reads three text files",
+                "sample": "the first %d sequences (%d events, %d lines), one thread, %.1f s" % (n_users, int(ip[-1]), o["total_lines"], dt)}
+        out["cpu_baseline"] = port
+        try:   # the reference's OWN compiled builder where oracle/_ref travelled with the snapshot (built from /root/reference by build())
+            from oracle import ref_fileio as rf
+            if os.path.exists(rf._LIB_PATH):
+                workers = os.cpu_count() or 1
+                r = rf.timed_build_sppmi(ip, it, csr.num_items, 5, 1, workers)
+                if r["nnz"] != len(o["key"]):
+                    raise RuntimeError("reference builder: %d entries, oracle: %d" % (r["nnz"], len(o["key"])))
+                out["cpu_baseline"] = {"value": r["total_lines"] / r["total_s"], "unit": "pair lines/s", "cores": workers, "kind": "reference",
+                                       "what": "the reference's own buffalo/data/fileio.hpp compiled from its source (oracle/_ref) + sort(1), as "
+                                               "StreamData._build_sppmi runs them: sort the pair lines, _parallel_build_sppmi, sort its output, "
+                                               "_chunking_into_bins; the Python loop that writes the pair lines (stream.py:257-267) is not timed",
+                                       "sample": "the first %d sequences (%d events, %d lines), %d workers, %.1f s" % (n_users, int(ip[-1]), r["total_lines"], workers, r["total_s"]),
+                                       "stages_s": {k: r[k] for k in ("sort_lines_s", "build_s", "sort_output_s", "chunk_s")}}
+                out["cpu_baseline_port"] = port
+        except Exception as e:
+            out["cpu_baseline_reference_error"] = "%s: %s" % (type(e).__name__, e)
     return out
 
 

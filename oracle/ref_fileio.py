@@ -172,6 +172,41 @@ def build_sppmi(indptr, items, num_items, windows, k, num_workers=1, num_chunks=
     return res
 
 
+def timed_build_sppmi(indptr, items, num_items, windows, k, num_workers):
+    """Wall time of the reference's compiled / external steps of `_build_sppmi` on a stream: sort(1) of the pair lines,
+    _parallel_build_sppmi, sort(1) of its output, _chunking_into_bins -- what stock buffalo spends after its Python loop has written
+    the pair lines (that loop, stream.py:257-267, is NOT timed: here the lines are written by numpy, in arbitrary order)."""
+    import time
+    indptr = np.asarray(indptr, dtype=np.int64)
+    items = np.asarray(items, dtype=np.int64) + 1
+    user = np.repeat(np.arange(indptr.shape[0]), np.diff(np.concatenate([[0], indptr])))
+    parts = []
+    for w in range(1, int(windows) + 1):
+        same = user[:-w] == user[w:]
+        a, b = items[:-w][same], items[w:][same]
+        parts.append(np.stack([a, b], 1))
+        parts.append(np.stack([b, a], 1))
+    pairs = np.concatenate(parts) if parts else np.zeros((0, 2), np.int64)
+    total_lines = int(pairs.shape[0])
+    out = {"total_lines": total_lines, "workers": int(num_workers)}
+    with tempfile.TemporaryDirectory() as d:
+        src, dst = os.path.join(d, "pairs.txt"), os.path.join(d, "sppmi.txt")
+        np.savetxt(src, pairs, fmt="%d %d")
+        t0 = time.perf_counter()
+        _psort_first_field(src, 1)
+        t1 = time.perf_counter()
+        nnz = int(lib().ref_parallel_build_sppmi(src.encode(), dst.encode(), total_lines, int(num_items), int(k), int(num_workers)))
+        t2 = time.perf_counter()
+        _psort_first_field(dst, 1)
+        t3 = time.perf_counter()
+        if nnz:
+            chunks = 2 * max(1, min(int(num_workers), 20))
+            lib().ref_chunking_into_bins(dst.encode(), d.encode(), nnz, chunks, 0, max(1, min(int(num_workers), 20)))
+        t4 = time.perf_counter()
+    out.update(nnz=nnz, sort_lines_s=t1 - t0, build_s=t2 - t1, sort_output_s=t3 - t2, chunk_s=t4 - t3, total_s=t4 - t0)
+    return out
+
+
 def canonical_rows(group):
     """(indptr, key, val) with every row's entries ordered by (key, val): the order-free form two SPPMI groups are compared in."""
     indptr, key, val = group["indptr"], group["key"], group["val"]
