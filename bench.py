@@ -373,6 +373,40 @@ def extra_sppmi(csr, seed, cpu=True):
     return out
 
 
+def extra_ingest(csr, seed, cpu=True):
+    """COO records -> compressed rows on the device (bfh_coo_to_csr) -- the matrix's records in shuffled order,
+    host arrays in, host (indptr, key, val) out -- beside the reference's own compiled sorter on a sample."""
+    from buffalo_amd import ingest
+    rng = np.random.default_rng(seed)
+    perm = rng.permutation(csr.nnz)
+    rows = np.ascontiguousarray(csr.rows()[perm].astype(np.int32))
+    cols = np.ascontiguousarray(csr.keys[perm])
+    vals = np.ascontiguousarray(csr.vals[perm])
+    ingest.coo_to_csr(rows, cols, vals, csr.num_users, csr.num_items, with_stats=True)
+    t0 = time.perf_counter()
+    g, st = ingest.coo_to_csr(rows, cols, vals, csr.num_users, csr.num_items, with_stats=True)
+    dt = time.perf_counter() - t0
+    assert np.array_equal(g["indptr"], csr.indptr) and np.array_equal(g["key"], csr.keys)       # the shuffle is undone
+    out = {"config": "%d shuffled (row, col, val) records -> rowwise group of %d x %d; host arrays in -> host arrays out" % (csr.nnz, csr.num_users, csr.num_items),
+           "records": csr.nnz, "device_ms": st["kernel_ms"], "wall_ms": dt * 1e3, "records_per_s_device": csr.nnz / (st["kernel_ms"] * 1e-3)}
+    if cpu:
+        try:
+            from oracle import ref_fileio as rf
+            if os.path.exists(rf._LIB_PATH):
+                n = min(csr.nnz, 3000000)
+                workers = os.cpu_count() or 1
+                r = rf.timed_sort_and_compressed_binarization(rows[:n], cols[:n], vals[:n], csr.num_users, 1, workers)
+                assert np.array_equal(r["indptr"], np.cumsum(np.bincount(rows[:n], minlength=csr.num_users)))
+                out["cpu_baseline"] = {"value": n / r["total_s"], "unit": "records/s", "cores": workers, "kind": "reference",
+                                       "what": "the reference's own buffalo/data/fileio.hpp compiled from its source (oracle/_ref): "
+                                               "_sort_and_compressed_binarization, i.e. parse the working text file, stable parallel sort by "
+                                               "(row, col), indptr, binary chunks",
+                                       "sample": "the first %d shuffled records, %d workers, %.1f s" % (n, workers, r["total_s"])}
+        except Exception as e:
+            out["cpu_baseline_reference_error"] = "%s: %s" % (type(e).__name__, e)
+    return out
+
+
 def measured_stream_bandwidth(n_bytes=1 << 30, reps=20):
     """What this box's HBM delivers to a trivial kernel ("always also report the fraction of measured
     triad bandwidth"): STREAM triad a = b + s * c (two reads + one write per element) and a plain copy over 1 GiB fp32 arrays,
@@ -602,7 +636,7 @@ def main():
             del obj
             extra = {}
             for name, fn in (("als_ml20m_d128", extra_als), ("warp_ml20m_d256", extra_warp), ("topk_ml20m_d128_k100", extra_topk),
-                             ("sppmi_ml20m_stream_w5", extra_sppmi)):
+                             ("sppmi_ml20m_stream_w5", extra_sppmi), ("coo_to_csr_ml20m", extra_ingest)):
                 try:
                     extra[name] = fn(csr, args.seed, cpu=not args.no_cpu_baseline)
                 except Exception as e:   # the headline line is never lost to a secondary measurement

@@ -172,6 +172,22 @@ def build_sppmi(indptr, items, num_items, windows, k, num_workers=1, num_chunks=
     return res
 
 
+def timed_sort_and_compressed_binarization(rows, cols, vals, max_key, sort_key, num_workers):
+    """Wall time of the reference's compiled `_sort_and_compressed_binarization` (fileio.hpp:263-420: parse the working text file in
+    4 MiB splits, stable parallel sort, indptr, binary chunks) on 0-based COO records; the file is written here, untimed."""
+    import time
+    n = int(np.asarray(rows).shape[0])
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "working.txt")
+        np.savetxt(src, np.stack([np.asarray(rows, np.float64) + 1, np.asarray(cols, np.float64) + 1, np.asarray(vals, np.float64)], 1), fmt="%d %d %g")
+        t0 = time.perf_counter()
+        files = lib().ref_sort_and_compressed_binarization(src.encode(), d.encode(), n, int(max_key), int(sort_key), int(num_workers))
+        dt = time.perf_counter() - t0
+        assert files == num_workers + 1
+        indptr = np.fromfile(os.path.join(d, "indptr.bin"), dtype=np.int64)
+    return {"records": n, "workers": int(num_workers), "total_s": dt, "indptr": indptr}
+
+
 def timed_build_sppmi(indptr, items, num_items, windows, k, num_workers):
     """Wall time of the reference's compiled / external steps of `_build_sppmi` on a stream: sort(1) of the pair lines,
     _parallel_build_sppmi, sort(1) of its output, _chunking_into_bins -- what stock buffalo spends after its Python loop has written
