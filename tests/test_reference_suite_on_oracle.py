@@ -3,11 +3,13 @@
 tests/algo/test_{als,bpr,warp,eals}.py of /root/reference run as they are (tests/golden/run_reference_tests.py algo): the reference's
 fronts, option classes, data package (over its compiled fileio.hpp and the in-memory h5py), evaluation, top-k / most_similar by
 item name and serialization are its own unmodified Python; only the compiled training classes are the oracle's, and the data are
-ML-100K-SHAPED synthetic files in the formats of its tests/preprocess.py (MovieLens itself is not in this image).  52 tests:
+ML-100K-SHAPED synthetic files in the formats of its tests/preprocess.py (MovieLens itself is not in this image).  52 + 10 tests:
 NDCG@10 / MAP@10 thresholds after training (test05: ALS, iALS++ at d=100 and d=256, BPRMF 500 epochs on 4 workers, WARP, eALS),
 the callback cadence, recommendation and `most_similar` of planted neighbours before and after normalisation, save / load.
-Left out: the MovieLens-20M and GPU tests, test10 (compares wall-clock times), and test_cfr.py (stock buffalo's Stream.create()
-raises with data.sppmi set -- see tests/golden/make_data_vectors.py).
+Left out: the MovieLens-20M and GPU tests and test10 (compares wall-clock times).  test_cfr.py (10 more tests) runs with ONE repair
+applied in-process: stock buffalo's Stream.create() raises TypeError from its temporary-file cleanup whenever data.sppmi is set
+(stream.py:212, 316), which stops every CFR test that builds its data, with the reference's compiled classes as much as with the
+oracle's; run_reference_tests.repair_stream_cleanup drops the non-path entry before that cleanup runs.
 
 This is what SURVEY.md section 8(c) calls the only results-level tests the reference has (statistical thresholds), here passed by
 the oracle THROUGH the reference's own code.  Each file runs in its own process (the BPRMF file alone sleeps ~2 minutes in the
@@ -23,15 +25,15 @@ from concurrent.futures import ThreadPoolExecutor
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-EXPECTED = {"test_als": 12, "test_bpr": 10, "test_warp": 10, "test_eals": 10}
+EXPECTED = {"test_als": 12, "test_bpr": 10, "test_warp": 10, "test_eals": 10, "test_cfr": 10}
 
 
-LANES = (("test_bpr",), ("test_als", "test_warp", "test_eals"))     # ~140 s and ~80 s: two processes at a time keep the cores free enough
+LANES = (("test_bpr",), ("test_als", "test_warp", "test_eals", "test_cfr"))     # ~140 s and ~110 s: two processes at a time keep the cores free enough
 
 
 def _run_file(name, private_tmp):
     env = dict(os.environ, OMP_NUM_THREADS="4")
-    cmd = [sys.executable, os.path.join(ROOT, "tests", "golden", "run_reference_tests.py"), "algo", name]
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "golden", "run_reference_tests.py")] + (["algo-cfr"] if name == "test_cfr" else ["algo", name])
     if private_tmp:
         cmd = ["unshare", "-m", "sh", "-c", "mount -t tmpfs tmpfs /tmp && exec " + " ".join(shlex.quote(c) for c in cmd)]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
