@@ -212,8 +212,40 @@ def algo_tests(files=None, before=None):
     return res
 
 
+def dropin_probe():
+    """INTEGRATION.md section 7's shortest drop-in, wired for real: `buffalo.algo.cuda._bpr.CyBPR` / `_als.CyALS` ARE
+    `buffalo_amd.backend.CyBPR` / `CyALS`, and stock buffalo's unmodified fronts are constructed with accelerator = True.  On a GPU
+    box that trains; in this container (no GPU) the product must refuse loudly at handle creation -- which shows that the reference's
+    front reached libbuffalo_hip through its own import path and that nothing falls back to a CPU path."""
+    import make_front_traces as G
+    G.install_reference()
+    from buffalo_amd import backend
+    from buffalo_amd._lib import BuffaloHipError
+    sys.modules["buffalo.algo.cuda._bpr"].CyBPR = backend.CyBPR
+    sys.modules["buffalo.algo.cuda._als"].CyALS = backend.CyALS
+    from buffalo.algo.als import ALS, inited_CUALS
+    from buffalo.algo.bpr import BPRMF, inited_CUBPR
+    from buffalo.algo.options import ALSOption, BPRMFOption
+    assert inited_CUALS and inited_CUBPR
+    outcome = {}
+    for name, cls, opt_cls in (("ALS", ALS, ALSOption), ("BPRMF", BPRMF, BPRMFOption)):
+        opt = opt_cls().get_default_option()
+        opt.accelerator = True
+        try:
+            model = cls(opt)
+            outcome[name] = "constructed over %s.%s" % (type(model.obj).__module__, type(model.obj).__name__)
+        except BuffaloHipError as e:
+            outcome[name] = "BuffaloHipError: %s" % e
+    for k, v in outcome.items():
+        print("dropin %s -> %s" % (k, v))
+    return outcome
+
+
 if __name__ == "__main__":
     mode = sys.argv[1] if len(sys.argv) > 1 else "data"
+    if mode == "dropin":
+        dropin_probe()
+        sys.exit(0)
     if mode == "algo":
         r = algo_tests(sys.argv[2:] or None)
         sys.exit(0 if r.wasSuccessful() else 1)

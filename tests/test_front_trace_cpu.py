@@ -233,3 +233,23 @@ def test_golden_traces_are_current(tmp_path):
     assert json.load(open(out)) == GOLDEN
     for k, path in G.MODEL_FILES.items():
         assert open(path, "rb").read() == open(str(tmp_path / (k + ".bin")), "rb").read()
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/buffalo"), reason="/root/reference is not here")
+def test_no_cython_drop_in_reaches_the_library_from_stock_buffalo_s_fronts():
+    """with `buffalo.algo.cuda._bpr.CyBPR` / `_als.CyALS` bound to `buffalo_amd.backend`'s classes, stock
+    buffalo's unmodified `ALS` / `BPRMF` with accelerator = True construct the product's handle.  Without a GPU that must fail
+    loudly inside libbuffalo_hip (no CPU fallback) -- on a GPU box the same binding trains."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "golden", "run_reference_tests.py"), "dropin"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("dropin ")]
+    assert len(lines) == 2
+    import torch
+    for l in lines:
+        if torch.cuda.is_available():
+            assert "constructed over buffalo_amd.backend.Cy" in l, l
+        else:
+            assert "BuffaloHipError: no HIP device available" in l, l
