@@ -93,6 +93,51 @@ def test_oracle_follows_the_text_level_flow(oracle, num_users, num_items, max_le
         assert Counter((r, c) for r, c, _ in got)[next((r, c) for r, c, _ in got if r == c)] == 2   # "p p v" is written twice
 
 
+def _device_formulation(indptr, items, num_items, windows, k):
+    """What csrc/sppmi.hip does, step for step in numpy: every pair line as the key first * I + second, sorted; distinct
+    keys with their counts; appearances of an id = keys that start with it; one value per distinct key from the reference's double
+    expression with probe = the larger id; keys whose probe is the FIRST ID OF THE LAST SORTED KEY -- the group stock buffalo never
+    writes -- dropped; entry (a, b) from its own key (twice when a == b); six-digit text round trip."""
+    keys = []
+    beg = 0
+    for end in indptr:
+        seq = [int(x) for x in items[beg:end]]
+        beg = int(end)
+        for i in range(len(seq)):
+            for j in range(i + 1, min(i + windows + 1, len(seq))):
+                keys += [seq[i] * num_items + seq[j], seq[j] * num_items + seq[i]]
+    if not keys:
+        return []
+    keys = np.sort(np.asarray(keys, dtype=np.int64))
+    uniq, cnt = np.unique(keys, return_counts=True)
+    app = np.bincount(keys // num_items, minlength=num_items)
+    eof_group = int(uniq[-1] // num_items)
+    log_d, log_k = math.log(len(keys)), math.log(k)
+    out = []
+    for key, c in zip(uniq.tolist(), cnt.tolist()):
+        a, b = divmod(key, num_items)
+        probe, other = max(a, b), min(a, b)
+        sppmi = math.log(c) + log_d - math.log(app[probe]) - math.log(app[other]) - log_k
+        if sppmi > 0 and probe != eof_group:
+            out += [(a, b, np.float32("%g" % sppmi))] * (2 if a == b else 1)
+    return out
+
+
+@pytest.mark.parametrize("num_users,num_items,max_len,windows,k,seed", [(60, 25, 14, 3, 1, 0), (200, 90, 30, 5, 2, 1), (40, 7, 9, 2, 1, 2),
+                                                                       (5, 300, 40, 50, 1, 3), (1, 10, 12, 3, 1, 5)])
+def test_the_device_s_formulation_is_the_oracle_s(oracle, num_users, num_items, max_len, windows, k, seed):
+    """No GPU here: the formulation the kernels implement, restated in numpy, against the oracle -- in particular the rule that finds
+    the reference's unwritten end-of-file group from the sorted keys alone."""
+    indptr, items = _stream(num_users, num_items, max_len, seed)
+    got = _device_formulation(indptr, items, num_items, windows, k)
+    want = _triples(oracle.build_sppmi(indptr, items, num_items, windows, k))
+    _, _, exact_zero = _text_level(indptr, items, num_items, windows, k)
+    assert [t[:2] for t in got] == sorted(t[:2] for t in got)       # already in (row, col) order: no second sort on the device
+    _same_up_to_exact_zeros(got, want, exact_zero, ulp=1)
+    if not exact_zero:
+        assert [t[:2] for t in got] == [t[:2] for t in want]
+
+
 def test_oracle_edge_cases(oracle):
     g = oracle.build_sppmi(np.array([0, 1, 1], np.int64), np.array([3], np.int32), 5, 4, 1)      # nobody has two events
     assert g["total_lines"] == 0 and len(g["key"]) == 0 and np.all(g["indptr"] == 0)
