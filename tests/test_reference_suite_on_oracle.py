@@ -48,7 +48,10 @@ def _run_file(name, private_tmp):
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/tests/algo"), reason="/root/reference is not here")
 def test_the_reference_s_algorithm_tests_pass_over_the_oracle():
-    private_tmp = subprocess.run(["unshare", "-m", "sh", "-c", "mount -t tmpfs tmpfs /tmp"], capture_output=True).returncode == 0
+    try:
+        private_tmp = subprocess.run(["unshare", "-m", "sh", "-c", "mount -t tmpfs tmpfs /tmp"], capture_output=True, timeout=30).returncode == 0
+    except (OSError, subprocess.TimeoutExpired):
+        private_tmp = False
 
     def lane(names):
         out = []
