@@ -393,7 +393,7 @@ class SGD {
             double beta1 = opt_.d("beta1");
             double beta2 = opt_.d("beta1");  // sic (lib/algo.cc:396)
             const float lrf = (float)lr;
-            const float ru2 = (float)(2 * reg_u), ri2 = (float)(2 * reg_i), rb2 = (float)(2 * reg_b);
+            const float ru2 = (float)(2 * reg_u), ri2 = (float)(2 * reg_i);
 #pragma omp parallel for schedule(static)
             for (int u = 0; u < P_rows_; ++u) {
                 float* g = &gradP_[(size_t)u * D];
@@ -421,10 +421,13 @@ class SGD {
                 else update_adagrad(g, &velQ_[(size_t)i * D], D);
                 for (int k = 0; k < D; ++k) q[k] += lrf * g[k];
                 if (use_bias) {
-                    gradQb_[i] -= Qb_[i] * rb2;
+                    // lib/algo.cc:418-420 / :447-449 are SCALAR C++ statements on matrix elements, not Eigen expressions: a float
+                    // element combined with the double options is computed in double and rounded once when it is stored
+                    // (found by running the reference's own sources next to this file: oracle/ref_sgd.cc)
+                    gradQb_[i] = (float)((double)gradQb_[i] - (double)Qb_[i] * (2 * reg_b));
                     if (adam) update_adam(&gradQb_[i], &momQb_[i], &velQb_[i], 1, beta1, beta2);
                     else update_adagrad(&gradQb_[i], &velQb_[i], 1);
-                    Qb_[i] += lrf * gradQb_[i];
+                    Qb_[i] = (float)((double)Qb_[i] + lr * (double)gradQb_[i]);
                 }
             }
             if (pcn) {
@@ -506,7 +509,7 @@ class BPR : public SGD {
         const bool update_i = opt_.b("update_i");
         const bool update_j = opt_.b("update_j");
         const float reg_u = (float)opt_.d("reg_u"), reg_i = (float)opt_.d("reg_i");
-        const float reg_j = (float)opt_.d("reg_j"), reg_b = (float)opt_.d("reg_b");
+        const float reg_j = (float)opt_.d("reg_j");
         const int num_negative_samples = opt_.i("num_negative_samples");
         const double sample_power = opt_.d("sampling_power");
         const bool verify_neg = opt_.b("verify_neg");
@@ -522,6 +525,9 @@ class BPR : public SGD {
 
         int processed_samples = 0, total_samples = job.size;
         const float alpha = (float)job.alpha;
+        // the bias updates (bpr.cc:161, 167) are scalar C++ statements: `double alpha`, `double reg_b` and float operands give a
+        // double expression that is rounded once when it is stored
+        const double alpha_d = job.alpha, reg_b_d = opt_.d("reg_b");
         std::vector<float> item_deriv(D);
         for (size_t si = 0; si < job.samples.size(); ++si) {
             const auto& _seen = job.samples[si];
@@ -609,11 +615,11 @@ class BPR : public SGD {
                         // item_deriv (a concrete matrix) holds logit * OLD P_u.
                         if (update_i) {
                             for (int k = 0; k < D; ++k) Qp[k] += alpha * (item_deriv[k] - reg_i * Qp[k]);
-                            if (use_bias) Qb_[pos] += alpha * (logit - reg_b * Qb_[pos]);
+                            if (use_bias) Qb_[pos] = (float)((double)Qb_[pos] + alpha_d * ((double)logit - reg_b_d * (double)Qb_[pos]));
                         }
                         if (update_j) {
                             for (int k = 0; k < D; ++k) Qn[k] += alpha * (-item_deriv[k] - reg_j * Qn[k]);
-                            if (use_bias) Qb_[neg] += alpha * (-logit - reg_b * Qb_[neg]);
+                            if (use_bias) Qb_[neg] = (float)((double)Qb_[neg] + alpha_d * (-(double)logit - reg_b_d * (double)Qb_[neg]));
                         }
                         for (int k = 0; k < D; ++k)
                             Pu[k] += alpha * (logit * (Qp[k] - Qn[k]) - reg_u * Pu[k]);
@@ -636,12 +642,14 @@ class BPR : public SGD {
     // The SGD branch of the loop body above (bpr.cc:119-131, 157-171) applied to a GIVEN list of triples, one after
     // the other: lets a test replay any schedule of an epoch (e.g. the item-major walk of the HIP backend) through
     // the same arithmetic.  Sequential, single thread; `alpha` is the learning rate of every step.
-    void apply_triples(int64_t n, const int32_t* users, const int32_t* positives, const int32_t* negatives, float alpha) {
+    void apply_triples(int64_t n, const int32_t* users, const int32_t* positives, const int32_t* negatives, double alpha_d) {
+        const float alpha = (float)alpha_d;
+        const double reg_b_d = opt_.d("reg_b");     // the bias statements are scalar C++ in double, as in process_job
         const bool use_bias = opt_.b("use_bias");
         const bool update_i = opt_.b("update_i");
         const bool update_j = opt_.b("update_j");
         const float reg_u = (float)opt_.d("reg_u"), reg_i = (float)opt_.d("reg_i");
-        const float reg_j = (float)opt_.d("reg_j"), reg_b = (float)opt_.d("reg_b");
+        const float reg_j = (float)opt_.d("reg_j");
         const int D = D_;
         std::vector<float> item_deriv(D);
         for (int64_t t = 0; t < n; ++t) {
@@ -665,11 +673,11 @@ class BPR : public SGD {
                 for (int k = 0; k < D; ++k) item_deriv[k] = logit * Pu[k];
             if (update_i) {
                 for (int k = 0; k < D; ++k) Qp[k] += alpha * (item_deriv[k] - reg_i * Qp[k]);
-                if (use_bias) Qb_[pos] += alpha * (logit - reg_b * Qb_[pos]);
+                if (use_bias) Qb_[pos] = (float)((double)Qb_[pos] + alpha_d * ((double)logit - reg_b_d * (double)Qb_[pos]));
             }
             if (update_j) {
                 for (int k = 0; k < D; ++k) Qn[k] += alpha * (-item_deriv[k] - reg_j * Qn[k]);
-                if (use_bias) Qb_[neg] += alpha * (-logit - reg_b * Qb_[neg]);
+                if (use_bias) Qb_[neg] = (float)((double)Qb_[neg] + alpha_d * (-(double)logit - reg_b_d * (double)Qb_[neg]));
             }
             for (int k = 0; k < D; ++k) Pu[k] += alpha * (logit * (Qp[k] - Qn[k]) - reg_u * Pu[k]);
         }
@@ -1685,7 +1693,7 @@ int orc_bpr_apply_triples(void* hp, int64_t n, const int32_t* u, const int32_t* 
     Handle* h = (Handle*)hp;
     BPR* b = h->kind == 0 ? dynamic_cast<BPR*>(h->sgd) : nullptr;
     if (!b) return 0;
-    b->apply_triples(n, u, p, q, (float)alpha);
+    b->apply_triples(n, u, p, q, alpha);
     return 1;
 }
 double orc_sgd_compute_loss(void* hp, int n, const int32_t* u, const int32_t* p, const int32_t* q) {

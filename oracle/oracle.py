@@ -20,13 +20,17 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libbuffalo_oracle.so")
+# BUFFALO_ORACLE_LIB: another build of the same source (tests/test_oracle_vs_reference_sources.py loads the one without floating-point
+# contraction, oracle/_ref/libbuffalo_oracle_exact.so, in a process of its own)
+_LIB_PATH = os.environ.get("BUFFALO_ORACLE_LIB") or os.path.join(_HERE, "libbuffalo_oracle.so")
 _lib = None
 
 
 def build(force=False):
     """Compile the oracle with the reference's CPU flags (oracle/Makefile)."""
     src = os.path.join(_HERE, "buffalo_oracle.cc")
+    if os.environ.get("BUFFALO_ORACLE_LIB"):
+        return _LIB_PATH
     if (not force and os.path.exists(_LIB_PATH)
             and os.path.getmtime(_LIB_PATH) >= os.path.getmtime(src)):
         return _LIB_PATH
