@@ -24,8 +24,14 @@
 // NDCG / MAP thresholds, top-k by item name, serialization) pass with these
 // classes bound where its fronts import CyALS / CyBPRMF / CyWARP / CyEALS, on
 // ML-100K-shaped synthetic files (tests/test_reference_suite_on_oracle.py).
-// That bounds the learning behaviour, not the last digit: the training
-// arithmetic itself stays unpinned.
+// That bounds the learning behaviour, not the last digit.  Closer: the
+// reference's own lib/algo.cc, bpr.cc, warp.cc, als.cc, cfr.cc, eals.cc compile
+// unmodified against stand-ins for Eigen / json11 / spdlog written here
+// (oracle/stand_in_3rd) and run beside this file on the same inputs
+// (tests/test_oracle_vs_reference_sources.py): BPRMF and WARP bit-identical
+// when both are built without FP contraction, ALS / CFR / eALS within their
+// solvers' conditioning.  What remains unpinned is what Eigen itself does
+// inside an expression -- the stand-ins and this file share one reading of it.
 //
 // All citations are relative to /root/reference/.
 // Quirk numbers (Q-n) refer to SURVEY.md section 7.4.

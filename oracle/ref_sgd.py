@@ -41,10 +41,10 @@ def available():
 def build(force=False):
     if not reference_present():
         return all(os.path.exists(_path(k)) for k in ("bpr", "warp"))
-    deps = [os.path.join(_HERE, "ref_sgd.cc"), os.path.join(_HERE, "buffalo_oracle.cc")]
+    deps = [os.path.join(_HERE, "ref_sgd.cc"), os.path.join(_HERE, "ref_als.cc"), os.path.join(_HERE, "ref_cfr_eals.cc"), os.path.join(_HERE, "buffalo_oracle.cc")]
     deps += [os.path.join(r, f) for r, _, fs in os.walk(os.path.join(_HERE, "stand_in_3rd")) for f in fs]
     newest = max(os.path.getmtime(p) for p in deps)
-    libs = [os.path.join(_HERE, "_ref", n) for n in ("libbuffalo_bpr_on_stand_ins.so", "libbuffalo_warp_on_stand_ins.so",
+    libs = [os.path.join(_HERE, "_ref", n) for n in ("libbuffalo_bpr_on_stand_ins.so", "libbuffalo_warp_on_stand_ins.so", "libbuffalo_als_on_stand_ins.so", "libbuffalo_cfr_eals_on_stand_ins.so",
                                                       "libbuffalo_bpr_on_stand_ins_exact.so", "libbuffalo_warp_on_stand_ins_exact.so",
                                                       "libbuffalo_oracle_exact.so")]
     if force or any(not os.path.exists(p) or os.path.getmtime(p) < newest for p in libs):
@@ -141,3 +141,154 @@ class RefBPRMF(_RefSGD):
 
 class RefWARP(_RefSGD):
     KIND = "warp"
+
+
+class RefALS:
+    """~ OracleALS / CyALS (buffalo/algo/_als.pyx:24-63) over the reference's als.cc on the stand-ins (no contraction-free twin: its dense
+    products and solves are the stand-in's own loops, compared with a tolerance)."""
+
+    def __init__(self):
+        if not build():
+            raise RuntimeError("oracle/_ref/libbuffalo_als_on_stand_ins.so is not built and /root/reference is absent")
+        L = self._L = C.CDLL(os.path.join(_HERE, "_ref", "libbuffalo_als_on_stand_ins.so"))
+        vp, i32 = C.c_void_p, C.c_int
+        pf, pi32, pi64, pd = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_double)
+        for name, (res, args) in {"create": (vp, []), "destroy": (None, [vp]), "init": (i32, [vp, C.c_char_p]),
+                                  "initialize_model": (None, [vp, pf, i32, pf, i32]), "precompute": (None, [vp, i32]),
+                                  "partial_update": (None, [vp, i32, i32, pi64, pi32, pf, i32, pd]), "get_ff": (None, [vp, pf, i32])}.items():
+            fn = getattr(L, "refals_" + name)
+            fn.restype, fn.argtypes = res, args
+        self._h = L.refals_create()
+        self._keep = {}
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._L.refals_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def init(self, opt_path):
+        if isinstance(opt_path, str):
+            opt_path = opt_path.encode("utf-8")
+        return bool(self._L.refals_init(self._h, opt_path))
+
+    def initialize_model(self, P, Q):
+        assert P.dtype == np.float32 and Q.dtype == np.float32 and P.flags["C_CONTIGUOUS"] and Q.flags["C_CONTIGUOUS"]
+        self._keep.update(P=P, Q=Q)
+        self._L.refals_initialize_model(self._h, _ptr(P, C.c_float), P.shape[0], _ptr(Q, C.c_float), Q.shape[0])
+
+    def precompute(self, axis):
+        self._L.refals_precompute(self._h, int(axis))
+
+    def get_ff(self, d):
+        out = np.empty((d, d), np.float32)
+        self._L.refals_get_ff(self._h, _ptr(out, C.c_float), int(d))
+        return out
+
+    def partial_update(self, start_x, next_x, indptr, keys, vals, axis):
+        assert indptr.dtype == np.int64 and keys.dtype == np.int32 and vals.dtype == np.float32
+        out = (C.c_double * 2)()
+        self._L.refals_partial_update(self._h, int(start_x), int(next_x), _ptr(indptr, C.c_int64), _ptr(keys, C.c_int32), _ptr(vals, C.c_float), int(axis), out)
+        return float(out[0]), float(out[1])
+
+
+def _cfr_eals_lib():
+    if "cfr_eals" not in _libs:
+        if not build():
+            raise RuntimeError("oracle/_ref/libbuffalo_cfr_eals_on_stand_ins.so is not built and /root/reference is absent")
+        L = C.CDLL(os.path.join(_HERE, "_ref", "libbuffalo_cfr_eals_on_stand_ins.so"))
+        vp, i32, f64 = C.c_void_p, C.c_int, C.c_double
+        pf, pi32, pi64 = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+        for name, (res, args) in {
+            "refcfr_create": (vp, []), "refcfr_destroy": (None, [vp]), "refcfr_init": (i32, [vp, C.c_char_p]),
+            "refcfr_set_embedding": (None, [vp, pf, i32, C.c_char_p]), "refcfr_precompute": (None, [vp, C.c_char_p]),
+            "refcfr_partial_update_user": (f64, [vp, i32, i32, pi64, pi32, pf]),
+            "refcfr_partial_update_item": (f64, [vp, i32, i32, pi64, pi32, pf, pi64, pi32, pf]),
+            "refcfr_partial_update_context": (f64, [vp, i32, i32, pi64, pi32, pf]),
+            "refeals_create": (vp, []), "refeals_destroy": (None, [vp]), "refeals_init": (i32, [vp, C.c_char_p]),
+            "refeals_initialize_model": (None, [vp, pf, pf, pf, i32, i32]), "refeals_precompute_cache": (None, [vp, i32, pi64, pi32, i32]),
+            "refeals_update": (i32, [vp, pi64, pi32, pf, i32]), "refeals_estimate_loss": (None, [vp, i32, pi64, pi32, pf, i32, pf]),
+        }.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _libs["cfr_eals"] = L
+    return _libs["cfr_eals"]
+
+
+class RefCFR:
+    """~ OracleCFR / CyCFR (buffalo/algo/_cfr.pyx:25-71) over the reference's cfr.cc on the stand-ins."""
+
+    def __init__(self):
+        self._L = _cfr_eals_lib()
+        self._h = self._L.refcfr_create()
+        self._keep = {}
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._L.refcfr_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    @staticmethod
+    def _b(x):
+        return x if isinstance(x, bytes) else str(x).encode("utf-8")
+
+    def init(self, opt_path):
+        return bool(self._L.refcfr_init(self._h, self._b(opt_path)))
+
+    def set_embedding(self, F, obj_type):
+        assert F.dtype == np.float32 and F.flags["C_CONTIGUOUS"]
+        self._keep[self._b(obj_type)] = F
+        self._L.refcfr_set_embedding(self._h, _ptr(F, C.c_float), F.shape[0], self._b(obj_type))
+
+    def precompute(self, obj_type):
+        self._L.refcfr_precompute(self._h, self._b(obj_type))
+
+    def partial_update_user(self, start_x, next_x, indptrs, keys, vals):
+        return self._L.refcfr_partial_update_user(self._h, int(start_x), int(next_x), _ptr(indptrs, C.c_int64), _ptr(keys, C.c_int32), _ptr(vals, C.c_float))
+
+    def partial_update_item(self, start_x, next_x, indptrs_u, keys_u, vals_u, indptrs_c, keys_c, vals_c):
+        return self._L.refcfr_partial_update_item(self._h, int(start_x), int(next_x), _ptr(indptrs_u, C.c_int64), _ptr(keys_u, C.c_int32),
+                                                  _ptr(vals_u, C.c_float), _ptr(indptrs_c, C.c_int64), _ptr(keys_c, C.c_int32), _ptr(vals_c, C.c_float))
+
+    def partial_update_context(self, start_x, next_x, indptrs, keys, vals):
+        return self._L.refcfr_partial_update_context(self._h, int(start_x), int(next_x), _ptr(indptrs, C.c_int64), _ptr(keys, C.c_int32), _ptr(vals, C.c_float))
+
+
+class RefEALS:
+    """~ OracleEALS / CyEALS (buffalo/algo/_eals.pyx:23-67) over the reference's eals.cc / eals.hpp on the stand-ins (+ a written-out ssyrk)."""
+
+    def __init__(self):
+        self._L = _cfr_eals_lib()
+        self._h = self._L.refeals_create()
+        self._keep = {}
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._L.refeals_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def init(self, opt_path):
+        return bool(self._L.refeals_init(self._h, opt_path if isinstance(opt_path, bytes) else str(opt_path).encode("utf-8")))
+
+    def initialize_model(self, P, Q, Cw):
+        self._keep.update(P=P, Q=Q, C=Cw)
+        self._L.refeals_initialize_model(self._h, _ptr(P, C.c_float), _ptr(Q, C.c_float), _ptr(Cw, C.c_float), P.shape[0], Q.shape[0])
+
+    def precompute_cache(self, nnz, indptr, keys, axis):
+        self._L.refeals_precompute_cache(self._h, int(nnz), _ptr(indptr, C.c_int64), _ptr(keys, C.c_int32), int(axis))
+
+    def update(self, indptr, keys, vals, axis):
+        return bool(self._L.refeals_update(self._h, _ptr(indptr, C.c_int64), _ptr(keys, C.c_int32), _ptr(vals, C.c_float), int(axis)))
+
+    def estimate_loss(self, nnz, indptr, keys, vals, axis):
+        out = (C.c_float * 2)()
+        self._L.refeals_estimate_loss(self._h, int(nnz), _ptr(indptr, C.c_int64), _ptr(keys, C.c_int32), _ptr(vals, C.c_float), int(axis), out)
+        return float(out[0]), float(out[1])
