@@ -41,10 +41,10 @@ def available():
 def build(force=False):
     if not reference_present():
         return all(os.path.exists(_path(k)) for k in ("bpr", "warp"))
-    deps = [os.path.join(_HERE, "ref_sgd.cc"), os.path.join(_HERE, "ref_als.cc"), os.path.join(_HERE, "ref_cfr_eals.cc"), os.path.join(_HERE, "buffalo_oracle.cc")]
+    deps = [os.path.join(_HERE, "ref_sgd.cc"), os.path.join(_HERE, "ref_als.cc"), os.path.join(_HERE, "ref_cfr_eals.cc"), os.path.join(_HERE, "ref_core.cc"), os.path.join(_HERE, "buffalo_oracle.cc")]
     deps += [os.path.join(r, f) for r, _, fs in os.walk(os.path.join(_HERE, "stand_in_3rd")) for f in fs]
     newest = max(os.path.getmtime(p) for p in deps)
-    libs = [os.path.join(_HERE, "_ref", n) for n in ("libbuffalo_bpr_on_stand_ins.so", "libbuffalo_warp_on_stand_ins.so", "libbuffalo_als_on_stand_ins.so", "libbuffalo_cfr_eals_on_stand_ins.so",
+    libs = [os.path.join(_HERE, "_ref", n) for n in ("libbuffalo_bpr_on_stand_ins.so", "libbuffalo_warp_on_stand_ins.so", "libbuffalo_als_on_stand_ins.so", "libbuffalo_cfr_eals_on_stand_ins.so", "libbuffalo_core_on_stand_ins.so",
                                                       "libbuffalo_bpr_on_stand_ins_exact.so", "libbuffalo_warp_on_stand_ins_exact.so",
                                                       "libbuffalo_oracle_exact.so")]
     if force or any(not os.path.exists(p) or os.path.getmtime(p) < newest for p in libs):
@@ -292,3 +292,30 @@ class RefEALS:
         out = (C.c_float * 2)()
         self._L.refeals_estimate_loss(self._h, int(nnz), _ptr(indptr, C.c_int64), _ptr(keys, C.c_int32), _ptr(vals, C.c_float), int(axis), out)
         return float(out[0]), float(out[1])
+
+
+def _core_lib():
+    if "core" not in _libs:
+        if not build():
+            raise RuntimeError("oracle/_ref/libbuffalo_core_on_stand_ins.so is not built and /root/reference is absent")
+        L = C.CDLL(os.path.join(_HERE, "_ref", "libbuffalo_core_on_stand_ins.so"))
+        i32 = C.c_int
+        pf, pi32 = C.POINTER(C.c_float), C.POINTER(C.c_int32)
+        L.refcore_quickselect.restype, L.refcore_quickselect.argtypes = None, [pf, i32, i32, pi32, i32, i32, i32]
+        L.refcore_dot_topn.restype, L.refcore_dot_topn.argtypes = None, [pi32, i32, pf, i32, i32, pf, i32, i32, pf, i32, pi32, pf, pi32, i32, i32, i32]
+        _libs["core"] = L
+    return _libs["core"]
+
+
+def dot_topn(indexes, P, Q, Qb, out_keys, out_scores, pool, k, num_threads=1):
+    """buffalo.parallel._core.dot_topn (_core.pyx:38-58) over the reference's _core.hpp on the stand-ins; same arguments as oracle.dot_topn."""
+    qb_rows = Qb.shape[0] if Qb.ndim == 2 and Qb.shape[1] != 0 else 0
+    _core_lib().refcore_dot_topn(_ptr(indexes, C.c_int32), indexes.shape[0], _ptr(P, C.c_float), P.shape[0], P.shape[1], _ptr(Q, C.c_float), Q.shape[0],
+                                 Q.shape[1], _ptr(Qb, C.c_float), qb_rows, _ptr(out_keys, C.c_int32), _ptr(out_scores, C.c_float),
+                                 _ptr(pool, C.c_int32), pool.shape[0], int(k), int(num_threads))
+
+
+def quickselect(scores, result, sorted, num_threads=1):
+    """buffalo.parallel._core.quickselect (_core.pyx:30-35) over the reference's _core.hpp on the stand-ins."""
+    _core_lib().refcore_quickselect(_ptr(scores, C.c_float), scores.shape[0], scores.shape[1], _ptr(result, C.c_int32), result.shape[1], int(bool(sorted)),
+                                    int(num_threads))

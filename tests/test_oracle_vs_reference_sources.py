@@ -90,3 +90,41 @@ def test_eals_and_cfr_within_rounding():
     assert [x["algo"] for x in rows] == ["eals"] * 3 + ["cfr"] * 4 and all(x["moved"] > 1e-2 for x in rows)
     for x in rows:
         assert x["max_rel_diff"] <= 1e-4 and x["loss_rel_diff"] <= 1e-5, x
+
+
+def test_topk_identical_to_the_reference_s_core_header():
+    """buffalo/parallel/_core.hpp on the stand-ins beside the oracle's dot_topn / quickselect: random factors (ties included through
+    repeated rows), with and without bias, pool, self-exclusion (P is Q), k above the candidate count.  Keys and scores identical."""
+    import numpy as np
+    from oracle import oracle
+    ref_sgd.build()
+    rng = np.random.default_rng(0)
+    for case in range(12):
+        n_p, n_q, d, k = int(rng.integers(5, 60)), int(rng.integers(3, 80)), int(rng.integers(1, 70)), int(rng.integers(1, 25))
+        P = rng.normal(size=(n_p, d)).astype(np.float32)
+        Q = rng.normal(size=(n_q, d)).astype(np.float32)
+        Q[rng.integers(0, n_q, size=max(1, n_q // 5))] = Q[0]                      # ties
+        same = case % 4 == 0
+        if same:
+            P = Q
+        Qb = rng.normal(size=(n_q, 1)).astype(np.float32) if case % 3 == 0 else np.array([[]], dtype=np.float32)
+        pool = rng.choice(n_q, size=int(rng.integers(1, n_q + 1)), replace=False).astype(np.int32) if case % 2 else np.array([], dtype=np.int32)
+        idx = rng.integers(0, P.shape[0], size=9).astype(np.int32)
+        outs = []
+        for fn in (oracle.dot_topn, ref_sgd.dot_topn):
+            keys, scores = np.full((len(idx), k), -7, np.int32), np.full((len(idx), k), -7, np.float32)
+            fn(idx, P, Q, Qb, keys, scores, pool, k, 2)
+            outs.append((keys, scores))
+        assert np.array_equal(outs[0][0], outs[1][0]), case
+        assert np.array_equal(outs[0][1].view(np.int32), outs[1][1].view(np.int32)), case
+        S = rng.normal(size=(7, int(rng.integers(k, 200)))).astype(np.float32)
+        for sorted_ in (True, False):
+            res = []
+            for fn in (oracle.quickselect, ref_sgd.quickselect):
+                r = np.empty((S.shape[0], k), np.int32)
+                fn(S, r, sorted_, 2)
+                res.append(r)
+            if sorted_:
+                assert np.array_equal(res[0], res[1]), case
+            else:                                                                    # nth_element leaves the first k in no particular order
+                assert np.array_equal(np.sort(res[0], axis=1), np.sort(res[1], axis=1)), case
