@@ -36,6 +36,7 @@ def bpr_logit(x, table):
 # lib/algo_impl/bpr/bpr.cc:119-171 -- one (u, pos, neg) SGD step, in place (Q-1)
 # ---------------------------------------------------------------------------------------------
 def bpr_sgd_step(P, Q, Qb, u, pos, neg, alpha, opt, table):
+    alpha_d = alpha
     alpha = f32(alpha)
     reg_u, reg_i, reg_j, reg_b = (f32(opt[k]) for k in ("reg_u", "reg_i", "reg_j", "reg_b"))
     x = f32(np.dot(P[u], Q[pos] - Q[neg]))
@@ -45,12 +46,12 @@ def bpr_sgd_step(P, Q, Qb, u, pos, neg, alpha, opt, table):
     item_deriv = (logit * P[u]).astype(np.float32)  # concrete: OLD P_u
     if opt["update_i"]:
         Q[pos] += alpha * (item_deriv - reg_i * Q[pos])
-        if opt["use_bias"]:
-            Qb[pos, 0] += alpha * (logit - reg_b * Qb[pos, 0])
+        if opt["use_bias"]:   # bpr.cc:161 is a scalar C++ statement: double alpha, double reg_b -> a double expression rounded once on store
+            Qb[pos, 0] = f32(float(Qb[pos, 0]) + float(alpha_d) * (float(logit) - float(opt["reg_b"]) * float(Qb[pos, 0])))
     if opt["update_j"]:
         Q[neg] += alpha * (-item_deriv - reg_j * Q[neg])
-        if opt["use_bias"]:
-            Qb[neg, 0] += alpha * (-logit - reg_b * Qb[neg, 0])
+        if opt["use_bias"]:   # bpr.cc:167
+            Qb[neg, 0] = f32(float(Qb[neg, 0]) + float(alpha_d) * (-float(logit) - float(opt["reg_b"]) * float(Qb[neg, 0])))
     # lazy expression g evaluated now, with the UPDATED item rows
     g = logit * (Q[pos] - Q[neg]) - reg_u * P[u]
     P[u] += alpha * g
