@@ -181,6 +181,43 @@ def main():
         users, pos, neg = (np.arange(12, dtype=np.int32), np.arange(12, dtype=np.int32), np.arange(20, 32, dtype=np.int32))
         return o.compute_loss(users, pos, neg)
 
+    def run_decay(cls, opt, P, Q, Qb):
+        """The learning-rate thread (algo.cc:261-306): with min_lr < lr a job carries the rate add_jobs reads when it queues it, which the
+        progress thread lowers as jobs complete -- timing, in general (Q-8).  One user per add_jobs call, each call made only after the
+        previous job is done and accounted for, makes every job's rate a function of completed work alone."""
+        o = cls()
+        path = H.write_opt(opt)
+        assert o.init(path)
+        os.unlink(path)
+        o.initialize_model(P, Q, Qb, csr.nnz)
+        o.set_cumulative_table(H.cum_table(csr, opt), csr.num_items)
+        o.launch_workers()
+        for _ in range(epochs):
+            for x in range(csr.num_users):
+                beg = int(csr.indptr[x - 1]) if x else 0
+                o.add_jobs(x, x + 1, csr.indptr, np.ascontiguousarray(csr.keys[beg:int(csr.indptr[x])]))
+                o.wait_until_done()
+                time.sleep(0.004)
+            o.update_parameters()
+        o.join()
+        return 0.0
+
+    for kw in (dict(), dict(use_bias=False, num_negative_samples=2)):
+        opt = bpr_opt(d=20, lr=0.05, min_lr=0.004, num_iters=epochs, random_seed=7, num_workers=1, **kw)
+        rng = np.random.default_rng(1)
+        P0 = rng.normal(scale=0.3, size=(csr.num_users, 20)).astype(np.float32)
+        Q0 = rng.normal(scale=0.3, size=(csr.num_items, 20)).astype(np.float32)
+        Qb0 = rng.normal(scale=0.1, size=(csr.num_items, 1)).astype(np.float32) * (1 if opt["use_bias"] else 0)
+        A, B = [x.copy() for x in (P0, Q0, Qb0)], [x.copy() for x in (P0, Q0, Qb0)]
+        run_decay(oracle.OracleBPRMF, opt, *A)
+        run_decay(ref_sgd.RefBPRMF, opt, *B)
+        const = [x.copy() for x in (P0, Q0, Qb0)]                 # the same run at a constant rate: the decay must have made a difference
+        run_decay(oracle.OracleBPRMF, dict(opt, min_lr=opt["lr"]), *const)
+        print(json.dumps({"algo": "bpr", "options": dict(kw, lr_decay=True), "max_abs_diff": [float(np.abs(a - b).max()) for a, b in zip(A, B)],
+                          "identical": [bool(np.array_equal(a, b)) for a, b in zip(A, B)], "loss": [0.0, 0.0],
+                          "moved": float(np.abs(A[0] - P0).max()), "scale": float(np.abs(A[0]).max()),
+                          "decay_effect": float(np.abs(A[0] - const[0]).max())}), flush=True)
+
     for algo, cases, ocls, rcls, mk, d in (("bpr", BPR, oracle.OracleBPRMF, ref_sgd.RefBPRMF, bpr_opt, 20),
                                            ("warp", WARP, oracle.OracleWARP, ref_sgd.RefWARP, warp_opt, 24)):
         for kw in cases:
