@@ -196,7 +196,7 @@ def main():
             for x in range(csr.num_users):
                 beg = int(csr.indptr[x - 1]) if x else 0
                 o.add_jobs(x, x + 1, csr.indptr, np.ascontiguousarray(csr.keys[beg:int(csr.indptr[x])]))
-                time.sleep(0.004)          # one user's job takes microseconds; then the queue is empty and wait_until_done returns at once
+                time.sleep(0.010)          # one user's job takes microseconds; then the queue is empty and wait_until_done returns at once
                 o.wait_until_done()        # (called first it would find the job still queued and sleep its 100 ms, algo.cc:470)
             o.update_parameters()
         o.join()
