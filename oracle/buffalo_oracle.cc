@@ -5,33 +5,30 @@
 // path.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
 // may load this library, and only as the checker / the timed CPU baseline.
 //
-// PARITY UNPINNED: the reference ships no golden vectors or known-answer tests
-// for the training arithmetic and its C++ cannot be
-// compiled here (Eigen / json11 / spdlog submodules are empty).  This file is
-// therefore pinned only by (a) line-by-line correspondence with the reference
-// sources cited on every function and (b) the independent numpy
-// transliterations + analytic micro-cases in tests/test_oracle_pins.py.
-// The inference-side selection (dot_topn / quickselect, bottom of this file)
-// IS pinned by the reference: its own tests compare those functions with numpy
-// argsort (tests/parallel/test_base.py:38-101) and are restated as
-// test_topn_reference_test01/03/04 in tests/test_oracle_pins.py.  The data
-// ingestion restatements (orc_coo_to_csr, orc_build_sppmi) ARE pinned by the
-// reference's own compiled code: buffalo/data/fileio.hpp builds with the
-// standard library alone (oracle/_ref, oracle/ref_fileio.cc) and
-// tests/test_oracle_ref_fileio.py holds the two functions to it bit for bit.
-// The training classes are additionally run THROUGH the reference: 52 of its
-// own algorithm tests (tests/algo/test_{als,bpr,warp,eals}.py, unmodified:
-// NDCG / MAP thresholds, top-k by item name, serialization) pass with these
-// classes bound where its fronts import CyALS / CyBPRMF / CyWARP / CyEALS, on
-// ML-100K-shaped synthetic files (tests/test_reference_suite_on_oracle.py).
-// That bounds the learning behaviour, not the last digit.  Closer: the
-// reference's own lib/algo.cc, bpr.cc, warp.cc, als.cc, cfr.cc, eals.cc compile
-// unmodified against stand-ins for Eigen / json11 / spdlog written here
-// (oracle/stand_in_3rd) and run beside this file on the same inputs
-// (tests/test_oracle_vs_reference_sources.py): BPRMF and WARP bit-identical
-// when both are built without FP contraction, ALS / CFR / eALS within their
-// solvers' conditioning.  What remains unpinned is what Eigen itself does
-// inside an expression -- the stand-ins and this file share one reading of it.
+// WHAT PINS THIS FILE (DESIGN.md section 7 has the table):
+//  * The reference BINARY cannot be built here: its training C++ needs Eigen
+//    (json11, spdlog), empty submodules absent from this image, and it ships no
+//    golden vectors or known-answer tests for training results.
+//    WHAT EIGEN DOES INSIDE AN EXPRESSION (evaluation order, vectorised
+//    reductions, GEMM / Cholesky summation) IS THEREFORE UNPINNED BY THE
+//    REFERENCE; builder-made pins only (numpy transliterations, analytic
+//    micro-cases, float64 recurrences: tests/test_oracle_pins.py).
+//  * Everything else in the training sources IS held to the reference: its own
+//    lib/algo.cc, bpr.cc, warp.cc, als.cc, cfr.cc, eals.cc and parallel/_core.hpp
+//    compile unmodified against stand-ins for Eigen / json11 / spdlog written
+//    here (oracle/stand_in_3rd) and run beside this file on the same inputs
+//    (tests/test_oracle_vs_reference_sources.py): BPRMF and WARP bit-identical
+//    when both are built without FP contraction (incl. the learning-rate
+//    thread), top-k identical, ALS / CFR / eALS within their solvers'
+//    conditioning.  The stand-ins and this file share one reading of Eigen.
+//  * Its own tests: tests/parallel/test_base.py unmodified over dot_topn; 62 of
+//    its algorithm tests (tests/algo/test_{als,bpr,warp,eals,cfr}.py: NDCG / MAP
+//    thresholds, top-k by item name, serialization) with these classes bound
+//    where its fronts import CyALS / CyBPRMF / CyWARP / CyEALS / CyCFR, on
+//    ML-100K-shaped synthetic files (tests/test_reference_suite_on_oracle.py).
+//  * The data-ingestion restatements (orc_coo_to_csr, orc_build_sppmi): the
+//    reference's own compiled buffalo/data/fileio.hpp (oracle/_ref), bit for bit
+//    (tests/test_oracle_ref_fileio.py).
 //
 // All citations are relative to /root/reference/.
 // Quirk numbers (Q-n) refer to SURVEY.md section 7.4.
