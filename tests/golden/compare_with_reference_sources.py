@@ -25,10 +25,13 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 BPR = [dict(), dict(optimizer="adagrad"), dict(optimizer="adam", per_coordinate_normalize=True), dict(optimizer="adam", use_bias=False),
        dict(num_negative_samples=2, use_bias=False), dict(sampling_power=1.0, verify_neg=False), dict(update_i=False),
-       dict(update_j=False, reg_u=0.1), dict(optimizer="adagrad", per_coordinate_normalize=True, num_negative_samples=3)]
+       dict(update_j=False, reg_u=0.1), dict(optimizer="adagrad", per_coordinate_normalize=True, num_negative_samples=3),
+       dict(d=300, num_negative_samples=2), dict(d=1), dict(update_i=False, update_j=False), dict(reg_u=0.0, reg_i=0.0, reg_j=0.0, reg_b=0.0),
+       dict(sampling_power=0.5), dict(random_seed=777, optimizer="adam", sampling_power=2.0)]
 WARP = [dict(max_trials=10, threshold=0.3), dict(max_trials=20, threshold=0.5, score_func="l2"),
         dict(max_trials=8, threshold=0.2, optimizer="adam", per_coordinate_normalize=True),
-        dict(max_trials=30, threshold=0.5, reg_u=0.01, reg_i=0.02, reg_j=0.03), dict(max_trials=500, threshold=1.0, optimizer="adagrad")]
+        dict(max_trials=30, threshold=0.5, reg_u=0.01, reg_i=0.02, reg_j=0.03), dict(max_trials=500, threshold=1.0, optimizer="adagrad"),
+        dict(max_trials=2, threshold=0.5), dict(max_trials=3, threshold=100.0), dict(d=256, max_trials=12, threshold=0.4, score_func="l2", reg_i=0.02)]
 
 
 ALS = [  # (options, chunks): the iALS++ path is fed in one chunk -- for start_x > 0 stock buffalo sizes its Yui buffer by the wrong
@@ -221,7 +224,8 @@ def main():
     for algo, cases, ocls, rcls, mk, d in (("bpr", BPR, oracle.OracleBPRMF, ref_sgd.RefBPRMF, bpr_opt, 20),
                                            ("warp", WARP, oracle.OracleWARP, ref_sgd.RefWARP, warp_opt, 24)):
         for kw in cases:
-            opt = mk(d=d, lr=0.05, min_lr=0.05, num_iters=epochs, random_seed=7, num_workers=1, **kw)
+            opt = mk(**dict(dict(d=d, lr=0.05, min_lr=0.05, num_iters=epochs, random_seed=7, num_workers=1), **kw))
+            d = opt["d"]
             rng = np.random.default_rng(1)
             P0 = rng.normal(scale=0.3, size=(csr.num_users, d)).astype(np.float32)
             Q0 = rng.normal(scale=0.3, size=(csr.num_items, d)).astype(np.float32)

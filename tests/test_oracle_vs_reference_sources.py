@@ -7,7 +7,7 @@ scalars cast to float, 8-lane row products) is the stand-in's reading, the same 
 files -- option parsing, queue and worker thread, sampling and rejection with std::mt19937, unordered_set order, the logistic
 table, which rows are updated in which order, gradient accumulation, the adam / adagrad / per-coordinate passes, WARP's trial loop
 and projection, the loss functions -- runs as the reference wrote it, beside the oracle's restatement of it, on the same inputs
-(tests/golden/compare_with_reference_sources.py: 9 BPRMF and 5 WARP configurations, one worker, three epochs, plus two BPRMF runs
+(tests/golden/compare_with_reference_sources.py: 15 BPRMF and 8 WARP configurations, one worker, three epochs, plus two BPRMF runs
 with a decaying learning rate fed one user per add_jobs call so that the rate thread's effect is a function of completed work).
 
 Built WITHOUT floating-point contraction the two must agree TO THE BIT.  (They do; getting there corrected the oracle once: the
@@ -41,7 +41,7 @@ def _compare(exact):
                        env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     rows = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(rows) == 16 and all(x["moved"] > 1e-3 for x in rows)           # every configuration trained
+    assert len(rows) == 25 and sum(x["moved"] > 1e-3 for x in rows) >= 23       # every configuration ran; all but the two that cannot move trained
     assert sum("decay_effect" in x for x in rows) == 2 and all(x.get("decay_effect", 1.0) > 1e-2 for x in rows)   # the decayed rate mattered
     return rows
 
