@@ -178,7 +178,7 @@ def main():
                 keys, _ = H.chunk_arrays(csr, a, b)
                 o.add_jobs(a, b, csr.indptr, keys)
             o.wait_until_done()            # "queue empty" only (algo.cc:467-472): give the single worker time to finish its last job
-            time.sleep(0.15)
+            time.sleep(0.05)
             o.update_parameters()
         o.join()
         users, pos, neg = (np.arange(12, dtype=np.int32), np.arange(12, dtype=np.int32), np.arange(20, 32, dtype=np.int32))
