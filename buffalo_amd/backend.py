@@ -135,8 +135,8 @@ class _Base:
 
     def set_comm(self, comm):
         """Attach an RCCL rank (`Comm`); None detaches.  From then on the object exchanges with its peers by itself."""
-        self._keep["comm"] = comm
-        self._call("set_comm", comm._h if comm is not None else None)
+        self._call("set_comm", comm._h if comm is not None else None)   # finishes an exchange in flight on the OLD communicator
+        self._keep["comm"] = comm                                         # ... which may only go away after that
 
     def device_buffer(self, name):
         p, n = C.c_void_p(), C.c_size_t()

@@ -1822,7 +1822,7 @@ class AlsHandle : public HandleBase {
             p.yui = yui_.get();
         } else if (auto_resident_ && keys && vals && !A.indptr_host.empty()) {
             // the reference hands keys / vals over on every call (cuda/_als.pyx:52-67): a chunk seen before -- same row range,
-            // same length, same sampled checksum of both host buffers -- is served from its place in a full-size device copy
+            // same length, same 64-bit hash over both host buffers -- is served from its place in a full-size device copy
             const int64_t total = A.indptr_host.back();
             BFH_REQUIRE(end <= total, "partial_update: indptr disagrees with the placeholder's");
             if (A.keys.size() < static_cast<size_t>(total)) {
@@ -1831,7 +1831,7 @@ class AlsHandle : public HandleBase {
                 A.chunks.clear();
             }
             if (yui_.size() < static_cast<size_t>(n)) yui_.resize(static_cast<size_t>(n));
-            const uint64_t sig = sample_signature(keys, n) * 31u + sample_signature(reinterpret_cast<const int32_t*>(vals), n);
+            const uint64_t sig = content_signature(keys, n) * 31u + content_signature(reinterpret_cast<const int32_t*>(vals), n);
             auto it = A.chunks.find({start_x, next_x});
             if (it == A.chunks.end() || it->second.first != n || it->second.second != sig) {
                 if (n) {
@@ -2097,10 +2097,10 @@ class AlsHandle : public HandleBase {
         BFH_REQUIRE(bounds && n_bounds == comm_->size() + 1, "publish_rows: need world_size + 1 row boundaries");
         const int rows = axis == 0 ? P_rows_ : Q_rows_;
         BFH_REQUIRE(bounds[0] == 0 && bounds[n_bounds - 1] == rows, "publish_rows: boundaries must cover [0, rows)");
+        for (int r = 0; r + 1 < n_bounds; ++r) BFH_REQUIRE(bounds[r] <= bounds[r + 1], "publish_rows: boundaries must ascend");   // before the group opens
         float* F = axis == 0 ? P_.get() : Q_.get();
         comm_->group_start();
         for (int r = 0; r + 1 < n_bounds; ++r) {
-            BFH_REQUIRE(bounds[r] <= bounds[r + 1], "publish_rows: boundaries must ascend");
             const size_t cnt = static_cast<size_t>(bounds[r + 1] - bounds[r]) * vdim_;
             comm_->broadcast_bytes(F + static_cast<size_t>(bounds[r]) * vdim_, cnt * sizeof(float), r, stream);
         }

@@ -1165,14 +1165,29 @@ class BprHandle : public SgdHandle {
         const int64_t n = stage_chunk(start_x, next_x, indptr, keys, &p);
         *loss_sum = 0.0;
         *n_samples = static_cast<double>(n) * num_neg_;
-        if (n == 0) return;
+        if (comm_) exchange_arm();   // Z = the replicated state (sgd: Q | Qb, else the gradient buffers) before this rank changes it
+        if (n == 0) {
+            // an empty chunk of this rank's shard: nothing to walk, but every exchange point of the call is a collective the
+            // other ranks enter -- take part with a zero delta
+            if (comm_ && optimizer_ == "sgd") {
+                exchange_histogram(resident_ ? keys_.get() : p.keys, resident_ ? resident_nnz_ : 0);
+                const int64_t points = comm_segments_ > 0 ? comm_segments_ : 1;
+                for (int64_t k = 0; k < points; ++k) {
+                    exchange_finish();   // no local work since the last begin: Q <- Z exactly
+                    exchange_weights(0.0, current_lr(), num_neg_, uniform_);
+                    exchange_begin();
+                }
+                if (!comm_overlap_ || points == 1) exchange_finish();
+                sync_stream();
+            }
+            return;
+        }
         BFH_REQUIRE(uniform_ || have_cum_, "sampling_power != 0 needs set_cumulative_table");
         BFH_REQUIRE(uniform_ || cum_total_ > 0, "cumulative table is empty");
         BprConsts c = consts(current_lr());
         c.total = n * num_neg_;
         if (compute_loss_) BFH_HIP(hipMemsetAsync(scratch_.get(), 0, sizeof(double), stream));
         if (comm_ && optimizer_ == "sgd") {
-            exchange_arm();
             // the popularity every rank weighs its rows by: the resident matrix when there is one, else this call's chunk
             exchange_histogram(resident_ ? keys_.get() : p.keys, resident_ ? resident_nnz_ : n);
         }
@@ -1183,8 +1198,17 @@ class BprHandle : public SgdHandle {
             if (optimizer_ == "sgd") exchange_finish();
             launch<false>(p, c, start_x, next_x);
             if (comm_ && optimizer_ == "sgd") {
+                // the user-major walks make one exchange point per call; with "comm_segments" = k every rank must still enter k
+                // collectives (a rank whose chunk does not fit the item-major plan lands here while the others cut theirs)
+                const int64_t points = comm_segments_ > 0 ? comm_segments_ : 1;
+                comm_blocking_call_ = points == 1;
                 exchange_weights(static_cast<double>(c.total), c.lr, num_neg_, uniform_);
                 exchange_begin();
+                for (int64_t k = 1; k < points; ++k) {
+                    exchange_finish(false);
+                    exchange_weights(0.0, c.lr, num_neg_, uniform_);
+                    exchange_begin();
+                }
             }
         }
         if (comm_ && (!comm_overlap_ || comm_blocking_call_)) exchange_finish();

@@ -3,7 +3,14 @@
 #include "comm.hpp"
 
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <rccl/rccl.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <chrono>
+#include <thread>
 
 namespace bfh {
 
@@ -52,9 +59,74 @@ void check(ncclResult_t r, const char* what) {
     if (r != ncclSuccess) throw Error(BFH_ERR_HIP, std::string("RCCL ") + what + ": " + rccl().GetErrorString(r));
 }
 
+// ---- the shared-memory test transport (comm.hpp) ---------------------------------------------------------------
+constexpr char kShmMagic[8] = {'B', 'F', 'H', 'S', 'H', 'M', '1', 0};
+constexpr size_t kShmSlot = size_t(4) << 20;      // bytes a rank stages per round
+constexpr size_t kShmHeader = 4096;
+constexpr int kShmMaxRanks = 16;
+constexpr double kShmTimeoutS = 120.0;
+
+struct ShmHeader {
+    std::atomic<uint32_t> arrived;
+    std::atomic<uint32_t> generation;
+    std::atomic<uint32_t> attached;
+};
+
+bool shm_requested() {
+    const char* t = std::getenv("BFH_COMM_TRANSPORT");
+    return t && std::string(t) == "shm";
+}
+
 }  // namespace
 
+struct Comm::Shm {
+    std::string name;
+    int fd = -1;
+    size_t bytes = 0;
+    char* base = nullptr;
+    ShmHeader* hdr = nullptr;
+    std::vector<char> host;
+    char* slot(int r) { return base + kShmHeader + static_cast<size_t>(r) * kShmSlot; }
+    // central-counter barrier; the last rank to arrive opens the next generation
+    void barrier(int n) {
+        const uint32_t gen = hdr->generation.load(std::memory_order_acquire);
+        if (hdr->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == static_cast<uint32_t>(n)) {
+            hdr->arrived.store(0, std::memory_order_relaxed);
+            hdr->generation.fetch_add(1, std::memory_order_release);
+            return;
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        int spins = 0;
+        while (hdr->generation.load(std::memory_order_acquire) == gen) {
+            if (++spins < 2000) continue;
+            std::this_thread::yield();
+            if ((spins & 0xfff) == 0 &&
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > kShmTimeoutS)
+                throw Error(BFH_ERR_HIP, "shm transport: a rank did not reach the collective within " + std::to_string(int(kShmTimeoutS)) +
+                                             " s (ranks must issue the same collectives in the same order)");
+        }
+    }
+    ~Shm() {
+        bool last = false;
+        if (hdr) last = hdr->attached.fetch_sub(1, std::memory_order_acq_rel) == 1;
+        if (base) munmap(base, bytes);
+        if (fd >= 0) close(fd);
+        if (last) shm_unlink(name.c_str());
+    }
+};
+
 void Comm::unique_id(char* out128) {
+    if (shm_requested()) {   // the id names the segment: magic + 16 random bytes
+        std::memset(out128, 0, 128);
+        std::memcpy(out128, kShmMagic, sizeof(kShmMagic));
+        int fd = open("/dev/urandom", O_RDONLY);
+        if (fd < 0 || read(fd, out128 + 8, 16) != 16) {
+            if (fd >= 0) close(fd);
+            throw Error(BFH_ERR_HIP, "shm transport: /dev/urandom is not readable");
+        }
+        close(fd);
+        return;
+    }
     ncclUniqueId id;
     check(rccl().GetUniqueId(&id), "ncclGetUniqueId");
     static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
@@ -68,6 +140,29 @@ Comm::Comm(int n_ranks, int rank, const char* id128, int dev) {
     size_ = n_ranks;
     BFH_HIP(hipSetDevice(dev));
     BFH_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    if (std::memcmp(id128, kShmMagic, sizeof(kShmMagic)) == 0) {
+        BFH_REQUIRE(n_ranks <= kShmMaxRanks, "shm transport: at most 16 ranks");
+        shm_ = new Shm();
+        static const char* hex = "0123456789abcdef";
+        shm_->name = "/bfh_";
+        for (int i = 0; i < 16; ++i) {
+            const unsigned char b = static_cast<unsigned char>(id128[8 + i]);
+            shm_->name += hex[b >> 4];
+            shm_->name += hex[b & 15];
+        }
+        shm_->bytes = kShmHeader + static_cast<size_t>(n_ranks) * kShmSlot;
+        shm_->fd = shm_open(shm_->name.c_str(), O_CREAT | O_RDWR, 0600);
+        if (shm_->fd < 0 || ftruncate(shm_->fd, static_cast<off_t>(shm_->bytes)) != 0)   // a fresh segment reads as zeros: counters start at 0
+            throw Error(BFH_ERR_HIP, "shm transport: cannot create " + shm_->name);
+        void* m = mmap(nullptr, shm_->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, shm_->fd, 0);
+        if (m == MAP_FAILED) throw Error(BFH_ERR_HIP, "shm transport: mmap failed");
+        shm_->base = static_cast<char*>(m);
+        shm_->hdr = reinterpret_cast<ShmHeader*>(m);
+        shm_->hdr->attached.fetch_add(1, std::memory_order_acq_rel);
+        shm_->host.resize(kShmSlot);
+        shm_->barrier(n_ranks);   // every rank is attached before the first collective
+        return;
+    }
     ncclUniqueId id;
     std::memcpy(&id, id128, sizeof(id));
     ncclComm_t c = nullptr;
@@ -76,24 +171,62 @@ Comm::Comm(int n_ranks, int rank, const char* id128, int dev) {
 }
 
 Comm::~Comm() {
+    delete shm_;
     if (comm_) (void)rccl().CommDestroy(static_cast<ncclComm_t>(comm_));
     if (stream) (void)hipStreamDestroy(stream);
 }
 
+// rounds of at most one slot per rank: D2H into the rank's slot | barrier | sum the slots in rank order | barrier | H2D
+template <typename T>
+void Comm::shm_all_reduce(const T* send, T* recv, size_t count, hipStream_t s) {
+    BFH_HIP(hipStreamSynchronize(s));
+    const size_t per = kShmSlot / sizeof(T);
+    T* out = reinterpret_cast<T*>(shm_->host.data());
+    for (size_t off = 0; off < count; off += per) {
+        const size_t n = std::min(per, count - off);
+        BFH_HIP(hipMemcpy(shm_->slot(rank_), send + off, n * sizeof(T), hipMemcpyDeviceToHost));
+        shm_->barrier(size_);
+        const T* a = reinterpret_cast<const T*>(shm_->slot(0));
+        for (size_t i = 0; i < n; ++i) out[i] = a[i];
+        for (int r = 1; r < size_; ++r) {
+            const T* b = reinterpret_cast<const T*>(shm_->slot(r));
+            for (size_t i = 0; i < n; ++i) out[i] += b[i];
+        }
+        shm_->barrier(size_);
+        BFH_HIP(hipMemcpy(recv + off, out, n * sizeof(T), hipMemcpyHostToDevice));
+    }
+}
+
 void Comm::all_reduce_f32(const float* send, float* recv, size_t count, hipStream_t s) {
+    if (shm_) { shm_all_reduce(send, recv, count, s); return; }
     if (count) check(rccl().AllReduce(send, recv, count, ncclFloat32, ncclSum, static_cast<ncclComm_t>(comm_), s), "ncclAllReduce(f32)");
 }
 void Comm::all_reduce_i32(const int* send, int* recv, size_t count, hipStream_t s) {
+    if (shm_) { shm_all_reduce(send, recv, count, s); return; }
     if (count) check(rccl().AllReduce(send, recv, count, ncclInt32, ncclSum, static_cast<ncclComm_t>(comm_), s), "ncclAllReduce(i32)");
 }
 void Comm::all_reduce_f64(const double* send, double* recv, size_t count, hipStream_t s) {
+    if (shm_) { shm_all_reduce(send, recv, count, s); return; }
     if (count) check(rccl().AllReduce(send, recv, count, ncclFloat64, ncclSum, static_cast<ncclComm_t>(comm_), s), "ncclAllReduce(f64)");
 }
 void Comm::broadcast_bytes(void* buf, size_t bytes, int root, hipStream_t s) {
+    if (shm_) {
+        BFH_REQUIRE(root >= 0 && root < size_, "broadcast: bad root");
+        BFH_HIP(hipStreamSynchronize(s));
+        char* p = static_cast<char*>(buf);
+        for (size_t off = 0; off < bytes; off += kShmSlot) {
+            const size_t n = std::min(kShmSlot, bytes - off);
+            if (rank_ == root) BFH_HIP(hipMemcpy(shm_->slot(0), p + off, n, hipMemcpyDeviceToHost));
+            shm_->barrier(size_);
+            if (rank_ != root) BFH_HIP(hipMemcpy(p + off, shm_->slot(0), n, hipMemcpyHostToDevice));
+            shm_->barrier(size_);
+        }
+        return;
+    }
     if (bytes) check(rccl().Broadcast(buf, buf, bytes, ncclInt8, root, static_cast<ncclComm_t>(comm_), s), "ncclBroadcast");
 }
-void Comm::group_start() { check(rccl().GroupStart(), "ncclGroupStart"); }
-void Comm::group_end() { check(rccl().GroupEnd(), "ncclGroupEnd"); }
+void Comm::group_start() { if (shm_) return; check(rccl().GroupStart(), "ncclGroupStart"); }
+void Comm::group_end() { if (shm_) return; check(rccl().GroupEnd(), "ncclGroupEnd"); }
 
 }  // namespace bfh
 

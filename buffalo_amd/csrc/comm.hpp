@@ -2,6 +2,13 @@
 // One process per GPU; collectives run over xGMI on the stream the caller names.  librccl is opened at run time
 // (dlopen by SONAME, so a process that already loaded RCCL -- e.g. through torch -- shares that copy); a single-GPU
 // user never loads it.
+//
+// TEST TRANSPORT (environment BFH_COMM_TRANSPORT=shm, read when the id is made and when the communicator is built): RCCL
+// refuses two ranks on one device, so on a one-GPU box the exchange code of the handles could only ever see a world of one.
+// With the knob the same Comm interface runs over a POSIX shared-memory segment: every collective waits for its stream,
+// stages the operands through host slots (one per rank), sums them IN RANK ORDER -- the same arithmetic on every rank --
+// and copies the result back.  Host-blocking and slow by construction: it exists so that N processes sharing one GPU
+// execute exchange_begin / exchange_finish / exchange_gradients / publish_rows with N > 1 under `pytest -m gpu`.
 #pragma once
 #include "common.hpp"
 
@@ -27,6 +34,10 @@ class Comm : public HandleBase {
  private:
     void* comm_ = nullptr;
     int rank_ = 0, size_ = 1;
+    // shm test transport
+    struct Shm;
+    Shm* shm_ = nullptr;
+    template <typename T> void shm_all_reduce(const T* send, T* recv, size_t count, hipStream_t s);
 };
 
 }  // namespace bfh

@@ -1,9 +1,32 @@
 // Options (JSON) reader + ABI odds and ends.
 #include "common.hpp"
 
+#include <thread>
+
 namespace bfh {
 
 thread_local std::string g_create_error;
+
+uint64_t content_signature(const int32_t* keys, int64_t n) {
+    const int64_t per_thread = int64_t(1) << 20;   // below ~4 MB a second thread costs more than it hashes
+    unsigned hw = std::thread::hardware_concurrency();
+    const int parts = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>({8, hw ? hw : 1, n / per_thread})));
+    uint64_t h[8] = {0};
+    if (parts == 1) {
+        h[0] = content_signature_range(keys, n);
+    } else {
+        const int64_t step = ((n / parts) + 7) / 8 * 8;
+        std::vector<std::thread> th;
+        for (int t = 0; t < parts; ++t) {
+            const int64_t b = std::min<int64_t>(n, t * step), e = t + 1 == parts ? n : std::min<int64_t>(n, (t + 1) * step);
+            th.emplace_back([&h, keys, b, e, t] { h[t] = content_signature_range(keys + b, e - b); });
+        }
+        for (auto& x : th) x.join();
+    }
+    uint64_t r = 0x9E3779B97F4A7C15ull ^ static_cast<uint64_t>(n);
+    for (int t = 0; t < parts; ++t) r = (r ^ (h[t] + (r << 6) + (r >> 2))) * 0xff51afd7ed558ccdull;
+    return r ^ (r >> 33);
+}
 
 namespace {
 struct JsonReader {

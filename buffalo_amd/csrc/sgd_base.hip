@@ -435,16 +435,23 @@ __global__ __launch_bounds__(256) void delta_finish_kernel(float* __restrict__ X
 // (profiles/r02_local_sgd_study_*): the plain sum leaves |Qb| 4.5x and |Q| 2x too large (lr 0.002) or diverges (lr 0.05);
 // with the weights and 4 exchange points per epoch loss, |P|, |Q|, |Qb| land within 0.01 / 0.1 / 3.5 / 1.5 %.
 __global__ void exchange_weight_kernel(const int* __restrict__ gcnt, const int64_t* __restrict__ cum, int64_t cum_total, int rows, double pos_scale,
-                                       double neg_total, double neg_uniform, double share, double lr_kq, double lr_kb, int n_ranks,
-                                       float* __restrict__ W, float* __restrict__ Wb) {
+                                       double neg_total, double neg_uniform, const float* __restrict__ summed, double stiff_q, double stiff_b,
+                                       int n_ranks, float* __restrict__ W, float* __restrict__ Wb) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows) return;
+    // the ranks' interval sizes and learning rates, summed by the same all-reduce as the deltas: their means are the same
+    // numbers on every rank, so W -- and with it Z -- stays bit-identical across the ranks
+    const double share = neg_total > 0 ? static_cast<double>(summed[0]) / n_ranks / neg_total : 0.0;
+    const double lr = static_cast<double>(summed[1]) / n_ranks;
     double pneg = neg_uniform;
     if (cum) pneg = static_cast<double>(cum[i] - (i ? cum[i - 1] : 0)) / static_cast<double>(cum_total);
     const double m = (gcnt[i] * pos_scale + neg_total * pneg) * share;
     auto weight = [&](double x) { return (n_ranks > 1 && x > 1e-9) ? -expm1(-n_ranks * x) / (n_ranks * -expm1(-x)) : 1.0; };
-    W[i] = static_cast<float>(weight(lr_kq * m));
-    Wb[i] = static_cast<float>(weight(lr_kb * m));
+    W[i] = static_cast<float>(weight(lr * stiff_q * m));
+    Wb[i] = static_cast<float>(weight(lr * stiff_b * m));
+}
+__global__ void exchange_scalars_kernel(float* __restrict__ S, float interval, float lr) {
+    S[0] = interval; S[1] = lr; S[2] = 0.f; S[3] = 0.f;
 }
 // X = Z + R  (gradients: state after the last optimizer step + every rank's accumulation since)
 __global__ __launch_bounds__(256) void delta_apply_kernel(float* __restrict__ X, const float* __restrict__ Z, const float* __restrict__ R, int64_t n) {
@@ -469,7 +476,7 @@ void SgdHandle::set_comm(Comm* c) {
 void SgdHandle::exchange_arm() {
     if (!comm_ || x_inited_ || !model_on_gpu_) return;
     const size_t n = x_count(), nq = static_cast<size_t>(Q_rows_) * vdim_;
-    if (xZ_.size() < n) { xZ_.resize(n); xS_.resize(n); xR_.resize(n); }
+    if (xZ_.size() < n) { xZ_.resize(n, true, stream); xS_.resize(n, true, stream); xR_.resize(n, true, stream); }
     const bool grad = optimizer_ != "sgd";
     BFH_HIP(hipMemcpyAsync(xZ_.get(), grad ? gradQ_.get() : Q_.get(), nq * sizeof(float), hipMemcpyDeviceToDevice, stream));
     BFH_HIP(hipMemcpyAsync(xZ_.get() + nq, grad ? gradQb_.get() : Qb_.get(), static_cast<size_t>(Q_rows_) * sizeof(float), hipMemcpyDeviceToDevice, stream));
@@ -511,16 +518,13 @@ void SgdHandle::exchange_histogram(const int32_t* keys, int64_t n) {
     x_gcnt_ready_ = true;
 }
 
-// weights of the exchange interval that is about to begin: `interval_triples` = this rank's triples inside it
+// what the exchange that begins next covers: `interval_triples` = this rank's triples inside it, `lr` = its learning rate.
+// The weights themselves are computed in exchange_finish from the sums over the ranks (exchange_weight_kernel).
 void SgdHandle::exchange_weights(double interval_triples, double lr, int num_neg, bool uniform) {
-    if (!comm_ || !x_gcnt_ready_) return;
-    const double glob_triples = static_cast<double>(num_nnz_) * num_neg;          // one epoch over all ranks
-    const double pos_scale = x_gcnt_total_ > 0 ? static_cast<double>(num_nnz_) / x_gcnt_total_ * num_neg : 0.0;   // counted keys -> the whole matrix
-    const double share = glob_triples > 0 ? interval_triples / glob_triples : 0.0;
-    hipLaunchKernelGGL(exchange_weight_kernel, dim3((Q_rows_ + 255) / 256), dim3(256), 0, stream, static_cast<const int*>(x_gcnt_.get()),
-                       uniform ? nullptr : static_cast<const int64_t*>(cum_.get()), cum_total_, Q_rows_, pos_scale, glob_triples, uniform ? 1.0 / Q_rows_ : 0.0,
-                       share, lr * comm_stiffness_q_milli_ * 1e-3, lr * comm_stiffness_milli_ * 1e-3, comm_->size(), xW_.get(), xWb_.get());
-    BFH_HIP(hipGetLastError());
+    x_w_interval_ = interval_triples;
+    x_w_lr_ = lr;
+    x_w_num_neg_ = num_neg;
+    x_w_uniform_ = uniform;
 }
 
 // Q | Qb -> S (and Z), one all-reduce on the communicator's stream behind everything issued on `stream` so far
@@ -536,10 +540,11 @@ void SgdHandle::exchange_begin() {
                        static_cast<const float*>(xZ_.get()), S, nq);
     hipLaunchKernelGGL(delta_begin_kernel, stream_grid(Q_rows_), dim3(256), 0, stream, static_cast<const float*>(Qb_.get()),
                        static_cast<const float*>(xZ_.get() + nq), S + nq, static_cast<int64_t>(Q_rows_));
+    hipLaunchKernelGGL(exchange_scalars_kernel, dim3(1), dim3(1), 0, stream, S + x_scalars(), static_cast<float>(x_w_interval_), static_cast<float>(x_w_lr_));
     BFH_HIP(hipGetLastError());
     BFH_HIP(hipEventRecord(x_ready_, stream));
     BFH_HIP(hipStreamWaitEvent(comm_->comm_stream(), x_ready_, 0));
-    comm_->all_reduce_f32(S, xR_.get(), static_cast<size_t>(nq) + static_cast<size_t>(Q_rows_), comm_->comm_stream());
+    comm_->all_reduce_f32(S, xR_.get(), x_count(), comm_->comm_stream());
     BFH_HIP(hipEventRecord(x_done_, comm_->comm_stream()));
     x_pending_ = true;
     stats.exchanges += 1;
@@ -549,6 +554,14 @@ void SgdHandle::exchange_finish(bool progressed) {
     if (!x_pending_) return;
     const int64_t nq = static_cast<int64_t>(Q_rows_) * vdim_;
     BFH_HIP(hipStreamWaitEvent(stream, x_done_, 0));
+    if (x_gcnt_ready_) {
+        const double glob_triples = static_cast<double>(num_nnz_) * x_w_num_neg_;          // one epoch over all ranks
+        const double pos_scale = x_gcnt_total_ > 0 ? static_cast<double>(num_nnz_) / x_gcnt_total_ * x_w_num_neg_ : 0.0;   // counted keys -> the whole matrix
+        hipLaunchKernelGGL(exchange_weight_kernel, dim3((Q_rows_ + 255) / 256), dim3(256), 0, stream, static_cast<const int*>(x_gcnt_.get()),
+                           x_w_uniform_ ? nullptr : static_cast<const int64_t*>(cum_.get()), cum_total_, Q_rows_, pos_scale, glob_triples,
+                           x_w_uniform_ ? 1.0 / Q_rows_ : 0.0, static_cast<const float*>(xR_.get() + x_scalars()), comm_stiffness_q_milli_ * 1e-3,
+                           comm_stiffness_milli_ * 1e-3, comm_->size(), xW_.get(), xWb_.get());
+    }
     hipLaunchKernelGGL(delta_finish_kernel, stream_grid(nq), dim3(256), 0, stream, Q_.get(), xZ_.get(), static_cast<const float*>(xS_.get()),
                        static_cast<const float*>(xR_.get()), static_cast<const float*>(xW_.get()), vdim_, nq, progressed ? 1 : 0);
     hipLaunchKernelGGL(delta_finish_kernel, stream_grid(Q_rows_), dim3(256), 0, stream, Qb_.get(), xZ_.get() + nq, static_cast<const float*>(xS_.get() + nq),
@@ -760,7 +773,7 @@ int64_t SgdHandle::stage_chunk(int start_x, int next_x, const int64_t* indptr, c
             pr->rows = rows_.get() + beg;
         } else if (auto_resident_) {
             // every chunk keeps its place in a full-size device copy of the matrix; it is uploaded when its row range is new or
-            // the sampled checksum of the host buffer differs from the one it was uploaded with
+            // the 64-bit hash over the whole host buffer differs from the one it was uploaded with
             const int64_t total = indptr_host_.empty() ? n : indptr_host_.back();
             BFH_REQUIRE(end <= total, "partial_update: indptr disagrees with the placeholder's");
             if (keys_.size() < static_cast<size_t>(total)) {
@@ -768,7 +781,7 @@ int64_t SgdHandle::stage_chunk(int start_x, int next_x, const int64_t* indptr, c
                 rows_.resize(static_cast<size_t>(total));
                 chunks_.clear();
             }
-            const uint64_t sig = sample_signature(keys, n);
+            const uint64_t sig = content_signature(keys, n);
             auto it = chunks_.find({start_x, next_x});
             if (it == chunks_.end() || it->second.n != n || it->second.sig != sig) {
                 BFH_HIP(hipMemcpyAsync(keys_.get() + beg, keys, n * sizeof(int32_t), hipMemcpyHostToDevice, stream));

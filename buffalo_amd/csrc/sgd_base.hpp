@@ -154,7 +154,7 @@ class SgdHandle : public HandleBase {
     int xcd_fresh_ = -1, xcd_v4_ = 0;  // re-read before store; float4-per-lane rows (hot-row atomics then cost 4x the line operations)
     int xcd_hot_tau_ = 100;        // permille: tolerated collision probability of a replica row (0 = no hot rows)
     // the reference's call pattern hands the chunk's keys over on EVERY call (cuda/_bpr.pyx:60-74) and copies the model back
-    // after every epoch.  auto_resident: a chunk seen before -- same row range, same length, same sampled checksum of the host
+    // after every epoch.  auto_resident: a chunk seen before -- same row range, same length, same 64-bit hash over the whole host
     // buffer -- is served from its copy in HBM (and keeps its item-major regrouping); lazy_sync: synchronize(device_to_host)
     // only marks the host arrays stale, the copy happens on synchronize(2) / destroy (default off = the reference behaviour);
     // pin_host: the caller's factor arrays are page-locked for the duration of the model (D2H at PCIe rate)
@@ -199,7 +199,7 @@ class SgdHandle : public HandleBase {
     bool comm_blocking_call_ = false;   // this call is one segment: its exchange is finished before it returns
     int64_t comm_forced_segments_ = 1;  // exchange segments of the current call (identical on every rank)
     bool x_inited_ = false, x_pending_ = false;
-    DevBuf<float> xZ_, xS_, xR_;    // [Q_rows * vdim + ceil4(Q_rows)]: state at the last exchange, own delta, summed deltas
+    DevBuf<float> xZ_, xS_, xR_;    // [x_count()]: state at the last exchange, own delta, summed deltas
     DevBuf<float> xW_, xWb_;        // [Q_rows] combination weight of every factor row / bias for the exchange in flight (sum .. mean)
     DevBuf<int> x_gcnt_;            // [Q_rows] positives per item over all ranks
     double x_gcnt_total_ = 0;
@@ -207,7 +207,13 @@ class SgdHandle : public HandleBase {
     int comm_stiffness_milli_ = 250;   // curvature the saturation model assumes for the biases (permille); 0: plain sum
     int comm_stiffness_q_milli_ = 25;  // ... and for the factor rows (the reference's default regulariser)
     hipEvent_t x_ready_ = nullptr, x_done_ = nullptr;
-    size_t x_count() const { return static_cast<size_t>(Q_rows_) * vdim_ + ((static_cast<size_t>(Q_rows_) + 3) / 4) * 4; }
+    // Q | Qb (padded to 4) | 4 scalars that travel with the delta: [0] this rank's triples inside the interval, [1] its lr --
+    // their sums come back with R, so the combination weights are computed from the SAME numbers on every rank
+    size_t x_scalars() const { return static_cast<size_t>(Q_rows_) * vdim_ + ((static_cast<size_t>(Q_rows_) + 3) / 4) * 4; }
+    size_t x_count() const { return x_scalars() + 4; }
+    double x_w_interval_ = 0, x_w_lr_ = 0;   // what exchange_weights announced for the exchange that begins next
+    int x_w_num_neg_ = 1;
+    bool x_w_uniform_ = true;
 
     EventTimer t_main_, t_opt_, t_aux_;
 };

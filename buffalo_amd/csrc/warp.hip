@@ -31,7 +31,7 @@ struct WarpConsts {
     int chunk;
     int64_t total;
     double* loss_out;        // [0] partial loss sum
-    unsigned long long* cnt; // [0] scored negatives, [1] accepted positives
+    unsigned long long* cnt; // [0] scored negatives, [1] accepted positives, [2] candidate rows fetched (scored + speculated)
     // two-pass accumulation (sgd_base.hpp GatherParams): record Phi and the violating negative of every accepted
     // positive (Q_rows: rejected); the two item-side gradient rows are summed by grad_gather_kernel
     int two_pass;
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void warp_update_kernel(SgdParams p, WarpConst
     int cur_u = -1;
     WRow<K> pu, gacc;
     double loss = 0.0;
-    unsigned long long scored = 0, accepted = 0;
+    unsigned long long scored = 0, accepted = 0, loaded = 0;
 
     auto flush_user = [&]() {
         if (cur_u < 0) return;
@@ -203,6 +203,7 @@ __global__ __launch_bounds__(256) void warp_update_kernel(SgdParams p, WarpConst
                             }
                         }
                     }
+                    loaded += nb;
                     if (bsz < WARP_SPEC) bsz <<= 1;
                 };
                 uint32_t a0 = 0;       // attempt the in-kernel sampler starts from
@@ -310,6 +311,7 @@ __global__ __launch_bounds__(256) void warp_update_kernel(SgdParams p, WarpConst
         if (loss != 0.0) atomicAdd(c.loss_out, loss);
         if (scored) atomicAdd(c.cnt, scored);
         if (accepted) atomicAdd(c.cnt + 1, accepted);
+        if (loaded) atomicAdd(c.cnt + 2, loaded);
     }
 }
 
@@ -349,7 +351,7 @@ class WarpHandle : public SgdHandle {
         threshold_ = opt_.num("threshold");
         // warp.cc:76-83: only the exact string "l2" selects the L2 score (Q-23)
         l2_ = opt_.str("score_func") == "l2";
-        cnt_.resize(2, true, stream);
+        cnt_.resize(3, true, stream);
     }
 
     void partial_update(int start_x, int next_x, const int64_t* indptr, const int32_t* keys, double* loss_sum, double* n_samples) {
@@ -357,7 +359,8 @@ class WarpHandle : public SgdHandle {
         const int64_t n = stage_chunk(start_x, next_x, indptr, keys, &p);
         *loss_sum = 0.0;
         *n_samples = static_cast<double>(n);
-        if (n == 0) return;
+        if (comm_) exchange_arm();   // Z = the gradient buffers BEFORE this model accumulates anything (they are exchanged as deltas)
+        if (n == 0) return;          // no collective in WARP's partial_update: an empty shard chunk may return
         WarpConsts c{};
         c.reg_u = reg_u_; c.reg_i = reg_i_; c.reg_j = reg_j_;
         c.threshold = threshold_;
@@ -367,7 +370,7 @@ class WarpHandle : public SgdHandle {
         c.loss_out = scratch_.get();
         c.cnt = cnt_.get();
         BFH_HIP(hipMemsetAsync(scratch_.get(), 0, sizeof(double), stream));
-        BFH_HIP(hipMemsetAsync(cnt_.get(), 0, 2 * sizeof(unsigned long long), stream));
+        BFH_HIP(hipMemsetAsync(cnt_.get(), 0, 3 * sizeof(unsigned long long), stream));
         const bool two_pass = accum_two_pass_ != 0;
         // candidates from the pre-pass: 4 while most positives accept one of their first draws, 8 once they do not
         const int S = presample_ < 0 ? (last_T_ > 2.0 ? 8 : 4) : presample_;
@@ -424,7 +427,7 @@ class WarpHandle : public SgdHandle {
             acc_gather(p, 1, true, true, sab_pos, sab_neg, true, false);
             t_aux_.end(slot2, stream);
         }
-        unsigned long long cnt[2] = {0, 0};
+        unsigned long long cnt[3] = {0, 0, 0};
         BFH_HIP(hipMemcpyAsync(loss_sum, scratch_.get(), sizeof(double), hipMemcpyDeviceToHost, stream));
         BFH_HIP(hipMemcpyAsync(cnt, cnt_.get(), sizeof(cnt), hipMemcpyDeviceToHost, stream));
         sync_stream();
@@ -433,6 +436,7 @@ class WarpHandle : public SgdHandle {
         stats.samples += n;
         stats.scored_negatives += static_cast<int64_t>(cnt[0]);
         stats.accepted += static_cast<int64_t>(cnt[1]);
+        stats.loaded_rows += static_cast<int64_t>(cnt[2]);
         last_T_ = static_cast<double>(cnt[0]) / static_cast<double>(n);
         advance_progress(start_x, next_x, indptr);
     }

@@ -60,6 +60,7 @@ typedef struct {
     double h2d_bytes, d2h_bytes;
     int64_t merges;           /* BPRMF policy 2: reconciliations of the per-XCD item-factor replicas */
     int64_t exchanges;        /* multi-GPU: all-reduce exchange points (bfh_*_set_comm) */
+    int64_t loaded_rows;      /* WARP: candidate rows fetched by the trial loop (scored + speculated), for the byte model */
 } bfh_stats;
 
 const char* bfh_version(void);

@@ -15,6 +15,10 @@ if HARNESS not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` through gpurun)")
+    # quarantine: a device test that has NOT yet run on a device carries this marker INSTEAD of `gpu`, so the default `-m gpu`
+    # selection (what the driver runs with -x at round end) only ever holds tests whose bounds were measured.  Run them with
+    # `-m gpu_unmeasured` on a box, commit the measurement under profiles/, then switch the marker to `gpu`.
+    config.addinivalue_line("markers", "gpu_unmeasured: device test awaiting its first run on a device (not in the `-m gpu` selection)")
 
 
 def has_gpu():
@@ -26,12 +30,13 @@ def has_gpu():
 
 
 def pytest_collection_modifyitems(config, items):
-    if has_gpu():
-        return
-    skip = pytest.mark.skip(reason="no GPU visible")
+    gpu = has_gpu()
+    asked = "gpu_unmeasured" in (config.getoption("-m") or "")
     for item in items:
-        if "gpu" in item.keywords:
-            item.add_marker(skip)
+        if "gpu_unmeasured" in item.keywords and not (gpu and asked):
+            item.add_marker(pytest.mark.skip(reason="quarantined until measured on a device: select with -m gpu_unmeasured on a GPU box"))
+        elif "gpu" in item.keywords and not gpu:
+            item.add_marker(pytest.mark.skip(reason="no GPU visible"))
 
 
 @pytest.fixture

@@ -32,6 +32,13 @@ CASES = {
     "als_llt_d32": ("als", (150, 90, 1), dict(d=32, num_iters=3, optimizer="llt", random_seed=7, num_workers=2, validation={"topk": 10}), 5),
     "als_manual_cg_d64": ("als", (150, 90, 2), dict(d=64, num_iters=4, optimizer="manual_cg", random_seed=9, num_workers=2, alpha=4.0,
                                                      reg_u=0.05, reg_i=0.2, validation={"topk": 10}), 6),
+    # a WELL-POSED whole run on the reference's default solver family: d = 64 over 2,000 items, twelve CG steps, regulariser 5 --
+    # the oracle stays within 1e-4 of the float64 recurrence through all four epochs, so a device run must reach this model to 5e-3.
+    # (The three-step case above cannot be held that way: from the |N(0, 1/d^2)| start its first user half-epoch returns rows of
+    # size ~y / reg, the next system has a condition number beyond fp32, and the oracle ITSELF ends 7 % from the float64 recurrence.)
+    "als_manual_cg_d64_wellposed": ("als", (1200, 2000, 12, 0.10, 0.01), dict(d=64, num_iters=4, optimizer="manual_cg", num_cg_max_iters=12,
+                                                                             random_seed=9, num_workers=2, alpha=1.0, reg_u=5.0, reg_i=5.0,
+                                                                             validation={"topk": 10}), 11),
     "eals_d16": ("eals", (150, 90, 3), dict(d=16, num_iters=4, random_seed=3, num_workers=2, c0=64.0, exponent=0.5, validation={"topk": 10}), 7),
     # the SGD fronts in ACCELERATOR mode (the path this repository replaces): `CuBPRMF` / the WARP scaffold's object is the oracle
     # behind the accelerator's method surface, in its deterministic modes (counter sampler, CSR order, jobs processed inside
@@ -73,11 +80,11 @@ def accelerator_over_oracle(oracle_cls):
     return OracleBehindTheAcceleratorSurface
 
 
-def coordinate_text(U, I, seed):
+def coordinate_text(U, I, seed, p_in=0.45, p_out=0.04):
     """A planted coordinate file: 6 taste groups, in-group cells likelier, integer values 1..5, lines in no particular order."""
     rng = np.random.default_rng(seed)
     ug, ig = rng.integers(0, 6, U), rng.integers(0, 6, I)
-    p = np.where(ug[:, None] == ig[None, :], 0.45, 0.04)
+    p = np.where(ug[:, None] == ig[None, :], p_in, p_out)
     rows, cols = np.nonzero(rng.random((U, I)) < p)
     order = rng.permutation(len(rows))
     rows, cols = rows[order], cols[order]
