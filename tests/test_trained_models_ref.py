@@ -146,7 +146,7 @@ def _replaying_backend(records):
     return Replaying
 
 
-@pytest.mark.gpu_unmeasured
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", sorted(mk.CASES))
 def test_stand_in_front_over_the_device_reaches_stock_buffalo_s_model(tmp_path, monkeypatch, name):
     """Same file, same seeds, the HIP backend: initial factors and validation split are identical by construction, the epochs run
