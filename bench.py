@@ -581,7 +581,7 @@ def main():
     import torch.distributed as dist
     from buffalo_amd import synth
     from buffalo_amd.backend import CyBPR
-    from buffalo_amd.dist import DataParallelSGD, HipEngine, shard_csr
+    from buffalo_amd.dist import shard_csr
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -597,14 +597,15 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("BFH_DIST_BACKEND", "nccl")
         # torch.distributed is the control plane only (rendezvous, barrier, max of the elapsed times: gloo on CPU tensors);
-        # the data plane is the library's own RCCL rank (bfh_comm_*).  BFH_COMM=torch (or a gloo-only test run) selects the
-        # older path that all-reduces the backend's buffers through torch.distributed instead.
+        # the data plane is the library's own communicator (bfh_comm_*: RCCL over xGMI).  Test hooks for one-GPU boxes:
+        # BFH_DIST_BACKEND=gloo + BFH_COMM_TRANSPORT=shm + BFH_DEVICE_OVERRIDE=0 run N ranks on one device through the
+        # library's shared-memory test transport (RCCL refuses two ranks on one GPU).  BFH_COMM=torch selects the emergency
+        # path below that all-reduces the backend's buffers through torch.distributed (bench-only; not the product).
         if backend == "nccl":
             dist.init_process_group("cpu:gloo,cuda:nccl")
-            comm_mode = os.environ.get("BFH_COMM", "library")
         else:
             dist.init_process_group(backend)
-            comm_mode = "torch"
+        comm_mode = os.environ.get("BFH_COMM", "library")
     assert world == args.gpus, "WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus)
 
     csr = load_matrix(args.shape, args.seed)
@@ -660,17 +661,28 @@ def main():
         else:
             comm, comm_mode = None, "torch"
             comm_note = "library communicator unavailable (%s): fell back to torch.distributed" % comm_note
-    dp = DataParallelSGD(HipEngine(obj, I, D, opt["optimizer"]), opt["optimizer"]) if (world > 1 and comm_mode == "torch") else None
+    fallback = None
+    if world > 1 and comm_mode == "torch":
+        # emergency path (the library's communicator could not be built on this node): the blocking delta all-reduce
+        # T <- Z + sum_r (T_r - Z) on the backend's Q / Qb through torch.distributed.  Not the product path; labelled in `config`.
+        tq, tb = obj.device_tensor("Q", (I, D)), obj.device_tensor("Qb", (I,))
+        fallback = [(t, torch.empty_like(t)) for t in (tq, tb)]
     edges = np.linspace(0, n_local_users, (args.minibatches if world > 1 else 1) + 1).astype(int)
 
     def step():
         for a, b in zip(edges[:-1], edges[1:]):
-            if b <= a:
-                continue
-            if dp is not None:
-                dp.minibatch(int(a), int(b), ip, None)
-            else:
-                obj.add_jobs(int(a), int(b), ip, None)
+            if fallback is not None:
+                for t, z in fallback:
+                    z.copy_(t)
+                torch.cuda.current_stream().synchronize()
+            obj.add_jobs(int(a), int(b), ip, None)          # an empty chunk still enters the call's collectives
+            if fallback is not None:
+                torch.cuda.synchronize()
+                for t, z in fallback:
+                    t.sub_(z)
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                    t.add_(z)
+                torch.cuda.current_stream().synchronize()
         obj.update_parameters()
 
     def barrier():
@@ -695,6 +707,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     st = obj.stats()
+    breakdown = None
+    if world > 1:
+        # per step, the slowest rank of each: where a scaling run's time goes (device times from HIP events inside the library)
+        b = torch.tensor([st["kernel_ms"], st["aux_ms"], st["exchange_kernel_ms"], st["allreduce_ms"], float(local_nnz)], dtype=torch.float64)
+        lo = b.clone()
+        dist.all_reduce(b, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        k = 1.0 / max(steps, 1)
+        breakdown = {"walk_kernel_ms": float(b[0]) * k, "sort_merge_presample_ms": float(b[1]) * k, "exchange_kernel_ms": float(b[2]) * k,
+                     "allreduce_ms": float(b[3]) * k, "what": "max over ranks, per step; allreduce_ms = the collective on the stream it ran on, "
+                     "incl. the wait for the slowest rank (blocking exchanges only)",
+                     "walk_kernel_ms_min_rank": float(lo[0]) * k, "shard_nnz_min_max": [int(lo[4]), int(b[4])]}
 
     if rank == 0:
         updates = float(total_nnz) * opt["num_negative_samples"] * steps
@@ -724,8 +748,8 @@ def main():
                                    % (args.shape, U, I, nnz, "" if args.scaling == "strong" or world == 1 else " per GPU", D),
                        "parallelism": "1 GPU" if world == 1 else "dp%d: users sharded, Q replicated, %.1f RCCL delta all-reduce/epoch (%s)"
                                       % (world, (st["exchanges"] / max(steps, 1)) if comm is not None else args.minibatches,
-                                         "inside the library, pipelined behind the next walk" if comm is not None
-                                         else (comm_note or "through torch.distributed")),
+                                         ("inside the library (%s)" % os.environ.get("BFH_COMM_TRANSPORT", "RCCL")) if comm is not None
+                                         else (comm_note or "EMERGENCY PATH through torch.distributed")),
                        "hogwild": {"0": "write-through (sc1) racy stores on item rows", "1": "fp32 atomics on item rows",
                                    "2": "per-XCD item-factor replicas (plain stores through the XCD's L2, merged by the delta rule "
                                         "%.1f times per epoch); popular rows stay chip-wide on fp32 atomics"
@@ -751,6 +775,8 @@ def main():
                                                      / 1e9 / HBM_PEAK_GBS)},
             "epoch_ms": elapsed / steps * 1e3,
         }
+        if breakdown is not None:
+            out["breakdown"] = breakdown
         if world == 1:
             try:   # the same box's HBM under a trivial kernel, next to the 8 TB/s the fraction is quoted against
                 m = measured_stream_bandwidth()

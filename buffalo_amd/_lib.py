@@ -21,7 +21,8 @@ class Stats(C.Structure):
     _fields_ = [("samples", C.c_int64), ("scored_negatives", C.c_int64), ("accepted", C.c_int64),
                 ("launches", C.c_int64), ("kernel_ms", C.c_double), ("optimizer_ms", C.c_double),
                 ("aux_ms", C.c_double), ("h2d_bytes", C.c_double), ("d2h_bytes", C.c_double),
-                ("merges", C.c_int64), ("exchanges", C.c_int64), ("loaded_rows", C.c_int64)]
+                ("merges", C.c_int64), ("exchanges", C.c_int64), ("loaded_rows", C.c_int64),
+                ("exchange_kernel_ms", C.c_double), ("allreduce_ms", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

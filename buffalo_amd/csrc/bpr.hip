@@ -46,6 +46,7 @@ namespace bfh {
 
 struct BprConsts {
     float lr, reg_u, reg_i, reg_j, reg_b;
+    double lr_d, reg_b_d;   // the bias statements of the reference are scalar C++ in double (bpr.cc:81, 99, 162, 168)
     int use_bias, update_i, update_j, verify_neg, uniform, num_neg, pcn, compute_loss, atomic, sequential;
     int64_t cum_total;
     const float* exp_table;
@@ -70,6 +71,12 @@ struct BprConsts {
     float* coef_out;      // [total]
     uint32_t* neg_out;    // [total]
 };
+
+// new bias = (float)(b + alpha * (+-logit - reg_b * b)) with the product and sums in double, as the reference's scalar statement rounds
+__device__ __forceinline__ float bias_step(float b, float signed_logit, double lr, double reg_b) {
+    return static_cast<float>(static_cast<double>(b) + lr * (static_cast<double>(signed_logit) - reg_b * static_cast<double>(b)));
+}
+
 
 // The XCD this wave runs on (0..7), from the hardware register: the address of a wave's item-factor
 // replica depends on it, so it must be the truth, not a guess from blockIdx.
@@ -426,18 +433,19 @@ __global__ __launch_bounds__(256) void bpr_update_kernel(SgdParams p, BprConsts 
                         else row_store<K, V4, true>(qj, Qj, lane, vdim);
                     }
                     if (c.use_bias && lane == 0) {
-                        const float dbi = c.update_i ? c.lr * (logit - c.reg_b * bi) : 0.f;
-                        if (same) bj = bi + dbi;
-                        const float dbj = c.lr * (-logit - c.reg_b * bj);
+                        // bpr.cc:162, 168 are scalar statements with `double alpha`, `double reg_b`: evaluated in double, stored as float
+                        const float bi_new = c.update_i ? bias_step(bi, logit, c.lr_d, c.reg_b_d) : bi;
+                        if (same) bj = bi_new;
+                        const float bj_new = bias_step(bj, -logit, c.lr_d, c.reg_b_d);
                         if (c.update_i) {
-                            if (at_i) atomic_add_f32(Bi, dbi);
-                            else if (V4 && !rep) coh_store(Bi, bi + dbi);
-                            else *Bi = bi + dbi;
+                            if (at_i) atomic_add_f32(Bi, bi_new - bi);
+                            else if (V4 && !rep) coh_store(Bi, bi_new);
+                            else *Bi = bi_new;
                         }
                         if (c.update_j) {
-                            if (at_j) atomic_add_f32(Bj, dbj);
-                            else if (V4 && !rep) coh_store(Bj, bj + dbj);
-                            else *Bj = bj + dbj;
+                            if (at_j) atomic_add_f32(Bj, bj_new - bj);
+                            else if (V4 && !rep) coh_store(Bj, bj_new);
+                            else *Bj = bj_new;
                         }
                     }
                 } else {
@@ -634,6 +642,8 @@ class BprHandle : public SgdHandle {
     BprConsts consts(double lr) {
         BprConsts c{};
         c.lr = static_cast<float>(lr);
+        c.lr_d = lr;
+        c.reg_b_d = reg_b_d_;
         c.reg_u = reg_u_; c.reg_i = reg_i_; c.reg_j = reg_j_; c.reg_b = reg_b_;
         c.use_bias = use_bias_; c.update_i = update_i_; c.update_j = update_j_;
         c.verify_neg = verify_neg_; c.uniform = uniform_; c.num_neg = num_neg_; c.neg_limit = im_neg_limit_;

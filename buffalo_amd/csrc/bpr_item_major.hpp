@@ -427,12 +427,13 @@ __global__ __launch_bounds__(256, K <= 4 ? (PIPE ? 5 : 6) : 1) void bpr_item_maj
                 }
                 float dbj = 0.f;
                 if (c.use_bias) {
-                    const float dbi = c.update_i ? c.lr * (logit - c.reg_b * bi) : 0.f;
-                    bi += dbi;
-                    dbi_acc += dbi;
+                    const float bi_new = c.update_i ? bias_step(bi, logit, c.lr_d, c.reg_b_d) : bi;   // bpr.cc:162 in double
+                    dbi_acc += bi_new - bi;
+                    bi = bi_new;
                     if (same) bj = bi;
-                    dbj = c.update_j ? c.lr * (-logit - c.reg_b * bj) : 0.f;
-                    bj += dbj;
+                    const float bj_new = c.update_j ? bias_step(bj, -logit, c.lr_d, c.reg_b_d) : bj;  // bpr.cc:168
+                    dbj = bj_new - bj;
+                    bj = bj_new;
                     if (same) { bi = bj; dbi_acc += dbj; }
                 }
                 // ---------------- write the two per-triple rows back ----------------
@@ -694,12 +695,13 @@ __global__ __launch_bounds__(256, 5) void bpr_item_major_dual_kernel(SgdParams p
                 }
                 float dbj = 0.f;
                 if (c.use_bias) {
-                    const float dbi = c.update_i ? c.lr * (logit - c.reg_b * bi) : 0.f;
-                    bi += dbi;
-                    dbi_acc += dbi;
+                    const float bi_new = c.update_i ? bias_step(bi, logit, c.lr_d, c.reg_b_d) : bi;   // bpr.cc:162 in double
+                    dbi_acc += bi_new - bi;
+                    bi = bi_new;
                     if (same) bj = bi;
-                    dbj = c.update_j ? c.lr * (-logit - c.reg_b * bj) : 0.f;
-                    bj += dbj;
+                    const float bj_new = c.update_j ? bias_step(bj, -logit, c.lr_d, c.reg_b_d) : bj;  // bpr.cc:168
+                    dbj = bj_new - bj;
+                    bj = bj_new;
                     if (same) { bi = bj; dbi_acc += dbj; }
                 }
                 // ---- write the two per-triple rows back ----

@@ -21,6 +21,7 @@ struct Rccl {
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclBroadcast) Broadcast = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
@@ -45,6 +46,7 @@ Rccl& rccl() {
         x.GetUniqueId = reinterpret_cast<decltype(x.GetUniqueId)>(sym("ncclGetUniqueId"));
         x.CommInitRank = reinterpret_cast<decltype(x.CommInitRank)>(sym("ncclCommInitRank"));
         x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(sym("ncclCommDestroy"));
+        x.CommCount = reinterpret_cast<decltype(x.CommCount)>(sym("ncclCommCount"));
         x.AllReduce = reinterpret_cast<decltype(x.AllReduce)>(sym("ncclAllReduce"));
         x.Broadcast = reinterpret_cast<decltype(x.Broadcast)>(sym("ncclBroadcast"));
         x.GroupStart = reinterpret_cast<decltype(x.GroupStart)>(sym("ncclGroupStart"));
@@ -168,6 +170,9 @@ Comm::Comm(int n_ranks, int rank, const char* id128, int dev) {
     ncclComm_t c = nullptr;
     check(rccl().CommInitRank(&c, n_ranks, id, rank), "ncclCommInitRank");
     comm_ = c;
+    int count = 0;
+    check(rccl().CommCount(c, &count), "ncclCommCount");
+    BFH_REQUIRE(count == n_ranks, "comm_create: RCCL reports " + std::to_string(count) + " ranks, expected " + std::to_string(n_ranks));
 }
 
 Comm::~Comm() {

@@ -536,15 +536,19 @@ void SgdHandle::exchange_begin() {
     BFH_REQUIRE(!grad, "exchange_begin is the Hogwild (sgd) exchange");
     BFH_REQUIRE(x_inited_, "exchange_begin before exchange_arm");
     float* S = xS_.get();
+    const int xk = t_xk_.begin(stream);
     hipLaunchKernelGGL(delta_begin_kernel, stream_grid(nq), dim3(256), 0, stream, static_cast<const float*>(Q_.get()),
                        static_cast<const float*>(xZ_.get()), S, nq);
     hipLaunchKernelGGL(delta_begin_kernel, stream_grid(Q_rows_), dim3(256), 0, stream, static_cast<const float*>(Qb_.get()),
                        static_cast<const float*>(xZ_.get() + nq), S + nq, static_cast<int64_t>(Q_rows_));
     hipLaunchKernelGGL(exchange_scalars_kernel, dim3(1), dim3(1), 0, stream, S + x_scalars(), static_cast<float>(x_w_interval_), static_cast<float>(x_w_lr_));
     BFH_HIP(hipGetLastError());
+    t_xk_.end(xk, stream);
     BFH_HIP(hipEventRecord(x_ready_, stream));
     BFH_HIP(hipStreamWaitEvent(comm_->comm_stream(), x_ready_, 0));
+    const int ar = t_ar_.begin(comm_->comm_stream());
     comm_->all_reduce_f32(S, xR_.get(), x_count(), comm_->comm_stream());
+    t_ar_.end(ar, comm_->comm_stream());
     BFH_HIP(hipEventRecord(x_done_, comm_->comm_stream()));
     x_pending_ = true;
     stats.exchanges += 1;
@@ -554,6 +558,7 @@ void SgdHandle::exchange_finish(bool progressed) {
     if (!x_pending_) return;
     const int64_t nq = static_cast<int64_t>(Q_rows_) * vdim_;
     BFH_HIP(hipStreamWaitEvent(stream, x_done_, 0));
+    const int xk = t_xk_.begin(stream);
     if (x_gcnt_ready_) {
         const double glob_triples = static_cast<double>(num_nnz_) * x_w_num_neg_;          // one epoch over all ranks
         const double pos_scale = x_gcnt_total_ > 0 ? static_cast<double>(num_nnz_) / x_gcnt_total_ * x_w_num_neg_ : 0.0;   // counted keys -> the whole matrix
@@ -567,6 +572,7 @@ void SgdHandle::exchange_finish(bool progressed) {
     hipLaunchKernelGGL(delta_finish_kernel, stream_grid(Q_rows_), dim3(256), 0, stream, Qb_.get(), xZ_.get() + nq, static_cast<const float*>(xS_.get() + nq),
                        static_cast<const float*>(xR_.get() + nq), static_cast<const float*>(xWb_.get()), 1, static_cast<int64_t>(Q_rows_), progressed ? 1 : 0);
     BFH_HIP(hipGetLastError());
+    t_xk_.end(xk, stream);
     x_pending_ = false;
 }
 
@@ -575,21 +581,27 @@ void SgdHandle::exchange_gradients() {
     if (!comm_ || optimizer_ == "sgd") return;
     const int64_t nq = static_cast<int64_t>(Q_rows_) * vdim_;
     float* S = xS_.get();
+    int xk = t_xk_.begin(stream);
     // Z holds the residue the gradient buffers kept after the last step (Q-6: they are never re-zeroed); zero before the first
     hipLaunchKernelGGL(delta_begin_kernel, stream_grid(nq), dim3(256), 0, stream, static_cast<const float*>(gradQ_.get()),
                        static_cast<const float*>(xZ_.get()), S, nq);
     hipLaunchKernelGGL(delta_begin_kernel, stream_grid(Q_rows_), dim3(256), 0, stream, static_cast<const float*>(gradQb_.get()),
                        static_cast<const float*>(xZ_.get() + nq), S + nq, static_cast<int64_t>(Q_rows_));
     BFH_HIP(hipGetLastError());
+    t_xk_.end(xk, stream);
+    const int ar = t_ar_.begin(stream);
     comm_->group_start();
     comm_->all_reduce_f32(S, xR_.get(), static_cast<size_t>(nq) + static_cast<size_t>(Q_rows_), stream);
     if (pcn_) comm_->all_reduce_i32(cntQ_.get(), cntQ_.get(), static_cast<size_t>(Q_rows_), stream);
     comm_->group_end();
+    t_ar_.end(ar, stream);
+    xk = t_xk_.begin(stream);
     hipLaunchKernelGGL(delta_apply_kernel, stream_grid(nq), dim3(256), 0, stream, gradQ_.get(), static_cast<const float*>(xZ_.get()),
                        static_cast<const float*>(xR_.get()), nq);
     hipLaunchKernelGGL(delta_apply_kernel, stream_grid(Q_rows_), dim3(256), 0, stream, gradQb_.get(), static_cast<const float*>(xZ_.get() + nq),
                        static_cast<const float*>(xR_.get() + nq), static_cast<int64_t>(Q_rows_));
     BFH_HIP(hipGetLastError());
+    t_xk_.end(xk, stream);
     stats.exchanges += 1;
 }
 
@@ -637,7 +649,8 @@ bool SgdHandle::init(const char* opt_path) {
     reg_u_ = static_cast<float>(opt_.num("reg_u"));
     reg_i_ = static_cast<float>(opt_.num("reg_i"));
     reg_j_ = static_cast<float>(opt_.num("reg_j"));
-    reg_b_ = static_cast<float>(opt_.num_or("reg_b", 0.0));
+    reg_b_d_ = opt_.num_or("reg_b", 0.0);
+    reg_b_ = static_cast<float>(reg_b_d_);
     update_i_ = opt_.boolean_or("update_i", true);
     update_j_ = opt_.boolean_or("update_j", true);
     use_bias_ = opt_.boolean_or("use_bias", false);
@@ -835,6 +848,8 @@ void SgdHandle::harvest_timers() {
     stats.kernel_ms += t_main_.drain();
     stats.optimizer_ms += t_opt_.drain();
     stats.aux_ms += t_aux_.drain();
+    stats.exchange_kernel_ms += t_xk_.drain();
+    stats.allreduce_ms += t_ar_.drain();
 }
 
 void SgdHandle::synchronize(bool device_to_host, bool force) {

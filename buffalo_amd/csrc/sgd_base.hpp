@@ -123,6 +123,7 @@ class SgdHandle : public HandleBase {
     std::string optimizer_;
     bool use_bias_ = false, update_i_ = true, update_j_ = true, pcn_ = false, compute_loss_ = false;
     float reg_u_ = 0, reg_i_ = 0, reg_j_ = 0, reg_b_ = 0;
+    double reg_b_d_ = 0;   // reg_b as the reference holds it (a double, bpr.cc:81)
     double lr_ = 0, min_lr_ = 0, beta1_ = 0;
     uint32_t seed_ = 0, epoch_ = 0;
     int iters_ = 0;
@@ -215,7 +216,7 @@ class SgdHandle : public HandleBase {
     int x_w_num_neg_ = 1;
     bool x_w_uniform_ = true;
 
-    EventTimer t_main_, t_opt_, t_aux_;
+    EventTimer t_main_, t_opt_, t_aux_, t_xk_, t_ar_;   // dominant kernel, optimizer, everything else, exchange kernels, all-reduces
 };
 
 // kernels implemented in sgd_base.hip

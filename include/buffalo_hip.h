@@ -61,6 +61,9 @@ typedef struct {
     int64_t merges;           /* BPRMF policy 2: reconciliations of the per-XCD item-factor replicas */
     int64_t exchanges;        /* multi-GPU: all-reduce exchange points (bfh_*_set_comm) */
     int64_t loaded_rows;      /* WARP: candidate rows fetched by the trial loop (scored + speculated), for the byte model */
+    double exchange_kernel_ms; /* multi-GPU: HIP-event time of the delta / weight / apply kernels around the all-reduces */
+    double allreduce_ms;       /* multi-GPU: time of the all-reduces on the stream they ran on (blocking exchanges; an exchange
+                                  still in flight when the call returns is not counted) */
 } bfh_stats;
 
 const char* bfh_version(void);

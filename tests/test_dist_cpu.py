@@ -77,7 +77,7 @@ def _oracle(kind, opt, P, Q, Qb, nnz_total):
 
 def _worker(rank, world, port, kind, out_dir):
     import torch.distributed as dist
-    from buffalo_amd.dist import DataParallelSGD, shard_csr
+    from dist_harness import DataParallelSGD, shard_csr
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     csr, opt, P, Q, Qb = _make_problem(kind)
     u0, u1, ip, keys, off = shard_csr(csr.indptr, csr.keys, rank, world)
@@ -162,7 +162,7 @@ def test_sgd_delta_allreduce_keeps_replicas_consistent(tmp_path):
 # ------------------------------------------------------------------------------------------------
 def _pipe_worker(rank, world, port, out_dir):
     import torch.distributed as dist
-    from buffalo_amd.dist import DataParallelSGD, shard_csr
+    from dist_harness import DataParallelSGD, shard_csr
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     csr, opt, P, Q, Qb = _make_problem("bpr_sgd")
     u0, u1, ip, keys, off = shard_csr(csr.indptr, csr.keys, rank, world)
@@ -209,7 +209,7 @@ def _quality_worker(rank, world, port, pipelined, seed, out_dir, minibatches=1):
     import torch.distributed as dist
     import helpers as H
     from buffalo_amd import synth
-    from buffalo_amd.dist import DataParallelSGD, shard_csr
+    from dist_harness import DataParallelSGD, shard_csr
     from conftest import bpr_opt
     from oracle import oracle as orc
     if world > 1:
@@ -332,7 +332,7 @@ def _als_oracle(opt, P, Q):
 
 def _als_worker(rank, world, port, optimizer, d, out_dir):
     import torch.distributed as dist
-    from buffalo_amd.dist import DataParallelALS
+    from dist_harness import DataParallelALS
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     csr, opt, P, Q = _als_problem(optimizer, d)
     t = csr.transpose()

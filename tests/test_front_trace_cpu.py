@@ -157,13 +157,13 @@ def test_validation_metrics_match_the_reference_evaluation_code(monkeypatch):
 
 
 def test_par_classes_match_the_reference_par_classes(monkeypatch):
-    """buffalo_amd.parallel.ParALS / ParBPRMF (product code) against the reference's parallel/base.py:77-156, both around the same
+    """The harness's ParALS / ParBPRMF stand-ins against the reference's parallel/base.py:77-156, both around the same
     recording dot_topn: what reaches dot_topn (indices, factor matrices, bias, pool, k, output buffers, "P is Q") and what comes
     back to the caller (kept keys -- incl. the reference's slip when a key is unknown --, index / key lists with -1 dropped
     under repr, scores, the errors for an empty pool and for normalised factors)."""
     import buffalo_front.algo.als as ha
     import buffalo_front.algo.bpr as hb
-    from buffalo_amd import parallel as par
+    from buffalo_front import parallel as par
     from buffalo_front.algo.options import ALSOption, BPRMFOption
     from buffalo_front.data import Data, MatrixMarketOptions
     monkeypatch.setattr(ha, "CyALS", G.Recorder)

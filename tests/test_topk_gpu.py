@@ -182,8 +182,8 @@ def test_resident_factors_of_a_training_handle(oracle):
 
 
 def test_par_classes_mirror_reference_surface(oracle):
-    """ParALS / ParBPRMF (parallel/base.py:77-156) over a minimal algo object."""
-    from buffalo_amd import parallel as par
+    """ParALS / ParBPRMF (parallel/base.py:77-156; the harness stand-in) over a minimal algo object, ranking on the device."""
+    from buffalo_front import parallel as par
 
     class Algo:
         pass
