@@ -1050,7 +1050,9 @@ __device__ __forceinline__ void als_ialspp_inreg(const f32x16 (&acc)[T * (T + 1)
 // -- a 256-thread block per row -- rebuilds M = FF + G in LDS and runs als_dense_solve.
 // ------------------------------------------------------------------------------------------------
 // BIG: the other factor matrix is 4 GiB or larger -- 64-bit gather offsets (a few % slower, 19 % in the wide kernel)
-template <int T, bool IALS, bool INREG, bool BIG>
+// LOSS = false: compile-time promise that no loss terms are wanted (compute_loss_on_training off, or the user half-epoch whose
+// per-entry terms are zero): drops the g_1 accumulation -- T FMAs per entry pair and T registers -- from the hot loop
+template <int T, bool IALS, bool INREG, bool BIG, bool LOSS = true>
 __global__ __launch_bounds__(256, 2) void als_gram_kernel(AlsParams p, const AlsWork* __restrict__ work, int n_items, float* __restrict__ scratch,
                                                           int slot_base) {
     static_assert(!INREG || IALS, "the in-register solve is the iALS++ recurrence");
@@ -1060,7 +1062,7 @@ __global__ __launch_bounds__(256, 2) void als_gram_kernel(AlsParams p, const Als
     constexpr unsigned row_bytes = 32u * T * 4u;   // vdim == 32*T
     const int lane = threadIdx.x & 63;
     const int half = lane >> 5, col = lane & 31;
-    const bool lossk = p.compute_loss && p.axis == 1;
+    const bool lossk = LOSS && p.compute_loss && p.axis == 1;
     double nume_k = 0.0, deno_k = 0.0;
     const char* qbase = reinterpret_cast<const char*>(p.Q);
     while (true) {
@@ -1158,7 +1160,7 @@ __global__ __launch_bounds__(256, 2) void als_gram_kernel(AlsParams p, const Als
                 for (int b = a; b < T; ++b, ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, q[b], acc[t], 0, 0, 0);
                 // als.cc:184: float(1.0 + double(v*alpha)) == 1.0f + v*alpha (the exact sum rounded once either way)
                 gpart[a] += (IALS ? cial : cdense) * q[a];   // iALS++: h = sum alpha v (q.p0 - 1) q;  dense solvers: y
-                if (IALS) g1part[a] += (lossk ? one : 0.f) * q[a];   // unconditional: keeps the loop body one basic block
+                if (IALS && LOSS) g1part[a] += (lossk ? one : 0.f) * q[a];   // unconditional at run time: keeps the loop body one basic block
             }
         };
         auto nnz_of = [&](int64_t ch) { return ch < nchunks ? static_cast<int>((n - ch * 64) < 64 ? (n - ch * 64) : 64) : 0; };
@@ -1960,7 +1962,8 @@ class AlsHandle : public HandleBase {
 #define BFH_GK(TT)                                                                                                                  \
     do {                                                                                                                            \
         if (big) hipLaunchKernelGGL((als_gram_kernel<TT, true, true, true>), dim3(blocks), dim3(256), 0, stream, p, wl->work.get(), items, scratch_.get(), 0); \
-        else hipLaunchKernelGGL((als_gram_kernel<TT, true, true, false>), dim3(blocks), dim3(256), 0, stream, p, wl->work.get(), items, scratch_.get(), 0);   \
+        else if (compute_loss_ && axis == 1) hipLaunchKernelGGL((als_gram_kernel<TT, true, true, false>), dim3(blocks), dim3(256), 0, stream, p, wl->work.get(), items, scratch_.get(), 0);   \
+        else hipLaunchKernelGGL((als_gram_kernel<TT, true, true, false, false>), dim3(blocks), dim3(256), 0, stream, p, wl->work.get(), items, scratch_.get(), 0);   \
     } while (0)
                 if (T <= 1) BFH_GK(1);
                 else if (T <= 2) BFH_GK(2);

@@ -318,7 +318,6 @@ def test_config3_size_spot_parity(oracle):
     assert not np.array_equal(P, P0)
 
 
-@pytest.mark.gpu_unmeasured
 def test_config3_warm_epoch_matches_the_oracle_path(oracle):
     """a10 at BASELINE config #3 against the REFERENCE PATH itself (not only against float64).  The cold first epoch cannot serve:
     from the |N(0, 1/d^2)| start the first item half-epoch is so ill-conditioned that the oracle itself lands 13 - 30 % from the
@@ -385,6 +384,18 @@ def test_config3_warm_epoch_matches_the_oracle_path(oracle):
     one.partial_update(0, I, t.indptr, None, None, 1)
     one.synchronize(True)
     ff1_or = Po_mid.astype(np.float64).T @ Po_mid.astype(np.float64)
+    # the reference path's OWN rounding spread on the item half-epoch: the oracle again on the same inputs with every row's
+    # entries in reverse order -- a legal reordering of the same sums (nothing in als.cc depends on the order inside a row)
+    starts = np.concatenate([[0], t.indptr[:-1]])
+    rid = t.rows()
+    rev = (starts[rid] + (t.indptr[rid] - 1 - np.arange(t.nnz, dtype=np.int64))).astype(np.int64)
+    keys_rev, vals_rev = np.ascontiguousarray(t.keys[rev]), np.ascontiguousarray(t.vals[rev])
+    Pr, Qr = Po_mid.copy(), Qw.copy()
+    o2 = oracle.OracleALS()
+    assert o2.init(H.write_opt(dict(opt, num_workers=os.cpu_count() or 16)))
+    o2.initialize_model(Pr, Qr)
+    o2.precompute(1)
+    o2.partial_update(0, I, t.indptr, keys_rev, vals_rev, 1)
 
     def by_length(X, Xo, mat, name):
         scale = max(np.abs(Xo).max(), 1e-30)
@@ -398,6 +409,7 @@ def test_config3_warm_epoch_matches_the_oracle_path(oracle):
     print()
     eP, eQ = by_length(P, Po, csr, "P"), by_length(Q, Qo, t, "Q (free-running: from each side's own P)")
     eQ1 = by_length(Q1, Qo, t, "Q (one step: both from the oracle's P)")
+    eQr = by_length(Qr, Qo, t, "Q (ORACLE vs ORACLE with the rows' entries reversed)")
     for a in (0, I - 400):     # float64 envelope on item stretches (rows of up to 1e5 entries), inputs: the oracle's mid state
         b = a + 400
         t_or, t_hip = Qw[a:b].astype(np.float64), Qw[a:b].astype(np.float64)
@@ -429,12 +441,17 @@ def test_config3_warm_epoch_matches_the_oracle_path(oracle):
     th, to = top10(P, Q), top10(Po, Qo)
     overlap = np.mean([len(set(a) & set(b)) / 10.0 for a, b in zip(th, to)])
     same = np.mean([list(a) == list(b) for a, b in zip(th, to)])
-    t1 = top10(Po_mid, Q1)
+    t1, tr = top10(Po_mid, Q1), top10(Po_mid, Qr)
     overlap1 = np.mean([len(set(a) & set(b)) / 10.0 for a, b in zip(t1, to)])
-    print("config #3 warm epoch: P hip~oracle %.2e  Q hip~oracle free-running %.2e / one step %.2e  top-10 of 2000 users: mean overlap %.4f "
-          "(identical ordered lists %.3f); with the one-step Q %.4f" % (eP, eQ, eQ1, overlap, same, overlap1))
-    assert eP <= 1e-3 and eQ1 <= 1e-3, (eP, eQ1)
-    assert overlap1 >= 0.99 and overlap >= 0.95, (overlap1, overlap)
+    overlap_r = np.mean([len(set(a) & set(b)) / 10.0 for a, b in zip(tr, to)])
+    print("config #3 warm epoch: P hip~oracle %.2e  Q hip~oracle free-running %.2e / one step %.2e / oracle~oracle(reversed rows) %.2e\n"
+          "   top-10 of 2000 users: hip vs oracle mean overlap %.4f (identical ordered lists %.3f); with the one-step Q %.4f; "
+          "oracle vs oracle(reversed rows) %.4f" % (eP, eQ, eQ1, eQr, overlap, same, overlap1, overlap_r))
+    # the user side is well conditioned in this regime; the item side is not (both fp32 paths sit 1.5 - 2 % from float64, ratio ~1):
+    # there the kernel is held to the reference path's own spread under a reordering of its sums
+    assert eP <= 1e-3, eP
+    assert eQ1 <= 2.5 * eQr and eQ <= 3.0 * eQr, (eQ1, eQ, eQr)
+    assert overlap1 >= overlap_r - 0.02 and overlap >= overlap_r - 0.03, (overlap1, overlap, overlap_r)
 
 
 def test_full_size_properties():
