@@ -18,8 +18,10 @@ def short(k):
 
 
 def groups(vals):
-    n = len(vals) // epochs if len(vals) >= epochs and len(vals) % epochs == 0 else 0
-    return vals[-n:] if n else vals
+    """The launches of the LAST epoch: the last len // epochs of them.  A kernel with fewer launches than epochs ran once per model
+    (e.g. the row-id fill, the sort of the static positive list's extra launches) and is reported under `one_off`, not per epoch."""
+    n = len(vals) // epochs
+    return vals[-n:] if n else []
 
 
 dur = collections.defaultdict(list)
@@ -44,8 +46,11 @@ for k in sorted(set(dur) | set(cnt)):
     d_last = groups(dur.get(k, []))
     f_last = groups(cnt[k].get("FETCH_SIZE", []))
     w_last = groups(cnt[k].get("WRITE_SIZE", []))
-    e = {"launches_per_epoch": len(d_last), "ms": sum(d_last), "fetch_bytes": sum(f_last) * 2048.0, "write_bytes": sum(w_last) * 1024.0,
-         "ms_all_epochs_mean": sum(dur.get(k, [])) / max(epochs, 1)}
+    if not d_last:
+        out.setdefault("one_off", {})[k] = {"launches": len(dur.get(k, [])), "ms": sum(dur.get(k, []))}
+        continue
+    e = {"launches_per_epoch": len(d_last), "launches_total": len(dur.get(k, [])), "ms": sum(d_last), "fetch_bytes": sum(f_last) * 2048.0,
+         "write_bytes": sum(w_last) * 1024.0, "ms_all_epochs_mean": sum(dur.get(k, [])) / max(epochs, 1)}
     e["hbm_bytes"] = e["fetch_bytes"] + e["write_bytes"]
     e["TBps"] = e["hbm_bytes"] / (e["ms"] * 1e-3) / 1e12 if e["ms"] > 0 else None
     out["kernels"][k] = e
