@@ -68,7 +68,7 @@ struct BprConsts {
     // adam / adagrad, two-pass accumulation (sgd_base.hpp GatherParams): this kernel only records the logit and the
     // negative of every triple; the item-side gradient rows are summed by grad_gather_kernel
     int two_pass;
-    float* coef_out;      // [total]
+    float2* uc_out;       // [total] (user as int bits, logit): the fused list of sgd_base.hpp GatherParams::uc
     uint32_t* neg_out;    // [total]
 };
 
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(256) void bpr_update_kernel(SgdParams p, BprConsts 
                     }
                 }
             }
-            if (!SGD && !INJECT && c.two_pass && valid) c.coef_out[t] = my_coef;
+            if (!SGD && !INJECT && c.two_pass && valid) c.uc_out[t] = make_float2(__builtin_bit_cast(float, my_u), my_coef);   // logit >= 0: never "rejected"
         }
         if (!c.sequential) flush_user();
     }
@@ -1110,9 +1110,9 @@ class BprHandle : public SgdHandle {
         // adam / adagrad: P, Q are frozen, so the item-side gradients are summed by the sorted gather (no per-triple atomics)
         const bool two_pass = !INJECT && optimizer_ != "sgd" && accum_two_pass_ != 0;
         if (two_pass) {
-            acc_prepare(c.total);
+            acc_prepare(c.total, true);
             c.two_pass = 1;
-            c.coef_out = acc_coef_.get();
+            c.uc_out = acc_uc_.get();
             c.neg_out = acc_neg_.get();
         }
         int64_t seg_work = n_work;          // work items per launch
@@ -1146,7 +1146,7 @@ class BprHandle : public SgdHandle {
             const int slot = t_aux_.begin(stream);
             acc_build_positive_list(p, start_x, next_x);
             const float sab_pos[3] = {1.f, 0.f, 0.f}, sab_neg[3] = {-1.f, 0.f, 0.f};
-            acc_gather(p, num_neg_, update_i_, update_j_, sab_pos, sab_neg, false, use_bias_);
+            acc_gather(p, num_neg_, update_i_, update_j_, sab_pos, sab_neg, false, use_bias_, true);
             t_aux_.end(slot, stream);
         }
     }

@@ -35,7 +35,7 @@ struct WarpConsts {
     // two-pass accumulation (sgd_base.hpp GatherParams): record Phi and the violating negative of every accepted
     // positive (Q_rows: rejected); the two item-side gradient rows are summed by grad_gather_kernel
     int two_pass;
-    float* coef_out;         // [total]
+    float2* uc_out;          // [total] (user as int bits, Phi; Phi = -1: rejected) -- the fused list of sgd_base.hpp GatherParams::uc
     uint32_t* neg_out;       // [total]
     // pre-drawn unseen candidates (warp_presample_kernel): cand[t * S + k] = k-th unseen draw of positive t (-1: the attempt
     // cap was reached first), next_attempt[t] = the attempt the in-kernel sampler continues from
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void warp_update_kernel(SgdParams p, WarpConst
                 my_pos = p.keys[t];
             }
             const int n_here = static_cast<int>((t_end - t0) < 64 ? (t_end - t0) : 64);
-            float my_phi = 0.f;                                     // two-pass: lane j keeps positive j's Phi / negative,
+            float my_phi = -1.f;                                    // two-pass: lane j keeps positive j's Phi (-1: rejected) / negative,
             uint32_t my_nego = static_cast<uint32_t>(p.Q_rows);    // stored coalesced after the walk
             int my_c[S > 0 ? S : 1];
             int my_next = 0;
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void warp_update_kernel(SgdParams p, WarpConst
                 accepted += 1;
             }
             if (c.two_pass && t < t_end) {
-                c.coef_out[t] = my_phi;
+                c.uc_out[t] = make_float2(__builtin_bit_cast(float, my_u), my_phi);
                 c.neg_out[t] = my_nego;
             }
         }
@@ -387,9 +387,9 @@ class WarpHandle : public SgdHandle {
             c.next_attempt = next_.get();
         }
         if (two_pass) {
-            acc_prepare(n);
+            acc_prepare(n, true);
             c.two_pass = 1;
-            c.coef_out = acc_coef_.get();
+            c.uc_out = acc_uc_.get();
             c.neg_out = acc_neg_.get();
         }
         const int64_t n_work = (c.total + c.chunk - 1) / c.chunk;
@@ -424,7 +424,7 @@ class WarpHandle : public SgdHandle {
             const int slot2 = t_aux_.begin(stream);
             acc_build_positive_list(p, start_x, next_x);
             const float sab_pos[3] = {1.f, l2_ ? -1.f : 0.f, -reg_i_}, sab_neg[3] = {-1.f, l2_ ? 1.f : 0.f, -reg_j_};
-            acc_gather(p, 1, true, true, sab_pos, sab_neg, true, false);
+            acc_gather(p, 1, true, true, sab_pos, sab_neg, true, false, true);
             t_aux_.end(slot2, stream);
         }
         unsigned long long cnt[3] = {0, 0, 0};

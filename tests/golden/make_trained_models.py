@@ -35,9 +35,11 @@ CASES = {
     # a WELL-POSED whole run on the reference's default solver family: d = 64 over 2,000 items, twelve CG steps, regulariser 5 --
     # the oracle stays within 1e-4 of the float64 recurrence through all four epochs, so a device run must reach this model to 5e-3.
     # (The three-step case above cannot be held that way: from the |N(0, 1/d^2)| start its first user half-epoch returns rows of
-    # size ~y / reg, the next system has a condition number beyond fp32, and the oracle ITSELF ends 7 % from the float64 recurrence.)
+    # size ~y / reg, the next system has a condition number beyond fp32, and the oracle ITSELF ends 2 % from the float64 recurrence.)
+    # One worker: with two, the per-thread loss sums of 3,200 rows are combined in scheduling order and the reported loss wobbles in
+    # its last digit from run to run (the factors do not).
     "als_manual_cg_d64_wellposed": ("als", (1200, 2000, 12, 0.10, 0.01), dict(d=64, num_iters=4, optimizer="manual_cg", num_cg_max_iters=12,
-                                                                             random_seed=9, num_workers=2, alpha=1.0, reg_u=5.0, reg_i=5.0,
+                                                                             random_seed=9, num_workers=1, alpha=1.0, reg_u=5.0, reg_i=5.0,
                                                                              validation={"topk": 10}), 11),
     "eals_d16": ("eals", (150, 90, 3), dict(d=16, num_iters=4, random_seed=3, num_workers=2, c0=64.0, exponent=0.5, validation={"topk": 10}), 7),
     # the SGD fronts in ACCELERATOR mode (the path this repository replaces): `CuBPRMF` / the WARP scaffold's object is the oracle
