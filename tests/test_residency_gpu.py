@@ -1,6 +1,6 @@
 """The reference's call pattern at speed (/root/reference/buffalo/algo/bpr.py:170-217, cuda/_bpr.pyx:60-74): keys are handed
 over on every call and the model is copied back after every epoch.  auto_resident keeps a chunk it has seen in HBM (same row
-range, same length, same sampled checksum of the host buffer), lazy_sync defers the per-epoch copy-back."""
+range, same length, same 64-bit hash over the WHOLE host buffer), lazy_sync defers the per-epoch copy-back."""
 import numpy as np
 import pytest
 
@@ -71,6 +71,38 @@ def test_chunks_are_uploaded_once_and_again_when_their_content_changes(oracle, m
             o.update_parameters()
         o.join()
         assert H.relerr(P[:, :32], Po) < 1e-5 and H.relerr(Q[:, :32], Qo) < 1e-5 and H.relerr(Qb, Qbo) < 1e-5
+
+
+@pytest.mark.gpu_unmeasured
+def test_one_changed_key_anywhere_is_seen():
+    """The reference always uses the buffer it is handed (cuda/_bpr.pyx:60-74).  A chunk of 3 M keys (above the size where the
+    hash runs on several threads) is served from HBM while its content is unchanged and re-uploaded when ONE key changes -- at a
+    position the sampled checksum of rounds 1-2 (2 K strided keys + both ends) never looked at."""
+    from buffalo_amd import synth
+    csr = synth.generate(20000, 3000, 3_000_000, seed=5)
+    opt = bpr_opt(d=32, lr=0.01, min_lr=0.01, num_iters=4, random_seed=3)
+    obj, P, Q, Qb = _setup(csr, opt, dict())
+    keys = csr.keys.copy()
+    sent = []
+    for epoch in range(4):
+        if epoch == 2:                      # swap two neighbouring keys of one long row: still sorted input? no -- replace by an unused item
+            stride = max(1, csr.nnz // 2048)
+            pos = (stride // 2) + 7 * stride + 3          # between two sampled positions, far from both ends
+            u = int(np.searchsorted(csr.indptr, pos, side="right"))
+            row_beg = 0 if u == 0 else int(csr.indptr[u - 1])
+            row = set(keys[row_beg:int(csr.indptr[u])].tolist())
+            lo = int(keys[pos - 1]) if pos > row_beg else -1
+            hi = int(keys[pos + 1]) if pos + 1 < int(csr.indptr[u]) else csr.num_items
+            cand = [c for c in range(lo + 1, hi) if c not in row]
+            if not cand:
+                pytest.skip("no free item id between the neighbours at the probed position")
+            keys[pos] = cand[0]
+        obj.add_jobs(0, csr.num_users, csr.indptr, keys)
+        obj.update_parameters()
+        sent.append(obj.stats()["h2d_bytes"])
+    assert sent[1] == sent[0]                                   # unchanged buffer: served from HBM
+    assert sent[2] - sent[1] == csr.nnz * 4                     # one key changed somewhere in the middle: uploaded again
+    assert sent[3] == sent[2]
 
 
 def test_auto_resident_off_resends_every_call():
