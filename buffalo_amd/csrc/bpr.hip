@@ -1110,7 +1110,7 @@ class BprHandle : public SgdHandle {
         // adam / adagrad: P, Q are frozen, so the item-side gradients are summed by the sorted gather (no per-triple atomics)
         const bool two_pass = !INJECT && optimizer_ != "sgd" && accum_two_pass_ != 0;
         if (two_pass) {
-            acc_prepare(c.total, true);
+            acc_prepare(c.total);
             c.two_pass = 1;
             c.uc_out = acc_uc_.get();
             c.neg_out = acc_neg_.get();
@@ -1146,7 +1146,7 @@ class BprHandle : public SgdHandle {
             const int slot = t_aux_.begin(stream);
             acc_build_positive_list(p, start_x, next_x);
             const float sab_pos[3] = {1.f, 0.f, 0.f}, sab_neg[3] = {-1.f, 0.f, 0.f};
-            acc_gather(p, num_neg_, update_i_, update_j_, sab_pos, sab_neg, false, use_bias_, true);
+            acc_gather(p, num_neg_, update_i_, update_j_, sab_pos, sab_neg, use_bias_);
             t_aux_.end(slot, stream);
         }
     }

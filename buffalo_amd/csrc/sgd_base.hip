@@ -183,7 +183,7 @@ __global__ void sgd_update_bias_kernel(float* __restrict__ X, float* __restrict_
 // ------------------------------------------------------------------------------------------------
 // grad_gather_kernel: the item side of gradient accumulation (see GatherParams in sgd_base.hpp).
 // A wave owns kGatherChunk consecutive incidences of the item-sorted list.  Per 64 incidences the lanes
-// fetch (item, index), the user and the coefficient in parallel (coalesced list reads + two 4-byte gathers);
+// fetch (item, index) coalesced and the (user, coefficient) record of the triple with one 8-byte gather;
 // the wave then walks them with UN user rows in flight (dword per lane: element k*64+lane, so every load and
 // every flushed atomic covers whole 128-B lines), sums  c * P[u]  in registers while the item stays the same
 // and pushes the run with one atomic row add.  Bound: HBM / Infinity-Cache gathers of 4*vdim bytes per incidence.
@@ -238,30 +238,16 @@ __global__ __launch_bounds__(256) void grad_gather_kernel(GatherParams g) {
                 if (it < static_cast<uint32_t>(g.Q_rows)) {
                     const int32_t idx = g.inc_idx[kk];
                     bool any = false;
-                    if (g.uc) {   // fused list: one 8-byte gather carries the user and the coefficient (negative = rejected)
-                        const int64_t base = g.pos_list ? static_cast<int64_t>(idx) * g.num_neg : static_cast<int64_t>(idx);
-                        const int slots = g.pos_list ? g.num_neg : 1;
-                        for (int sl = 0; sl < slots; ++sl) {
-                            const float2 v = g.uc[base + sl];
-                            if (v.y >= 0.f) {
-                                my_c += v.y;
-                                my_u = __builtin_bit_cast(int, v.x);
-                                any = true;
-                            }
+                    // one 8-byte gather carries the user and the coefficient (negative = rejected)
+                    const int64_t base = g.pos_list ? static_cast<int64_t>(idx) * g.num_neg : static_cast<int64_t>(idx);
+                    const int slots = g.pos_list ? g.num_neg : 1;
+                    for (int sl = 0; sl < slots; ++sl) {
+                        const float2 v = g.uc[base + sl];
+                        if (v.y >= 0.f) {
+                            my_c += v.y;
+                            my_u = __builtin_bit_cast(int, v.x);
+                            any = true;
                         }
-                    } else if (g.pos_list) {
-                        const int64_t base = static_cast<int64_t>(idx) * g.num_neg;
-                        for (int sl = 0; sl < g.num_neg; ++sl) {
-                            if (!g.accept || g.accept[base + sl] < static_cast<uint32_t>(g.Q_rows)) {
-                                my_c += g.coef[base + sl];
-                                any = true;
-                            }
-                        }
-                        if (any) my_u = g.rows[idx];
-                    } else if (!g.accept || g.accept[idx] < static_cast<uint32_t>(g.Q_rows)) {
-                        my_c = g.coef[idx];
-                        my_u = g.rows[idx / g.num_neg];
-                        any = true;
                     }
                     if (any) my_item = static_cast<int>(it);
                 }
@@ -349,11 +335,9 @@ static int acc_bits_for(int64_t range) {
     return b;
 }
 
-void SgdHandle::acc_prepare(int64_t triples, bool fused_uc) {
+void SgdHandle::acc_prepare(int64_t triples) {
     const size_t n = static_cast<size_t>(triples);
-    if (fused_uc) {
-        if (acc_uc_.size() < n) acc_uc_.resize(n);
-    } else if (acc_coef_.size() < n) acc_coef_.resize(n);
+    if (acc_uc_.size() < n) acc_uc_.resize(n);
     if (acc_neg_.size() < n) acc_neg_.resize(n);
     if (acc_key_b_.size() < n) acc_key_b_.resize(n);
     if (acc_idx_b_.size() < n) acc_idx_b_.resize(n);
@@ -379,13 +363,10 @@ void SgdHandle::acc_build_positive_list(const SgdParams& p, int start_x, int nex
 }
 
 void SgdHandle::acc_gather(const SgdParams& p, int num_neg, bool do_pos, bool do_neg, const float sab_pos[3], const float sab_neg[3],
-                           bool use_accept, bool with_bias, bool fused_uc) {
+                           bool with_bias) {
     const int64_t n = p.chunk_nnz, triples = n * num_neg;
     GatherParams g{};
-    g.rows = p.rows;
-    g.coef = acc_coef_.get();
-    g.accept = use_accept ? acc_neg_.get() : nullptr;
-    g.uc = fused_uc ? acc_uc_.get() : nullptr;
+    g.uc = acc_uc_.get();
     g.P = p.P; g.Q = p.Q;
     g.gradQ = p.gradQ;
     g.gradQb = with_bias ? p.gradQb : nullptr;

@@ -46,13 +46,10 @@ struct GatherParams {
     const uint32_t* inc_key;   // [n] item of every incidence, ascending; entries >= Q_rows (rejected positives) are ignored
     const int32_t* inc_idx;    // [n] pos_list: chunk-local nnz position; else chunk-local triple index (position * num_neg + slot)
     int64_t n;
-    const int32_t* rows;       // [chunk nnz] user of every nnz position
-    const float* coef;         // [chunk nnz * num_neg] coefficient of every triple (pass 1)
-    const uint32_t* accept;    // [chunk nnz * num_neg] or null: the triple counts only if accept[t] < Q_rows (WARP: its negative)
-    // fused form (WARP): uc[t] = (user as int bits, coefficient; coefficient < 0 = the positive was rejected) -- ONE 8-byte gather per
-    // incidence instead of three 4-byte ones (row id, coefficient, accept flag: a sector each, a quarter of the gathers' traffic at
-    // configs[4] size, profiles/r03_warp_pmc_c5_one_gpu.json).  rows / coef / accept are not read when it is set.
-    const float2* uc;
+    // uc[t] = (user as int bits, coefficient) of triple t, written by pass 1 -- ONE 8-byte gather per incidence carries everything
+    // the gather needs (rounds 1-2 read a row id, a coefficient and WARP's accept flag: three 4-byte gathers, a sector each, a
+    // quarter of the gathers' counter traffic at configs[4] size).  A negative coefficient = the positive was rejected (WARP).
+    const float2* uc;          // [chunk nnz * num_neg]
     const float* P;
     const float* Q;            // read only when a != 0 or b != 0
     float* gradQ;
@@ -112,10 +109,9 @@ class SgdHandle : public HandleBase {
     virtual bool project_unit_ball() const { return false; }
     // two-pass accumulation: buffers of pass 1 for a chunk of `triples` triples; the item-sorted positive incidence
     // list of the staged chunk (cached for a resident matrix); the item-side gather over both lists
-    void acc_prepare(int64_t triples, bool fused_uc = false);
+    void acc_prepare(int64_t triples);
     void acc_build_positive_list(const SgdParams& p, int start_x, int next_x);
-    void acc_gather(const SgdParams& p, int num_neg, bool do_pos, bool do_neg, const float sab_pos[3], const float sab_neg[3], bool use_accept,
-                    bool with_bias, bool fused_uc = false);
+    void acc_gather(const SgdParams& p, int num_neg, bool do_pos, bool do_neg, const float sab_pos[3], const float sab_neg[3], bool with_bias);
 
  public:
     int kind_;  // 0 bpr, 1 warp
@@ -188,8 +184,7 @@ class SgdHandle : public HandleBase {
     int num_cus_ = 256;
 
     // two-pass accumulation
-    DevBuf<float> acc_coef_;                 // [triples] pass-1 coefficient
-    DevBuf<float2> acc_uc_;                  // [triples] fused (user, coefficient) of pass 1 (WARP)
+    DevBuf<float2> acc_uc_;                  // [triples] (user, coefficient) of pass 1
     DevBuf<uint32_t> acc_neg_;               // [triples] pass-1 negative (Q_rows: none)
     DevBuf<uint32_t> acc_key_a_, acc_key_b_; // sort input / output keys (negatives)
     DevBuf<int32_t> acc_iota_, acc_idx_b_;   // 0..n-1, sorted triple indices

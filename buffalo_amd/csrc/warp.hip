@@ -387,7 +387,7 @@ class WarpHandle : public SgdHandle {
             c.next_attempt = next_.get();
         }
         if (two_pass) {
-            acc_prepare(n, true);
+            acc_prepare(n);
             c.two_pass = 1;
             c.uc_out = acc_uc_.get();
             c.neg_out = acc_neg_.get();
@@ -424,7 +424,7 @@ class WarpHandle : public SgdHandle {
             const int slot2 = t_aux_.begin(stream);
             acc_build_positive_list(p, start_x, next_x);
             const float sab_pos[3] = {1.f, l2_ ? -1.f : 0.f, -reg_i_}, sab_neg[3] = {-1.f, l2_ ? 1.f : 0.f, -reg_j_};
-            acc_gather(p, 1, true, true, sab_pos, sab_neg, true, false, true);
+            acc_gather(p, 1, true, true, sab_pos, sab_neg, false);
             t_aux_.end(slot2, stream);
         }
         unsigned long long cnt[3] = {0, 0, 0};

@@ -73,7 +73,6 @@ def test_chunks_are_uploaded_once_and_again_when_their_content_changes(oracle, m
         assert H.relerr(P[:, :32], Po) < 1e-5 and H.relerr(Q[:, :32], Qo) < 1e-5 and H.relerr(Qb, Qbo) < 1e-5
 
 
-@pytest.mark.gpu_unmeasured
 def test_one_changed_key_anywhere_is_seen():
     """The reference always uses the buffer it is handed (cuda/_bpr.pyx:60-74).  A chunk of 3 M keys (above the size where the
     hash runs on several threads) is served from HBM while its content is unchanged and re-uploaded when ONE key changes -- at a
