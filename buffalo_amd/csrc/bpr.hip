@@ -551,6 +551,17 @@ __global__ __launch_bounds__(256) void xcd_broadcast_kernel(const T* __restrict_
     }
 }
 
+// the same for the rows whose flag equals `only` (P: the users that have replicas)
+template <typename T>
+__global__ __launch_bounds__(256) void xcd_broadcast_rows_kernel(const T* __restrict__ S, T* __restrict__ rep, int64_t n, int64_t stride, int copies,
+                                                                  const uint8_t* __restrict__ flag, int row_len, int only) {
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        if (flag[i / row_len] != only) continue;
+        const T v = S[i];
+        for (int x = 0; x < copies; ++x) rep[x * stride + i] = v;
+    }
+}
+
 __device__ __forceinline__ float4 f4_sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 __device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4_fma(float sc, float4 a, float4 b) { return make_float4(sc * a.x + b.x, sc * a.y + b.y, sc * a.z + b.z, sc * a.w + b.w); }
@@ -562,11 +573,14 @@ __device__ __forceinline__ float f4_fma(float sc, float a, float b) { return sc 
 // Hot rows live in S itself (updated there with atomics) and are skipped; `row_len` = elements per row.
 // `base` is what the replicas started the segment from: S itself (policy 2, null), or a ninth copy when S
 // also receives atomic steps during the segment (policy 3: the register-resident rows are flushed into S).
+// `hot` (per row, or null): with `only` == 0 rows whose flag is non-zero are skipped (the item rows that live chip-wide); with
+// `only` != 0 exactly the rows whose flag equals it are merged (P: the users that have replicas, ImQueues::hot_user == 2).
 template <typename T>
 __global__ __launch_bounds__(256) void xcd_merge_kernel(T* __restrict__ S, T* __restrict__ rep, int64_t n, int64_t stride, float scale,
-                                                         int write_replicas, const uint8_t* __restrict__ hot, int row_len, T* __restrict__ base) {
+                                                         int write_replicas, const uint8_t* __restrict__ hot, int row_len, T* __restrict__ base,
+                                                         int only = 0) {
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
-        if (hot && hot[i / row_len]) continue;
+        if (hot && (only ? hot[i / row_len] != only : hot[i / row_len] != 0)) continue;
         const T s_now = S[i];
         const T s0 = base ? base[i] : s_now;
         T r[kXcdReplicas];
@@ -821,14 +835,26 @@ class BprHandle : public SgdHandle {
         // user overshoots (|P| 390 vs 430, one run in three diverging), so above lr 0.01 the owner form stays.
         const bool p_rep = im_user_replicas_ > 0 ||
                            (im_user_replicas_ < 0 && !im_single_wave_ && users_here < static_cast<int64_t>(nq) * 3072 && c.lr <= 0.01f);
+        // Whole matrices keep one owner XCD per user -- except for the HEAVY users, the ones the collision rule below would put on
+        // fp32 atomics (ML-20M shape: degree >= ~780, 2 % of the users, 17 % of the triples; `xcd_hot_tau = 0` showed those atomics
+        // cost 8 % of the walk).  They alone get the replica treatment: their entries are spread over the queues, so a heavy user's
+        // share of one queue is nq times smaller and its row is updated with plain stores on the XCD's replica; 13 MB of replicas
+        // instead of 640, merged by the delta rule with the item replicas.  Same lr bound as the all-user form.
+        const int64_t waves0 = im_resident_waves();
+        const double inflight0 = (!im_prefetch() ? 0.25 : (c.fresh ? 0.5 : 2.0)) * (static_cast<double>(waves0) / nq) * (im_dual() ? 2.0 : 1.0);
+        const double tau0 = xcd_hot_tau_ * 1e-3;
+        const bool p_hyb = !p_rep && im_user_hybrid_ && !im_single_wave_ && c.lr <= 0.01f && tau0 > 0.0 && inflight0 > 0.0 && nq > 1;
+        // degree from which the owner-share rule fires: deg * num_neg / (triples / nq) * inflight >= tau
+        const int64_t heavy_deg = p_hyb ? std::max<int64_t>(1, static_cast<int64_t>(std::ceil(tau0 * (static_cast<double>(c.total) / nq) / (inflight0 * num_neg_)))) : 0;
+        const int spread_mode = p_rep ? 1 : (p_hyb ? 2 : 0);
         const bool cached = keeps && im_gen_ == csr_generation_ && im_start_ == start_x && im_next_ == next_x && im_n_ == n && im_built_blocks_ == blocks && im_built_nq_ == nq &&
-                            im_built_spread_ == p_rep;
+                            im_built_spread_mode_ == spread_mode && im_built_heavy_deg_ == heavy_deg;
         if (!cached) {
             im_key_a_.resize(static_cast<size_t>(n)); im_key_b_.resize(static_cast<size_t>(n));
             im_pos_a_.resize(static_cast<size_t>(n)); im_pos_b_.resize(static_cast<size_t>(n));
             im_qbeg_dev_.resize(kImMaxQueues + 1);
             hipLaunchKernelGGL(im_keys_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, stream, p.rows, p.keys, n, nq,
-                               static_cast<uint32_t>(blocks), static_cast<uint32_t>(Q_rows_), p_rep ? 1 : 0, im_key_a_.get(), im_pos_a_.get());
+                               static_cast<uint32_t>(blocks), static_cast<uint32_t>(Q_rows_), spread_mode, p.indptr, heavy_deg, im_key_a_.get(), im_pos_a_.get());
             BFH_HIP(hipGetLastError());
             int bits = 1;
             while ((int64_t(1) << bits) < static_cast<int64_t>(nq) * blocks * Q_rows_) ++bits;
@@ -839,7 +865,7 @@ class BprHandle : public SgdHandle {
             BFH_HIP(hipMemcpyAsync(im_qbeg_, im_qbeg_dev_.get(), (nq + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
             sync_stream();
             im_gen_ = keeps ? csr_generation_ : -1;
-            im_start_ = start_x; im_next_ = next_x; im_n_ = n; im_built_blocks_ = blocks; im_built_nq_ = nq; im_built_spread_ = p_rep;
+            im_start_ = start_x; im_next_ = next_x; im_n_ = n; im_built_blocks_ = blocks; im_built_nq_ = nq; im_built_spread_mode_ = spread_mode; im_built_heavy_deg_ = heavy_deg;
         }
         // ---- per-row policy flags ----
         const int64_t waves = im_resident_waves();
@@ -904,7 +930,7 @@ class BprHandle : public SgdHandle {
                            im_drift_budget_milli_ * 1e-3, hot_.get(), im_flush_.get());
         BFH_HIP(hipMemsetAsync(im_hot_user_.get(), 0, im_hot_user_.bytes(), stream));
         hipLaunchKernelGGL(im_user_flags_kernel, dim3((next_x - start_x + 255) / 256), dim3(256), 0, stream, p.indptr, start_x, next_x - start_x,
-                           static_cast<double>(num_neg_), p_rep ? triples : triples / nq, inflight, tau, im_hot_user_.get());
+                           static_cast<double>(num_neg_), triples / nq, triples, inflight, tau, spread_mode, heavy_deg, im_hot_user_.get());
         BFH_HIP(hipGetLastError());
         // ---- replicas of the item factors (+ the copy they started from) ----
         xcd_alloc(true);
@@ -916,11 +942,14 @@ class BprHandle : public SgdHandle {
         xcd_broadcast(true);
         const int64_t np4 = static_cast<int64_t>(P_rows_) * vdim_ / 4;          // replica stride (float4s)
         const int64_t up4 = users_here * vdim_ / 4, uoff4 = static_cast<int64_t>(start_x) * vdim_ / 4;   // this call's rows
-        if (p_rep) {
-            // eight replicas + the copy they started from (P itself receives the hot users' atomics and whatever the drain launch does)
+        const bool p_any = p_rep || p_hyb;
+        if (p_any) {
+            // eight replicas + the copy they started from, addressed like P (only the rows of users with flag 2 are ever touched);
+            // P itself receives the hot users' atomics and whatever the drain launch does
             if (repP_.size() < static_cast<size_t>(kXcdReplicas + 1) * P_rows_ * vdim_) repP_.resize(static_cast<size_t>(kXcdReplicas + 1) * P_rows_ * vdim_);
-            hipLaunchKernelGGL((xcd_broadcast_kernel<float4>), dim3(static_cast<unsigned>(std::min<int64_t>((up4 + 255) / 256, 8192))), dim3(256), 0, stream,
-                               reinterpret_cast<const float4*>(P_.get()) + uoff4, reinterpret_cast<float4*>(repP_.get()) + uoff4, up4, np4, kXcdReplicas + 1);
+            hipLaunchKernelGGL((xcd_broadcast_rows_kernel<float4>), dim3(static_cast<unsigned>(std::min<int64_t>((up4 + 255) / 256, 8192))), dim3(256), 0, stream,
+                               reinterpret_cast<const float4*>(P_.get()) + uoff4, reinterpret_cast<float4*>(repP_.get()) + uoff4, up4, np4, kXcdReplicas + 1,
+                               static_cast<const uint8_t*>(im_hot_user_.get()) + start_x, vdim_ / 4, 2);
             BFH_HIP(hipGetLastError());
         }
         // ---- queues, slice order, segments ----
@@ -931,7 +960,7 @@ class BprHandle : public SgdHandle {
         for (int i = 0; i < 16; ++i) q.xcd_queue[i] = im_xcd_queue_[i];
         q.p_nt = im_p_nt_;
         q.hot_user = im_hot_user_.get();
-        q.rep_P = p_rep ? repP_.get() : nullptr;
+        q.rep_P = p_any ? repP_.get() : nullptr;
         q.rep_pstride = static_cast<int64_t>(P_rows_) * vdim_;
         q.flush_every = im_flush_.get();
         q.strict = im_single_wave_;
@@ -1007,11 +1036,11 @@ class BprHandle : public SgdHandle {
             // refreshed; this segment's own delta goes out behind the merge and travels while the next walk runs
             exchange_finish(true);
             xcd_merge(sgm + 1 < segments, c.hot, true);
-            if (p_rep) {   // P <- P + sum_x (P_x - B); hot users' rows were updated in P itself and are skipped
+            if (p_any) {   // P <- P + sum_x (P_x - B) for the users that have replicas (flag 2); the others were updated in P itself
                 hipLaunchKernelGGL((xcd_merge_kernel<float4>), dim3(static_cast<unsigned>(std::min<int64_t>((up4 + 255) / 256, 8192))), dim3(256), 0, stream,
                                    reinterpret_cast<float4*>(P_.get()) + uoff4, reinterpret_cast<float4*>(repP_.get()) + uoff4, up4, np4, 1.0f,
                                    sgm + 1 < segments ? 1 : 0, static_cast<const uint8_t*>(im_hot_user_.get()) + start_x, vdim_ / 4,
-                                   reinterpret_cast<float4*>(repP_.get()) + kXcdReplicas * np4 + uoff4);
+                                   reinterpret_cast<float4*>(repP_.get()) + kXcdReplicas * np4 + uoff4, 2);
                 BFH_HIP(hipGetLastError());
             }
             t_aux_.end(slot, stream);

@@ -49,7 +49,7 @@ struct ImQueues {
     int64_t t_beg[kImMaxQueues], t_end[kImMaxQueues];   // ticket range of this launch
     int* tickets;              // [nq] tickets handed out so far in this launch's range
     unsigned long long* done;  // triples processed (checked by the host)
-    const uint8_t* hot_user;   // [P_rows] 1: P[u] is updated with atomics
+    const uint8_t* hot_user;   // [P_rows] 0: plain loads / stores on P[u] (one owner XCD); 1: fp32 atomics on P[u]; 2: plain on this XCD's replica of P[u]
     const uint8_t* flush_every;  // [Q_rows] triples between two flushes of the register-resident item row (1..64)
     const int32_t* neg_pre;    // [chunk nnz * num_neg] negatives drawn by bpr_presample_kernel, or null: draw in the walk
     float* rep_P;              // null: a user's entries all sit in the queue of ONE XCD, which alone touches P[u].  Otherwise
@@ -117,13 +117,18 @@ __global__ void xcd_probe_kernel(int* seen) {
 // sort key of every entry: ((owner queue of the user) * blocks + block) * Q_rows + item.  `blocks` > 1 cuts an
 // item's entries inside a queue into that many runs (by a hash of the nnz position), visited at different times.
 // `spread`: the queue is a hash of the position instead of the user's owner (per-XCD replicas of P, ImQueues::rep_P).
+// `spread` = 2: only the entries of HEAVY users (degree >= heavy_deg: the users the collision rule would put on atomics) are spread
+// over the queues -- they get per-XCD replicas of their row, everybody else keeps one owner XCD.
 __global__ __launch_bounds__(256) void im_keys_kernel(const int32_t* __restrict__ rows, const int32_t* __restrict__ keys, int64_t n, int nq,
-                                                      uint32_t blocks, uint32_t q_rows, int spread, uint32_t* __restrict__ kout,
-                                                      int32_t* __restrict__ vout) {
+                                                      uint32_t blocks, uint32_t q_rows, int spread, const int64_t* __restrict__ indptr,
+                                                      int64_t heavy_deg, uint32_t* __restrict__ kout, int32_t* __restrict__ vout) {
     const int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
     if (t >= n) return;
     const uint32_t blk = blocks > 1 ? ((static_cast<uint32_t>(t) * 2654435761u) >> 16) % blocks : 0u;
-    const uint32_t queue = spread ? ((static_cast<uint32_t>(t) * 0x85EBCA6Bu) >> 11) % static_cast<uint32_t>(nq) : static_cast<uint32_t>(rows[t] % nq);
+    const int u = rows[t];
+    bool sp = spread == 1;
+    if (spread == 2) sp = (indptr[u] - (u ? indptr[u - 1] : 0)) >= heavy_deg;
+    const uint32_t queue = sp ? ((static_cast<uint32_t>(t) * 0x85EBCA6Bu) >> 11) % static_cast<uint32_t>(nq) : static_cast<uint32_t>(u % nq);
     kout[t] = (queue * blocks + blk) * q_rows + static_cast<uint32_t>(keys[t]);
     vout[t] = static_cast<int32_t>(t);
 }
@@ -160,13 +165,25 @@ __global__ void im_item_flags_kernel(const int* __restrict__ cnt, const int64_t*
     flush_every[i] = static_cast<uint8_t>(f);
 }
 
-__global__ void im_user_flags_kernel(const int64_t* __restrict__ indptr, int first_row, int rows, double num_neg, double queue_triples,
-                                     double inflight, double tau, uint8_t* __restrict__ hot_user) {
+// mode 0: every user has one owner XCD -- flag 1 (atomics) where the collision rule fires at the owner queue's share, else 0;
+// mode 1: every user is replicated per XCD (its entries are spread over the queues: 1/nq of the share) -- 1 where the rule still
+//         fires, else 2 (replica);
+// mode 2: only the users with degree >= heavy_deg (= where the owner-share rule fires; the threshold the keys were built with) are
+//         replicated: they get 1 / 2 by the spread-share rule, everybody else 0.
+__global__ void im_user_flags_kernel(const int64_t* __restrict__ indptr, int first_row, int rows, double num_neg, double owner_queue_triples,
+                                     double all_triples, double inflight, double tau, int mode, int64_t heavy_deg, uint8_t* __restrict__ hot_user) {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= rows) return;
     const int g = first_row + u;
-    const double deg = static_cast<double>(indptr[g] - (g ? indptr[g - 1] : 0));
-    hot_user[g] = (tau > 0.0 && deg * num_neg / queue_triples * inflight >= tau) ? 1 : 0;
+    const int64_t degi = indptr[g] - (g ? indptr[g - 1] : 0);
+    const double deg = static_cast<double>(degi);
+    const bool hot_owner = tau > 0.0 && deg * num_neg / owner_queue_triples * inflight >= tau;
+    const bool hot_spread = tau > 0.0 && deg * num_neg / all_triples * inflight >= tau;
+    uint8_t f = 0;
+    if (mode == 0) f = hot_owner ? 1 : 0;
+    else if (mode == 1) f = hot_spread ? 1 : 2;
+    else f = degi >= heavy_deg ? (hot_spread ? 1 : 2) : 0;
+    hot_user[g] = f;
 }
 
 // float4-per-lane registers -> dword-per-lane order (element k*64 + lane), so that one atomic
@@ -342,9 +359,10 @@ __global__ __launch_bounds__(256, K <= 4 ? (PIPE ? 5 : 6) : 1) void bpr_item_maj
                     const int64_t uend = p.indptr[my_u] - p.shift;
                     my_neg = bpr_sample_negative(p, c, static_cast<uint64_t>(p.nnz_offset + p.shift + pos_idx), slot, ubeg, uend);
                 }
-                my_pol = drain ? 3 : ((q.hot_user[my_u] ? 1 : 0) | (c.hot[my_neg] ? 2 : 0));
+                const int fu = q.hot_user[my_u];   // bit 0: atomics on P[u]; bit 2: this XCD's replica of P[u]; bit 1: the negative's row is chip-wide
+                my_pol = drain ? 3 : ((fu == 1 ? 1 : 0) | (c.hot[my_neg] ? 2 : 0) | (fu == 2 ? 4 : 0));
             }
-            auto pu_ptr = [&](int u, bool hot) -> float* { return (hot ? p.P : Prep) + static_cast<size_t>(u) * vdim; };
+            auto pu_ptr = [&](int u, int pol) -> float* { return ((pol & 4) ? Prep : p.P) + static_cast<size_t>(u) * vdim; };
             auto qj_ptr = [&](int j, bool hot) -> float* { return (hot ? p.Q : Qrep) + static_cast<size_t>(j) * vdim; };
             auto bj_ptr = [&](int j, bool hot) -> float* { return (hot ? p.Qb : Qbrep) + j; };
 
@@ -357,7 +375,7 @@ __global__ __launch_bounds__(256, K <= 4 ? (PIPE ? 5 : 6) : 1) void bpr_item_maj
                     const int u = __builtin_amdgcn_readlane(my_u, j), ng = __builtin_amdgcn_readlane(my_neg, j);
                     const int pl = __builtin_amdgcn_readlane(my_pol, j);
                     const bool hj = (pl & 2) != 0;
-                    pload(s.pu, pu_ptr(u, (pl & 1) != 0));
+                    pload(s.pu, pu_ptr(u, pl));
                     rload(s.qj, qj_ptr(ng, hj));
                     s.bj = c.use_bias ? coh_load(bj_ptr(ng, hj)) : 0.f;
                 }
@@ -379,7 +397,7 @@ __global__ __launch_bounds__(256, K <= 4 ? (PIPE ? 5 : 6) : 1) void bpr_item_maj
                 if (u == prev_u) {
                     // consecutive slots of one entry (num_negative_samples > 1): carry the updated row
                 } else if (!PIPE || u == prev2_u) {
-                    pload(pu, pu_ptr(u, at_u));
+                    pload(pu, pu_ptr(u, pol));
                 } else {
                     pu = s.pu;
                 }
@@ -437,7 +455,7 @@ __global__ __launch_bounds__(256, K <= 4 ? (PIPE ? 5 : 6) : 1) void bpr_item_maj
                     if (same) { bi = bj; dbi_acc += dbj; }
                 }
                 // ---------------- write the two per-triple rows back ----------------
-                float* Pu = pu_ptr(u, at_u);
+                float* Pu = pu_ptr(u, pol);
                 float* Qj = qj_ptr(neg, at_j);
                 const bool fr_u = PIPE && c.fresh && !at_u, fr_j = PIPE && c.fresh && !at_j && !same && c.update_j;
                 Row<K> fu, fj;
@@ -625,7 +643,8 @@ __global__ __launch_bounds__(256, 5) void bpr_item_major_dual_kernel(SgdParams p
                     const int64_t uend = p.indptr[u_[sidx]] - p.shift;
                     ng_[sidx] = bpr_sample_negative(p, c, static_cast<uint64_t>(p.nnz_offset + p.shift + pos_idx), slot, ubeg, uend);
                 }
-                pl_[sidx] = (q.hot_user[u_[sidx]] ? 1 : 0) | (c.hot[ng_[sidx]] ? 2 : 0);
+                const int fu = q.hot_user[u_[sidx]];
+                pl_[sidx] = (fu == 1 ? 1 : 0) | (c.hot[ng_[sidx]] ? 2 : 0) | (fu == 2 ? 4 : 0);
             }
         }
         const int n_mine = half ? n_sl[1] : n_sl[0];
@@ -644,7 +663,7 @@ __global__ __launch_bounds__(256, 5) void bpr_item_major_dual_kernel(SgdParams p
             const bool act = j < n_mine;
             const bool at_u = (pol & 1) != 0, at_j = (pol & 2) != 0;
             const bool same = item == neg;
-            float* const Pu = (at_u ? p.P : Prep) + static_cast<size_t>(act ? u : 0) * vdim + l32;
+            float* const Pu = ((pol & 4) ? Prep : p.P) + static_cast<size_t>(act ? u : 0) * vdim + l32;
             float* const Qj = (at_j ? p.Q : Qrep) + static_cast<size_t>(act ? neg : 0) * vdim + l32;
             float* const Bj = (at_j ? p.Qb : Qbrep) + (act ? neg : 0);
             if (act) {

@@ -149,7 +149,9 @@ class SgdHandle : public HandleBase {
     int im_neg_limit_ = 0;         // policy 3 study knob: fold the uniform negatives into the first rows of Q
     int im_p_nt_ = 0;              // policy 3 study knob: non-temporal hint on the per-triple P rows
     int im_user_replicas_ = -1;    // policy 3: per-XCD replicas of P instead of one owner XCD per user (-1: for small shards, 0 / 1)
-    bool im_built_spread_ = false;
+    int im_user_hybrid_ = 1;       // policy 3, whole matrices: per-XCD replicas of P for the HEAVY users only (the ones the collision rule would put on atomics)
+    int im_built_spread_mode_ = 0; // what the cached item-major keys were built with: 0 owner queues, 1 every entry spread, 2 heavy users' entries spread
+    int64_t im_built_heavy_deg_ = 0;
     int im_max_stale_ = 16;        // policy 3: updates of one item row that may be in flight unseen by the other waves (at lr 0.05; x 0.05 / lr)
                                    // 16: |P| within 0.1 % of the threaded oracle's after 24 epochs at lr 0.05 (64: -1.1 %), no cost at lr 0.002
     int xcd_fresh_ = -1, xcd_v4_ = 0;  // re-read before store; float4-per-lane rows (hot-row atomics then cost 4x the line operations)

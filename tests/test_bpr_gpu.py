@@ -164,6 +164,12 @@ def test_triples_parallel_disjoint_rows(oracle):
     (128, dict(num_negative_samples=2, use_bias=False), dict(im_dual=1, im_max_stale=1, xcd_hot_tau=1)),   # flush every triple, atomic rows
     (40, dict(update_j=False), dict(im_dual=1, im_presample=0, im_user_replicas=1)),
     (32, dict(update_i=False), dict(im_dual=1, n_chunks=3)),
+    # lr <= 0.01: the heavy users alone get per-XCD replicas of P (im_user_hybrid, the whole-matrix default).  Every user of this
+    # matrix has one entry, so with the collision threshold at 0.5 all of them count as heavy at the owner's share and none at the
+    # spread share: every row goes through a replica and the delta-rule merge; with the knob off through its owner XCD
+    (128, dict(lr=0.005, min_lr=0.005), dict(xcd_hot_tau=500)),
+    (128, dict(lr=0.005, min_lr=0.005, num_negative_samples=2), dict(xcd_hot_tau=500, im_dual=0, xcd_sync_updates=1024)),
+    (96, dict(lr=0.005, min_lr=0.005), dict(xcd_hot_tau=500, im_user_hybrid=0)),
 ])
 def test_item_major_conflict_free(oracle, d, kw, modes):
     """hogwild_atomic=3 (item-major walk, users owned by XCDs, Q[i] in registers, Q[j] in per-XCD replicas):
@@ -176,7 +182,7 @@ def test_item_major_conflict_free(oracle, d, kw, modes):
     rng = np.random.default_rng(5)
     keys = rng.permutation(I)[:U].astype(np.int32)
     csr = synth.CSR(U, I, np.arange(1, U + 1, dtype=np.int64), keys, np.ones(U, np.float32))
-    opt = bpr_opt(d=d, lr=0.05, min_lr=0.05, num_iters=1, random_seed=11, **kw)
+    opt = bpr_opt(**dict(dict(d=d, lr=0.05, min_lr=0.05, num_iters=1, random_seed=11), **kw))
     vdim = _vdim(d)
     P, Q, Qb = _factors(csr, d, vdim, bias=opt["use_bias"])
     P0, Q0 = P.copy(), Q.copy()
