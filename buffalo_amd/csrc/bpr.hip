@@ -846,7 +846,7 @@ class BprHandle : public SgdHandle {
         const bool p_hyb = !p_rep && im_user_hybrid_ && !im_single_wave_ && c.lr <= 0.01f && tau0 > 0.0 && inflight0 > 0.0 && nq > 1;
         // degree from which the owner-share rule fires: deg * num_neg / (triples / nq) * inflight >= tau
         const int64_t heavy_deg = p_hyb ? std::max<int64_t>(1, static_cast<int64_t>(std::ceil(tau0 * (static_cast<double>(c.total) / nq) / (inflight0 * num_neg_)))) : 0;
-        const int spread_mode = p_rep ? 1 : (p_hyb ? 2 : 0);
+        const int spread_mode = p_rep ? 1 : (p_hyb ? (im_user_hybrid_ >= 2 ? 3 : 2) : 0);
         const bool cached = keeps && im_gen_ == csr_generation_ && im_start_ == start_x && im_next_ == next_x && im_n_ == n && im_built_blocks_ == blocks && im_built_nq_ == nq &&
                             im_built_spread_mode_ == spread_mode && im_built_heavy_deg_ == heavy_deg;
         if (!cached) {
@@ -930,7 +930,7 @@ class BprHandle : public SgdHandle {
                            im_drift_budget_milli_ * 1e-3, hot_.get(), im_flush_.get());
         BFH_HIP(hipMemsetAsync(im_hot_user_.get(), 0, im_hot_user_.bytes(), stream));
         hipLaunchKernelGGL(im_user_flags_kernel, dim3((next_x - start_x + 255) / 256), dim3(256), 0, stream, p.indptr, start_x, next_x - start_x,
-                           static_cast<double>(num_neg_), triples / nq, triples, inflight, tau, spread_mode, heavy_deg, im_hot_user_.get());
+                           static_cast<double>(num_neg_), triples / nq, triples, inflight, tau, spread_mode >= 2 ? 2 : spread_mode, heavy_deg, im_hot_user_.get());
         BFH_HIP(hipGetLastError());
         // ---- replicas of the item factors (+ the copy they started from) ----
         xcd_alloc(true);

@@ -126,9 +126,24 @@ __global__ __launch_bounds__(256) void im_keys_kernel(const int32_t* __restrict_
     if (t >= n) return;
     const uint32_t blk = blocks > 1 ? ((static_cast<uint32_t>(t) * 2654435761u) >> 16) % blocks : 0u;
     const int u = rows[t];
-    bool sp = spread == 1;
-    if (spread == 2) sp = (indptr[u] - (u ? indptr[u - 1] : 0)) >= heavy_deg;
-    const uint32_t queue = sp ? ((static_cast<uint32_t>(t) * 0x85EBCA6Bu) >> 11) % static_cast<uint32_t>(nq) : static_cast<uint32_t>(u % nq);
+    const uint32_t h = (static_cast<uint32_t>(t) * 0x85EBCA6Bu) >> 11;
+    uint32_t queue = static_cast<uint32_t>(u % nq);
+    if (spread == 1) {
+        queue = h % static_cast<uint32_t>(nq);
+    } else if (spread >= 2) {
+        const int64_t deg = indptr[u] - (u ? indptr[u - 1] : 0);
+        if (deg >= heavy_deg) {
+            // spread == 3: only over as many queues (the owner's and its neighbours) as bring the user's share of one queue under
+            // the threshold -- a user just above it gets two replicas in use, not eight, and the rows an XCD keeps hot stay few
+            uint32_t r = static_cast<uint32_t>(nq);
+            if (spread == 3) {
+                r = 2;
+                while (r < static_cast<uint32_t>(nq) && deg >= heavy_deg * static_cast<int64_t>(r)) r <<= 1;
+                if (r > static_cast<uint32_t>(nq)) r = static_cast<uint32_t>(nq);
+            }
+            queue = (queue + h % r) % static_cast<uint32_t>(nq);
+        }
+    }
     kout[t] = (queue * blocks + blk) * q_rows + static_cast<uint32_t>(keys[t]);
     vout[t] = static_cast<int32_t>(t);
 }

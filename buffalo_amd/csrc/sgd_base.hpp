@@ -149,7 +149,8 @@ class SgdHandle : public HandleBase {
     int im_neg_limit_ = 0;         // policy 3 study knob: fold the uniform negatives into the first rows of Q
     int im_p_nt_ = 0;              // policy 3 study knob: non-temporal hint on the per-triple P rows
     int im_user_replicas_ = -1;    // policy 3: per-XCD replicas of P instead of one owner XCD per user (-1: for small shards, 0 / 1)
-    int im_user_hybrid_ = 1;       // policy 3, whole matrices: per-XCD replicas of P for the HEAVY users only (the ones the collision rule would put on atomics)
+    int im_user_hybrid_ = 2;       // policy 3, whole matrices: per-XCD replicas of P for the HEAVY users only (the ones the collision rule would put on
+                                   // atomics): 1 = their entries over all queues, 2 = over as few neighbouring queues as bring the share under the threshold
     int im_built_spread_mode_ = 0; // what the cached item-major keys were built with: 0 owner queues, 1 every entry spread, 2 heavy users' entries spread
     int64_t im_built_heavy_deg_ = 0;
     int im_max_stale_ = 16;        // policy 3: updates of one item row that may be in flight unseen by the other waves (at lr 0.05; x 0.05 / lr)

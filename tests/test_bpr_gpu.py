@@ -168,7 +168,7 @@ def test_triples_parallel_disjoint_rows(oracle):
     # matrix has one entry, so with the collision threshold at 0.5 all of them count as heavy at the owner's share and none at the
     # spread share: every row goes through a replica and the delta-rule merge; with the knob off through its owner XCD
     (128, dict(lr=0.005, min_lr=0.005), dict(xcd_hot_tau=500)),
-    (128, dict(lr=0.005, min_lr=0.005, num_negative_samples=2), dict(xcd_hot_tau=500, im_dual=0, xcd_sync_updates=1024)),
+    (128, dict(lr=0.005, min_lr=0.005, num_negative_samples=2), dict(xcd_hot_tau=500, im_dual=0, xcd_sync_updates=1024, im_user_hybrid=1)),
     (96, dict(lr=0.005, min_lr=0.005), dict(xcd_hot_tau=500, im_user_hybrid=0)),
 ])
 def test_item_major_conflict_free(oracle, d, kw, modes):
