@@ -144,6 +144,10 @@ Comm::Comm(int n_ranks, int rank, const char* id128, int dev) {
     BFH_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     if (std::memcmp(id128, kShmMagic, sizeof(kShmMagic)) == 0) {
         BFH_REQUIRE(n_ranks <= kShmMaxRanks, "shm transport: at most 16 ranks");
+        struct Guard {   // a throw below must not leak the mapping (the destructor of a half-built Comm never runs)
+            Shm*& p; bool armed = true;
+            ~Guard() { if (armed) { delete p; p = nullptr; } }
+        } guard{shm_};
         shm_ = new Shm();
         static const char* hex = "0123456789abcdef";
         shm_->name = "/bfh_";
@@ -163,6 +167,7 @@ Comm::Comm(int n_ranks, int rank, const char* id128, int dev) {
         shm_->hdr->attached.fetch_add(1, std::memory_order_acq_rel);
         shm_->host.resize(kShmSlot);
         shm_->barrier(n_ranks);   // every rank is attached before the first collective
+        guard.armed = false;
         return;
     }
     ncclUniqueId id;

@@ -5,8 +5,9 @@
 // latent dimensions of every row, driven by a cache of the predictions vhat of the observed entries that
 // is kept in BOTH orientations and linked by index maps (eals.cc:49-100).
 //
-// Device formulation: one wave per row.  The row's entries sit one per lane (up to 4 per lane in registers:
-// key, value, vhat, weight; longer rows stream them from HBM each step); for every dimension d the lanes form
+// Device formulation: one wave per row (one 1024-thread block above 4096 entries).  The row's entries sit one per lane (up to 4 per lane
+// in registers: key, value, vhat, weight; longer rows keep vhat in HBM and a transposed 16-dimension slice of the gathered rows in a
+// scratch slot); for every dimension d the lanes form
 // the numerator / denominator terms of eals.cc:196-213 against the gathered column element Y[key][d], three
 // wave reductions finish the step (the p.S[:,d] product rides on the numerator), the new coordinate is
 // broadcast through LDS and folded back into vhat.  The mirrored cache of the other orientation is written once
@@ -39,8 +40,18 @@ struct EalsParams {
     int n_list;
 };
 
-constexpr int EALS_REG = 4;   // entries per lane kept in registers (rows up to 256 entries)
+constexpr int EALS_REG = 4;    // entries per lane kept in registers (rows up to 256 entries)
+constexpr int EALS_DB = 16;    // dimensions per block: 16 floats = the 64-byte sector a 4-byte gather of Y[key][d] pulls anyway
+constexpr int EALS_LIGHT = 64 * EALS_REG;
+constexpr int EALS_HEAVY = 4096;   // above: one 1024-thread block per row; (EALS_LIGHT, EALS_HEAVY]: one wave per row, both over HBM scratch
 
+// Round 3: the coordinate of dimension d needs Y[key][d] of EVERY entry of the row -- a 4-byte gather that costs a 64-byte sector, 128
+// times per entry at d = 128: the epoch was bound by 16x its useful traffic (131 ms on the ML-20M shape).  Both kernels now walk the
+// dimensions in blocks of 16: the 64-byte segment Y[key][16 b .. 16 b + 15] of every entry is fetched ONCE per block (registers for
+// rows up to 256 entries; otherwise transposed into a per-row scratch [16][n] that the 16 steps then read coalesced), and the entry
+// constants w - c_i (a second sector gather per step on the user side) once per row.
+
+// rows up to EALS_LIGHT entries: one wave per row, everything in registers
 __global__ __launch_bounds__(256) void eals_update_kernel(EalsParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -53,160 +64,191 @@ __global__ __launch_bounds__(256) void eals_update_kernel(EalsParams p) {
         if (item >= p.n_list) break;
         const int x = p.row_list[item];
         const int64_t beg = x == 0 ? 0 : p.indptr[x - 1], end = p.indptr[x];
-        const int64_t n = end - beg;
         float* xrow = p.X + static_cast<size_t>(x) * vdim;
         wave_lds_sync();
         for (int e = lane; e < vdim; e += 64) xs[e] = xrow[e];
         wave_lds_sync();
         const float cx = p.axis == 1 ? p.Cw[x] : 0.f;
-        const bool inreg = n <= 64 * EALS_REG;
         int rk[EALS_REG];
-        float rv[EALS_REG], rh[EALS_REG], rc[EALS_REG];
-        if (inreg) {
+        float rv[EALS_REG], rh[EALS_REG], rw[EALS_REG], rm[EALS_REG];   // value, vhat, w = 1 + alpha v, w - c
+        bool ok[EALS_REG];
+#pragma unroll
+        for (int s = 0; s < EALS_REG; ++s) {
+            const int64_t ind = beg + s * 64 + lane;
+            ok[s] = ind < end;
+            rk[s] = ok[s] ? p.keys[ind] : 0;
+            rv[s] = ok[s] ? p.vals[ind] : 0.f;
+            rh[s] = ok[s] ? p.own[ind] : 0.f;
+            rw[s] = 1.f + p.alpha * rv[s];
+            rm[s] = rw[s] - (p.axis == 0 ? (ok[s] ? p.Cw[rk[s]] : 0.f) : cx);
+        }
+        for (int db = 0; db < D; db += EALS_DB) {
+            float yb[EALS_REG][EALS_DB];
 #pragma unroll
             for (int s = 0; s < EALS_REG; ++s) {
-                const int64_t ind = beg + s * 64 + lane;
-                const bool ok = ind < end;
-                rk[s] = ok ? p.keys[ind] : 0;
-                rv[s] = ok ? p.vals[ind] : 0.f;
-                rh[s] = ok ? p.own[ind] : 0.f;
-                rc[s] = p.axis == 0 ? (ok ? p.Cw[rk[s]] : 0.f) : cx;
-            }
-        }
-        for (int d = 0; d < D; ++d) {
-            const float xd = xs[d];
-            float num = 0.f, den = 0.f;
-            float yds[EALS_REG];
-            if (inreg) {
+                const float4* src = reinterpret_cast<const float4*>(p.Y + static_cast<size_t>(rk[s]) * vdim + db);
 #pragma unroll
-                for (int s = 0; s < EALS_REG; ++s) {
-                    const bool ok = beg + s * 64 + lane < end;
-                    const float yd = ok ? p.Y[static_cast<size_t>(rk[s]) * vdim + d] : 0.f;
-                    yds[s] = yd;
-                    const float pq = xd * yd;
-                    const float vf = rh[s] - pq;
-                    const float w = 1.f + p.alpha * rv[s];
-                    const float wmc = w - rc[s];
-                    if (ok) {
-                        num += (w * rv[s] - wmc * vf) * yd;
-                        den += wmc * yd * yd;
+                for (int q4 = 0; q4 < EALS_DB / 4; ++q4) {
+                    const float4 v = ok[s] ? src[q4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    yb[s][4 * q4] = v.x; yb[s][4 * q4 + 1] = v.y; yb[s][4 * q4 + 2] = v.z; yb[s][4 * q4 + 3] = v.w;
+                }
+            }
+#pragma unroll
+            for (int dd = 0; dd < EALS_DB; ++dd) {
+                const int d = db + dd;
+                if (d < D) {
+                    const float xd = xs[d];
+                    float num = 0.f, den = 0.f;
+#pragma unroll
+                    for (int s = 0; s < EALS_REG; ++s) {
+                        const float yd = yb[s][dd];
+                        const float pq = xd * yd;
+                        const float vf = rh[s] - pq;
+                        if (ok[s]) {
+                            num += (rw[s] * rv[s] - rm[s] * vf) * yd;
+                            den += rm[s] * yd * yd;
+                        }
+                        rh[s] = vf;
                     }
-                    rh[s] = vf;
-                }
-            } else {
-                for (int64_t ind = beg + lane; ind < end; ind += 64) {
-                    const int y = p.keys[ind];
-                    const float v = p.vals[ind];
-                    const float yd = p.Y[static_cast<size_t>(y) * vdim + d];
-                    const float pq = xd * yd;
-                    const float vf = p.own[ind] - pq;
-                    const float w = 1.f + p.alpha * v;
-                    const float wmc = w - (p.axis == 0 ? p.Cw[y] : cx);
-                    num += (w * v - wmc * vf) * yd;
-                    den += wmc * yd * yd;
-                    p.own[ind] = vf;
-                }
-            }
-            float dot = 0.f;   // x . S[:, d] (S symmetric)
-            for (int e = lane; e < D; e += 64) dot += xs[e] * p.S[static_cast<size_t>(d) * vdim + e];
-            num = wave_sum(num);
-            den = wave_sum(den);
-            dot = wave_sum(dot);
-            const float sdd = p.S[static_cast<size_t>(d) * vdim + d];
-            if (p.axis == 0) {   // eals.cc:214-215
-                num += -dot + xd * sdd;
-                den += sdd + p.reg;
-            } else {             // eals.cc:261-262
-                num += -cx * (dot - xd * sdd);
-                den += cx * sdd + p.reg;
-            }
-            const float xn = num / den;
-            wave_lds_sync();
-            if (lane == 0) xs[d] = xn;
-            wave_lds_sync();
-            if (inreg) {
+                    float dot = 0.f;   // x . S[:, d] (S symmetric)
+                    for (int e = lane; e < D; e += 64) dot += xs[e] * p.S[static_cast<size_t>(d) * vdim + e];
+                    num = wave_sum(num);
+                    den = wave_sum(den);
+                    dot = wave_sum(dot);
+                    const float sdd = p.S[static_cast<size_t>(d) * vdim + d];
+                    if (p.axis == 0) {   // eals.cc:214-215
+                        num += -dot + xd * sdd;
+                        den += sdd + p.reg;
+                    } else {             // eals.cc:261-262
+                        num += -cx * (dot - xd * sdd);
+                        den += cx * sdd + p.reg;
+                    }
+                    const float xn = num / den;
+                    wave_lds_sync();
+                    if (lane == 0) xs[d] = xn;
+                    wave_lds_sync();
 #pragma unroll
-                for (int s = 0; s < EALS_REG; ++s) rh[s] += xn * yds[s];
-            } else {
-                for (int64_t ind = beg + lane; ind < end; ind += 64)
-                    p.own[ind] += xn * p.Y[static_cast<size_t>(p.keys[ind]) * vdim + d];
+                    for (int s = 0; s < EALS_REG; ++s) rh[s] += xn * yb[s][dd];
+                }
             }
         }
         for (int e = lane; e < D; e += 64) xrow[e] = xs[e];
-        if (inreg) {
 #pragma unroll
-            for (int s = 0; s < EALS_REG; ++s) {
-                const int64_t ind = beg + s * 64 + lane;
-                if (ind < end) {
-                    p.own[ind] = rh[s];
-                    p.other[p.map[ind]] = rh[s];
-                }
+        for (int s = 0; s < EALS_REG; ++s) {
+            const int64_t ind = beg + s * 64 + lane;
+            if (ind < end) {
+                p.own[ind] = rh[s];
+                p.other[p.map[ind]] = rh[s];
             }
-        } else {
-            for (int64_t ind = beg + lane; ind < end; ind += 64) p.other[p.map[ind]] = p.own[ind];
         }
     }
 }
 
-// Rows above EALS_HEAVY entries: one 1024-thread block per row.  The per-dimension sums are formed by all 16 waves
-// (entries strided over the block, vhat streamed from HBM), combined through LDS, and every thread derives the new
-// coordinate redundantly -- three barriers per dimension instead of a 131 K-entry row crawling through one wave.
-constexpr int EALS_HEAVY = 1024;
-
-__global__ __launch_bounds__(1024) void eals_update_heavy_kernel(EalsParams p) {
+// Rows above EALS_LIGHT entries.  BS = 64: one wave per row (ticketed, longest first); BS = 1024: one block per row, the per-dimension
+// sums combined through LDS -- three barriers per dimension instead of a 131 K-entry row crawling through one wave.
+// `scratch`: per thread group (1 + EALS_DB) * cap floats: w - c of every entry | Y[key][16 b + dd] as [dd][entry].
+// vhat lives in HBM (coalesced); a step's closing update vhat += x_new * y is folded into the NEXT step's pass (the same two
+// roundings in the same order), so every dimension costs one pass over the row: 24 bytes per entry instead of 220.
+template <int BS>
+__global__ __launch_bounds__(BS) void eals_update_long_kernel(EalsParams p, float* __restrict__ scratch, int64_t cap) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* xs = lds;                 // [vdim]
-    float* red = lds + p.vdim;       // [3][16]
+    float* red = lds + p.vdim;       // [3][16]  (BS = 1024)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int D = p.d, vdim = p.vdim;
-    for (int item = blockIdx.x; item < p.n_list; item += gridDim.x) {
+    float* wmc = scratch + static_cast<size_t>(blockIdx.x) * (1 + EALS_DB) * cap;
+    float* yb = wmc + cap;
+    auto group_sync = [&]() {
+        if constexpr (BS == 64) wave_lds_sync();
+        else __syncthreads();
+    };
+    while (true) {
+        int item = 0;
+        if constexpr (BS == 64) {
+            if (lane == 0) item = atomicAdd(p.ticket, 1);
+            item = __builtin_amdgcn_readfirstlane(item);
+        } else {
+            __syncthreads();
+            if (tid == 0) reinterpret_cast<int*>(red)[0] = atomicAdd(p.ticket, 1);
+            __syncthreads();
+            item = reinterpret_cast<int*>(red)[0];
+        }
+        if (item >= p.n_list) break;
         const int x = p.row_list[item];
         const int64_t beg = x == 0 ? 0 : p.indptr[x - 1], end = p.indptr[x];
+        const int64_t n = end - beg;
         float* xrow = p.X + static_cast<size_t>(x) * vdim;
-        __syncthreads();
-        for (int e = tid; e < vdim; e += 1024) xs[e] = xrow[e];
-        __syncthreads();
+        group_sync();
+        for (int e = tid; e < vdim; e += BS) xs[e] = xrow[e];
         const float cx = p.axis == 1 ? p.Cw[x] : 0.f;
-        for (int d = 0; d < D; ++d) {
-            const float xd = xs[d];
-            float num = 0.f, den = 0.f;
-            for (int64_t ind = beg + tid; ind < end; ind += 1024) {
-                const int y = p.keys[ind];
-                const float v = p.vals[ind];
-                const float yd = p.Y[static_cast<size_t>(y) * vdim + d];
-                const float pq = xd * yd;
-                const float vf = p.own[ind] - pq;
-                const float w = 1.f + p.alpha * v;
-                const float wmc = w - (p.axis == 0 ? p.Cw[y] : cx);
-                num += (w * v - wmc * vf) * yd;
-                den += wmc * yd * yd;
-                p.own[ind] = vf;
-            }
-            float dot = tid < D ? xs[tid] * p.S[static_cast<size_t>(d) * vdim + tid] : 0.f;   // D <= 1024
-            num = wave_sum(num);
-            den = wave_sum(den);
-            dot = wave_sum(dot);
-            if (lane == 0) { red[wv] = num; red[16 + wv] = den; red[32 + wv] = dot; }
-            __syncthreads();
-            float tn = 0.f, td = 0.f, tt = 0.f;
-#pragma unroll
-            for (int w = 0; w < 16; ++w) { tn += red[w]; td += red[16 + w]; tt += red[32 + w]; }
-            const float sdd = p.S[static_cast<size_t>(d) * vdim + d];
-            if (p.axis == 0) {
-                tn += -tt + xd * sdd;
-                td += sdd + p.reg;
-            } else {
-                tn += -cx * (tt - xd * sdd);
-                td += cx * sdd + p.reg;
-            }
-            const float xn = tn / td;
-            __syncthreads();
-            if (tid == 0) xs[d] = xn;
-            for (int64_t ind = beg + tid; ind < end; ind += 1024) p.own[ind] += xn * p.Y[static_cast<size_t>(p.keys[ind]) * vdim + d];
-            __syncthreads();
+        for (int64_t i = tid; i < n; i += BS) {
+            const float w = 1.f + p.alpha * p.vals[beg + i];
+            wmc[i] = w - (p.axis == 0 ? p.Cw[p.keys[beg + i]] : cx);
         }
-        for (int e = tid; e < D; e += 1024) xrow[e] = xs[e];
-        for (int64_t ind = beg + tid; ind < end; ind += 1024) p.other[p.map[ind]] = p.own[ind];
+        group_sync();
+        for (int db = 0; db < D; db += EALS_DB) {
+            for (int64_t i = tid; i < n; i += BS) {   // the block's 64-byte segment of every entry, transposed into [dd][entry]
+                const float4* src = reinterpret_cast<const float4*>(p.Y + static_cast<size_t>(p.keys[beg + i]) * vdim + db);
+#pragma unroll
+                for (int q4 = 0; q4 < EALS_DB / 4; ++q4) {
+                    const float4 v = src[q4];
+                    yb[(4 * q4 + 0) * cap + i] = v.x; yb[(4 * q4 + 1) * cap + i] = v.y;
+                    yb[(4 * q4 + 2) * cap + i] = v.z; yb[(4 * q4 + 3) * cap + i] = v.w;
+                }
+            }
+            float pend = 0.f;   // x_new of the previous step of this block, still to be folded into vhat
+            const int nd = D - db < EALS_DB ? D - db : EALS_DB;
+            for (int dd = 0; dd < nd; ++dd) {
+                const int d = db + dd;
+                const float xd = xs[d];
+                float num = 0.f, den = 0.f;
+                const float* yd_ = yb + static_cast<size_t>(dd) * cap;
+                const float* yp_ = yb + static_cast<size_t>(dd > 0 ? dd - 1 : 0) * cap;
+                for (int64_t i = tid; i < n; i += BS) {
+                    const float yd = yd_[i];
+                    float vh = p.own[beg + i];
+                    if (dd > 0) vh += pend * yp_[i];
+                    const float pq = xd * yd;
+                    const float vf = vh - pq;
+                    const float v = p.vals[beg + i];
+                    const float w = 1.f + p.alpha * v;
+                    const float wm = wmc[i];
+                    num += (w * v - wm * vf) * yd;
+                    den += wm * yd * yd;
+                    p.own[beg + i] = vf;
+                }
+                float dot = 0.f;   // x . S[:, d] (S symmetric)
+                for (int e = tid; e < D; e += BS) dot += xs[e] * p.S[static_cast<size_t>(d) * vdim + e];
+                num = wave_sum(num);
+                den = wave_sum(den);
+                dot = wave_sum(dot);
+                if constexpr (BS != 64) {
+                    if (lane == 0) { red[wv] = num; red[16 + wv] = den; red[32 + wv] = dot; }
+                    __syncthreads();
+                    num = den = dot = 0.f;
+#pragma unroll
+                    for (int w2 = 0; w2 < BS / 64; ++w2) { num += red[w2]; den += red[16 + w2]; dot += red[32 + w2]; }
+                }
+                const float sdd = p.S[static_cast<size_t>(d) * vdim + d];
+                if (p.axis == 0) {   // eals.cc:214-215
+                    num += -dot + xd * sdd;
+                    den += sdd + p.reg;
+                } else {             // eals.cc:261-262
+                    num += -cx * (dot - xd * sdd);
+                    den += cx * sdd + p.reg;
+                }
+                const float xn = num / den;
+                group_sync();
+                if (tid == 0) xs[d] = xn;
+                group_sync();
+                pend = xn;
+            }
+            const float* yl_ = yb + static_cast<size_t>(nd - 1) * cap;   // close the block: the last step's update of vhat
+            for (int64_t i = tid; i < n; i += BS) p.own[beg + i] += pend * yl_[i];
+            group_sync();
+        }
+        for (int e = tid; e < D; e += BS) xrow[e] = xs[e];
+        for (int64_t i = tid; i < n; i += BS) p.other[p.map[beg + i]] = p.own[beg + i];
     }
 }
 
@@ -280,6 +322,13 @@ __global__ __launch_bounds__(256) void eals_sqsum_kernel(const float* __restrict
 
 class EalsHandle : public AlsHandle {
  public:
+    ~EalsHandle() override {
+        for (int k = 0; k < 2; ++k) {
+            if (side_done_[k]) (void)hipEventDestroy(side_done_[k]);
+            if (side_stream_[k]) (void)hipStreamDestroy(side_stream_[k]);
+        }
+        if (side_go_) (void)hipEventDestroy(side_go_);
+    }
     bool init_eals(const char* opt_path) {   // eals.cc:19-31
         std::string err;
         if (!opt_.load(opt_path ? opt_path : "", &err)) {
@@ -340,8 +389,9 @@ class EalsHandle : public AlsHandle {
         DevBuf<int64_t> indptr, map;
         DevBuf<int32_t> keys;
         DevBuf<float> vals, vhat;
-        DevBuf<int32_t> light, heavy;   // row ids with <= / > EALS_HEAVY entries (empty rows are light: the regulariser still moves them)
-        int n_light = 0, n_heavy = 0;
+        DevBuf<int32_t> light, mid, heavy;   // row ids with <= EALS_LIGHT / <= EALS_HEAVY / more entries, the long ones longest first (empty rows are light: the regulariser still moves them)
+        int n_light = 0, n_mid = 0, n_heavy = 0;
+        int64_t longest = 0;
         int64_t nnz = 0;
     };
     // eals.cc:49-100: the orientation's structure stays resident; vhat from the current factors; the index map by a host sort
@@ -361,20 +411,26 @@ class EalsHandle : public AlsHandle {
         BFH_HIP(hipMemcpyAsync(s.indptr.get(), indptr, sizeof(int64_t) * rows, hipMemcpyHostToDevice, stream));
         if (nnz) BFH_HIP(hipMemcpyAsync(s.keys.get(), keys, sizeof(int32_t) * nnz, hipMemcpyHostToDevice, stream));
         {
-            std::vector<int32_t> li, hv;
+            std::vector<int32_t> li, md, hv;
             int64_t prev = 0;
+            s.longest = 0;
             for (int x = 0; x < rows; ++x) {
-                (indptr[x] - prev > EALS_HEAVY ? hv : li).push_back(x);
+                const int64_t n = indptr[x] - prev;
+                (n > EALS_HEAVY ? hv : (n > EALS_LIGHT ? md : li)).push_back(x);
+                s.longest = std::max(s.longest, n);
                 prev = indptr[x];
             }
-            std::stable_sort(hv.begin(), hv.end(), [&](int a, int b) {   // longest first
-                return indptr[a] - (a ? indptr[a - 1] : 0) > indptr[b] - (b ? indptr[b - 1] : 0);
-            });
+            auto longer = [&](int a, int b) { return indptr[a] - (a ? indptr[a - 1] : 0) > indptr[b] - (b ? indptr[b - 1] : 0); };
+            std::stable_sort(hv.begin(), hv.end(), longer);   // longest first
+            std::stable_sort(md.begin(), md.end(), longer);
             s.n_light = static_cast<int>(li.size());
+            s.n_mid = static_cast<int>(md.size());
             s.n_heavy = static_cast<int>(hv.size());
             s.light.resize(std::max<size_t>(1, li.size()));
+            s.mid.resize(std::max<size_t>(1, md.size()));
             s.heavy.resize(std::max<size_t>(1, hv.size()));
             if (!li.empty()) BFH_HIP(hipMemcpyAsync(s.light.get(), li.data(), li.size() * 4, hipMemcpyHostToDevice, stream));
+            if (!md.empty()) BFH_HIP(hipMemcpyAsync(s.mid.get(), md.data(), md.size() * 4, hipMemcpyHostToDevice, stream));
             if (!hv.empty()) BFH_HIP(hipMemcpyAsync(s.heavy.get(), hv.data(), hv.size() * 4, hipMemcpyHostToDevice, stream));
             BFH_HIP(hipStreamSynchronize(stream));   // li / hv are locals
         }
@@ -437,24 +493,59 @@ class EalsHandle : public AlsHandle {
         p.own = s.vhat.get(); p.other = side_[1 - axis].vhat.get(); p.map = s.map.get();
         p.rows = axis == 0 ? P_rows_ : Q_rows_;
         p.d = d_; p.vdim = vdim_; p.axis = axis; p.alpha = alpha_; p.reg = axis == 0 ? reg_u_ : reg_i_;
-        p.ticket = ticket_.get();
-        BFH_HIP(hipMemsetAsync(ticket_.get(), 0, sizeof(int), stream));
+        // three launches over disjoint rows (heavy / mid / light), each with its own ticket, side by side on three streams: the few
+        // blocks of the longest rows would otherwise leave most of the chip idle while they crawl through their 128 steps
+        if (tickets3_.size() < 3) tickets3_.resize(3);
+        if (!side_stream_[0]) {
+            for (int k = 0; k < 2; ++k) {
+                BFH_HIP(hipStreamCreateWithFlags(&side_stream_[k], hipStreamNonBlocking));
+                BFH_HIP(hipEventCreateWithFlags(&side_done_[k], hipEventDisableTiming));
+            }
+            BFH_HIP(hipEventCreateWithFlags(&side_go_, hipEventDisableTiming));
+        }
+        BFH_HIP(hipMemsetAsync(tickets3_.get(), 0, 3 * sizeof(int), stream));
         const int slot = t_main_.begin(stream);
-        if (s.n_heavy) {   // the long rows first, one block each
+        BFH_HIP(hipEventRecord(side_go_, stream));
+        if (s.n_heavy) {   // the longest rows, one 1024-thread block each (main stream)
             EalsParams ph = p;
             ph.row_list = s.heavy.get();
             ph.n_list = s.n_heavy;
-            hipLaunchKernelGGL(eals_update_heavy_kernel, dim3(std::min(s.n_heavy, num_cus_ * 2)), dim3(1024), (static_cast<size_t>(vdim_) + 48) * sizeof(float),
-                               stream, ph);
+            ph.ticket = tickets3_.get();
+            const int groups = std::min(s.n_heavy, num_cus_ * 2);
+            const int64_t cap = ((s.longest + 63) / 64) * 64;
+            const size_t need = static_cast<size_t>(groups) * (1 + EALS_DB) * cap;
+            if (scratch_h_.size() < need) scratch_h_.resize(need);
+            hipLaunchKernelGGL(eals_update_long_kernel<1024>, dim3(groups), dim3(1024), (static_cast<size_t>(vdim_) + 48) * sizeof(float), stream, ph,
+                               scratch_h_.get(), cap);
             BFH_HIP(hipGetLastError());
+        }
+        if (s.n_mid) {     // (EALS_LIGHT, EALS_HEAVY] entries: one wave per row over a scratch slot
+            EalsParams pm = p;
+            pm.row_list = s.mid.get();
+            pm.n_list = s.n_mid;
+            pm.ticket = tickets3_.get() + 1;
+            const int groups = std::min(s.n_mid, num_cus_ * 16);
+            const int64_t cap = EALS_HEAVY;
+            const size_t need = static_cast<size_t>(groups) * (1 + EALS_DB) * cap;
+            if (scratch_m_.size() < need) scratch_m_.resize(need);
+            BFH_HIP(hipStreamWaitEvent(side_stream_[0], side_go_, 0));
+            hipLaunchKernelGGL(eals_update_long_kernel<64>, dim3(groups), dim3(64), (static_cast<size_t>(vdim_) + 48) * sizeof(float), side_stream_[0], pm,
+                               scratch_m_.get(), cap);
+            BFH_HIP(hipGetLastError());
+            BFH_HIP(hipEventRecord(side_done_[0], side_stream_[0]));
+            BFH_HIP(hipStreamWaitEvent(stream, side_done_[0], 0));
         }
         if (s.n_light) {
             p.row_list = s.light.get();
             p.n_list = s.n_light;
+            p.ticket = tickets3_.get() + 2;
             int blocks = (s.n_light + 3) / 4;
-            if (blocks > num_cus_ * 8) blocks = num_cus_ * 8;
-            hipLaunchKernelGGL(eals_update_kernel, dim3(blocks), dim3(256), static_cast<size_t>(4) * vdim_ * sizeof(float), stream, p);
+            if (blocks > num_cus_ * 4) blocks = num_cus_ * 4;
+            BFH_HIP(hipStreamWaitEvent(side_stream_[1], side_go_, 0));
+            hipLaunchKernelGGL(eals_update_kernel, dim3(blocks), dim3(256), static_cast<size_t>(4) * vdim_ * sizeof(float), side_stream_[1], p);
             BFH_HIP(hipGetLastError());
+            BFH_HIP(hipEventRecord(side_done_[1], side_stream_[1]));
+            BFH_HIP(hipStreamWaitEvent(stream, side_done_[1], 0));
         }
         t_main_.end(slot, stream);
         pull_factor(axis);
@@ -502,6 +593,10 @@ class EalsHandle : public AlsHandle {
     bool cached_[2] = {false, false};
     Side side_[2];
     DevBuf<float> Cw_, CQ_, S2_;
+    DevBuf<float> scratch_m_, scratch_h_;   // per thread group (1 + EALS_DB) * cap floats (eals_update_long_kernel)
+    DevBuf<int> tickets3_;
+    hipStream_t side_stream_[2] = {nullptr, nullptr};
+    hipEvent_t side_done_[2] = {nullptr, nullptr}, side_go_ = nullptr;
 };
 
 }  // namespace bfh

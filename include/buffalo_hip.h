@@ -175,6 +175,8 @@ int bfh_als_synchronize(void* h, int device_to_host);
  *   "im_user_replicas" (3) 1 = per-XCD replicas of P (entries spread over the queues by position, delta rule at the merges)
  *                      instead of one owner XCD per user; -1 (default) = when a call has fewer than 3072 users per queue
  *                      (the shards of an 8-GPU ML-20M run) and lr <= 0.01, 0 = never;
+ *   "im_user_hybrid"   (3) otherwise (whole matrices, lr <= 0.01): replicas for the HEAVY users only -- the ones "xcd_hot_tau" would put
+ *                      on atomics; 2 (default) = their entries over as few neighbouring queues as needed, 1 = over all, 0 = off;
  *   "im_drift_budget"  (3, permille) lr-weighted positive steps of a row per merge interval above which its negative
  *                      updates also go to the chip-wide copy;  "im_blocks" runs an item's entries are cut into per queue (0 = ceil(160 lr));
  *   "im_presample"     (3) 1 = draw the call's negatives in CSR order before the walk;  "xcd_fresh" re-read a row right
