@@ -746,9 +746,9 @@ def main():
             "config": {"workload": "BPRMF sgd, %s-shaped synthetic (%d x %d, %d nnz%s), d=%d, 1 negative/positive, "
                                    "uniform sampling + verify_neg, CSR + factors resident in HBM"
                                    % (args.shape, U, I, nnz, "" if args.scaling == "strong" or world == 1 else " per GPU", D),
-                       "parallelism": "1 GPU" if world == 1 else "dp%d: users sharded, Q replicated, %.1f RCCL delta all-reduce/epoch (%s)"
+                       "parallelism": "1 GPU" if world == 1 else "dp%d: users sharded, Q replicated, %.1f delta all-reduce/epoch (%s)"
                                       % (world, (st["exchanges"] / max(steps, 1)) if comm is not None else args.minibatches,
-                                         ("inside the library (%s)" % os.environ.get("BFH_COMM_TRANSPORT", "RCCL")) if comm is not None
+                                         ("inside the library, transport %s" % os.environ.get("BFH_COMM_TRANSPORT", "RCCL over xGMI")) if comm is not None
                                          else (comm_note or "EMERGENCY PATH through torch.distributed")),
                        "hogwild": {"0": "write-through (sc1) racy stores on item rows", "1": "fp32 atomics on item rows",
                                    "2": "per-XCD item-factor replicas (plain stores through the XCD's L2, merged by the delta rule "
