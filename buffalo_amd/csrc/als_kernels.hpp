@@ -1077,7 +1077,9 @@ __global__ __launch_bounds__(256, 2) void als_gram_kernel(AlsParams p, const Als
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-        if (solve_here) {   // M = FF + G: start the accumulators from the FF tiles (64 KB, L2-resident)
+        // "als_debug" ablation bits (timing studies only, results are wrong): 1 no block solve, 2 no FF tiles / FF p0 before the pass,
+        // 4 no per-entry residual dot
+        if (solve_here && !(p.debug & 2)) {   // M = FF + G: start the accumulators from the FF tiles (64 KB, L2-resident)
             const float* Fl = p.FF + half * 4 * (32 * T) + col;
             asm volatile("" : "+v"(Fl));   // keep the 10 tiles' address arithmetic inside the item loop (hoisted, it spills)
             int t = 0;
@@ -1102,7 +1104,7 @@ __global__ __launch_bounds__(256, 2) void als_gram_kernel(AlsParams p, const Als
 #pragma unroll
             for (int b = 0; b < T; ++b) p0r[b] = Pu0[b * 32 + col];
         }
-        if (solve_here) {   // f0 = FF p0 while the accumulators still hold FF alone
+        if (solve_here && !(p.debug & 2)) {   // f0 = FF p0 while the accumulators still hold FF alone
             wave_lds_sync();
             if (half == 0) {
 #pragma unroll
@@ -1146,7 +1148,7 @@ __global__ __launch_bounds__(256, 2) void als_gram_kernel(AlsParams p, const Als
             const float wgt = ctx ? one : p.alpha * v;
             const float cdense = ctx ? (v - bself) * one : one + wgt;
             float cial = wgt;
-            if (IALS) {   // als.cc:292-296: residual = Yui - 1 against the row at entry, coefficient residual * val * alpha
+            if (IALS && !(p.debug & 4)) {   // als.cc:292-296: residual = Yui - 1 against the row at entry, coefficient residual * val * alpha
                 float part = 0.f;
 #pragma unroll
                 for (int b = 0; b < T; ++b) part += q[b] * p0r[b];
