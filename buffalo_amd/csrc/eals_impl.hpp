@@ -149,15 +149,16 @@ __global__ __launch_bounds__(256) void eals_update_kernel(EalsParams p) {
 // `scratch`: per thread group (1 + EALS_DB) * cap floats: w - c of every entry | Y[key][16 b + dd] as [dd][entry].
 // vhat lives in HBM (coalesced); a step's closing update vhat += x_new * y is folded into the NEXT step's pass (the same two
 // roundings in the same order), so every dimension costs one pass over the row: 24 bytes per entry instead of 220.
+// `row_off` (BS = 1024): the scratch of list item k starts at (1 + EALS_DB) * row_off[k] floats and is as long as the row (rounded up
+// to 64 entries) -- a slot of the longest row's size per block would cost gigabytes for the few 10^5-entry rows of a real catalogue.
 template <int BS>
-__global__ __launch_bounds__(BS) void eals_update_long_kernel(EalsParams p, float* __restrict__ scratch, int64_t cap) {
+__global__ __launch_bounds__(BS) void eals_update_long_kernel(EalsParams p, float* __restrict__ scratch, int64_t cap, const int64_t* __restrict__ row_off) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* xs = lds;                 // [vdim]
     float* red = lds + p.vdim;       // [3][16]  (BS = 1024)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int D = p.d, vdim = p.vdim;
     float* wmc = scratch + static_cast<size_t>(blockIdx.x) * (1 + EALS_DB) * cap;
-    float* yb = wmc + cap;
     auto group_sync = [&]() {
         if constexpr (BS == 64) wave_lds_sync();
         else __syncthreads();
@@ -177,6 +178,11 @@ __global__ __launch_bounds__(BS) void eals_update_long_kernel(EalsParams p, floa
         const int x = p.row_list[item];
         const int64_t beg = x == 0 ? 0 : p.indptr[x - 1], end = p.indptr[x];
         const int64_t n = end - beg;
+        if (row_off) {   // this row's own slot
+            cap = ((n + 63) / 64) * 64;
+            wmc = scratch + static_cast<size_t>(row_off[item]) * (1 + EALS_DB);
+        }
+        float* const yb_ = wmc + cap;
         float* xrow = p.X + static_cast<size_t>(x) * vdim;
         group_sync();
         for (int e = tid; e < vdim; e += BS) xs[e] = xrow[e];
@@ -192,8 +198,8 @@ __global__ __launch_bounds__(BS) void eals_update_long_kernel(EalsParams p, floa
 #pragma unroll
                 for (int q4 = 0; q4 < EALS_DB / 4; ++q4) {
                     const float4 v = src[q4];
-                    yb[(4 * q4 + 0) * cap + i] = v.x; yb[(4 * q4 + 1) * cap + i] = v.y;
-                    yb[(4 * q4 + 2) * cap + i] = v.z; yb[(4 * q4 + 3) * cap + i] = v.w;
+                    yb_[(4 * q4 + 0) * cap + i] = v.x; yb_[(4 * q4 + 1) * cap + i] = v.y;
+                    yb_[(4 * q4 + 2) * cap + i] = v.z; yb_[(4 * q4 + 3) * cap + i] = v.w;
                 }
             }
             float pend = 0.f;   // x_new of the previous step of this block, still to be folded into vhat
@@ -202,8 +208,8 @@ __global__ __launch_bounds__(BS) void eals_update_long_kernel(EalsParams p, floa
                 const int d = db + dd;
                 const float xd = xs[d];
                 float num = 0.f, den = 0.f;
-                const float* yd_ = yb + static_cast<size_t>(dd) * cap;
-                const float* yp_ = yb + static_cast<size_t>(dd > 0 ? dd - 1 : 0) * cap;
+                const float* yd_ = yb_ + static_cast<size_t>(dd) * cap;
+                const float* yp_ = yb_ + static_cast<size_t>(dd > 0 ? dd - 1 : 0) * cap;
                 for (int64_t i = tid; i < n; i += BS) {
                     const float yd = yd_[i];
                     float vh = p.own[beg + i];
@@ -243,7 +249,7 @@ __global__ __launch_bounds__(BS) void eals_update_long_kernel(EalsParams p, floa
                 group_sync();
                 pend = xn;
             }
-            const float* yl_ = yb + static_cast<size_t>(nd - 1) * cap;   // close the block: the last step's update of vhat
+            const float* yl_ = yb_ + static_cast<size_t>(nd - 1) * cap;   // close the block: the last step's update of vhat
             for (int64_t i = tid; i < n; i += BS) p.own[beg + i] += pend * yl_[i];
             group_sync();
         }
@@ -391,7 +397,8 @@ class EalsHandle : public AlsHandle {
         DevBuf<float> vals, vhat;
         DevBuf<int32_t> light, mid, heavy;   // row ids with <= EALS_LIGHT / <= EALS_HEAVY / more entries, the long ones longest first (empty rows are light: the regulariser still moves them)
         int n_light = 0, n_mid = 0, n_heavy = 0;
-        int64_t longest = 0;
+        int64_t longest = 0, heavy_entries = 0;   // sum of the heavy rows' lengths, each rounded up to 64
+        DevBuf<int64_t> heavy_off;                // [n_heavy] scratch offset (entries) of every heavy row, in list order
         int64_t nnz = 0;
     };
     // eals.cc:49-100: the orientation's structure stays resident; vhat from the current factors; the index map by a host sort
@@ -432,6 +439,16 @@ class EalsHandle : public AlsHandle {
             if (!li.empty()) BFH_HIP(hipMemcpyAsync(s.light.get(), li.data(), li.size() * 4, hipMemcpyHostToDevice, stream));
             if (!md.empty()) BFH_HIP(hipMemcpyAsync(s.mid.get(), md.data(), md.size() * 4, hipMemcpyHostToDevice, stream));
             if (!hv.empty()) BFH_HIP(hipMemcpyAsync(s.heavy.get(), hv.data(), hv.size() * 4, hipMemcpyHostToDevice, stream));
+            std::vector<int64_t> off(hv.size());
+            s.heavy_entries = 0;
+            for (size_t k = 0; k < hv.size(); ++k) {
+                off[k] = s.heavy_entries;
+                const int64_t n = indptr[hv[k]] - (hv[k] ? indptr[hv[k] - 1] : 0);
+                s.heavy_entries += ((n + 63) / 64) * 64;
+            }
+            s.heavy_off.resize(std::max<size_t>(1, off.size()));
+            if (!off.empty()) BFH_HIP(hipMemcpyAsync(s.heavy_off.get(), off.data(), off.size() * 8, hipMemcpyHostToDevice, stream));
+            BFH_HIP(hipStreamSynchronize(stream));   // off is a local
             BFH_HIP(hipStreamSynchronize(stream));   // li / hv are locals
         }
         const int slot = t_aux_.begin(stream);
@@ -512,11 +529,10 @@ class EalsHandle : public AlsHandle {
             ph.n_list = s.n_heavy;
             ph.ticket = tickets3_.get();
             const int groups = std::min(s.n_heavy, num_cus_ * 2);
-            const int64_t cap = ((s.longest + 63) / 64) * 64;
-            const size_t need = static_cast<size_t>(groups) * (1 + EALS_DB) * cap;
+            const size_t need = static_cast<size_t>(s.heavy_entries) * (1 + EALS_DB);   // every heavy row has its own slot
             if (scratch_h_.size() < need) scratch_h_.resize(need);
             hipLaunchKernelGGL(eals_update_long_kernel<1024>, dim3(groups), dim3(1024), (static_cast<size_t>(vdim_) + 48) * sizeof(float), stream, ph,
-                               scratch_h_.get(), cap);
+                               scratch_h_.get(), int64_t(0), static_cast<const int64_t*>(s.heavy_off.get()));
             BFH_HIP(hipGetLastError());
         }
         if (s.n_mid) {     // (EALS_LIGHT, EALS_HEAVY] entries: one wave per row over a scratch slot
@@ -530,7 +546,7 @@ class EalsHandle : public AlsHandle {
             if (scratch_m_.size() < need) scratch_m_.resize(need);
             BFH_HIP(hipStreamWaitEvent(side_stream_[0], side_go_, 0));
             hipLaunchKernelGGL(eals_update_long_kernel<64>, dim3(groups), dim3(64), (static_cast<size_t>(vdim_) + 48) * sizeof(float), side_stream_[0], pm,
-                               scratch_m_.get(), cap);
+                               scratch_m_.get(), cap, static_cast<const int64_t*>(nullptr));
             BFH_HIP(hipGetLastError());
             BFH_HIP(hipEventRecord(side_done_[0], side_stream_[0]));
             BFH_HIP(hipStreamWaitEvent(stream, side_done_[0], 0));
