@@ -48,6 +48,7 @@ struct AlsParams {
     const float* bias_self;
     const float* bias_other;
     float out_scale;       // the pass's tiles / vector are multiplied by this before they reach the scratch slot (cfr.cc:130-131)
+    const float* split;    // als_gram_kernel<SPLIT>: {S, S^2, 1/S^2, weight cut} written by als_split_scale_kernel (device-side, no host round trip)
     int accumulate;        // add into the row's (zeroed) slot instead of overwriting it: two passes build one system
     float ff_scale;        // the solve kernel's M = ff_scale * FF + slot
 };
@@ -912,6 +913,81 @@ __device__ __forceinline__ float als_rows_reduce(float (&z)[16], int lane) {
     return z[0] + __shfl_xor(z[0], 1, 64);
 }
 
+// two floats -> two packed f16 pairs h, l: h = x rounded to nearest f16 (11 bits, error <= 2^-12 |x|), l = the (exact fp32) remainder
+// rounded the same way (error <= 2^-12 |remainder| <= 2^-24 |x|): h + l carries x to fp32's own precision.  gfx950's
+// v_cvt_pk_f16_f32 rounds a pair per instruction.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void als_split_f16(float x0, float x1, unsigned& h, unsigned& l) {
+    const f32x2_t x = {x0, x1};
+    const f16x2_t hh = __builtin_convertvector(x, f16x2_t);
+    const f32x2_t r = {x0 - static_cast<float>(hh[0]), x1 - static_cast<float>(hh[1])};
+    const f16x2_t ll = __builtin_convertvector(r, f16x2_t);
+    h = __builtin_bit_cast(unsigned, hh);
+    l = __builtin_bit_cast(unsigned, ll);
+}
+
+// Scale of the split pass (als_gram_kernel<SPLIT>), decided on the device per call from two fixed-order reductions:
+// qmax = max |Q| over the other factor matrix and wmean = the mean positive weight alpha v of the call's entries.
+//   S    = the power of two that puts S sqrt(64 wmean) qmax just under 2^15 (f16 overflows at 65504; f16's 11+11 bits need
+//          |S x| >= 2^-3 for a full remainder, so typical entries sit ~2^12 above that);
+//   wcut = 64 wmean: the few entries heavier than that (and negative ones) go through the fp32 instruction instead.
+// `part`: [ALS_STAT_BLOCKS][3] doubles (max |q|, sum of positive weights, their count) written by the first kernel.
+constexpr int ALS_STAT_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void als_split_stats_kernel(const float* __restrict__ Q, size_t nq, const float* __restrict__ vals, size_t nv, float alpha,
+                                                              double* __restrict__ part) {
+    __shared__ float smq[256];
+    __shared__ double sms[256], smc[256];
+    float qm = 0.f;
+    double ws = 0.0, wc = 0.0;
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    const size_t tid = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const float4* Q4 = reinterpret_cast<const float4*>(Q);   // hipMalloc'd, vdim % 32 == 0
+    for (size_t e = tid; e < nq / 4; e += stride) {
+        const float4 v = Q4[e];
+        qm = fmaxf(qm, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    for (size_t e = tid; e < nv; e += stride) {
+        const float w = alpha * vals[e];
+        if (w > 0.f) { ws += static_cast<double>(w); wc += 1.0; }
+    }
+    smq[threadIdx.x] = qm; sms[threadIdx.x] = ws; smc[threadIdx.x] = wc;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {   // fixed tree: the same bits on every run
+        if (static_cast<int>(threadIdx.x) < st) {
+            smq[threadIdx.x] = fmaxf(smq[threadIdx.x], smq[threadIdx.x + st]);
+            sms[threadIdx.x] += sms[threadIdx.x + st];
+            smc[threadIdx.x] += smc[threadIdx.x + st];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { part[blockIdx.x * 3 + 0] = static_cast<double>(smq[0]); part[blockIdx.x * 3 + 1] = sms[0]; part[blockIdx.x * 3 + 2] = smc[0]; }
+}
+__global__ __launch_bounds__(64) void als_split_scale_kernel(const double* __restrict__ part, int nblocks, float* __restrict__ out) {
+    double qm = 0.0, ws = 0.0, wc = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 64) { qm = fmax(qm, part[b * 3]); ws += part[b * 3 + 1]; wc += part[b * 3 + 2]; }
+    for (int st = 32; st > 0; st >>= 1) {   // butterfly: every lane ends with the same, run-independent, sums
+        qm = fmax(qm, __shfl_xor(qm, st, 64));
+        ws += __shfl_xor(ws, st, 64);
+        wc += __shfl_xor(wc, st, 64);
+    }
+    if (threadIdx.x != 0) return;
+    const double wmean = wc > 0.0 ? ws / wc : 0.0;
+    int e = 0;
+    const double top = sqrt(64.0 * wmean) * qm;   // the largest |x| that stays on the f16 path
+    if (top > 0.0 && top < 1e300) {
+        e = static_cast<int>(floor(log2(32768.0 / top)));
+        if (e > 40) e = 40;
+        if (e < -40) e = -40;
+    }
+    out[0] = static_cast<float>(ldexp(1.0, e));
+    out[1] = static_cast<float>(ldexp(1.0, 2 * e));
+    out[2] = static_cast<float>(ldexp(1.0, -2 * e));
+    out[3] = static_cast<float>(64.0 * wmean);
+}
+
 // sum over the 32 lanes of each half-wave (every lane receives its half's total): 4 DPP row rotations leave each 16-lane row's
 // sum in all of its lanes, one ds_swizzle (bit mode, xor 16: no LDS memory, no SGPR round trip) fetches the half's other row
 __device__ __forceinline__ float half_sum(float v, int /*half*/) {
@@ -962,7 +1038,7 @@ __device__ __forceinline__ float als_block_matvec(const f32x16 (&acc)[T * (T + 1
 template <int T>
 __device__ __forceinline__ void als_ialspp_inreg(const f32x16 (&acc)[T * (T + 1) / 2], const float (&h)[T], const float (&g1)[T], const float (&f0)[T],
                                                  const AlsParams& p, float* pc, float* dl, float* tmp, int lane, int half, int col, float ada,
-                                                 double& nume, double& deno) {
+                                                 double& nume, double& deno, float ms = 1.0f /* acc holds M / ms (split pass: ms = 1/S^2) */) {
     float* out = tmp;        // 32: row-product results
     float* pvs = tmp + 32;   // 32: CG direction
     if (p.compute_loss) {   // als.cc:288-309 on the row at entry: with g_w = G p0 - h,
@@ -973,7 +1049,7 @@ __device__ __forceinline__ void als_ialspp_inreg(const f32x16 (&acc)[T * (T + 1)
             const float pv = pc[blk * 32 + col];
             pp += pv * pv;
             if (p.axis == 1) {
-                pmp += pv * (2.0f * f0[blk] - als_block_matvec<T>(acc, pc, out, blk, lane, half, col));
+                pmp += pv * (2.0f * f0[blk] - ms * als_block_matvec<T>(acc, pc, out, blk, lane, half, col));
                 pg += pv * (g1[blk] - h[blk]);
             }
         }
@@ -993,7 +1069,7 @@ __device__ __forceinline__ void als_ialspp_inreg(const f32x16 (&acc)[T * (T + 1)
 #pragma unroll
         for (int ja = 0; ja < T; ++ja)
             if (ja < blk) md += als_tile_colpart(acc[als_tri<T>(ja, blk)], dl + ja * 32, half);
-        md += __shfl_xor(md, 32, 64);
+        md = ms * (md + __shfl_xor(md, 32, 64));
         const float bi = f0[blk] + h[blk] + md + p.reg * pblk;   // als.cc:286-297: gradient of the block at the current row
         float xr = 0.f, rr = bi, pvr = bi;
         double rsold = static_cast<double>(wave_sum(half == 0 ? rr * rr : 0.f));
@@ -1003,7 +1079,7 @@ __device__ __forceinline__ void als_ialspp_inreg(const f32x16 (&acc)[T * (T + 1)
                 if (half == 0) pvs[col] = pvr;
                 wave_lds_sync();
                 float ap = als_tile_colpart(acc[als_tri<T>(blk, blk)], pvs, half);
-                ap += __shfl_xor(ap, 32, 64);
+                ap = ms * (ap + __shfl_xor(ap, 32, 64));
                 ap += p.reg * pvr;
                 const float pap = wave_sum(half == 0 ? pvr * ap : 0.f);
                 const float step_size = static_cast<float>(rsold / static_cast<double>(pap));
@@ -1052,16 +1128,47 @@ __device__ __forceinline__ void als_ialspp_inreg(const f32x16 (&acc)[T * (T + 1)
 // BIG: the other factor matrix is 4 GiB or larger -- 64-bit gather offsets (a few % slower, 19 % in the wide kernel)
 // LOSS = false: compile-time promise that no loss terms are wanted (compute_loss_on_training off, or the user half-epoch whose
 // per-entry terms are zero): drops the g_1 accumulation -- T FMAs per entry pair and T registers -- from the hot loop
-template <int T, bool IALS, bool INREG, bool BIG, bool LOSS = true>
-__global__ __launch_bounds__(256, 2) void als_gram_kernel(AlsParams p, const AlsWork* __restrict__ work, int n_items, float* __restrict__ scratch,
+// SPLIT (iALS++ in place only): the Gramian through the f16 matrix cores at fp32 accuracy.  x = S sqrt(alpha v) q is cut into two
+// f16 pieces h + l (each rounded to nearest, the remainder exact in fp32: h + l = x to 2^-24) and x x^T is taken as hh + hl + lh
+// (what is dropped is <= 2^-24 of a term; measured against f64 the rows are as close as the fp32 instruction's,
+// profiles/r03_als_split_f16.txt):
+// products of f16 pairs are exact in fp32 and v_mfma_f32_32x32x16_f16 accumulates in fp32.  One instruction eats SIXTEEN entries
+// in 32 cycles where v_mfma_f32_32x32x2_f32 eats two in 64: 3 x 32 / 16 = 6 matrix-core cycles per entry and tile instead of 32.
+// A and B of a 32x32x16 step hold, per lane, element [32 a + (lane & 31)] of eight entries (k = 8 (lane >> 5) + r) -- the same
+// registers serve as A and B, and since a Gramian sums over k ANY k order is right as long as both operands use the same one.
+// S (a power of two, als_split_scale_kernel) keeps S x inside f16's range; the accumulators hold S^2 M (the FF tiles are scaled
+// when they are copied to LDS) and every product read back out of them is multiplied by 1/S^2 -- exact, S being a power of two.
+// Entries with a negative weight (no square root) or heavier than 64x the mean go through the fp32 instruction in a side pass
+// per 64-entry chunk.  The pass is VALU-bound now (the cut is ~3 operations per loaded float), so the loop is software-pipelined
+// inside the wave: while the pieces of group j feed the matrix cores, the rows of group j+1 are weighted and cut and the rows of
+// group j+2 are on their way; at T = 4 that takes the whole 512-register file (one wave per SIMD).
+template <int T, bool IALS, bool INREG, bool BIG, bool LOSS = true, bool SPLIT = false>
+__global__ __launch_bounds__(256, (SPLIT && T >= 3) ? 1 : 2) void als_gram_kernel(AlsParams p, const AlsWork* __restrict__ work, int n_items, float* __restrict__ scratch,
                                                           int slot_base) {
     static_assert(!INREG || IALS, "the in-register solve is the iALS++ recurrence");
+    static_assert(!SPLIT || INREG, "the split-f16 pass is written for the in-place iALS++ rows");
     __shared__ __attribute__((aligned(16))) float s_vec[INREG ? 4 * (2 * 32 * T + 64) : 4];   // per wave: p | delta | 64 exchange floats
+    // the FF tiles every in-place row starts from: one copy per block in LDS (64 KB at vdim 128; two blocks a CU fit the 160 KB),
+    // read back conflict-free (a half-wave reads 32 consecutive floats) instead of 40 KB of L2 round trips per row
+    __shared__ __attribute__((aligned(16))) float s_ff[INREG ? (32 * T) * (32 * T) : 4];
     constexpr int NT = T * (T + 1) / 2;
     constexpr int UP = 4;
     constexpr unsigned row_bytes = 32u * T * 4u;   // vdim == 32*T
     const int lane = threadIdx.x & 63;
     const int half = lane >> 5, col = lane & 31;
+    // split pass: S, S^2, 1/S^2 and the weight cut (als_split_scale_kernel); 1, 1, 1, +inf otherwise
+    const float sS = SPLIT ? p.split[0] : 1.0f, sS2 = SPLIT ? p.split[1] : 1.0f, sI2 = SPLIT ? p.split[2] : 1.0f;
+    const float wcut = SPLIT ? p.split[3] : 0.f;
+    if (INREG && (SPLIT || !(p.debug & 8))) {
+        const float4* src = reinterpret_cast<const float4*>(p.FF);
+        float4* dst = reinterpret_cast<float4*>(s_ff);
+        for (int e = threadIdx.x; e < (32 * T) * (32 * T) / 4; e += blockDim.x) {
+            float4 v = src[e];
+            if (SPLIT) { v.x *= sS2; v.y *= sS2; v.z *= sS2; v.w *= sS2; }
+            dst[e] = v;
+        }
+        __syncthreads();
+    }
     const bool lossk = LOSS && p.compute_loss && p.axis == 1;
     double nume_k = 0.0, deno_k = 0.0;
     const char* qbase = reinterpret_cast<const char*>(p.Q);
@@ -1080,15 +1187,26 @@ __global__ __launch_bounds__(256, 2) void als_gram_kernel(AlsParams p, const Als
         // "als_debug" ablation bits (timing studies only, results are wrong): 1 no block solve, 2 no FF tiles / FF p0 before the pass,
         // 4 no per-entry residual dot
         if (solve_here && !(p.debug & 2)) {   // M = FF + G: start the accumulators from the FF tiles (64 KB, L2-resident)
-            const float* Fl = p.FF + half * 4 * (32 * T) + col;
-            asm volatile("" : "+v"(Fl));   // keep the 10 tiles' address arithmetic inside the item loop (hoisted, it spills)
-            int t = 0;
+            if (!SPLIT && (p.debug & 8)) {   // bit 8: the tiles from L2 as before this round (A/B only, same values)
+                const float* Fl = p.FF + half * 4 * (32 * T) + col;
+                asm volatile("" : "+v"(Fl));   // keep the 10 tiles' address arithmetic inside the item loop (hoisted, it spills)
+                int t = 0;
 #pragma unroll
-            for (int a = 0; a < T; ++a)
+                for (int a = 0; a < T; ++a)
 #pragma unroll
-                for (int b = a; b < T; ++b, ++t)
+                    for (int b = a; b < T; ++b, ++t)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[t][e] = Fl[(a * 32 + (e & 3) + 8 * (e >> 2)) * (32 * T) + b * 32];
+                        for (int e = 0; e < 16; ++e) acc[t][e] = Fl[(a * 32 + (e & 3) + 8 * (e >> 2)) * (32 * T) + b * 32];
+            } else {
+                const float* Fl = s_ff + half * 4 * (32 * T) + col;
+                int t = 0;
+#pragma unroll
+                for (int a = 0; a < T; ++a)
+#pragma unroll
+                    for (int b = a; b < T; ++b, ++t)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[t][e] = Fl[(a * 32 + (e & 3) + 8 * (e >> 2)) * (32 * T) + b * 32];
+            }
         }
         float gpart[T], g1part[T];
 #pragma unroll
@@ -1112,7 +1230,7 @@ __global__ __launch_bounds__(256, 2) void als_gram_kernel(AlsParams p, const Als
             }
             wave_lds_sync();
 #pragma unroll
-            for (int b = 0; b < T; ++b) f0r[b] = als_block_matvec<T>(acc, pc, pc + 2 * VD0, b, lane, half, col);
+            for (int b = 0; b < T; ++b) f0r[b] = sI2 * als_block_matvec<T>(acc, pc, pc + 2 * VD0, b, lane, half, col);
         }
         const int64_t n = wk.kend - wk.kbeg;
         const int64_t nchunks = (n + 63) / 64;
@@ -1167,56 +1285,197 @@ __global__ __launch_bounds__(256, 2) void als_gram_kernel(AlsParams p, const Als
         };
         auto nnz_of = [&](int64_t ch) { return ch < nchunks ? static_cast<int>((n - ch * 64) < 64 ? (n - ch * 64) : 64) : 0; };
         auto groups_of = [&](int64_t ch) { return (nnz_of(ch) >> 1) / UP; };   // groups hold COMPLETE pairs only (no padding lane)
-        int myc, myc_n;
-        float myv, myv_n;
-        fetch_keys(0, myc, myv);
-        fetch_keys(1, myc_n, myv_n);
-        float qa[UP][T], va[UP];
-        if (groups_of(0) > 0) {
+        if constexpr (!SPLIT) {
+            int myc, myc_n;
+            float myv, myv_n;
+            fetch_keys(0, myc, myv);
+            fetch_keys(1, myc_n, myv_n);
+            float qa[UP][T], va[UP];
+            if (groups_of(0) > 0) {
+    #pragma unroll
+                for (int uu = 0; uu < UP; ++uu) load_pair(myc, myv, uu, qa[uu], va[uu]);
+            }
+            for (int64_t ch = 0; ch < nchunks; ++ch) {
+                const int npairs = (nnz_of(ch) + 1) >> 1;
+                const int ngroups = groups_of(ch);
+                for (int gidx = 0; gidx < ngroups; ++gidx) {
+                    // Branch-free body: the loads of the NEXT group (the following group of this chunk, else the first
+                    // group of the next chunk; harmless rows when the item ends here) and the MFMAs of the current one
+                    // sit in one basic block, and the scheduler is told to interleave them -- left alone it emits the
+                    // VALU/VMEM work as one clump and then UP*NT MFMAs back to back, and since both waves of a SIMD
+                    // run the same loop they fall into step: while one clump issues the matrix core idles
+                    // (measured: 66 % MFMA-busy with every busy cycle stalling BOTH waves; 8.2 -> 7.7 ms per epoch).
+                    float qb[UP][T], vb[UP];
+                    const bool here = gidx + 1 < ngroups;
+                    const int src_c = here ? myc : myc_n;
+                    const float src_v = here ? myv : myv_n;
+                    const int pr0 = here ? (gidx + 1) * UP : 0;
+    #pragma unroll
+                    for (int uu = 0; uu < UP; ++uu) load_pair(src_c, src_v, pr0 + uu, qb[uu], vb[uu]);
+    #pragma unroll
+                    for (int uu = 0; uu < UP; ++uu) consume(qa[uu], va[uu], 1.0f);
+    #pragma unroll
+                    for (int uu = 0; uu < UP; ++uu) {
+                        va[uu] = vb[uu];
+    #pragma unroll
+                        for (int b = 0; b < T; ++b) qa[uu][b] = qb[uu][b];
+                    }
+    #pragma unroll
+                    for (int i = 0; i < UP * NT; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                     // one MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x006, IALS ? 3 : 2, 0);                          // two VALU / SALU (three with the per-entry residual dot)
+                        if (i % 2 == 0 && i / 2 < UP * T) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // one of the UP*T row loads
+                    }
+                }
+                // <= UP leftover pairs: only the last chunk of the item has them; its last pair may be half padding
+                for (int pr = ngroups * UP; pr < npairs; ++pr) {
+                    float q1[T], v1;
+                    load_pair(myc, myv, pr, q1, v1);
+                    consume(q1, v1, (ch * 64 + 2 * pr + half < n) ? 1.0f : 0.f);
+                }
+                myc = myc_n;
+                myv = myv_n;
+                fetch_keys(ch + 2, myc_n, myv_n);
+            }
+        } else {
+            // ---- split-f16 pass (see the kernel's header): groups of 16 entries, two register sets, no copies ----
+            const int64_t ngroups = (n + 15) >> 4;   // the last group is padded with weight-0 entries of row 0
+            // per 64-entry chunk, one entry per lane: row id, weight alpha v, S sqrt(weight) (0: not on the f16 path)
+            int myc, myc_n;
+            float myw, myw_n, mys, mys_n;
+            auto fetch = [&](int64_t chunk, int& cc, float& ww, float& ss) {
+                float vvv;
+                fetch_keys(chunk, cc, vvv);
+                ww = p.alpha * vvv;
+                ss = (ww > 0.f && ww <= wcut) ? sS * __builtin_amdgcn_sqrtf(ww) : 0.f;
+            };
+            auto fix_outliers = [&](int cc, float ww, float ss) {   // negative / very heavy entries of a chunk: fp32 instruction, pairwise
+#ifdef BFH_X_NOFIX
+                return;
+#endif
+                const bool out = ss == 0.f && ww != 0.f;
+                if (__builtin_amdgcn_ballot_w64(out) == 0) return;
+                const float wfix = out ? ww * sS2 : 0.f;
+                for (int pr = 0; pr < 32; ++pr) {
+                    float q1[T], w1;
+                    load_pair(cc, wfix, pr, q1, w1);
+                    int t = 0;
 #pragma unroll
-            for (int uu = 0; uu < UP; ++uu) load_pair(myc, myv, uu, qa[uu], va[uu]);
-        }
-        for (int64_t ch = 0; ch < nchunks; ++ch) {
-            const int npairs = (nnz_of(ch) + 1) >> 1;
-            const int ngroups = groups_of(ch);
-            for (int gidx = 0; gidx < ngroups; ++gidx) {
-                // Branch-free body: the loads of the NEXT group (the following group of this chunk, else the first
-                // group of the next chunk; harmless rows when the item ends here) and the MFMAs of the current one
-                // sit in one basic block, and the scheduler is told to interleave them -- left alone it emits the
-                // VALU/VMEM work as one clump and then UP*NT MFMAs back to back, and since both waves of a SIMD
-                // run the same loop they fall into step: while one clump issues the matrix core idles
-                // (measured: 66 % MFMA-busy with every busy cycle stalling BOTH waves; 8.2 -> 7.7 ms per epoch).
-                float qb[UP][T], vb[UP];
-                const bool here = gidx + 1 < ngroups;
-                const int src_c = here ? myc : myc_n;
-                const float src_v = here ? myv : myv_n;
-                const int pr0 = here ? (gidx + 1) * UP : 0;
+                    for (int a = 0; a < T; ++a) {
+                        const float av = w1 * q1[a];
 #pragma unroll
-                for (int uu = 0; uu < UP; ++uu) load_pair(src_c, src_v, pr0 + uu, qb[uu], vb[uu]);
+                        for (int b = a; b < T; ++b, ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, q1[b], acc[t], 0, 0, 0);
+                    }
+                }
+            };
+            // lane (col, half) works on the entries 16 g + 8 half + r, r = 0 .. 7, of a chunk: ds_bpermute fetches their per-lane values
+            const int bsel = 32 * half;   // byte index of lane 8 half
+            auto load_group = [&](int src_c, int g, float (&q)[8][T]) {
 #pragma unroll
-                for (int uu = 0; uu < UP; ++uu) consume(qa[uu], va[uu], 1.0f);
+                for (int r = 0; r < 8; ++r) {
+                    const int c = __builtin_amdgcn_ds_bpermute(bsel + 64 * g + 4 * r, src_c);
+                    using off_t = typename std::conditional<BIG, size_t, unsigned>::type;
+                    const off_t voff = static_cast<off_t>(static_cast<unsigned>(c)) * row_bytes + static_cast<unsigned>(col) * 4u;
+                    const float* q_ = reinterpret_cast<const float*>(qbase + voff);
 #pragma unroll
-                for (int uu = 0; uu < UP; ++uu) {
-                    va[uu] = vb[uu];
+                    for (int b = 0; b < T; ++b) q[r][b] = q_[b * 32];
+                }
+            };
+            // the per-entry residual and h (als.cc:292-296), then x = S sqrt(alpha v) q cut into pieces; k0 = the group's first entry
+            auto prep = [&](float src_w, float src_s, int64_t k0, int g, float (&q)[8][T], u32x4 (&H)[T], u32x4 (&L)[T]) {
 #pragma unroll
-                    for (int b = 0; b < T; ++b) qa[uu][b] = qb[uu][b];
+                for (int r = 0; r < 8; ++r) {
+                    const float wgt = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bsel + 64 * g + 4 * r, __builtin_bit_cast(int, src_w)));
+                    const float sw = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bsel + 64 * g + 4 * r, __builtin_bit_cast(int, src_s)));
+                    float part = 0.f;
+#pragma unroll
+                    for (int b = 0; b < T; ++b) part = __builtin_fmaf(q[r][b], p0r[b], part);
+                    const float y = half_sum(part, half);
+                    const float cial = __builtin_fmaf(wgt, y, -wgt);   // alpha v (q.p0 - 1)
+                    const float one = (LOSS && lossk && k0 + 8 * half + r < n) ? 1.0f : 0.f;
+#pragma unroll
+                    for (int b = 0; b < T; ++b) {
+                        gpart[b] = __builtin_fmaf(cial, q[r][b], gpart[b]);
+                        if (LOSS) g1part[b] = __builtin_fmaf(one, q[r][b], g1part[b]);
+                        q[r][b] *= sw;
+                    }
                 }
 #pragma unroll
-                for (int i = 0; i < UP * NT; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                     // one MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x006, IALS ? 3 : 2, 0);                          // two VALU / SALU (three with the per-entry residual dot)
-                    if (i % 2 == 0 && i / 2 < UP * T) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // one of the UP*T row loads
+                for (int b = 0; b < T; ++b)
+#pragma unroll
+                    for (int j2 = 0; j2 < 4; ++j2) {
+                        unsigned h_, l_;
+                        als_split_f16(q[2 * j2][b], q[2 * j2 + 1][b], h_, l_);
+                        H[b][j2] = h_;
+                        L[b][j2] = l_;
+                    }
+            };
+            auto pass = [&](const u32x4 (&X)[T], const u32x4 (&Y)[T]) {
+                int t = 0;
+#pragma unroll
+                for (int a = 0; a < T; ++a)
+#pragma unroll
+                    for (int b = a; b < T; ++b, ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, X[a]), __builtin_bit_cast(f16x8_t, Y[b]), acc[t], 0, 0, 0);
+            };
+            auto gram16 = [&](const u32x4 (&H)[T], const u32x4 (&L)[T]) {   // small terms first
+                pass(L, H);
+                pass(H, L);
+                pass(H, H);
+            };
+            // issue order handed to the scheduler: one matrix instruction, its share of the VALU / SALU work, one row load, one LDS-pipe op
+            constexpr int VPER = (8 * (12 + 3 * T) + 24 * T + 16) / (3 * NT) + 1;
+            auto interleave = [&]() {
+#ifdef BFH_X_NOSGB
+                return;
+#endif
+#pragma unroll
+                for (int i = 0; i < 3 * NT; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x006, VPER, 0);
+                    if (i * 8 * T / (3 * NT) != (i + 1) * 8 * T / (3 * NT) || 8 * T >= 3 * NT) __builtin_amdgcn_sched_group_barrier(0x020, 8 * T >= 3 * NT ? (8 * T + 3 * NT - 1) / (3 * NT) : 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
+            };
+            fetch(0, myc, myw, mys);
+            fetch(1, myc_n, myw_n, mys_n);
+            float qA[8][T], qB[8][T];
+            u32x4 HA[T], LA[T], HB[T], LB[T];
+            if (ngroups > 0) {
+                fix_outliers(myc, myw, mys);
+                load_group(myc, 0, qA);
+                load_group(myc, 1, qB);
+                prep(myw, mys, 0, 0, qA, HA, LA);
             }
-            // <= UP leftover pairs: only the last chunk of the item has them; its last pair may be half padding
-            for (int pr = ngroups * UP; pr < npairs; ++pr) {
-                float q1[T], v1;
-                load_pair(myc, myv, pr, q1, v1);
-                consume(q1, v1, (ch * 64 + 2 * pr + half < n) ? 1.0f : 0.f);
+            int64_t jg = 0;
+            auto advance = [&]() {   // jg entered a new 64-entry chunk
+                myc = myc_n;
+                myw = myw_n;
+                mys = mys_n;
+                fetch((jg >> 2) + 1, myc_n, myw_n, mys_n);
+                fix_outliers(myc, myw, mys);
+            };
+            while (jg < ngroups) {
+                {   // pieces A = group jg; rows B = group jg + 1; rows A <- group jg + 2
+                    const int s = static_cast<int>(jg & 3);
+                    load_group(s < 2 ? myc : myc_n, (s + 2) & 3, qA);
+                    prep(s < 3 ? myw : myw_n, s < 3 ? mys : mys_n, (jg + 1) * 16, (s + 1) & 3, qB, HB, LB);
+                    gram16(HA, LA);
+                    interleave();
+                }
+                ++jg;
+                if ((jg & 3) == 0) advance();
+                if (jg >= ngroups) break;
+                {   // the same with the two register sets swapped
+                    const int s = static_cast<int>(jg & 3);
+                    load_group(s < 2 ? myc : myc_n, (s + 2) & 3, qB);
+                    prep(s < 3 ? myw : myw_n, s < 3 ? mys : mys_n, (jg + 1) * 16, (s + 1) & 3, qA, HA, LA);
+                    gram16(HB, LB);
+                    interleave();
+                }
+                ++jg;
+                if ((jg & 3) == 0) advance();
             }
-            myc = myc_n;
-            myv = myv_n;
-            fetch_keys(ch + 2, myc_n, myv_n);
         }
         constexpr int VD = 32 * T;   // vdim == 32*T on this path
         if (solve_here) {
@@ -1228,11 +1487,13 @@ __global__ __launch_bounds__(256, 2) void als_gram_kernel(AlsParams p, const Als
                 g1s[a] = g1part[a] + __shfl_xor(g1part[a], 32, 64);
             }
             double nume = 0.0, deno = 0.0;
+#ifndef BFH_X_NOSOLVE
             if (!(p.debug & 1)) {   // pc = p0 and delta = 0 were put in place before the pass
-                als_ialspp_inreg<T>(acc, gs, g1s, f0r, p, pc, pc + VD, pc + 2 * VD, lane, half, col, p.adaptive_reg ? static_cast<float>(n) : 1.0f, nume, deno);
+                als_ialspp_inreg<T>(acc, gs, g1s, f0r, p, pc, pc + VD, pc + 2 * VD, lane, half, col, p.adaptive_reg ? static_cast<float>(n) : 1.0f, nume, deno, sI2);
                 wave_lds_sync();
                 for (int e = lane; e < VD; e += 64) Pu[e] = pc[e];
             }
+#endif
             if (p.compute_loss && lane == 0) {   // row-level terms ride on lane 0's share of the per-nnz sums
                 nume_k += nume;
                 deno_k += deno;
@@ -1244,7 +1505,8 @@ __global__ __launch_bounds__(256, 2) void als_gram_kernel(AlsParams p, const Als
         float* S = scratch + static_cast<size_t>(wk.slot >= 0 && !p.accumulate ? slot_base + wk.slot : wk.row - p.start_x) * als_slot_floats(VD);
         float* Sl = S + half * 4 * VD + col;
         const bool atomic = wk.slot >= 0 || p.accumulate;   // chunk of a heavy row / second pass: summed into the slot (zeroed by the host)
-        const float osc = p.out_scale;
+        const float osc = p.out_scale * sI2;   // the tiles leave in M's units (gpart is not scaled: osg)
+        const float osg = p.out_scale;
         int t = 0;
 #pragma unroll
         for (int a = 0; a < T; ++a) {
@@ -1257,7 +1519,7 @@ __global__ __launch_bounds__(256, 2) void als_gram_kernel(AlsParams p, const Als
                     else *dst = acc[t][e] * osc;
                 }
             }
-            const float gs = (gpart[a] + __shfl_xor(gpart[a], 32, 64)) * osc;   // the two halves hold the k-parities of the same element
+            const float gs = (gpart[a] + __shfl_xor(gpart[a], 32, 64)) * osg;   // the two halves hold the k-parities of the same element
             const float g1s = g1part[a] + __shfl_xor(g1part[a], 32, 64);
             if (half == 0) {
                 float* gdst = S + VD * VD + a * 32 + col;
@@ -1720,6 +1982,7 @@ __global__ __launch_bounds__(256) void als_solve_kernel(AlsParams p, const AlsHe
 }
 
 // ------------------------------------------------------------------------------------------------
+#ifndef BFH_ALS_KERNELS_ONLY   // scripts/als_asm_stats.sh compiles single kernels out of this header
 class AlsHandle : public HandleBase {
  public:
     ~AlsHandle() override {
@@ -1960,17 +2223,26 @@ class AlsHandle : public HandleBase {
             const int items = wl->n_work;
             int blocks = (items + 3) / 4;                           // 4 independent waves per block, one work item each
             if (blocks > num_cus_ * 4) blocks = num_cus_ * 4;       // persistent: residency is set by the kernel's VGPR count
+            if (items > 0 && inreg && split_f16_ && T >= 2) {   // the scale of the split pass, decided on the device (no host round trip)
+                if (split_out_.size() < 4) { split_part_.resize(3 * ALS_STAT_BLOCKS); split_out_.resize(4); }
+                hipLaunchKernelGGL(als_split_stats_kernel, dim3(ALS_STAT_BLOCKS), dim3(256), 0, stream, p.Q, static_cast<size_t>(p.op_rows) * vdim_, p.vals,
+                                   static_cast<size_t>(n), alpha_, split_part_.get());
+                hipLaunchKernelGGL(als_split_scale_kernel, dim3(1), dim3(64), 0, stream, split_part_.get(), ALS_STAT_BLOCKS, split_out_.get());
+                BFH_HIP(hipGetLastError());
+                p.split = split_out_.get();
+            }
             if (items > 0 && inreg) {
-#define BFH_GK(TT)                                                                                                                  \
+#define BFH_GK(TT, SP)                                                                                                              \
     do {                                                                                                                            \
-        if (big) hipLaunchKernelGGL((als_gram_kernel<TT, true, true, true>), dim3(blocks), dim3(256), 0, stream, p, wl->work.get(), items, scratch_.get(), 0); \
-        else if (compute_loss_ && axis == 1) hipLaunchKernelGGL((als_gram_kernel<TT, true, true, false>), dim3(blocks), dim3(256), 0, stream, p, wl->work.get(), items, scratch_.get(), 0);   \
-        else hipLaunchKernelGGL((als_gram_kernel<TT, true, true, false, false>), dim3(blocks), dim3(256), 0, stream, p, wl->work.get(), items, scratch_.get(), 0);   \
+        if (big) hipLaunchKernelGGL((als_gram_kernel<TT, true, true, true, true, SP>), dim3(blocks), dim3(256), 0, stream, p, wl->work.get(), items, scratch_.get(), 0); \
+        else if (compute_loss_ && axis == 1) hipLaunchKernelGGL((als_gram_kernel<TT, true, true, false, true, SP>), dim3(blocks), dim3(256), 0, stream, p, wl->work.get(), items, scratch_.get(), 0);   \
+        else hipLaunchKernelGGL((als_gram_kernel<TT, true, true, false, false, SP>), dim3(blocks), dim3(256), 0, stream, p, wl->work.get(), items, scratch_.get(), 0);   \
     } while (0)
-                if (T <= 1) BFH_GK(1);
-                else if (T <= 2) BFH_GK(2);
-                else if (T <= 3) BFH_GK(3);
-                else BFH_GK(4);
+                // als_split_f16 (default on, d >= 64): the Gramian through the f16 matrix cores at fp32 accuracy (see als_gram_kernel)
+                if (T <= 1) BFH_GK(1, false);
+                else if (T <= 2) { if (split_f16_) BFH_GK(2, true); else BFH_GK(2, false); }
+                else if (T <= 3) { if (split_f16_) BFH_GK(3, true); else BFH_GK(3, false); }
+                else { if (split_f16_) BFH_GK(4, true); else BFH_GK(4, false); }
 #undef BFH_GK
                 BFH_HIP(hipGetLastError());
                 if (wl->n_heavy)   // heavy rows: chunk partials were summed in scratch_ (zeroed above)
@@ -2198,6 +2470,7 @@ class AlsHandle : public HandleBase {
         else if (name == "pin_host") pin_host_ = v != 0;
         else if (name == "als_v1") force_v1_ = v != 0;
         else if (name == "als_debug") debug_ = static_cast<int>(v);
+        else if (name == "als_split_f16") split_f16_ = v != 0;             // 0: the in-place iALS++ rows keep the fp32 matrix instruction
         else if (name == "als_inreg") no_inreg_ = v == 0;                 // 0: iALS++ rows go through the scratch + solve kernel instead of the in-register solve
         else if (name == "timing") timing = v != 0;
         else throw Error(BFH_ERR_INVALID, "unknown mode '" + name + "'");
@@ -2241,11 +2514,15 @@ class AlsHandle : public HandleBase {
     bool force_v1_ = false;
     int debug_ = 0;
     bool no_inreg_ = false;
+    bool split_f16_ = true;
+    DevBuf<double> split_part_;
+    DevBuf<float> split_out_;
     DevBuf<float> gscratch_;
     DevBuf<float> scratch_;
     std::map<std::tuple<int, int, int>, std::unique_ptr<WorkList>> work_cache_;
     EventTimer t_main_, t_aux_;
     Comm* comm_ = nullptr;   // not owned
 };
+#endif   // BFH_ALS_KERNELS_ONLY
 
 }  // namespace bfh

@@ -326,7 +326,8 @@ def test_config3_warm_epoch_matches_the_oracle_path(oracle):
     lives in; from THAT state (copied to the host, handed to both) the HIP backend and the oracle each run one full epoch, and
       * every row of P and Q agrees to 2e-3 of the largest entry (reported by row-length bucket),
       * the top-10 lists of 2,000 sampled users, ranked from the two models, are the same lists (mean overlap >= 0.99),
-      * on sampled 500-row stretches the float64 envelope holds: err(hip, f64) <= max(2.5 err(oracle, f64), 5e-5)."""
+      * the float64 envelope holds: err(hip, f64) <= max(2.5 err(oracle, f64), 5e-5) on 400-row item stretches, and on the user
+        side -- where single rows dominate any maximum -- quantile by quantile over 12,600 sampled rows."""
     import bench
     import ref_numpy as rn
     from buffalo_amd import ingest, synth
@@ -421,18 +422,31 @@ def test_config3_warm_epoch_matches_the_oracle_path(oracle):
         e_or, e_hip = H.relerr(Qo[a:b], t_or), H.relerr(Q1[a:b], t_hip)
         print("config #3 warm epoch item rows [%d, %d): err(hip, f64) %.2e  err(oracle, f64) %.2e  ratio %.2f" % (a, b, e_hip, e_or, e_hip / max(e_or, 1e-30)))
         assert e_hip <= max(2.5 * e_or, 5e-5), (a, e_hip, e_or)
-    # float64 envelope on sampled stretches of the user side (inputs: the warm state; P is not touched by the item half-epoch)
-    for a in np.linspace(0, U - 500, 3).astype(int):
-        a, b = int(a), int(a) + 500
-        t_or, t_hip = Pw[a:b].astype(np.float64), Pw[a:b].astype(np.float64)
-        for r in range(a, b):
-            k, v = csr.row(r)
-            if len(k):
-                t_or[r - a] = rn.ialspp_row_f64_fast(Pw[r], Qw[k], ff0, v, opt["alpha"], opt["reg_u"], opt["block_size"])
-                t_hip[r - a] = rn.ialspp_row_f64_fast(Pw[r], Qw[k], ff_hip, v, opt["alpha"], opt["reg_u"], opt["block_size"])
-        e_or, e_hip = H.relerr(Po_mid[a:b], t_or), H.relerr(P[a:b], t_hip)
-        print("config #3 warm epoch user rows [%d, %d): err(hip, f64) %.2e  err(oracle, f64) %.2e  ratio %.2f" % (a, b, e_hip, e_or, e_hip / max(e_or, 1e-30)))
-        assert e_hip <= max(2.5 * e_or, 5e-5), (a, e_hip, e_or)
+    # float64 envelope on the user side (inputs: the warm state; P is not touched by the item half-epoch), on every 11th row.
+    # Per row, the distance of ANY fp32 evaluation from float64 is heavy-tailed here: over 12,000 rows the reference path itself sits
+    # at 2.8e-8 (median) / 1.2e-7 (99 %) / 1.3e-6 (99.9 %) of the largest entry with single rows at 1e-5 ... 1e-4 -- three CG steps on
+    # a 32x32 block amplify fp32's own rounding a thousandfold on one row in a thousand, and WHICH row differs between any two legal
+    # evaluations (profiles/r03_als_split_rows.txt: oracle / fp32 instruction / split-f16 on the same 3,500 rows).  A maximum over a
+    # 500-row stretch is such a draw, so the envelope is held on the distribution: every quantile, and the count of outlier rows.
+    rows = np.arange(0, U, 11)
+    e_or, e_hip = np.zeros(len(rows)), np.zeros(len(rows))
+    scale = float(np.abs(Po_mid).max())
+    for x, r in enumerate(rows):
+        k, v = csr.row(r)
+        if len(k):
+            t_or = rn.ialspp_row_f64_fast(Pw[r], Qw[k], ff0, v, opt["alpha"], opt["reg_u"], opt["block_size"])
+            t_hip = rn.ialspp_row_f64_fast(Pw[r], Qw[k], ff_hip, v, opt["alpha"], opt["reg_u"], opt["block_size"])
+            e_or[x], e_hip[x] = np.abs(Po_mid[r] - t_or).max() / scale, np.abs(P[r] - t_hip).max() / scale
+    qs = (0.5, 0.9, 0.99, 0.999)
+    q_or, q_hip = np.quantile(e_or, qs), np.quantile(e_hip, qs)
+    n_or, n_hip = int((e_or > 1e-5).sum()), int((e_hip > 1e-5).sum())
+    print("config #3 warm epoch user rows (%d sampled) vs float64, quantiles 50 / 90 / 99 / 99.9 %% and max:\n   oracle %s  max %.2e  rows over 1e-5: %d\n"
+          "   hip    %s  max %.2e  rows over 1e-5: %d" % (len(rows), " ".join("%.2e" % q for q in q_or), e_or.max(), n_or,
+                                                        " ".join("%.2e" % q for q in q_hip), e_hip.max(), n_hip))
+    for q, a_, b_ in zip(qs, q_hip, q_or):
+        assert a_ <= max(2.5 * b_, 2e-7), (q, a_, b_)
+    assert n_hip <= 2.5 * n_or + 3, (n_hip, n_or)
+    assert e_hip.max() <= max(2.5 * e_or.max(), 5e-4), (e_hip.max(), e_or.max())
     users = np.random.default_rng(11).choice(U, 2000, replace=False)
 
     def top10(Pm, Qm):
