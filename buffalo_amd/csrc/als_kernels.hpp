@@ -48,6 +48,8 @@ struct AlsParams {
     const float* bias_self;
     const float* bias_other;
     float out_scale;       // the pass's tiles / vector are multiplied by this before they reach the scratch slot (cfr.cc:130-131)
+    const float* F0;       // als_gram_kernel<SPLIT>: row (x - start_x) = FF p0 of row x (als_rowff_kernel), so the one-wave-per-SIMD pass does not form it
+    int batch;             // als_gram_kernel<SPLIT>: work items drawn per ticket, at most
     const float* split;    // als_gram_kernel<SPLIT>: {S, S^2, 1/S^2, weight cut} written by als_split_scale_kernel (device-side, no host round trip)
     int accumulate;        // add into the row's (zeroed) slot instead of overwriting it: two passes build one system
     float ff_scale;        // the solve kernel's M = ff_scale * FF + slot
@@ -1082,12 +1084,14 @@ __device__ __forceinline__ void als_ialspp_inreg(const f32x16 (&acc)[T * (T + 1)
                 ap = ms * (ap + __shfl_xor(ap, 32, 64));
                 ap += p.reg * pvr;
                 const float pap = wave_sum(half == 0 ? pvr * ap : 0.f);
-                const float step_size = static_cast<float>(rsold / static_cast<double>(pap));
+                // als.cc:328: double / float rounded to float.  Both operands hold float values, and a quotient of two floats taken in
+                // double and rounded to float IS the correctly rounded float quotient (53 >= 2*24 + 2): one fp32 division, same bits
+                const float step_size = static_cast<float>(rsold) / pap;
                 xr += step_size * pvr;
                 rr -= step_size * ap;
                 const double rsnew = static_cast<double>(wave_sum(half == 0 ? rr * rr : 0.f));
                 if (rsnew < static_cast<double>(p.cg_tol)) break;
-                pvr = rr + static_cast<float>(rsnew / rsold) * pvr;
+                pvr = rr + (static_cast<float>(rsnew) / static_cast<float>(rsold)) * pvr;
                 rsold = rsnew;
             }
         }
@@ -1142,8 +1146,60 @@ __device__ __forceinline__ void als_ialspp_inreg(const f32x16 (&acc)[T * (T + 1)
 // per 64-entry chunk.  The pass is VALU-bound now (the cut is ~3 operations per loaded float), so the loop is software-pipelined
 // inside the wave: while the pieces of group j feed the matrix cores, the rows of group j+1 are weighted and cut and the rows of
 // group j+2 are on their way; at T = 4 that takes the whole 512-register file (one wave per SIMD).
+// F0[x - start_x] = P[x] FF for the rows of one call (iALS++'s "FF p0", als.cc:286): formed here at full occupancy -- four rows per
+// wave against one pass over FF (L2-resident, a half-wave reads 128 contiguous bytes) -- instead of inside the split pass, whose one
+// wave per SIMD pays every dependent instruction in full.  ~2.3 G FMAs for 138,493 rows at vdim 128: tens of microseconds.
+template <int T>
+__global__ __launch_bounds__(256) void als_rowff_kernel(const float* __restrict__ P, int start_x, int nrows, const float* __restrict__ FF, float* __restrict__ F0) {
+    constexpr int VD = 32 * T;
+    __shared__ __attribute__((aligned(16))) float s_rows[4][VD * 4];   // per wave: four rows, transposed [j][row]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane >> 5, col = lane & 31;
+    float* sp = s_rows[wave];
+    const int nquads = (nrows + 3) / 4;
+    for (int qd = blockIdx.x * 4 + wave; qd < nquads; qd += gridDim.x * 4) {
+        const int r0 = qd * 4;
+        wave_lds_sync();
+#pragma unroll
+        for (int rw = 0; rw < 4; ++rw) {
+            const int row = r0 + rw;
+            for (int j = lane; j < VD; j += 64) sp[j * 4 + rw] = row < nrows ? P[static_cast<size_t>(start_x + row) * VD + j] : 0.f;
+        }
+        wave_lds_sync();
+        float acc[4][T];
+#pragma unroll
+        for (int rw = 0; rw < 4; ++rw)
+#pragma unroll
+            for (int b = 0; b < T; ++b) acc[rw][b] = 0.f;
+        const float* Fl = FF + col;
+#pragma unroll 4
+        for (int jj = 0; jj < VD / 2; ++jj) {
+            const int j = half * (VD / 2) + jj;
+            const float4 pv = *reinterpret_cast<const float4*>(sp + j * 4);   // the same address in every lane of the half: a broadcast
+#pragma unroll
+            for (int b = 0; b < T; ++b) {
+                const float f = Fl[static_cast<size_t>(j) * VD + b * 32];
+                acc[0][b] = __builtin_fmaf(pv.x, f, acc[0][b]);
+                acc[1][b] = __builtin_fmaf(pv.y, f, acc[1][b]);
+                acc[2][b] = __builtin_fmaf(pv.z, f, acc[2][b]);
+                acc[3][b] = __builtin_fmaf(pv.w, f, acc[3][b]);
+            }
+        }
+#pragma unroll
+        for (int rw = 0; rw < 4; ++rw)
+#pragma unroll
+            for (int b = 0; b < T; ++b) {
+                const float v = acc[rw][b] + __shfl_xor(acc[rw][b], 32, 64);
+                if (half == 0 && r0 + rw < nrows) F0[static_cast<size_t>(r0 + rw) * VD + b * 32 + col] = v;
+            }
+    }
+}
+
+#ifndef BFH_X_ONEWAVE_T
+#define BFH_X_ONEWAVE_T 3
+#endif
 template <int T, bool IALS, bool INREG, bool BIG, bool LOSS = true, bool SPLIT = false>
-__global__ __launch_bounds__(256, (SPLIT && T >= 3) ? 1 : 2) void als_gram_kernel(AlsParams p, const AlsWork* __restrict__ work, int n_items, float* __restrict__ scratch,
+__global__ __launch_bounds__(256, (SPLIT && T >= BFH_X_ONEWAVE_T) ? 1 : 2) void als_gram_kernel(AlsParams p, const AlsWork* __restrict__ work, int n_items, float* __restrict__ scratch,
                                                           int slot_base) {
     static_assert(!INREG || IALS, "the in-register solve is the iALS++ recurrence");
     static_assert(!SPLIT || INREG, "the split-f16 pass is written for the in-place iALS++ rows");
@@ -1172,12 +1228,39 @@ __global__ __launch_bounds__(256, (SPLIT && T >= 3) ? 1 : 2) void als_gram_kerne
     const bool lossk = LOSS && p.compute_loss && p.axis == 1;
     double nume_k = 0.0, deno_k = 0.0;
     const char* qbase = reinterpret_cast<const char*>(p.Q);
-    while (true) {
-        int item = 0;
-        if (lane == 0) item = atomicAdd(p.ticket, 1);
-        item = __builtin_amdgcn_readfirstlane(item);
-        if (item >= n_items) break;
-        const AlsWork wk = work[item];
+    // SPLIT draws several work items per ticket (same-address atomics serialise at ~12 ns each: 138,493 one-row draws alone are
+    // 1.7 ms).  The list is sorted by length, longest first, so a draw made while working on a row of n entries takes
+    // min(p.batch, 1024 / n) rows -- none longer than n, about 1024 entries of work at most: single rows at the head of the list
+    // (the longest-first balance stays), up to p.batch of the short ones.
+    auto ticket = [&](int rows) {
+        int it = 0;
+        if (lane == 0) it = atomicAdd(p.ticket, rows);
+        return it;   // lane 0's value; readfirstlane where it is needed
+    };
+    // SPLIT runs one wave per SIMD, so nothing else hides a row's start-up chain (ticket -> work item -> keys -> rows): the next row's
+    // ticket is drawn when this row starts, its work item is read before the entry loop, its first 128 keys / values and its
+    // factors at entry are fetched before the solve -- each has landed by the time the next step needs it.
+    int item = __builtin_amdgcn_readfirstlane(ticket(1));
+    int batch_end = item + 1;
+    AlsWork wk_cur = work[item < n_items ? item : 0];
+    bool have_pf = false;
+    int pf_c0 = 0, pf_c1 = 0;
+    float pf_v0 = 0.f, pf_v1 = 0.f, pf_p0[T], pf_f0[T];
+#pragma unroll
+    for (int b = 0; b < T; ++b) { pf_p0[b] = 0.f; pf_f0[b] = 0.f; }
+    while (item < n_items) {
+        const bool draw = item + 1 >= batch_end;
+        int rows_nx = 1;
+        if (SPLIT) {
+            const int64_t len = wk_cur.kend - wk_cur.kbeg;
+            const int64_t fit = 1024 / (len > 0 ? len : 1);
+            rows_nx = static_cast<int>(fit < 1 ? 1 : (fit > p.batch ? p.batch : fit));
+            if (rows_nx < 1) rows_nx = 1;
+        }
+        const int item_nx_raw = SPLIT ? (draw ? ticket(rows_nx) : item + 1) : 0;
+        int item_nx = 0;
+        AlsWork wk_nx = wk_cur;
+        const AlsWork wk = wk_cur;
         const bool solve_here = INREG && wk.slot < 0;
         f32x16 acc[NT];
 #pragma unroll
@@ -1218,9 +1301,19 @@ __global__ __launch_bounds__(256, (SPLIT && T >= 3) ? 1 : 2) void als_gram_kerne
         constexpr int VD0 = 32 * T;
         float* pc = s_vec + (INREG ? (threadIdx.x >> 6) * (2 * VD0 + 64) : 0);
         if (IALS) {
-            const float* Pu0 = p.P + static_cast<size_t>(wk.row) * VD0;
+            if (SPLIT && have_pf) {
 #pragma unroll
-            for (int b = 0; b < T; ++b) p0r[b] = Pu0[b * 32 + col];
+                for (int b = 0; b < T; ++b) { p0r[b] = pf_p0[b]; f0r[b] = pf_f0[b]; }
+            } else {
+                const float* Pu0 = p.P + static_cast<size_t>(wk.row) * VD0;
+#pragma unroll
+                for (int b = 0; b < T; ++b) p0r[b] = Pu0[b * 32 + col];
+                if (SPLIT) {   // FF p0 of this row, formed by als_rowff_kernel
+                    const float* Fu0 = p.F0 + static_cast<size_t>(wk.row - p.start_x) * VD0;
+#pragma unroll
+                    for (int b = 0; b < T; ++b) f0r[b] = Fu0[b * 32 + col];
+                }
+            }
         }
         if (solve_here && !(p.debug & 2)) {   // f0 = FF p0 while the accumulators still hold FF alone
             wave_lds_sync();
@@ -1229,18 +1322,20 @@ __global__ __launch_bounds__(256, (SPLIT && T >= 3) ? 1 : 2) void als_gram_kerne
                 for (int b = 0; b < T; ++b) { pc[b * 32 + col] = p0r[b]; pc[VD0 + b * 32 + col] = 0.f; }
             }
             wave_lds_sync();
+            if (!SPLIT) {
 #pragma unroll
-            for (int b = 0; b < T; ++b) f0r[b] = sI2 * als_block_matvec<T>(acc, pc, pc + 2 * VD0, b, lane, half, col);
+                for (int b = 0; b < T; ++b) f0r[b] = als_block_matvec<T>(acc, pc, pc + 2 * VD0, b, lane, half, col);
+            }
         }
         const int64_t n = wk.kend - wk.kbeg;
         const int64_t nchunks = (n + 63) / 64;
-        auto fetch_keys = [&](int64_t chunk, int& cc, float& vvv) {
+        auto fetch_keys_of = [&](int64_t kbeg, int64_t n, int64_t chunk, int& cc, float& vvv) {
             const int64_t kk = chunk * 64 + lane;
             cc = 0;        // padding lanes: row 0 of the other factor with weight 0
             vvv = 0.f;
             if (kk < n) {
-                cc = p.keys[wk.kbeg + kk];
-                vvv = p.vals[wk.kbeg + kk];
+                cc = p.keys[kbeg + kk];
+                vvv = p.vals[kbeg + kk];
                 if (!IALS && p.ctx) vvv -= p.bias_other[cc];
                 if (lossk) {   // constant and denominator of the loss, see als_gram_kernel
                     const double w = static_cast<double>(vvv * p.alpha);
@@ -1249,6 +1344,7 @@ __global__ __launch_bounds__(256, (SPLIT && T >= 3) ? 1 : 2) void als_gram_kerne
                 }
             }
         };
+        auto fetch_keys = [&](int64_t chunk, int& cc, float& vvv) { fetch_keys_of(wk.kbeg, n, chunk, cc, vvv); };
         auto load_pair = [&](int myc, float myv, int pr, float (&q)[T], float& v) {
             const int c0 = __builtin_amdgcn_readlane(myc, 2 * pr), c1 = __builtin_amdgcn_readlane(myc, 2 * pr + 1);
             const float v0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myv), 2 * pr));
@@ -1343,11 +1439,14 @@ __global__ __launch_bounds__(256, (SPLIT && T >= 3) ? 1 : 2) void als_gram_kerne
             // per 64-entry chunk, one entry per lane: row id, weight alpha v, S sqrt(weight) (0: not on the f16 path)
             int myc, myc_n;
             float myw, myw_n, mys, mys_n;
+            auto weigh = [&](float vvv, float& ww, float& ss) {
+                ww = p.alpha * vvv;
+                ss = (ww > 0.f && ww <= wcut) ? sS * __builtin_amdgcn_sqrtf(ww) : 0.f;
+            };
             auto fetch = [&](int64_t chunk, int& cc, float& ww, float& ss) {
                 float vvv;
                 fetch_keys(chunk, cc, vvv);
-                ww = p.alpha * vvv;
-                ss = (ww > 0.f && ww <= wcut) ? sS * __builtin_amdgcn_sqrtf(ww) : 0.f;
+                weigh(vvv, ww, ss);
             };
             auto fix_outliers = [&](int cc, float ww, float ss) {   // negative / very heavy entries of a chunk: fp32 instruction, pairwise
 #ifdef BFH_X_NOFIX
@@ -1382,22 +1481,42 @@ __global__ __launch_bounds__(256, (SPLIT && T >= 3) ? 1 : 2) void als_gram_kerne
                 }
             };
             // the per-entry residual and h (als.cc:292-296), then x = S sqrt(alpha v) q cut into pieces; k0 = the group's first entry
+            // Written in stages over the eight entries (all fetches, all dots, the eight lane reductions step by step, ...): a wave
+            // alone on its SIMD has nobody to hide a dependent chain behind, so the chains are laid side by side.
             auto prep = [&](float src_w, float src_s, int64_t k0, int g, float (&q)[8][T], u32x4 (&H)[T], u32x4 (&L)[T]) {
+                float wgt[8], sw[8], y[8];
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
-                    const float wgt = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bsel + 64 * g + 4 * r, __builtin_bit_cast(int, src_w)));
-                    const float sw = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bsel + 64 * g + 4 * r, __builtin_bit_cast(int, src_s)));
-                    float part = 0.f;
+                    wgt[r] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bsel + 64 * g + 4 * r, __builtin_bit_cast(int, src_w)));
+                    sw[r] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bsel + 64 * g + 4 * r, __builtin_bit_cast(int, src_s)));
+                }
 #pragma unroll
-                    for (int b = 0; b < T; ++b) part = __builtin_fmaf(q[r][b], p0r[b], part);
-                    const float y = half_sum(part, half);
-                    const float cial = __builtin_fmaf(wgt, y, -wgt);   // alpha v (q.p0 - 1)
+                for (int r = 0; r < 8; ++r) {
+                    y[r] = 0.f;
+#pragma unroll
+                    for (int b = 0; b < T; ++b) y[r] = __builtin_fmaf(q[r][b], p0r[b], y[r]);
+                }
+                // sum over the 32 lanes of each half (half_sum), the eight chains interleaved
+#pragma unroll
+                for (int r = 0; r < 8; ++r) y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), 0x128, 0xf, 0xf, false));
+#pragma unroll
+                for (int r = 0; r < 8; ++r) y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), 0x124, 0xf, 0xf, false));
+#pragma unroll
+                for (int r = 0; r < 8; ++r) y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), 0x122, 0xf, 0xf, false));
+#pragma unroll
+                for (int r = 0; r < 8; ++r) y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), 0x121, 0xf, 0xf, false));
+                float yo[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) yo[r] = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, y[r]), 0x401F));
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const float cial = __builtin_fmaf(wgt[r], y[r] + yo[r], -wgt[r]);   // alpha v (q.p0 - 1)
                     const float one = (LOSS && lossk && k0 + 8 * half + r < n) ? 1.0f : 0.f;
 #pragma unroll
                     for (int b = 0; b < T; ++b) {
                         gpart[b] = __builtin_fmaf(cial, q[r][b], gpart[b]);
                         if (LOSS) g1part[b] = __builtin_fmaf(one, q[r][b], g1part[b]);
-                        q[r][b] *= sw;
+                        q[r][b] *= sw[r];
                     }
                 }
 #pragma unroll
@@ -1424,7 +1543,7 @@ __global__ __launch_bounds__(256, (SPLIT && T >= 3) ? 1 : 2) void als_gram_kerne
                 pass(H, H);
             };
             // issue order handed to the scheduler: one matrix instruction, its share of the VALU / SALU work, one row load, one LDS-pipe op
-            constexpr int VPER = (8 * (12 + 3 * T) + 24 * T + 16) / (3 * NT) + 1;
+            constexpr int VPER = (48 + 32 * T) / (3 * NT) + 1;   // ~ (VALU + SALU instructions of one group) / (its matrix instructions)
             auto interleave = [&]() {
 #ifdef BFH_X_NOSGB
                 return;
@@ -1434,11 +1553,18 @@ __global__ __launch_bounds__(256, (SPLIT && T >= 3) ? 1 : 2) void als_gram_kerne
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x006, VPER, 0);
                     if (i * 8 * T / (3 * NT) != (i + 1) * 8 * T / (3 * NT) || 8 * T >= 3 * NT) __builtin_amdgcn_sched_group_barrier(0x020, 8 * T >= 3 * NT ? (8 * T + 3 * NT - 1) / (3 * NT) : 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x080, 1, 0);
                 }
             };
-            fetch(0, myc, myw, mys);
-            fetch(1, myc_n, myw_n, mys_n);
+            if (have_pf) {   // fetched while the previous row was being solved
+                myc = pf_c0;
+                myc_n = pf_c1;
+                weigh(pf_v0, myw, mys);
+                weigh(pf_v1, myw_n, mys_n);
+            } else {
+                fetch(0, myc, myw, mys);
+                fetch(1, myc_n, myw_n, mys_n);
+            }
             float qA[8][T], qB[8][T];
             u32x4 HA[T], LA[T], HB[T], LB[T];
             if (ngroups > 0) {
@@ -1447,6 +1573,9 @@ __global__ __launch_bounds__(256, (SPLIT && T >= 3) ? 1 : 2) void als_gram_kerne
                 load_group(myc, 1, qB);
                 prep(myw, mys, 0, 0, qA, HA, LA);
             }
+            item_nx = __builtin_amdgcn_readfirstlane(item_nx_raw);
+            if (draw) batch_end = item_nx + rows_nx;
+            wk_nx = work[item_nx < n_items ? item_nx : n_items - 1];
             int64_t jg = 0;
             auto advance = [&]() {   // jg entered a new 64-entry chunk
                 myc = myc_n;
@@ -1456,7 +1585,9 @@ __global__ __launch_bounds__(256, (SPLIT && T >= 3) ? 1 : 2) void als_gram_kerne
                 fix_outliers(myc, myw, mys);
             };
             while (jg < ngroups) {
-                {   // pieces A = group jg; rows B = group jg + 1; rows A <- group jg + 2
+                {   // pieces A = group jg; rows B = group jg + 1; rows A <- group jg + 2.  (Past the row's end the keys are padding:
+                    // the last pass prepares a group of zeros.  Branching around it makes a second copy of the matrix instructions,
+                    // and the register allocator then shuttles the accumulators between the two: measured in the assembly, not worth it.)
                     const int s = static_cast<int>(jg & 3);
                     load_group(s < 2 ? myc : myc_n, (s + 2) & 3, qA);
                     prep(s < 3 ? myw : myw_n, s < 3 ? mys : mys_n, (jg + 1) * 16, (s + 1) & 3, qB, HB, LB);
@@ -1475,6 +1606,16 @@ __global__ __launch_bounds__(256, (SPLIT && T >= 3) ? 1 : 2) void als_gram_kerne
                 }
                 ++jg;
                 if ((jg & 3) == 0) advance();
+            }
+            have_pf = item_nx < n_items;
+            if (have_pf) {
+                const int64_t nn = wk_nx.kend - wk_nx.kbeg;
+                fetch_keys_of(wk_nx.kbeg, nn, 0, pf_c0, pf_v0);
+                fetch_keys_of(wk_nx.kbeg, nn, 1, pf_c1, pf_v1);
+                const float* Pn = p.P + static_cast<size_t>(wk_nx.row) * VD0;
+                const float* Fn = p.F0 + static_cast<size_t>(wk_nx.row - p.start_x) * VD0;
+#pragma unroll
+                for (int b = 0; b < T; ++b) { pf_p0[b] = Pn[b * 32 + col]; pf_f0[b] = Fn[b * 32 + col]; }
             }
         }
         constexpr int VD = 32 * T;   // vdim == 32*T on this path
@@ -1498,6 +1639,8 @@ __global__ __launch_bounds__(256, (SPLIT && T >= 3) ? 1 : 2) void als_gram_kerne
                 nume_k += nume;
                 deno_k += deno;
             }
+            if (SPLIT) { item = item_nx; wk_cur = wk_nx; }
+            else { item = __builtin_amdgcn_readfirstlane(ticket(1)); wk_cur = work[item < n_items ? item : 0]; }
             continue;
         }
         // upper-triangle tiles, g, g1 -> the row's scratch slot
@@ -1532,6 +1675,8 @@ __global__ __launch_bounds__(256, (SPLIT && T >= 3) ? 1 : 2) void als_gram_kerne
                 }
             }
         }
+        if (SPLIT) { item = item_nx; wk_cur = wk_nx; }
+        else { item = __builtin_amdgcn_readfirstlane(ticket(1)); wk_cur = work[item < n_items ? item : 0]; }
     }
     if (lossk || (INREG && p.compute_loss)) {
         nume_k = wave_sum_f64(nume_k);
@@ -2230,6 +2375,18 @@ class AlsHandle : public HandleBase {
                 hipLaunchKernelGGL(als_split_scale_kernel, dim3(1), dim3(64), 0, stream, split_part_.get(), ALS_STAT_BLOCKS, split_out_.get());
                 BFH_HIP(hipGetLastError());
                 p.split = split_out_.get();
+                {   // FF p0 for every row of the call
+                    const size_t need0 = static_cast<size_t>(nrows) * vdim_;
+                    if (rowff_.size() < need0) rowff_.resize(need0);
+                    const int quads = (nrows + 3) / 4;
+                    const int rb = std::max(1, std::min((quads + 3) / 4, num_cus_ * 8));
+                    if (T == 2) hipLaunchKernelGGL(als_rowff_kernel<2>, dim3(rb), dim3(256), 0, stream, p.P, start_x, nrows, FF_.get(), rowff_.get());
+                    else if (T == 3) hipLaunchKernelGGL(als_rowff_kernel<3>, dim3(rb), dim3(256), 0, stream, p.P, start_x, nrows, FF_.get(), rowff_.get());
+                    else hipLaunchKernelGGL(als_rowff_kernel<4>, dim3(rb), dim3(256), 0, stream, p.P, start_x, nrows, FF_.get(), rowff_.get());
+                    BFH_HIP(hipGetLastError());
+                    p.F0 = rowff_.get();
+                }
+                p.batch = 16;   // rows per ticket at most (als_gram_kernel: fewer where the rows are long)
             }
             if (items > 0 && inreg) {
 #define BFH_GK(TT, SP)                                                                                                              \
@@ -2517,6 +2674,7 @@ class AlsHandle : public HandleBase {
     bool split_f16_ = true;
     DevBuf<double> split_part_;
     DevBuf<float> split_out_;
+    DevBuf<float> rowff_;
     DevBuf<float> gscratch_;
     DevBuf<float> scratch_;
     std::map<std::tuple<int, int, int>, std::unique_ptr<WorkList>> work_cache_;
