@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3  # same guide: v_mfma_f32_32x32x2_f32, exact fp32 (the type ALS computes in)
+MFMA_F16_PEAK_TF = 2500.0     # dense f16/bf16 (MI355X_MICROARCH.md)
 D = 128
 CPU_KIND = "port"
 CPU_WHAT = ("restatement of reference CPU path (oracle/buffalo_oracle.cc, compiled with the reference's flags "
@@ -168,16 +169,22 @@ def extra_als(csr, seed, epochs=5, cpu=True):
     dt = (time.perf_counter() - t0) / epochs
     st = g.stats()
     T = D // 32
-    mfma_flop = 2 * nnz * (T * (T + 1) // 2) * 2 * 32 * 32          # issued: upper-triangle 32x32x2 tiles, both half-epochs
+    gram_flop = 2 * nnz * (T * (T + 1) // 2) * 2 * 32 * 32          # the upper-triangle tiles of both half-epochs, once (what the fp32 instruction issued)
+    mfma_flop = 3 * gram_flop                                       # issued now: x = h + l in f16, the three products hh + hl + lh (als_gram_kernel<SPLIT>)
     kernel_s = st["kernel_ms"] / epochs * 1e-3
     alg_bytes = 2 * nnz * (4 * D + 8) + (U + I) * (8 * D + 8) + (U + I) * 4 * D     # SURVEY 8(d) B_als, both half-epochs
     out = {"config": "ALS iALS++ (block 32, 3 CG steps), ml20m-shaped synthetic (%d x %d, %d nnz, values 1+Poisson(1)), d=%d, f32, "
                      "rowwise + colwise CSR and factors resident in HBM" % (U, I, nnz, D),
-           "epoch_ms": dt * 1e3, "interactions_per_s": 2 * nnz / dt, "kernel": "als_gram_kernel (Gramian on MFMA + in-register block CG)",
+           "epoch_ms": dt * 1e3, "interactions_per_s": 2 * nnz / dt, "kernel": "als_gram_kernel (Gramian on the f16 matrix cores at fp32 accuracy + in-register block CG)",
            "kernel_ms_per_epoch": kernel_s * 1e3, "gramian_ff_ms_per_epoch": st["aux_ms"] / epochs,
-           "mfma": {"issued_TFLOPs": mfma_flop / kernel_s / 1e12, "peak_TFLOPs": MFMA_F32_PEAK_TF,
-                    "frac": mfma_flop / kernel_s / 1e12 / MFMA_F32_PEAK_TF,
-                    "instruction": "v_mfma_f32_32x32x2_f32", "issued_flop_per_epoch": mfma_flop},
+           "mfma": {"issued_TFLOPs": mfma_flop / kernel_s / 1e12, "peak_TFLOPs": MFMA_F16_PEAK_TF,
+                    "frac": mfma_flop / kernel_s / 1e12 / MFMA_F16_PEAK_TF,
+                    "instruction": "v_mfma_f32_32x32x16_f16, three per tile and 16 entries (split-f16 pass; fp32 accuracy)",
+                    "issued_flop_per_epoch": mfma_flop,
+                    "gramian_TFLOPs": gram_flop / kernel_s / 1e12,
+                    "note": "the pass is VALU / latency bound at one wave per SIMD, not matrix-core bound: the same Gramian through "
+                            "v_mfma_f32_32x32x2_f32 (als_split_f16=0) needs %.1f ms of matrix-core time alone at its %.0f TFLOP/s peak"
+                            % (gram_flop / MFMA_F32_PEAK_TF / 1e9, MFMA_F32_PEAK_TF)},
            "hbm": {"algorithmic_bytes_per_epoch": alg_bytes, "achieved_GBps": alg_bytes / kernel_s / 1e9,
                    "frac": alg_bytes / kernel_s / 1e9 / HBM_PEAK_GBS}}
     del g

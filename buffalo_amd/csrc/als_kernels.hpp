@@ -1146,6 +1146,28 @@ __device__ __forceinline__ void als_ialspp_inreg(const f32x16 (&acc)[T * (T + 1)
 // per 64-entry chunk.  The pass is VALU-bound now (the cut is ~3 operations per loaded float), so the loop is software-pipelined
 // inside the wave: while the pieces of group j feed the matrix cores, the rows of group j+1 are weighted and cut and the rows of
 // group j+2 are on their way; at T = 4 that takes the whole 512-register file (one wave per SIMD).
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void als_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        als_static_for<N, I + 1>(f);
+    }
+}
+
+// row / column block of upper-triangle tile t (tiles numbered row by row: (0,0) (0,1) .. (0,T-1) (1,1) ..)
+template <int T>
+__host__ __device__ constexpr int als_tile_row(int t) {
+    int a = 0;
+    while (t >= T - a) { t -= T - a; ++a; }
+    return a;
+}
+template <int T>
+__host__ __device__ constexpr int als_tile_col(int t) {
+    int a = 0;
+    while (t >= T - a) { t -= T - a; ++a; }
+    return a + t;
+}
+
 // F0[x - start_x] = P[x] FF for the rows of one call (iALS++'s "FF p0", als.cc:286): formed here at full occupancy -- four rows per
 // wave against one pass over FF (L2-resident, a half-wave reads 128 contiguous bytes) -- instead of inside the split pass, whose one
 // wave per SIMD pays every dependent instruction in full.  ~2.3 G FMAs for 138,493 rows at vdim 128: tens of microseconds.
@@ -1542,6 +1564,101 @@ __global__ __launch_bounds__(256, (SPLIT && T >= BFH_X_ONEWAVE_T) ? 1 : 2) void 
                 pass(H, L);
                 pass(H, H);
             };
+            // One group's matrix instructions with the NEXT group's preparation and the rows of the one after laid between them BY HAND:
+            // a wave alone on its SIMD overlaps the two pipes only if the instruction stream alternates -- one matrix instruction
+            // (32 cycles in its pipe), then ~32 cycles of other work -- and the scheduler, asked with sched_group_barrier, clumps
+            // (measured in the assembly: runs of 3-10 matrix instructions, then 80 VALU).  So the preparation is cut into NS steps,
+            // spread evenly over the NM matrix instructions, with a full scheduling fence after every slot.
+            // Steps: 8 x (row id, weight, S sqrt(weight) of entry r)  |  8 x (the T loads of row r, group after next)  |  8 x (q_r . p0)
+            //        | 4 levels of the eight lane reductions  |  the eight swizzles  |  8 x (residual, h, scaling of entry r)  |  4T cuts.
+            constexpr int NM = 3 * NT, NS = 37 + 4 * T;
+            auto fused = [&](int src_c, float src_w, float src_s, int64_t k0, int gl, int gp, float (&ql)[8][T], float (&qp)[8][T],
+                             u32x4 (&Ho)[T], u32x4 (&Lo)[T], const u32x4 (&Hi)[T], const u32x4 (&Li)[T]) {
+                int cid[8];
+                float wgt[8], sw[8], y[8], yo[8];
+                als_static_for<NM>([&](auto Ic) {
+                    constexpr int i = decltype(Ic)::value;
+                    {
+                        constexpr int pr = i / NT, t = i % NT;   // small terms first: l h, h l, h h
+                        constexpr int a = als_tile_row<T>(t), b = als_tile_col<T>(t);
+                        // (pure instructions carry no ordering of their own: instruction selection is free to lay them on either side of
+                        //  a fence.  Empty asm statements -- ordered among themselves and with the fences -- tie every step's inputs
+                        //  and results to its slot.)
+                        const u32x4 X = pr == 0 ? Li[a] : Hi[a];
+                        const u32x4 Y = pr == 1 ? Li[b] : Hi[b];
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, X), __builtin_bit_cast(f16x8_t, Y), acc[t], 0, 0, 0);
+                    }
+                    constexpr int k_lo = i * NS / NM, k_hi = (i + 1) * NS / NM;
+                    als_static_for<k_hi - k_lo>([&](auto Jc) {
+                        constexpr int k = k_lo + decltype(Jc)::value;
+                        if constexpr (k < 8) {
+                            constexpr int r = k;
+                            cid[r] = __builtin_amdgcn_ds_bpermute(bsel + 64 * gl + 4 * r, src_c);
+                            wgt[r] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bsel + 64 * gp + 4 * r, __builtin_bit_cast(int, src_w)));
+                            sw[r] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bsel + 64 * gp + 4 * r, __builtin_bit_cast(int, src_s)));
+                        } else if constexpr (k < 16) {
+                            constexpr int r = k - 8;
+                            using off_t = typename std::conditional<BIG, size_t, unsigned>::type;
+                            const off_t voff = static_cast<off_t>(static_cast<unsigned>(cid[r])) * row_bytes + static_cast<unsigned>(col) * 4u;
+                            const float* q_ = reinterpret_cast<const float*>(qbase + voff);
+#pragma unroll
+                            for (int b = 0; b < T; ++b) ql[r][b] = q_[b * 32];
+                        } else if constexpr (k < 24) {
+                            constexpr int r = k - 16;
+#ifdef BFH_X_PIN_C
+                            asm volatile("" : "+v"(qp[r][0]));
+#endif
+                            y[r] = qp[r][0] * p0r[0];
+#pragma unroll
+                            for (int b = 1; b < T; ++b) y[r] = __builtin_fmaf(qp[r][b], p0r[b], y[r]);
+#ifdef BFH_X_PIN_C
+                            asm volatile("" : "+v"(y[r]));
+#endif
+                        } else if constexpr (k < 28) {
+                            constexpr int ctrl = k == 24 ? 0x128 : k == 25 ? 0x124 : k == 26 ? 0x122 : 0x121;   // row_ror 8, 4, 2, 1
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) {
+                                y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), ctrl, 0xf, 0xf, false));
+#ifdef BFH_X_PIN_D
+                                asm volatile("" : "+v"(y[r]));
+#endif
+                            }
+                        } else if constexpr (k < 29) {
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) yo[r] = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, y[r]), 0x401F));
+                        } else if constexpr (k < 37) {
+                            constexpr int r = k - 29;
+#ifdef BFH_X_PIN_F
+                            asm volatile("" : "+v"(yo[r]));
+#endif
+                            const float cial = __builtin_fmaf(wgt[r], y[r] + yo[r], -wgt[r]);   // alpha v (q.p0 - 1)
+                            const float one = (LOSS && lossk && k0 + 8 * half + r < n) ? 1.0f : 0.f;
+#pragma unroll
+                            for (int b = 0; b < T; ++b) {
+                                gpart[b] = __builtin_fmaf(cial, qp[r][b], gpart[b]);
+                                if (LOSS) g1part[b] = __builtin_fmaf(one, qp[r][b], g1part[b]);
+                                qp[r][b] *= sw[r];
+#ifdef BFH_X_PIN_F
+                                asm volatile("" : "+v"(qp[r][b]), "+v"(gpart[b]));
+#endif
+                            }
+                        } else {
+                            constexpr int b = (k - 37) / 4, j2 = (k - 37) % 4;
+                            unsigned h_, l_;
+#ifndef BFH_X_NO_PIN_G
+                            asm volatile("" : "+v"(qp[2 * j2][b]));
+#endif
+                            als_split_f16(qp[2 * j2][b], qp[2 * j2 + 1][b], h_, l_);
+#ifndef BFH_X_NO_PIN_G
+                            asm volatile("" : "+v"(h_), "+v"(l_));
+#endif
+                            Ho[b][j2] = h_;
+                            Lo[b][j2] = l_;
+                        }
+                    });
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            };
             // issue order handed to the scheduler: one matrix instruction, its share of the VALU / SALU work, one row load, one LDS-pipe op
             constexpr int VPER = (48 + 32 * T) / (3 * NT) + 1;   // ~ (VALU + SALU instructions of one group) / (its matrix instructions)
             auto interleave = [&]() {
@@ -1589,20 +1706,28 @@ __global__ __launch_bounds__(256, (SPLIT && T >= BFH_X_ONEWAVE_T) ? 1 : 2) void 
                     // the last pass prepares a group of zeros.  Branching around it makes a second copy of the matrix instructions,
                     // and the register allocator then shuttles the accumulators between the two: measured in the assembly, not worth it.)
                     const int s = static_cast<int>(jg & 3);
+#ifdef BFH_X_NOFUSE
                     load_group(s < 2 ? myc : myc_n, (s + 2) & 3, qA);
                     prep(s < 3 ? myw : myw_n, s < 3 ? mys : mys_n, (jg + 1) * 16, (s + 1) & 3, qB, HB, LB);
                     gram16(HA, LA);
                     interleave();
+#else
+                    fused(s < 2 ? myc : myc_n, s < 3 ? myw : myw_n, s < 3 ? mys : mys_n, (jg + 1) * 16, (s + 2) & 3, (s + 1) & 3, qA, qB, HB, LB, HA, LA);
+#endif
                 }
                 ++jg;
                 if ((jg & 3) == 0) advance();
                 if (jg >= ngroups) break;
                 {   // the same with the two register sets swapped
                     const int s = static_cast<int>(jg & 3);
+#ifdef BFH_X_NOFUSE
                     load_group(s < 2 ? myc : myc_n, (s + 2) & 3, qB);
                     prep(s < 3 ? myw : myw_n, s < 3 ? mys : mys_n, (jg + 1) * 16, (s + 1) & 3, qA, HA, LA);
                     gram16(HB, LB);
                     interleave();
+#else
+                    fused(s < 2 ? myc : myc_n, s < 3 ? myw : myw_n, s < 3 ? mys : mys_n, (jg + 1) * 16, (s + 2) & 3, (s + 1) & 3, qB, qA, HA, LA, HB, LB);
+#endif
                 }
                 ++jg;
                 if ((jg & 3) == 0) advance();
@@ -1700,14 +1825,6 @@ __global__ __launch_bounds__(256, (SPLIT && T >= BFH_X_ONEWAVE_T) ? 1 : 2) void 
 // FF + slot instead of the nnz pass.  The wave index picks one of W instantiations so that every tile,
 // operand and accumulator index is a compile-time constant.
 // ------------------------------------------------------------------------------------------------
-template <int N, int I = 0, class F>
-__device__ __forceinline__ void als_static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        als_static_for<N, I + 1>(f);
-    }
-}
-
 template <int T, int WV>
 struct AlsWide {
     static constexpr int W = (T + 1) / 2;

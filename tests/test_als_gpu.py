@@ -80,6 +80,8 @@ CASES = [
     (160, dict(optimizer="ialspp")),                    # 128 < vdim <= 256, block_size 32: als_wide_kernel, T = 5 (3 waves, middle row alone)
     (192, dict(optimizer="manual_cg")),                 # T = 6
     (224, dict(optimizer="ialspp", adaptive_reg=True)), # T = 7
+    (64, dict(optimizer="ialspp")),                     # in-place iALS++ below d = 128: the split-f16 pass at T = 2 (two waves per SIMD)
+    (96, dict(optimizer="ialspp")),                     # ... and T = 3 (one wave per SIMD)
 ]
 
 
@@ -88,8 +90,11 @@ CASES = [
                           (128, dict(optimizer="ialspp"), "ml100k"), (256, dict(optimizer="ialspp"), "ml100k"),
                           # rows above 4096 nnz are cut into chunks whose tiles are summed in a scratch slot
                           (32, dict(optimizer="manual_cg"), "heavy"), (128, dict(optimizer="ialspp"), "heavy"),
-                          (256, dict(optimizer="ialspp"), "heavy")])
-@pytest.mark.parametrize("design", ["inreg", "scratch"])
+                          (256, dict(optimizer="ialspp"), "heavy"),
+                          # a few entries 3000x heavier than the rest and a few negative ones: the split-f16 pass sends both kinds
+                          # through the fp32 instruction (als_gram_kernel: fix_outliers)
+                          (128, dict(optimizer="ialspp"), "outliers")])
+@pytest.mark.parametrize("design", ["inreg", "scratch", "fp32"])
 def test_half_epochs_match_oracle(oracle, d, kw, shape, design):
     """Every half-epoch starts from bit-identical factors (the GPU model is re-synchronised to the
     oracle's after each comparison), so differences are the kernels' own.  Truncated fp32 CG is
@@ -103,7 +108,15 @@ def test_half_epochs_match_oracle(oracle, d, kw, shape, design):
     from buffalo_amd import synth
     if design == "scratch" and not (d == 128 and kw.get("block_size", 32) == 32):
         pytest.skip("identical to 'inreg' unless the in-register iALS++ solve applies")
-    if shape == "tiny":
+    if design == "fp32" and not (d == 128 and kw.get("block_size", 32) == 32):
+        pytest.skip("'fp32' = the in-register solve with the fp32 matrix instruction instead of the split-f16 pass: d = 128 cases")
+    if shape == "outliers":
+        base = tiny_csr(U=320, I=280, density=0.2, seed=31, counts=True)
+        v = base.vals.copy()
+        v[::997] *= 3000.0
+        v[5::53] = -0.05
+        csr = synth.CSR(base.num_users, base.num_items, base.indptr, base.keys, v)
+    elif shape == "tiny":
         csr = tiny_csr(U=320, I=280, density=0.06, seed=31, counts=True)   # every row shorter than a wave
     elif shape == "heavy":
         csr = tiny_csr(U=4300, I=12, density=0.97, seed=5, counts=True)    # item rows of ~4170 nnz
@@ -113,7 +126,8 @@ def test_half_epochs_match_oracle(oracle, d, kw, shape, design):
     o, obj, (P, Q), (Po, Qo) = _setup(oracle, csr, d, opt, scale=0.1)
     # "inreg": iALS++ rows with block_size 32 are solved from the accumulator registers (the default);
     # "scratch": every row goes through the HBM scratch slot + dense-solve kernel
-    obj.set_mode("als_inreg", int(design == "inreg"))
+    obj.set_mode("als_inreg", int(design != "scratch"))
+    obj.set_mode("als_split_f16", int(design != "fp32"))
     t = csr.transpose()
     for it in range(2 if shape == "tiny" else 1):
         for axis, mat in ((0, csr), (1, t)):
