@@ -1132,20 +1132,6 @@ __device__ __forceinline__ void als_ialspp_inreg(const f32x16 (&acc)[T * (T + 1)
 // BIG: the other factor matrix is 4 GiB or larger -- 64-bit gather offsets (a few % slower, 19 % in the wide kernel)
 // LOSS = false: compile-time promise that no loss terms are wanted (compute_loss_on_training off, or the user half-epoch whose
 // per-entry terms are zero): drops the g_1 accumulation -- T FMAs per entry pair and T registers -- from the hot loop
-// SPLIT (iALS++ in place only): the Gramian through the f16 matrix cores at fp32 accuracy.  x = S sqrt(alpha v) q is cut into two
-// f16 pieces h + l (each rounded to nearest, the remainder exact in fp32: h + l = x to 2^-24) and x x^T is taken as hh + hl + lh
-// (what is dropped is <= 2^-24 of a term; measured against f64 the rows are as close as the fp32 instruction's,
-// profiles/r03_als_split_f16.txt):
-// products of f16 pairs are exact in fp32 and v_mfma_f32_32x32x16_f16 accumulates in fp32.  One instruction eats SIXTEEN entries
-// in 32 cycles where v_mfma_f32_32x32x2_f32 eats two in 64: 3 x 32 / 16 = 6 matrix-core cycles per entry and tile instead of 32.
-// A and B of a 32x32x16 step hold, per lane, element [32 a + (lane & 31)] of eight entries (k = 8 (lane >> 5) + r) -- the same
-// registers serve as A and B, and since a Gramian sums over k ANY k order is right as long as both operands use the same one.
-// S (a power of two, als_split_scale_kernel) keeps S x inside f16's range; the accumulators hold S^2 M (the FF tiles are scaled
-// when they are copied to LDS) and every product read back out of them is multiplied by 1/S^2 -- exact, S being a power of two.
-// Entries with a negative weight (no square root) or heavier than 64x the mean go through the fp32 instruction in a side pass
-// per 64-entry chunk.  The pass is VALU-bound now (the cut is ~3 operations per loaded float), so the loop is software-pipelined
-// inside the wave: while the pieces of group j feed the matrix cores, the rows of group j+1 are weighted and cut and the rows of
-// group j+2 are on their way; at T = 4 that takes the whole 512-register file (one wave per SIMD).
 template <int N, int I = 0, class F>
 __device__ __forceinline__ void als_static_for(F&& f) {
     if constexpr (I < N) {
@@ -1217,11 +1203,25 @@ __global__ __launch_bounds__(256) void als_rowff_kernel(const float* __restrict_
     }
 }
 
-#ifndef BFH_X_ONEWAVE_T
-#define BFH_X_ONEWAVE_T 3
-#endif
+// SPLIT (iALS++ in place only): the Gramian through the f16 matrix cores at fp32 accuracy.  x = S sqrt(alpha v) q is cut into two
+// f16 pieces h + l (each rounded to nearest, the remainder exact in fp32: h + l = x to 2^-24) and x x^T is taken as hh + hl + lh
+// (what is dropped is <= 2^-24 of a term; measured against f64 the rows are as close as the fp32 instruction's,
+// profiles/r03_als_split_f16.txt):
+// products of f16 pairs are exact in fp32 and v_mfma_f32_32x32x16_f16 accumulates in fp32.  One instruction eats SIXTEEN entries
+// in 32 cycles where v_mfma_f32_32x32x2_f32 eats two in 64: 3 x 32 / 16 = 6 matrix-core cycles per entry and tile instead of 32.
+// A and B of a 32x32x16 step hold, per lane, element [32 a + (lane & 31)] of eight entries (k = 8 (lane >> 5) + r) -- the same
+// registers serve as A and B, and since a Gramian sums over k ANY k order is right as long as both operands use the same one.
+// S (a power of two, als_split_scale_kernel) keeps S x inside f16's range; the accumulators hold S^2 M (the FF tiles are scaled
+// when they are copied to LDS) and every product read back out of them is multiplied by 1/S^2 -- exact, S being a power of two.
+// Entries with a negative weight (no square root) or heavier than 64x the mean go through the fp32 instruction in a side pass
+// per 64-entry chunk.  The pass is VALU-bound now (~230 VALU instructions per 16 entries against 30 matrix instructions), so the loop
+// is software-pipelined inside the wave: while the pieces of group j feed the matrix cores, the rows of group j+1 are weighted and
+// cut and the rows of group j+2 are on their way (`fused`); at T >= 3 that takes the 512-register file: ONE wave per SIMD, which
+// therefore pays every per-row step in full -- hence als_rowff_kernel, the drawn-ahead tickets and the prefetched keys below.
+// Counters (profiles/r03_als_split_counters.txt): per wave 47 % of the cycles issue VALU, 32 % wait on memory, the matrix pipe is
+// busy 22-32 %.
 template <int T, bool IALS, bool INREG, bool BIG, bool LOSS = true, bool SPLIT = false>
-__global__ __launch_bounds__(256, (SPLIT && T >= BFH_X_ONEWAVE_T) ? 1 : 2) void als_gram_kernel(AlsParams p, const AlsWork* __restrict__ work, int n_items, float* __restrict__ scratch,
+__global__ __launch_bounds__(256, (SPLIT && T >= 3) ? 1 : 2) void als_gram_kernel(AlsParams p, const AlsWork* __restrict__ work, int n_items, float* __restrict__ scratch,
                                                           int slot_base) {
     static_assert(!INREG || IALS, "the in-register solve is the iALS++ recurrence");
     static_assert(!SPLIT || INREG, "the split-f16 pass is written for the in-place iALS++ rows");
@@ -1471,9 +1471,6 @@ __global__ __launch_bounds__(256, (SPLIT && T >= BFH_X_ONEWAVE_T) ? 1 : 2) void 
                 weigh(vvv, ww, ss);
             };
             auto fix_outliers = [&](int cc, float ww, float ss) {   // negative / very heavy entries of a chunk: fp32 instruction, pairwise
-#ifdef BFH_X_NOFIX
-                return;
-#endif
                 const bool out = ss == 0.f && ww != 0.f;
                 if (__builtin_amdgcn_ballot_w64(out) == 0) return;
                 const float wfix = out ? ww * sS2 : 0.f;
@@ -1551,19 +1548,6 @@ __global__ __launch_bounds__(256, (SPLIT && T >= BFH_X_ONEWAVE_T) ? 1 : 2) void 
                         L[b][j2] = l_;
                     }
             };
-            auto pass = [&](const u32x4 (&X)[T], const u32x4 (&Y)[T]) {
-                int t = 0;
-#pragma unroll
-                for (int a = 0; a < T; ++a)
-#pragma unroll
-                    for (int b = a; b < T; ++b, ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, X[a]), __builtin_bit_cast(f16x8_t, Y[b]), acc[t], 0, 0, 0);
-            };
-            auto gram16 = [&](const u32x4 (&H)[T], const u32x4 (&L)[T]) {   // small terms first
-                pass(L, H);
-                pass(H, L);
-                pass(H, H);
-            };
             // One group's matrix instructions with the NEXT group's preparation and the rows of the one after laid between them BY HAND:
             // a wave alone on its SIMD overlaps the two pipes only if the instruction stream alternates -- one matrix instruction
             // (32 cycles in its pipe), then ~32 cycles of other work -- and the scheduler, asked with sched_group_barrier, clumps
@@ -1605,32 +1589,20 @@ __global__ __launch_bounds__(256, (SPLIT && T >= BFH_X_ONEWAVE_T) ? 1 : 2) void 
                             for (int b = 0; b < T; ++b) ql[r][b] = q_[b * 32];
                         } else if constexpr (k < 24) {
                             constexpr int r = k - 16;
-#ifdef BFH_X_PIN_C
-                            asm volatile("" : "+v"(qp[r][0]));
-#endif
                             y[r] = qp[r][0] * p0r[0];
 #pragma unroll
                             for (int b = 1; b < T; ++b) y[r] = __builtin_fmaf(qp[r][b], p0r[b], y[r]);
-#ifdef BFH_X_PIN_C
-                            asm volatile("" : "+v"(y[r]));
-#endif
                         } else if constexpr (k < 28) {
                             constexpr int ctrl = k == 24 ? 0x128 : k == 25 ? 0x124 : k == 26 ? 0x122 : 0x121;   // row_ror 8, 4, 2, 1
 #pragma unroll
                             for (int r = 0; r < 8; ++r) {
                                 y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), ctrl, 0xf, 0xf, false));
-#ifdef BFH_X_PIN_D
-                                asm volatile("" : "+v"(y[r]));
-#endif
                             }
                         } else if constexpr (k < 29) {
 #pragma unroll
                             for (int r = 0; r < 8; ++r) yo[r] = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, y[r]), 0x401F));
                         } else if constexpr (k < 37) {
                             constexpr int r = k - 29;
-#ifdef BFH_X_PIN_F
-                            asm volatile("" : "+v"(yo[r]));
-#endif
                             const float cial = __builtin_fmaf(wgt[r], y[r] + yo[r], -wgt[r]);   // alpha v (q.p0 - 1)
                             const float one = (LOSS && lossk && k0 + 8 * half + r < n) ? 1.0f : 0.f;
 #pragma unroll
@@ -1638,40 +1610,19 @@ __global__ __launch_bounds__(256, (SPLIT && T >= BFH_X_ONEWAVE_T) ? 1 : 2) void 
                                 gpart[b] = __builtin_fmaf(cial, qp[r][b], gpart[b]);
                                 if (LOSS) g1part[b] = __builtin_fmaf(one, qp[r][b], g1part[b]);
                                 qp[r][b] *= sw[r];
-#ifdef BFH_X_PIN_F
-                                asm volatile("" : "+v"(qp[r][b]), "+v"(gpart[b]));
-#endif
                             }
                         } else {
                             constexpr int b = (k - 37) / 4, j2 = (k - 37) % 4;
                             unsigned h_, l_;
-#ifndef BFH_X_NO_PIN_G
                             asm volatile("" : "+v"(qp[2 * j2][b]));
-#endif
                             als_split_f16(qp[2 * j2][b], qp[2 * j2 + 1][b], h_, l_);
-#ifndef BFH_X_NO_PIN_G
                             asm volatile("" : "+v"(h_), "+v"(l_));
-#endif
                             Ho[b][j2] = h_;
                             Lo[b][j2] = l_;
                         }
                     });
                     __builtin_amdgcn_sched_barrier(0);
                 });
-            };
-            // issue order handed to the scheduler: one matrix instruction, its share of the VALU / SALU work, one row load, one LDS-pipe op
-            constexpr int VPER = (48 + 32 * T) / (3 * NT) + 1;   // ~ (VALU + SALU instructions of one group) / (its matrix instructions)
-            auto interleave = [&]() {
-#ifdef BFH_X_NOSGB
-                return;
-#endif
-#pragma unroll
-                for (int i = 0; i < 3 * NT; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x006, VPER, 0);
-                    if (i * 8 * T / (3 * NT) != (i + 1) * 8 * T / (3 * NT) || 8 * T >= 3 * NT) __builtin_amdgcn_sched_group_barrier(0x020, 8 * T >= 3 * NT ? (8 * T + 3 * NT - 1) / (3 * NT) : 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x080, 1, 0);
-                }
             };
             if (have_pf) {   // fetched while the previous row was being solved
                 myc = pf_c0;
@@ -1706,28 +1657,14 @@ __global__ __launch_bounds__(256, (SPLIT && T >= BFH_X_ONEWAVE_T) ? 1 : 2) void 
                     // the last pass prepares a group of zeros.  Branching around it makes a second copy of the matrix instructions,
                     // and the register allocator then shuttles the accumulators between the two: measured in the assembly, not worth it.)
                     const int s = static_cast<int>(jg & 3);
-#ifdef BFH_X_NOFUSE
-                    load_group(s < 2 ? myc : myc_n, (s + 2) & 3, qA);
-                    prep(s < 3 ? myw : myw_n, s < 3 ? mys : mys_n, (jg + 1) * 16, (s + 1) & 3, qB, HB, LB);
-                    gram16(HA, LA);
-                    interleave();
-#else
                     fused(s < 2 ? myc : myc_n, s < 3 ? myw : myw_n, s < 3 ? mys : mys_n, (jg + 1) * 16, (s + 2) & 3, (s + 1) & 3, qA, qB, HB, LB, HA, LA);
-#endif
                 }
                 ++jg;
                 if ((jg & 3) == 0) advance();
                 if (jg >= ngroups) break;
                 {   // the same with the two register sets swapped
                     const int s = static_cast<int>(jg & 3);
-#ifdef BFH_X_NOFUSE
-                    load_group(s < 2 ? myc : myc_n, (s + 2) & 3, qB);
-                    prep(s < 3 ? myw : myw_n, s < 3 ? mys : mys_n, (jg + 1) * 16, (s + 1) & 3, qA, HA, LA);
-                    gram16(HB, LB);
-                    interleave();
-#else
                     fused(s < 2 ? myc : myc_n, s < 3 ? myw : myw_n, s < 3 ? mys : mys_n, (jg + 1) * 16, (s + 2) & 3, (s + 1) & 3, qB, qA, HA, LA, HB, LB);
-#endif
                 }
                 ++jg;
                 if ((jg & 3) == 0) advance();
@@ -1753,13 +1690,11 @@ __global__ __launch_bounds__(256, (SPLIT && T >= BFH_X_ONEWAVE_T) ? 1 : 2) void 
                 g1s[a] = g1part[a] + __shfl_xor(g1part[a], 32, 64);
             }
             double nume = 0.0, deno = 0.0;
-#ifndef BFH_X_NOSOLVE
             if (!(p.debug & 1)) {   // pc = p0 and delta = 0 were put in place before the pass
                 als_ialspp_inreg<T>(acc, gs, g1s, f0r, p, pc, pc + VD, pc + 2 * VD, lane, half, col, p.adaptive_reg ? static_cast<float>(n) : 1.0f, nume, deno, sI2);
                 wave_lds_sync();
                 for (int e = lane; e < VD; e += 64) Pu[e] = pc[e];
             }
-#endif
             if (p.compute_loss && lane == 0) {   // row-level terms ride on lane 0's share of the per-nnz sums
                 nume_k += nume;
                 deno_k += deno;
