@@ -931,19 +931,17 @@ __device__ __forceinline__ void als_split_f16(float x0, float x1, unsigned& h, u
     l = __builtin_bit_cast(unsigned, ll);
 }
 
-// Scale of the split pass (als_gram_kernel<SPLIT>), decided on the device per call from two fixed-order reductions:
-// qmax = max |Q| over the other factor matrix and wmean = the mean positive weight alpha v of the call's entries.
-//   S    = the power of two that puts S sqrt(64 wmean) qmax just under 2^15 (f16 overflows at 65504; f16's 11+11 bits need
-//          |S x| >= 2^-3 for a full remainder, so typical entries sit ~2^12 above that);
-//   wcut = 64 wmean: the few entries heavier than that (and negative ones) go through the fp32 instruction instead.
-// `part`: [ALS_STAT_BLOCKS][3] doubles (max |q|, sum of positive weights, their count) written by the first kernel.
+// Scale of the split pass (als_gram_kernel<SPLIT>), decided on the device from ONE fixed-order reduction, qmax = max |Q| over the
+// other factor matrix -- nothing that depends on how the rows are chunked or sharded, so every chunking and every rank of a
+// sharded run works with the same numbers:
+//   S    = the power of two that puts S qmax in [2^6, 2^7].  An entry's x = S sqrt(alpha v) q then stays below f16's 65504 for
+//          weights alpha v up to 2^16 / 2, and keeps a full 11-bit remainder (|x| >= 2^-3) down to |q| ~ 1e-3 qmax at weight 1;
+//   wcut = 2^15: heavier entries (and negative ones) go through the fp32 instruction instead.
+// `part`: [ALS_STAT_BLOCKS] floats written by the first kernel.
 constexpr int ALS_STAT_BLOCKS = 1024;
-__global__ __launch_bounds__(256) void als_split_stats_kernel(const float* __restrict__ Q, size_t nq, const float* __restrict__ vals, size_t nv, float alpha,
-                                                              double* __restrict__ part) {
+__global__ __launch_bounds__(256) void als_split_stats_kernel(const float* __restrict__ Q, size_t nq, float* __restrict__ part) {
     __shared__ float smq[256];
-    __shared__ double sms[256], smc[256];
     float qm = 0.f;
-    double ws = 0.0, wc = 0.0;
     const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
     const size_t tid = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const float4* Q4 = reinterpret_cast<const float4*>(Q);   // hipMalloc'd, vdim % 32 == 0
@@ -951,43 +949,29 @@ __global__ __launch_bounds__(256) void als_split_stats_kernel(const float* __res
         const float4 v = Q4[e];
         qm = fmaxf(qm, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
     }
-    for (size_t e = tid; e < nv; e += stride) {
-        const float w = alpha * vals[e];
-        if (w > 0.f) { ws += static_cast<double>(w); wc += 1.0; }
-    }
-    smq[threadIdx.x] = qm; sms[threadIdx.x] = ws; smc[threadIdx.x] = wc;
+    smq[threadIdx.x] = qm;
     __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {   // fixed tree: the same bits on every run
-        if (static_cast<int>(threadIdx.x) < st) {
-            smq[threadIdx.x] = fmaxf(smq[threadIdx.x], smq[threadIdx.x + st]);
-            sms[threadIdx.x] += sms[threadIdx.x + st];
-            smc[threadIdx.x] += smc[threadIdx.x + st];
-        }
+    for (int st = 128; st > 0; st >>= 1) {
+        if (static_cast<int>(threadIdx.x) < st) smq[threadIdx.x] = fmaxf(smq[threadIdx.x], smq[threadIdx.x + st]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) { part[blockIdx.x * 3 + 0] = static_cast<double>(smq[0]); part[blockIdx.x * 3 + 1] = sms[0]; part[blockIdx.x * 3 + 2] = smc[0]; }
+    if (threadIdx.x == 0) part[blockIdx.x] = smq[0];
 }
-__global__ __launch_bounds__(64) void als_split_scale_kernel(const double* __restrict__ part, int nblocks, float* __restrict__ out) {
-    double qm = 0.0, ws = 0.0, wc = 0.0;
-    for (int b = threadIdx.x; b < nblocks; b += 64) { qm = fmax(qm, part[b * 3]); ws += part[b * 3 + 1]; wc += part[b * 3 + 2]; }
-    for (int st = 32; st > 0; st >>= 1) {   // butterfly: every lane ends with the same, run-independent, sums
-        qm = fmax(qm, __shfl_xor(qm, st, 64));
-        ws += __shfl_xor(ws, st, 64);
-        wc += __shfl_xor(wc, st, 64);
-    }
+__global__ __launch_bounds__(64) void als_split_scale_kernel(const float* __restrict__ part, int nblocks, float wcut, float* __restrict__ out) {
+    float qm = 0.f;
+    for (int b = threadIdx.x; b < nblocks; b += 64) qm = fmaxf(qm, part[b]);
+    for (int st = 32; st > 0; st >>= 1) qm = fmaxf(qm, __shfl_xor(qm, st, 64));
     if (threadIdx.x != 0) return;
-    const double wmean = wc > 0.0 ? ws / wc : 0.0;
     int e = 0;
-    const double top = sqrt(64.0 * wmean) * qm;   // the largest |x| that stays on the f16 path
-    if (top > 0.0 && top < 1e300) {
-        e = static_cast<int>(floor(log2(32768.0 / top)));
+    if (qm > 0.f && qm < 3e38f) {   // a max is the same number in any order: the same S on every run and every rank
+        e = static_cast<int>(floor(log2(128.0 / static_cast<double>(qm))));
         if (e > 40) e = 40;
         if (e < -40) e = -40;
     }
     out[0] = static_cast<float>(ldexp(1.0, e));
     out[1] = static_cast<float>(ldexp(1.0, 2 * e));
     out[2] = static_cast<float>(ldexp(1.0, -2 * e));
-    out[3] = static_cast<float>(64.0 * wmean);
+    out[3] = wcut;
 }
 
 // sum over the 32 lanes of each half-wave (every lane receives its half's total): 4 DPP row rotations leave each 16-lane row's
@@ -1213,7 +1197,7 @@ __global__ __launch_bounds__(256) void als_rowff_kernel(const float* __restrict_
 // registers serve as A and B, and since a Gramian sums over k ANY k order is right as long as both operands use the same one.
 // S (a power of two, als_split_scale_kernel) keeps S x inside f16's range; the accumulators hold S^2 M (the FF tiles are scaled
 // when they are copied to LDS) and every product read back out of them is multiplied by 1/S^2 -- exact, S being a power of two.
-// Entries with a negative weight (no square root) or heavier than 64x the mean go through the fp32 instruction in a side pass
+// Entries with a negative weight (no square root) or heavier than 2^15 go through the fp32 instruction in a side pass
 // per 64-entry chunk.  The pass is VALU-bound now (~230 VALU instructions per 16 entries against 30 matrix instructions), so the loop
 // is software-pipelined inside the wave: while the pieces of group j feed the matrix cores, the rows of group j+1 are weighted and
 // cut and the rows of group j+2 are on their way (`fused`); at T >= 3 that takes the 512-register file: ONE wave per SIMD, which
@@ -2421,10 +2405,10 @@ class AlsHandle : public HandleBase {
             int blocks = (items + 3) / 4;                           // 4 independent waves per block, one work item each
             if (blocks > num_cus_ * 4) blocks = num_cus_ * 4;       // persistent: residency is set by the kernel's VGPR count
             if (items > 0 && inreg && split_f16_ && T >= 2) {   // the scale of the split pass, decided on the device (no host round trip)
-                if (split_out_.size() < 4) { split_part_.resize(3 * ALS_STAT_BLOCKS); split_out_.resize(4); }
-                hipLaunchKernelGGL(als_split_stats_kernel, dim3(ALS_STAT_BLOCKS), dim3(256), 0, stream, p.Q, static_cast<size_t>(p.op_rows) * vdim_, p.vals,
-                                   static_cast<size_t>(n), alpha_, split_part_.get());
-                hipLaunchKernelGGL(als_split_scale_kernel, dim3(1), dim3(64), 0, stream, split_part_.get(), ALS_STAT_BLOCKS, split_out_.get());
+                if (split_out_.size() < 4) { split_part_.resize(ALS_STAT_BLOCKS); split_out_.resize(4); }
+                hipLaunchKernelGGL(als_split_stats_kernel, dim3(ALS_STAT_BLOCKS), dim3(256), 0, stream, p.Q, static_cast<size_t>(p.op_rows) * vdim_,
+                                   split_part_.get());
+                hipLaunchKernelGGL(als_split_scale_kernel, dim3(1), dim3(64), 0, stream, split_part_.get(), ALS_STAT_BLOCKS, split_wcut_, split_out_.get());
                 BFH_HIP(hipGetLastError());
                 p.split = split_out_.get();
                 {   // FF p0 for every row of the call
@@ -2679,6 +2663,7 @@ class AlsHandle : public HandleBase {
         else if (name == "pin_host") pin_host_ = v != 0;
         else if (name == "als_v1") force_v1_ = v != 0;
         else if (name == "als_debug") debug_ = static_cast<int>(v);
+        else if (name == "als_split_wcut") split_wcut_ = static_cast<float>(v);   // weights above this take the fp32 side path (default 2^15; tests lower it)
         else if (name == "als_split_f16") split_f16_ = v != 0;             // 0: the in-place iALS++ rows keep the fp32 matrix instruction
         else if (name == "als_inreg") no_inreg_ = v == 0;                 // 0: iALS++ rows go through the scratch + solve kernel instead of the in-register solve
         else if (name == "timing") timing = v != 0;
@@ -2724,7 +2709,8 @@ class AlsHandle : public HandleBase {
     int debug_ = 0;
     bool no_inreg_ = false;
     bool split_f16_ = true;
-    DevBuf<double> split_part_;
+    float split_wcut_ = 32768.0f;
+    DevBuf<float> split_part_;
     DevBuf<float> split_out_;
     DevBuf<float> rowff_;
     DevBuf<float> gscratch_;
