@@ -182,6 +182,9 @@ def extra_als(csr, seed, epochs=5, cpu=True):
                     "instruction": "v_mfma_f32_32x32x16_f16, three per tile and 16 entries (split-f16 pass; fp32 accuracy)",
                     "issued_flop_per_epoch": mfma_flop,
                     "gramian_TFLOPs": gram_flop / kernel_s / 1e12,
+                    # what a block-diagonal formulation would need, 4 nnz d bs + 2 (U + I) d^2 -- the "useful" flops
+                    "useful_flop_per_epoch": 4 * nnz * D * 32 + 2 * (U + I) * D * D,
+                    "useful_frac_of_fp32_peak": (4 * nnz * D * 32 + 2 * (U + I) * D * D) / kernel_s / 1e12 / MFMA_F32_PEAK_TF,
                     "note": "the pass is VALU / latency bound at one wave per SIMD, not matrix-core bound: the same Gramian through "
                             "v_mfma_f32_32x32x2_f32 (als_split_f16=0) needs %.1f ms of matrix-core time alone at its %.0f TFLOP/s peak"
                             % (gram_flop / MFMA_F32_PEAK_TF / 1e9, MFMA_F32_PEAK_TF)},
