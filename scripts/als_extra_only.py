@@ -1,0 +1,7 @@
+import json, sys
+sys.path.insert(0, '.')
+import bench
+csr = bench.load_matrix("ml20m", 7)
+out = bench.extra_als(csr, 7, epochs=3, cpu=False)
+print(json.dumps(out["mfma"]))
+print(out["epoch_ms"], out["kernel_ms_per_epoch"])
