@@ -112,10 +112,13 @@ def cpu_baseline(csr, target_seconds=12.0):
     nnz_p, dt_p = run(probe_users, workers=8)
     want8 = int(min(csr.nnz, max(nnz_p, nnz_p / dt_p * 6.0)))
     nnz8, dt8 = run(min(csr.num_users, int(np.searchsorted(csr.indptr, want8)) + 1), workers=8)
-    return {"value": nnz1 / dt1, "unit": "updates/s", "cores": cores, "kind": CPU_KIND, "what": CPU_WHAT,
-            "sample": "first %d users (%d interactions, 1 epoch) of the same matrix, %d std::thread workers, %.1f s"
-                      % (n_users, nnz1, cores, dt1),
-            "value_8_workers": nnz8 / dt8, "sample_8_workers": "%d interactions, 8 workers, %.1f s" % (nnz8, dt8)}
+    # the headline figure is the 8-worker one -- the reference's own benchmark setting, and the faster of the two (its job queue
+    # is contended: all cores are SLOWER); the all-core run is kept beside it
+    return {"value": nnz8 / dt8, "unit": "updates/s", "cores": 8, "kind": CPU_KIND, "what": CPU_WHAT,
+            "sample": "first %d interactions (1 epoch) of the same matrix, 8 std::thread workers (the reference's benchmark setting, "
+                      "tests/algo/test_performance.py:53), %.1f s" % (nnz8, dt8),
+            "value_all_cores": nnz1 / dt1, "all_cores": cores,
+            "sample_all_cores": "first %d users (%d interactions, 1 epoch), %d workers, %.1f s" % (n_users, nnz1, cores, dt1)}
 
 
 ALS_OPT = {  # ALSOption defaults (/root/reference/buffalo/algo/options.py:66-86) at d=128 (=> iALS++, Q-13)
@@ -290,15 +293,19 @@ def _warp_cpu_baseline(indptr, keys, I, d, seed, start_entries=200000, seconds=6
                       % (m1, m1 / nnz, cores, d1)}
 
 
-def _warp_epochs(g, U, indptr, nnz, d, I, epochs):
+def _warp_epochs(g, U, indptr, nnz, d, I, epochs, until_T=None, max_epochs=None):
+    """`epochs` epochs; with `until_T`, further ones (at most `max_epochs` in all) until the trial loop scores that many negatives
+    per positive -- the regime training lives in, not the first epochs' T = 1 where every first draw violates the margin."""
     eps = []
-    for e in range(epochs):
+    e = 0
+    while e < epochs or (until_T is not None and e < (max_epochs or epochs) and eps[-1]["mean_scored_negatives_T"] < until_T):
         g.reset_stats()
         t0 = time.perf_counter()
         g.add_jobs(0, U, indptr, None)
         g.update_parameters()
         dt = time.perf_counter() - t0
         eps.append(warp_epoch_row(g.stats(), nnz, d, U, I, dt))
+        e += 1
     return eps
 
 
@@ -397,7 +404,7 @@ def extra_warp_c5(seed, epochs=6, cpu=True):
     g.initialize_model(P, Q, Qb, nnz, True)
     g.set_resident_csr(indptr, keys)
     up_s = time.perf_counter() - t0
-    eps = _warp_epochs(g, U, indptr, nnz, d, I, epochs)
+    eps = _warp_epochs(g, U, indptr, nnz, d, I, epochs, until_T=3.0, max_epochs=18)
     out = _warp_summary(eps, {
         "config": "WARP adagrad, dot score, max_trials 500, configs[4]-shaped synthetic (%d x %d, %d nnz), d=%d, f32, ONE GPU, everything "
                   "resident in HBM" % (U, I, nnz, d),
@@ -807,6 +814,37 @@ def main():
                 except Exception as e:   # the headline line is never lost to a secondary measurement
                     extra[name] = {"error": "%s: %s" % (type(e).__name__, e)}
             out["extra"] = extra
+            # the driver's record keeps the scalars of `roofline` / `cpu_baseline` and drops nested objects: configs[2] (ALS) and
+            # configs[4] (WARP) at BASELINE size, measured in this process, as flat keys
+            rf = out["roofline"]
+            ms = rf.get("measured_stream") or {}
+            if "triad_GBps" in ms:
+                rf["triad_GBps"], rf["frac_of_triad"] = ms["triad_GBps"], ms.get("frac_of_triad")
+            a = extra.get("als_ml20m_d128") or {}
+            if "epoch_ms" in a:
+                rf.update({"als_epoch_ms": a["epoch_ms"], "als_kernel_ms": a["kernel_ms_per_epoch"], "als_hbm_frac": a["hbm"]["frac"],
+                           "als_hbm_frac_of_epoch": a["hbm"]["algorithmic_bytes_per_epoch"] / (a["epoch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "als_useful_mfma_frac": a["mfma"]["useful_frac_of_fp32_peak"], "als_issued_mfma_frac_f16": a["mfma"]["frac"]})
+            w = extra.get("warp_ml20m_d256") or {}
+            if "epoch_ms" in w:
+                rf.update({"warp_ml20m_epoch_ms": w["epoch_ms"], "warp_ml20m_T": w["mean_scored_negatives_T"],
+                           "warp_ml20m_implemented_model_frac": w["implemented_model_frac"]})
+            c5 = extra.get("warp_c5_one_gpu") or {}
+            if "epoch_ms" in c5:
+                last = c5["epochs"][-1]
+                rf.update({"warp_c5_epoch_ms": c5["epoch_ms"], "warp_c5_T": c5["mean_scored_negatives_T"], "warp_c5_accepted_frac": last["accepted_frac"],
+                           "warp_c5_epochs_run": len(c5["epochs"]), "warp_c5_implemented_model_frac": c5["implemented_model_frac"],
+                           "warp_c5_sort_and_gather_ms": last["sort_and_gather_ms"], "warp_c5_trial_kernel_ms": last["trial_kernel_ms"]})
+                tr = c5.get("counter_traffic") or {}
+                if isinstance(tr, dict) and tr.get("hbm_bytes_per_epoch"):
+                    dev_ms = last["trial_kernel_ms"] + last["sort_and_gather_ms"] + last["optimizer_ms"]
+                    rf["warp_c5_traffic_frac"] = tr["hbm_bytes_per_epoch"] / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                    rf["warp_c5_traffic_source"] = "profiles/warp_pmc_latest.json (counter bytes of an earlier run of this workload) over this run's device time"
+            cb = out.get("cpu_baseline") or {}
+            for name, key in (("als_ml20m_d128", "als"), ("warp_ml20m_d256", "warp_ml20m"), ("warp_c5_one_gpu", "warp_c5")):
+                v = (extra.get(name) or {}).get("cpu_baseline") or {}
+                if "value" in v and cb:
+                    cb["%s_value" % key], cb["%s_unit" % key] = v["value"], v["unit"]
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.all_reduce(torch.zeros(1))

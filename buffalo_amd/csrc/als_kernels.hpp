@@ -2162,10 +2162,15 @@ __global__ __launch_bounds__(256) void als_solve_kernel(AlsParams p, const AlsHe
     }
 }
 
+}  // namespace bfh
+#include "als_pc.hpp"
+namespace bfh {
+
 // ------------------------------------------------------------------------------------------------
 #ifndef BFH_ALS_KERNELS_ONLY   // scripts/als_asm_stats.sh compiles single kernels out of this header
 class AlsHandle : public HandleBase {
  public:
+    struct WorkList;
     ~AlsHandle() override {
         unpin_host();
         if (stream) (void)hipStreamDestroy(stream);
@@ -2230,6 +2235,7 @@ class AlsHandle : public HandleBase {
         BFH_HIP(hipMemcpyAsync(Q_.get(), Q, nq * sizeof(float), hipMemcpyHostToDevice, stream));
         stats.h2d_bytes += static_cast<double>((np + nq) * sizeof(float));
         BFH_HIP(hipStreamSynchronize(stream));
+        ++fver_[0]; ++fver_[1];
         model_ = true;
     }
 
@@ -2271,6 +2277,7 @@ class AlsHandle : public HandleBase {
         if (yui_.size() < static_cast<size_t>(nnz)) yui_.resize(static_cast<size_t>(nnz));
         BFH_HIP(hipStreamSynchronize(stream));
         work_cache_.clear();
+        ++vals_ver_;
         A.resident = true;
     }
 
@@ -2360,6 +2367,7 @@ class AlsHandle : public HandleBase {
                     BFH_HIP(hipMemcpyAsync(A.keys.get() + beg, keys, n * sizeof(int32_t), hipMemcpyHostToDevice, stream));
                     BFH_HIP(hipMemcpyAsync(A.vals.get() + beg, vals, n * sizeof(float), hipMemcpyHostToDevice, stream));
                     stats.h2d_bytes += static_cast<double>(n * 8);
+                    ++vals_ver_;
                 }
                 A.chunks[{start_x, next_x}] = {n, sig};
             }
@@ -2374,6 +2382,7 @@ class AlsHandle : public HandleBase {
                 BFH_HIP(hipMemcpyAsync(vals_.get(), vals, n * sizeof(float), hipMemcpyHostToDevice, stream));
                 stats.h2d_bytes += static_cast<double>(n * 8);
             }
+            ++vals_ver_;
             p.keys = keys_.get();
             p.vals = vals_.get();
             p.yui = yui_.get();
@@ -2386,7 +2395,8 @@ class AlsHandle : public HandleBase {
         const bool big = static_cast<uint64_t>(p.op_rows) * vdim_ * 4 >= (1ull << 32);   // 64-bit gather offsets into the other factor
         // 128 < vdim <= 256: block-per-row kernel with the tiles spread over ceil(T/2) waves (als_wide_kernel)
         const bool wide_path = !gram_path && !force_v1_ && vdim_ > 128 && vdim_ <= 256 && code_ == 8 && block_size_ == 32 && d_ == vdim_;
-        const WorkList* wl = nullptr;
+        WorkList* wl = nullptr;
+        bool pc_launched = false;
         if (gram_path || wide_path) {
             wl = &work_list(axis, start_x, next_x, ip, beg);
             if (wl->n_heavy) BFH_HIP(hipMemsetAsync(scratch_.get(), 0, static_cast<size_t>(wl->n_heavy) * als_slot_floats(vdim_) * sizeof(float), stream));
@@ -2396,7 +2406,7 @@ class AlsHandle : public HandleBase {
             // wave-per-row Gramian pass; rows are solved from the accumulators (iALS++, block_size 32, d == vdim) or
             // go through an HBM scratch slot to the dense-solve kernel (see als_gram_kernel)
             const int T = vdim_ / 32;
-            const bool inreg = code_ == 8 && block_size_ == 32 && d_ == vdim_ && !no_inreg_;
+            bool inreg = code_ == 8 && block_size_ == 32 && d_ == vdim_ && !no_inreg_;
             const size_t per_row = als_slot_floats(vdim_);
             const size_t lds_h = als_gs_lds_bytes(vdim_);
             BFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(als_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2404,12 +2414,40 @@ class AlsHandle : public HandleBase {
             const int items = wl->n_work;
             int blocks = (items + 3) / 4;                           // 4 independent waves per block, one work item each
             if (blocks > num_cus_ * 4) blocks = num_cus_ * 4;       // persistent: residency is set by the kernel's VGPR count
+            // producer / consumer pairs (als_pc.hpp): the default for the in-place iALS++ rows at d = 64 / 96 / 128
+            bool use_pc = items > 0 && inreg && split_f16_ && pc_ && T >= 2 && T <= 4;
+            if (use_pc) {
+                scan_deferred(*wl, p, items);
+                if (wl->n_def_rows > 4096 || wl->n_def * 4 > items) {
+                    // weights mostly outside the f16 path (negative confidences, ...): every row of the call takes the route the flagged
+                    // ones would take -- fp32 instruction, scratch slot, dense-solve kernel (the branch below)
+                    use_pc = false;
+                    inreg = false;
+                }
+            }
             if (items > 0 && inreg && split_f16_ && T >= 2) {   // the scale of the split pass, decided on the device (no host round trip)
+                const int oside = axis == 0 ? 1 : 0;   // which factor is "the other side"
                 if (split_out_.size() < 4) { split_part_.resize(ALS_STAT_BLOCKS); split_out_.resize(4); }
-                hipLaunchKernelGGL(als_split_stats_kernel, dim3(ALS_STAT_BLOCKS), dim3(256), 0, stream, p.Q, static_cast<size_t>(p.op_rows) * vdim_,
-                                   split_part_.get());
-                hipLaunchKernelGGL(als_split_scale_kernel, dim3(1), dim3(64), 0, stream, split_part_.get(), ALS_STAT_BLOCKS, split_wcut_, split_out_.get());
-                BFH_HIP(hipGetLastError());
+                if (use_pc) {
+                    // ... together with the block-interleaved copy of the other factor the producers gather from; both are kept while that
+                    // factor does not change (the chunks of one half-epoch share them)
+                    const size_t nq = static_cast<size_t>(p.op_rows) * vdim_;
+                    if (qi_.size() < nq) { qi_.resize(nq); qi_side_ = -1; }
+                    if (qi_side_ != oside || qi_ver_ != fver_[oside] || qi_wcut_ != split_wcut_) {
+                        if (T == 2) hipLaunchKernelGGL(als_interleave_stats_kernel<2>, dim3(ALS_STAT_BLOCKS), dim3(256), 0, stream, p.Q, static_cast<size_t>(p.op_rows), qi_.get(), split_part_.get());
+                        else if (T == 3) hipLaunchKernelGGL(als_interleave_stats_kernel<3>, dim3(ALS_STAT_BLOCKS), dim3(256), 0, stream, p.Q, static_cast<size_t>(p.op_rows), qi_.get(), split_part_.get());
+                        else hipLaunchKernelGGL(als_interleave_stats_kernel<4>, dim3(ALS_STAT_BLOCKS), dim3(256), 0, stream, p.Q, static_cast<size_t>(p.op_rows), qi_.get(), split_part_.get());
+                        hipLaunchKernelGGL(als_split_scale_kernel, dim3(1), dim3(64), 0, stream, split_part_.get(), ALS_STAT_BLOCKS, split_wcut_, split_out_.get());
+                        BFH_HIP(hipGetLastError());
+                        qi_side_ = oside; qi_ver_ = fver_[oside]; qi_wcut_ = split_wcut_;
+                    }
+                } else {
+                    hipLaunchKernelGGL(als_split_stats_kernel, dim3(ALS_STAT_BLOCKS), dim3(256), 0, stream, p.Q, static_cast<size_t>(p.op_rows) * vdim_,
+                                       split_part_.get());
+                    hipLaunchKernelGGL(als_split_scale_kernel, dim3(1), dim3(64), 0, stream, split_part_.get(), ALS_STAT_BLOCKS, split_wcut_, split_out_.get());
+                    BFH_HIP(hipGetLastError());
+                    qi_side_ = -1;   // split_out_ was rewritten for another matrix
+                }
                 p.split = split_out_.get();
                 {   // FF p0 for every row of the call
                     const size_t need0 = static_cast<size_t>(nrows) * vdim_;
@@ -2422,8 +2460,57 @@ class AlsHandle : public HandleBase {
                     BFH_HIP(hipGetLastError());
                     p.F0 = rowff_.get();
                 }
-                p.batch = 16;   // rows per ticket at most (als_gram_kernel: fewer where the rows are long)
+                p.batch = 16;   // rows per ticket at most (fewer where the rows are long)
             }
+            if (use_pc) {
+                if (pc_err_.size() < 2) pc_err_.resize(2);
+                BFH_HIP(hipMemsetAsync(pc_err_.get(), 0, 2 * sizeof(int), stream));
+                const int nslots = wl->n_heavy + wl->n_def_rows;
+                if (wl->n_def_rows)   // (the heavy rows' slots were zeroed above)
+                    BFH_HIP(hipMemsetAsync(scratch_.get() + static_cast<size_t>(wl->n_heavy) * per_row, 0, static_cast<size_t>(wl->n_def_rows) * per_row * sizeof(float), stream));
+                (void)nslots;
+                const int pblocks = std::max(1, std::min((items + 3) / 4, num_cus_));
+                const bool lk = compute_loss_ && axis == 1;
+#define BFH_PC(TT, BG, LS)                                                                                                          \
+    do {                                                                                                                            \
+        BFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(als_pc_kernel<TT, BG, LS>), hipFuncAttributeMaxDynamicSharedMemorySize, AlsPc<TT>::LDS_B)); \
+        hipLaunchKernelGGL((als_pc_kernel<TT, BG, LS>), dim3(pblocks), dim3(512), AlsPc<TT>::LDS_B, stream, p, wl->work.get(), items, scratch_.get(), \
+                           qi_.get(), wl->defer.get(), pc_err_.get());                                                              \
+    } while (0)
+#define BFH_PC_T(TT)                                 \
+    do {                                             \
+        if (big) { if (lk) BFH_PC(TT, true, true); else BFH_PC(TT, true, false); }     \
+        else { if (lk) BFH_PC(TT, false, true); else BFH_PC(TT, false, false); }       \
+    } while (0)
+                if (T == 2) BFH_PC_T(2);
+                else if (T == 3) BFH_PC_T(3);
+                else BFH_PC_T(4);
+#undef BFH_PC_T
+#undef BFH_PC
+                BFH_HIP(hipGetLastError());
+                pc_launched = true;
+                if (wl->n_def > 0) {   // items with weights outside the f16 path: fp32 instruction, tiles into their scratch slots
+                    BFH_HIP(hipMemsetAsync(ticket_.get(), 0, sizeof(int), stream));
+                    const int dblocks = std::max(1, std::min((wl->n_def + 3) / 4, num_cus_ * 4));
+#define BFH_GD(TT)                                                                                                                  \
+    do {                                                                                                                            \
+        if (big) hipLaunchKernelGGL((als_gram_kernel<TT, true, false, true>), dim3(dblocks), dim3(256), 0, stream, p, wl->dlist.get(), wl->n_def, scratch_.get(), 0); \
+        else hipLaunchKernelGGL((als_gram_kernel<TT, true, false, false>), dim3(dblocks), dim3(256), 0, stream, p, wl->dlist.get(), wl->n_def, scratch_.get(), 0);   \
+    } while (0)
+                    if (T == 2) BFH_GD(2);
+                    else if (T == 3) BFH_GD(3);
+                    else BFH_GD(4);
+#undef BFH_GD
+                    BFH_HIP(hipGetLastError());
+                }
+                if (wl->n_heavy)
+                    hipLaunchKernelGGL(als_solve_kernel, dim3(wl->n_heavy), dim3(256), lds_h, stream, p, wl->heavy.get(), wl->n_heavy, scratch_.get(),
+                                       static_cast<int>(code_));
+                if (wl->n_def_rows)
+                    hipLaunchKernelGGL(als_solve_kernel, dim3(wl->n_def_rows), dim3(256), lds_h, stream, p, wl->dsolve.get(), wl->n_def_rows, scratch_.get(),
+                                       static_cast<int>(code_));
+                BFH_HIP(hipGetLastError());
+            } else
             if (items > 0 && inreg) {
 #define BFH_GK(TT, SP)                                                                                                              \
     do {                                                                                                                            \
@@ -2526,12 +2613,49 @@ class AlsHandle : public HandleBase {
             BFH_HIP(hipMemcpyAsync(hostF + off, p.P + off, cnt * sizeof(float), hipMemcpyDeviceToHost, stream));
             stats.d2h_bytes += static_cast<double>(cnt * sizeof(float));
         }
+        int pe[2] = {0, 0};
+        if (pc_launched) BFH_HIP(hipMemcpyAsync(pe, pc_err_.get(), 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
         BFH_HIP(hipStreamSynchronize(stream));
+        ++fver_[axis];   // the side just solved changed
         stats.kernel_ms += t_main_.drain();
         stats.launches += 1;
         stats.samples += n;
+        if (pc_launched) {
+            pc_same_simd_ = pe[1];
+            if (pe[0] & 1) throw Error(BFH_ERR_HIP, "als_pc_kernel: a producer / consumer hand-off timed out (results of this call are invalid)");
+            if (pe[0] & 2) throw Error(BFH_ERR_HIP, "als_pc_kernel: a weight outside the f16 path reached the kernel (stale weight scan)");
+        }
         *nume = l[0];
         *deno = l[1];
+    }
+
+    // Which work items hold weights the split pass cannot carry (als_defer_scan_kernel)?  Depends on the chunk's values only, so it is
+    // kept with the work list and redone when values were uploaded since (or the cut moved); the one host round trip it costs buys
+    // launch shapes the host knows.
+    void scan_deferred(WorkList& wl, const AlsParams& p, int items) {
+        if (wl.scan_ver == vals_ver_ && wl.scan_wcut == split_wcut_ && wl.scan_vals == p.vals) return;
+        if (wl.defer.size() < static_cast<size_t>(items)) {
+            wl.defer.resize(items);
+            wl.dlist.resize(items);
+            wl.dsolve.resize(items);
+            wl.dcount.resize(2);
+        }
+        BFH_HIP(hipMemsetAsync(wl.dcount.get(), 0, 2 * sizeof(int), stream));
+        hipLaunchKernelGGL(als_defer_scan_kernel, dim3((items + 3) / 4), dim3(256), 0, stream, wl.work.get(), items, p.vals, p.alpha, split_wcut_, wl.n_heavy,
+                           wl.defer.get(), wl.dlist.get(), wl.dsolve.get(), wl.dcount.get());
+        BFH_HIP(hipGetLastError());
+        int c[2] = {0, 0};
+        BFH_HIP(hipMemcpyAsync(c, wl.dcount.get(), 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
+        BFH_HIP(hipStreamSynchronize(stream));
+        wl.n_def = c[0];
+        wl.n_def_rows = c[1];
+        wl.scan_ver = vals_ver_;
+        wl.scan_wcut = split_wcut_;
+        wl.scan_vals = p.vals;
+        const size_t need = std::max<size_t>(1, static_cast<size_t>(wl.n_heavy) + (wl.n_def_rows <= 4096 ? wl.n_def_rows : 0)) * als_slot_floats(vdim_);
+        if (scratch_.size() < need) {   // (grow-only; the heavy rows' slots are zeroed by the caller before every use)
+            scratch_.resize(need);
+        }
     }
 
     struct WorkList {
@@ -2540,10 +2664,19 @@ class AlsHandle : public HandleBase {
         DevBuf<AlsHeavy> solve;   // split design: every non-empty row, longest first (slot = row - start_x)
         DevBuf<AlsWork> heavy_work;   // wide kernel's finalize launch: one item per heavy row (kend - kbeg = its nnz)
         int n_work = 0, n_heavy = 0, n_solve = 0;
+        // als_pc_kernel: items whose weights need the fp32 instruction (scan_deferred)
+        DevBuf<int> defer;             // per work item
+        DevBuf<AlsWork> dlist;         // the flagged items (whole rows with their scratch slot = n_heavy + j)
+        DevBuf<AlsHeavy> dsolve;       // the flagged whole rows, for als_solve_kernel
+        DevBuf<int> dcount;
+        int n_def = 0, n_def_rows = 0;
+        uint64_t scan_ver = ~uint64_t(0);
+        float scan_wcut = -1.f;
+        const float* scan_vals = nullptr;
     };
     // Work items of one partial_update call: one per non-empty row, rows above HEAVY nnz cut into
     // chunks; longest first (dynamic ticket order) so the tail is short.  Cached per (axis, range).
-    const WorkList& work_list(int axis, int start_x, int next_x, const int64_t* ip, int64_t shift) {
+    WorkList& work_list(int axis, int start_x, int next_x, const int64_t* ip, int64_t shift) {
         const auto key = std::make_tuple(axis, start_x, next_x);
         auto it = work_cache_.find(key);
         if (it != work_cache_.end()) return *it->second;
@@ -2626,6 +2759,7 @@ class AlsHandle : public HandleBase {
             BFH_HIP(hipMemcpyAsync(P_.get(), hostP_, np * sizeof(float), hipMemcpyHostToDevice, stream));
             BFH_HIP(hipMemcpyAsync(Q_.get(), hostQ_, nq * sizeof(float), hipMemcpyHostToDevice, stream));
             stats.h2d_bytes += static_cast<double>((np + nq) * sizeof(float));
+            ++fver_[0]; ++fver_[1];
         }
         BFH_HIP(hipStreamSynchronize(stream));
     }
@@ -2650,6 +2784,7 @@ class AlsHandle : public HandleBase {
         }
         comm_->group_end();
         BFH_HIP(hipStreamSynchronize(stream));
+        ++fver_[axis];
         stats.exchanges += 1;
     }
     void set_comm(Comm* c) {
@@ -2665,12 +2800,15 @@ class AlsHandle : public HandleBase {
         else if (name == "als_debug") debug_ = static_cast<int>(v);
         else if (name == "als_split_wcut") split_wcut_ = static_cast<float>(v);   // weights above this take the fp32 side path (default 2^15; tests lower it)
         else if (name == "als_split_f16") split_f16_ = v != 0;             // 0: the in-place iALS++ rows keep the fp32 matrix instruction
+        else if (name == "als_pc") pc_ = v != 0;                           // 0: the wave-per-row split kernel (round 3) instead of the producer / consumer pairs
         else if (name == "als_inreg") no_inreg_ = v == 0;                 // 0: iALS++ rows go through the scratch + solve kernel instead of the in-register solve
         else if (name == "timing") timing = v != 0;
         else throw Error(BFH_ERR_INVALID, "unknown mode '" + name + "'");
     }
 
     void device_buffer(const std::string& name, void** p, size_t* bytes) {
+        ++fver_[0]; ++fver_[1];   // whoever holds a raw pointer may write through it: cached views of the factors are dropped
+        if (name == "als_pc_same_simd") { *p = nullptr; *bytes = static_cast<size_t>(pc_same_simd_); return; }   // placement statistic of the last als_pc_kernel launch
         if (name == "P") { *p = P_.get(); *bytes = P_.bytes(); }
         else if (name == "Q") { *p = Q_.get(); *bytes = Q_.bytes(); }
         else if (name == "FF") { *p = FF_.get(); *bytes = FF_.bytes(); }
@@ -2709,7 +2847,16 @@ class AlsHandle : public HandleBase {
     int debug_ = 0;
     bool no_inreg_ = false;
     bool split_f16_ = true;
+    bool pc_ = true;
     float split_wcut_ = 32768.0f;
+    uint64_t fver_[2] = {1, 1};     // bumped whenever P (0) / Q (1) may have changed on the device
+    uint64_t vals_ver_ = 1;         // bumped whenever confidence values were uploaded
+    DevBuf<float> qi_;              // block-interleaved copy of the other factor (als_interleave_stats_kernel)
+    int qi_side_ = -1;
+    uint64_t qi_ver_ = 0;
+    float qi_wcut_ = -1.f;
+    DevBuf<int> pc_err_;
+    int pc_same_simd_ = 0;
     DevBuf<float> split_part_;
     DevBuf<float> split_out_;
     DevBuf<float> rowff_;

@@ -1,0 +1,659 @@
+// als_pc_kernel -- the in-place iALS++ row update (als.cc:211-358, block_size 32, d = 64 / 96 / 128) as PRODUCER / CONSUMER wave
+// pairs.  Included by als_kernels.hpp (needs als_ialspp_inreg, als_tile_row / als_tile_col, AlsParams, AlsWork).
+//
+// Why.  The split-f16 Gramian pass of als_gram_kernel<SPLIT> holds two sets of rows and pieces next to 160 accumulator registers:
+// 512 registers, ONE wave per SIMD, and a lone wave pays every dependent chain in full (profiles/r03_als_split_counters.txt: 47 %
+// of its cycles issue VALU, 32 % wait on memory, the matrix pipe is busy 22-32 %; the per-row block solve, ~8 k cycles of
+// latency-bound reductions, idles both pipes).  Here every SIMD of a CU carries TWO waves of 256 registers with complementary jobs:
+//   * the PRODUCER streams the work list: keys -> gather of the other side's rows (two groups of 16 entries in flight ahead of
+//     the one being prepared, across row boundaries) -> per-entry residual q.p0 - 1 and h = sum alpha v (q.p0 - 1) q
+//     (als.cc:292-296) -> x = S sqrt(alpha v) q cut into two f16 pieces (v_fma_mixlo/hi_f16: 4 instructions per pair of
+//     elements incl. the scaling) -> an 8 KB slot of a 3-deep LDS ring.  No matrix instruction, no accumulator.
+//   * the CONSUMER owns the accumulators: per group 8 ds_read_b128 + 3 T(T+1)/2 v_mfma_f32_32x32x16_f16, and at the end of a row the
+//     block recurrence from the registers (als_ialspp_inreg, unchanged).  While it solves, its producer fills the ring with the
+//     next row; while the producer waits on HBM, the matrix pipe runs.
+// The two waves of a pair talk through LDS only (sequence counters polled with s_sleep; every spin is bounded and raises an error
+// flag the host turns into an exception).  Roles are dealt from HW_REG_HW_ID's SIMD id so that each SIMD gets one of each; any
+// other placement is still correct.
+//
+// Operand layout (als_gram_kernel<SPLIT>'s): lane (half, col) works on the entries 16 g + 8 half + r, r = 0..7, of group g and on
+// the elements [32 b + col], b = 0..T-1 of their rows.  The rows are read from a block-interleaved copy of the other factor
+// (als_interleave_stats_kernel: position T col + b holds element 32 b + col), so a lane's T elements are ONE 4T-byte load and a
+// half-wave reads one contiguous row.
+//
+// Entries the f16 pieces cannot carry (weight alpha v negative, or above the cut) never reach this kernel: a scan of the weights
+// (als_defer_scan_kernel, cached per chunk) routes their rows through the fp32 instruction + the dense-solve kernel.
+#pragma once
+
+namespace bfh {
+
+template <int T>
+struct AlsPc {
+    static constexpr int NT = T * (T + 1) / 2;
+    static constexpr int VD = 32 * T;
+    static constexpr int NSLOT = 3;                        // ring depth per pair (groups of 16 entries)
+    static constexpr int NK = 3;                           // staged 64-entry key chunks per pair
+    static constexpr int SLOT_B = 2 * T * 1024;            // H[0..T-1] | L[0..T-1], each 64 lanes x 16 B
+    static constexpr int FF_B = NT * 4096;                 // the FF tiles in accumulator layout, scaled by S^2
+    static constexpr int KEY_B = NK * 3 * 64 * 4;          // (row id, weight, S sqrt(weight)) x 64 entries
+    static constexpr int BOX_B = 16 + 2 * VD * 4;          // row header (row, n, slot, -) | h | g1
+    static constexpr int VEC_B = (2 * VD + 64) * 4;        // the consumer's solve vectors: p | delta | 64 exchange floats
+    static constexpr int FLAG_B = 64;
+    static constexpr int PAIR_B = NSLOT * SLOT_B + KEY_B + 2 * BOX_B + VEC_B + FLAG_B;
+    static constexpr int ROLE_B = 64;
+    static constexpr int LDS_B = FF_B + 4 * PAIR_B + ROLE_B;
+    static_assert(LDS_B <= 160 * 1024, "one workgroup per CU: the layout has to fit the 160 KB of LDS");
+};
+// flag words of a pair (ints at the end of its LDS block)
+enum { PC_PROD = 0, PC_CONS = 1, PC_ROWS_PUB = 2, PC_ROWS_DONE = 3, PC_ROWS_FREE = 4, PC_ABORT = 5 };
+constexpr int PC_SPIN_LIMIT = 1 << 21;   // polls before a wait gives up (each >= ~100 cycles: tenths of a second)
+
+// Qi[row][T col + b] = Q[row][32 b + col]  and  part[block] = max |Q| over the block's share (the split pass's scale,
+// als_split_scale_kernel): one pass over the other factor per half-epoch
+template <int T>
+__global__ __launch_bounds__(256) void als_interleave_stats_kernel(const float* __restrict__ Q, size_t rows, float* __restrict__ Qi, float* __restrict__ part) {
+    __shared__ float smq[256];
+    float qm = 0.f;
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    const size_t total = rows * 32;
+    for (size_t e = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const size_t row = e >> 5;
+        const int col = static_cast<int>(e & 31);
+        const float* src = Q + row * (32 * T) + col;
+        float v[T];
+#pragma unroll
+        for (int b = 0; b < T; ++b) {
+            v[b] = src[32 * b];
+            qm = fmaxf(qm, fabsf(v[b]));
+        }
+        float* dst = Qi + row * (32 * T) + T * col;
+#pragma unroll
+        for (int b = 0; b < T; ++b) dst[b] = v[b];
+    }
+    smq[threadIdx.x] = qm;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (static_cast<int>(threadIdx.x) < st) smq[threadIdx.x] = fmaxf(smq[threadIdx.x], smq[threadIdx.x + st]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = smq[0];
+}
+
+// One wave per work item: does it hold a weight the f16 pieces cannot carry (negative: no square root; above the cut: S sqrt(w) q
+// could overflow; NaN)?  Such items are flagged (als_pc_kernel skips them) and listed for the fp32-instruction pass: whole rows get a
+// scratch slot behind the heavy rows' (slot = n_heavy + j) and an entry in the solve list, chunks of heavy rows keep their row's slot.
+// count[0] = listed items, count[1] = listed whole rows.
+__global__ __launch_bounds__(256) void als_defer_scan_kernel(const AlsWork* __restrict__ work, int n_items, const float* __restrict__ vals, float alpha,
+                                                             float wcut, int n_heavy, int* __restrict__ defer, AlsWork* __restrict__ dlist,
+                                                             AlsHeavy* __restrict__ dsolve, int* __restrict__ count) {
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (item >= n_items) return;
+    const AlsWork wk = work[item];
+    bool bad = false;
+    for (int k = wk.kbeg + lane; k < wk.kend; k += 64) {
+        const float w = alpha * vals[k];
+        bad = bad || (!(w > 0.f && w <= wcut) && w != 0.f);
+    }
+    const bool any = __builtin_amdgcn_ballot_w64(bad) != 0;
+    if (lane != 0) return;
+    defer[item] = any ? 1 : 0;
+    if (!any) return;
+    const int j = atomicAdd(count, 1);
+    AlsWork out = wk;
+    if (wk.slot < 0) {
+        const int r = atomicAdd(count + 1, 1);
+        out.slot = n_heavy + r;
+        dsolve[r] = AlsHeavy{wk.row, out.slot, static_cast<int64_t>(wk.kend - wk.kbeg)};
+    }
+    dlist[j] = out;
+}
+
+// ---- LDS hand-off between the two waves of a pair ----------------------------------------------------------------------------
+// All of a wave's DS instructions execute in issue order; the explicit lgkmcnt(0) before a counter store makes the data of the
+// slot / box visible before the counter is, and keeps the compiler from moving either across it.
+__device__ __forceinline__ void pc_publish(int* flag, int v) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// spin until *flag - v > 0; false = the pair gave up (timeout here or at the partner).  `seen` caches the last value read: the
+// counters only grow, so a wait the cached value already satisfies costs no LDS round trip
+__device__ __forceinline__ bool pc_wait_gt(int* flag, int v, int& seen, int* flg) {
+    if (seen - v > 0) return true;
+    for (int it = 0;; ++it) {
+        seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if (seen - v > 0) break;
+        if ((it & 63) == 63) {
+            const int ab = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flg + PC_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            if (ab != 0 || it > PC_SPIN_LIMIT) {   // (no global memory operation in here: the caller reports the time-out after its loop)
+                if (ab == 0) __hip_atomic_store(flg + PC_ABORT, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                return false;
+            }
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+    return true;
+}
+// after a wave's loops: a pair that gave up raises the kernel's error flag
+__device__ __forceinline__ void pc_report(int* flg, int* err, int lane) {
+    const int ab = __hip_atomic_load(flg + PC_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (ab != 0 && lane == 0) atomicOr(err, 1);
+}
+
+// a lane's T elements of an interleaved row: one load
+template <int T>
+__device__ __forceinline__ void pc_load_row(const char* __restrict__ ptr, float (&q)[T]) {
+    if constexpr (T == 4) {
+        const float4 v = *reinterpret_cast<const float4*>(ptr);
+        q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w;
+    } else if constexpr (T == 2) {
+        const float2 v = *reinterpret_cast<const float2*>(ptr);
+        q[0] = v.x; q[1] = v.y;
+    } else {
+        struct __attribute__((packed, aligned(4))) P3 { float a, b, c; };
+        const P3 v = *reinterpret_cast<const P3*>(ptr);
+        q[0] = v.a; q[1] = v.b; q[2] = v.c;
+    }
+}
+
+// (q0 s0, q1 s1) -> packed f16 pairs h (rounded to nearest) and l (the remainder q s - h, exact in the fused multiply-add, rounded
+// the same way): h + l carries the product to 2^-24.  v_fma_mix{lo,hi}_f16 take fp32 and f16 sources in one instruction.
+__device__ __forceinline__ void pc_split_pair(float q0, float s0, float q1, float s1, unsigned& h, unsigned& l) {
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(q0), "v"(s0));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(q1), "v"(s1));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l) : "v"(q0), "v"(s0), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(q1), "v"(s1), "v"(h));
+}
+
+struct PcCursor {   // where a pipeline stage stands in the pair's stream of groups (all wave-uniform)
+    int valid;
+    int row, kbeg, n, slot;   // the work item
+    int g, ng;                // group inside the item, groups of the item
+    int cseq;                 // running number of the 64-entry chunk that holds group g (key staging buffer = cseq % NK)
+    int rseq;                 // running number of the item (row box = rseq & 1)
+};
+
+// ---- producer ------------------------------------------------------------------------------------------------------------------
+template <int T, bool BIG, bool LOSS>
+__device__ __forceinline__ void als_pc_producer(const AlsParams& p, const AlsWork* __restrict__ work, int n_items, const float* __restrict__ Qi,
+                                                const int* __restrict__ defer, char* pl, int* err, int lane) {
+    using C = AlsPc<T>;
+    constexpr int VD = C::VD;
+    const int half = lane >> 5, col = lane & 31;
+    char* ring = pl;
+    int* ks = reinterpret_cast<int*>(pl + C::NSLOT * C::SLOT_B);
+    char* box = pl + C::NSLOT * C::SLOT_B + C::KEY_B;
+    int* flg = reinterpret_cast<int*>(pl + C::PAIR_B - C::FLAG_B);
+    const float sS = p.split[0], wcut = p.split[3];
+    const bool lossk = LOSS && p.compute_loss && p.axis == 1;
+    double nume_k = 0.0, deno_k = 0.0;
+    const char* qbase = reinterpret_cast<const char*>(Qi);
+    const unsigned lane_off = static_cast<unsigned>(col) * (4u * T);
+
+    // ---- the work list, drawn in batches (same-address atomics serialise at ~12 ns: one draw per row would cost 1.7 ms per half-epoch).
+    // The ticket of the NEXT batch is always under way while the current one [b_base, b_base + b_len) is worked through; the items
+    // themselves are wave-uniform reads (scalar loads: they do not count against the vector-memory counter the row loads are
+    // tracked with).
+    int b_base = 0, b_len = 0, b_pos = 0;
+    int tk_v = 0, tk_rows = 0;
+    auto draw = [&](int rows) {
+        tk_rows = rows;
+        if (lane == 0) tk_v = atomicAdd(p.ticket, rows);
+    };
+    auto rows_for = [&](int len) {
+        int fit = 1024 / (len > 0 ? len : 1);
+        fit = fit < 1 ? 1 : (fit > p.batch ? p.batch : fit);
+        return fit < 1 ? 1 : fit;
+    };
+    bool list_end = false;
+    draw(1);
+    // the next item that is not deferred; false at the end of the list
+    auto next_item = [&](int& row, int& kbeg, int& n, int& slot) -> bool {
+        for (;;) {
+            if (list_end) return false;
+            if (b_pos >= b_len) {
+                const int base = __builtin_amdgcn_readfirstlane(tk_v);
+                int len = n_items - base;
+                len = len < 0 ? 0 : (len > tk_rows ? tk_rows : len);
+                b_base = base; b_len = len; b_pos = 0;
+                if (len == 0) { list_end = true; return false; }
+                // the list is sorted longest first: nothing later is longer than the item at hand, so about 1024 entries per draw
+                draw(rows_for(work[base].kend - work[base].kbeg));
+            }
+            const int idx = b_base + b_pos++;
+            const AlsWork w = work[idx];
+            row = w.row; kbeg = w.kbeg; n = w.kend - w.kbeg; slot = w.slot;
+            if (!(defer && defer[idx])) return true;
+        }
+    };
+
+    // ---- key chunks: fetched one chunk ahead into (pk_c, pk_v), weighted and staged in LDS when stage A enters the chunk.
+    // The fetch is issued on EVERY step (for the chunk stage A will enter next -- the same one for up to four steps; clamped
+    // addresses instead of predication), like the row and p0 loads below: every path through a step then issues the same vector-memory
+    // operations in the same order, which is what keeps the compiler's s_waitcnt counts exact instead of vmcnt(0).
+    int pk_c = 0, pk_rseq = -1, pk_chunk = -1;
+    float pk_v = 0.f;
+    auto load_keys = [&](int kbeg, int n, int chunk, int rseq) {
+        int kk = chunk * 64 + lane;
+        kk = kk < n ? kk : n - 1;
+        kk = kk < 0 ? 0 : kk;
+        pk_c = p.keys[kbeg + kk];
+        pk_v = p.vals[kbeg + kk];
+        pk_rseq = rseq;
+        pk_chunk = chunk;
+    };
+
+    PcCursor A{}, A1{}, A2{};
+    int nx_valid = 0, nx_row = 0, nx_kbeg = 0, nx_n = 1, nx_slot = 0;
+    auto fetch_next = [&]() {
+        nx_valid = next_item(nx_row, nx_kbeg, nx_n, nx_slot) ? 1 : 0;
+        if (!nx_valid) { nx_row = 0; nx_kbeg = 0; nx_n = 1; nx_slot = -1; }
+    };
+    A.n = 1;
+    fetch_next();
+    if (nx_valid) {
+        A.valid = 1; A.row = nx_row; A.kbeg = nx_kbeg; A.n = nx_n; A.slot = nx_slot;
+        A.g = 0; A.ng = (nx_n + 15) >> 4; A.cseq = 0; A.rseq = 0;
+        fetch_next();
+    }
+    load_keys(A.kbeg, A.n, 0, 0);
+    auto advance = [&]() {   // stage A moves to the next group of the stream
+        if (!A.valid) return;
+        if (A.g + 1 < A.ng) {
+            ++A.g;
+            if ((A.g & 3) == 0) ++A.cseq;
+            return;
+        }
+        if (!nx_valid) { A.valid = 0; A.row = 0; A.kbeg = 0; A.n = 1; A.g = 0; return; }
+        A.row = nx_row; A.kbeg = nx_kbeg; A.n = nx_n; A.slot = nx_slot;
+        A.g = 0; A.ng = (nx_n + 15) >> 4; ++A.cseq; ++A.rseq;
+        fetch_next();
+    };
+
+    float raw[3][8][T];      // the rows of three groups: one being prepared, two on their way
+    float p0set[3][T];       // the row at entry (this lane's elements [32 b + col]) of the item a group opens
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) {
+#pragma unroll
+        for (int b = 0; b < T; ++b) {
+            p0set[s3][b] = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) raw[s3][r][b] = 0.f;
+        }
+    }
+    float p0cur[T], gpart[T], g1part[T];
+#pragma unroll
+    for (int b = 0; b < T; ++b) { p0cur[b] = 0.f; gpart[b] = 0.f; g1part[b] = 0.f; }
+    int gseq = 0;            // groups published
+    int rows_opened = 0;
+    int seen_cons = 0, seen_free = 0;
+    bool ok = true, bad_keys = false, bad_weight = false;
+
+    auto stage_a = [&](float (&rw)[8][T], float (&p0s)[T]) {
+        int* kb = ks + (A.cseq % C::NK) * 192;
+        const int chunk = A.g >> 2;
+        if (A.valid && (A.g & 3) == 0) {   // a new 64-entry chunk: weigh and stage its keys (fetched on the previous steps)
+            if (!(pk_rseq == A.rseq && pk_chunk == chunk)) bad_keys = true;   // (cannot happen: every chunk is fetched ahead)
+            const bool in = chunk * 64 + lane < A.n;
+            const float ww = in ? p.alpha * pk_v : 0.f;     // padding lanes: row 0 of the other factor with weight 0
+            const float ss = (ww > 0.f && ww <= wcut) ? sS * __builtin_amdgcn_sqrtf(ww) : 0.f;
+            if (lossk && in) {   // constant and denominator of the loss (als_gram_kernel's header)
+                const double w = static_cast<double>(ww);
+                deno_k += w;
+                nume_k += 1.0 + w;
+            }
+            if (ww != 0.f && ss == 0.f) bad_weight = true;   // a weight the scan should have routed elsewhere
+            kb[lane] = in ? pk_c : 0;
+            kb[64 + lane] = __builtin_bit_cast(int, ww);
+            kb[128 + lane] = __builtin_bit_cast(int, ss);
+            wave_lds_sync();
+        }
+        // the chunk stage A enters next: the following one of this item, else the first of the next item
+        if ((chunk + 1) * 64 < A.n) load_keys(A.kbeg, A.n, chunk + 1, A.rseq);
+        else load_keys(nx_kbeg, nx_n, 0, A.rseq + 1);
+        // The row at entry of stage A's item and the eight row loads, on every step (past the end of the list: row 0)
+        {
+            const float* Pu0 = p.P + static_cast<size_t>(A.row) * VD;
+#pragma unroll
+            for (int b = 0; b < T; ++b) p0s[b] = Pu0[b * 32 + col];
+        }
+        const int4 c0 = *reinterpret_cast<const int4*>(kb + 16 * (A.g & 3) + 8 * half);
+        const int4 c1 = *reinterpret_cast<const int4*>(kb + 16 * (A.g & 3) + 8 * half + 4);
+        const int keep = A.valid ? -1 : 0;
+        const int cid[8] = {c0.x & keep, c0.y & keep, c0.z & keep, c0.w & keep, c1.x & keep, c1.y & keep, c1.z & keep, c1.w & keep};
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            using off_t = typename std::conditional<BIG, size_t, unsigned>::type;
+            const off_t voff = static_cast<off_t>(static_cast<unsigned>(cid[r])) * (4u * VD) + lane_off;
+            pc_load_row<T>(qbase + voff, rw[r]);
+        }
+    };
+
+    // (The arithmetic of stage B runs on every step as well -- on row 0's data while the pipeline fills and drains -- and only the
+    // hand-off is conditional: a path that does not read the group's registers leaves their loads "pending" in the compiler's
+    // books, and the next load into them then waits for everything in flight.)
+    auto stage_b = [&](const PcCursor& Bc, float (&q)[8][T], const float (&p0s)[T]) {
+        const bool live = Bc.valid && ok;
+        char* bx = box + (Bc.rseq & 1) * C::BOX_B;
+        if (live && Bc.g == 0) {   // the item opens: its row at entry, fresh sums, the header for the consumer
+#pragma unroll
+            for (int b = 0; b < T; ++b) { p0cur[b] = p0s[b]; gpart[b] = 0.f; g1part[b] = 0.f; }
+            if (!pc_wait_gt(flg + PC_ROWS_FREE, Bc.rseq - 2, seen_free, flg)) { ok = false; return; }
+            if (lane == 0) *reinterpret_cast<int4*>(bx) = make_int4(Bc.row, Bc.n, Bc.slot, 0);
+            ++rows_opened;
+            pc_publish(flg + PC_ROWS_PUB, Bc.rseq + 1);
+        }
+        const int* kb = ks + (Bc.cseq % C::NK) * 192 + 16 * (Bc.g & 3) + 8 * half;
+        const float4 w0 = *reinterpret_cast<const float4*>(kb + 64), w1 = *reinterpret_cast<const float4*>(kb + 64 + 4);
+        const float4 s0 = *reinterpret_cast<const float4*>(kb + 128), s1 = *reinterpret_cast<const float4*>(kb + 128 + 4);
+        const float wgt[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+        const float sw[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        // als.cc:292-296: residual = Yui - 1 against the row at entry; laid out in stages over the eight entries so that the
+        // dependent chains run side by side
+        float y[8], yo[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            y[r] = q[r][0] * p0cur[0];
+#pragma unroll
+            for (int b = 1; b < T; ++b) y[r] = __builtin_fmaf(q[r][b], p0cur[b], y[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), 0x128, 0xf, 0xf, false));
+#pragma unroll
+        for (int r = 0; r < 8; ++r) y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), 0x124, 0xf, 0xf, false));
+#pragma unroll
+        for (int r = 0; r < 8; ++r) y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), 0x122, 0xf, 0xf, false));
+#pragma unroll
+        for (int r = 0; r < 8; ++r) y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), 0x121, 0xf, 0xf, false));
+#pragma unroll
+        for (int r = 0; r < 8; ++r) yo[r] = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, y[r]), 0x401F));
+        const int k0 = 16 * Bc.g + 8 * half;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const float cial = __builtin_fmaf(wgt[r], y[r] + yo[r], -wgt[r]);   // alpha v (q.p0 - 1)
+            const float one = (LOSS && lossk && k0 + r < Bc.n) ? 1.0f : 0.f;
+#pragma unroll
+            for (int b = 0; b < T; ++b) {
+                gpart[b] = __builtin_fmaf(cial, q[r][b], gpart[b]);
+                if (LOSS) g1part[b] = __builtin_fmaf(one, q[r][b], g1part[b]);
+            }
+        }
+        u32x4 H[T], L[T];
+#pragma unroll
+        for (int b = 0; b < T; ++b)
+#pragma unroll
+            for (int j2 = 0; j2 < 4; ++j2) {
+                unsigned h_, l_;
+                pc_split_pair(q[2 * j2][b], sw[2 * j2], q[2 * j2 + 1][b], sw[2 * j2 + 1], h_, l_);
+                H[b][j2] = h_;
+                L[b][j2] = l_;
+            }
+        if (!live) return;
+        if (!pc_wait_gt(flg + PC_CONS, gseq - C::NSLOT, seen_cons, flg)) { ok = false; return; }
+        char* sl = ring + (gseq % C::NSLOT) * C::SLOT_B + lane * 16;
+#pragma unroll
+        for (int b = 0; b < T; ++b) {
+            *reinterpret_cast<u32x4*>(sl + b * 1024) = H[b];
+            *reinterpret_cast<u32x4*>(sl + (T + b) * 1024) = L[b];
+        }
+        ++gseq;
+        pc_publish(flg + PC_PROD, gseq);
+        if (Bc.g == Bc.ng - 1) {   // the item closes: h (and g1) for the consumer; the two halves hold the k-parities of the same element
+            float* hb = reinterpret_cast<float*>(bx + 16);
+#pragma unroll
+            for (int b = 0; b < T; ++b) {
+                const float gs = gpart[b] + __shfl_xor(gpart[b], 32, 64);
+                const float g1s = g1part[b] + __shfl_xor(g1part[b], 32, 64);
+                if (half == 0) {
+                    hb[b * 32 + col] = gs;
+                    if (LOSS) hb[VD + b * 32 + col] = g1s;
+                }
+            }
+            pc_publish(flg + PC_ROWS_DONE, Bc.rseq + 1);
+        }
+    };
+
+    // Everything fetched so far is waited for HERE, by reading it: whatever the loop header inherits as "in flight" from the code
+    // before the loop, the compiler keeps waiting for on every trip.
+    asm volatile("" ::"v"(pk_c), "v"(pk_v), "v"(tk_v));
+    // three register sets in rotation: step S loads into set S and prepares the set loaded two steps earlier (one exit, at the
+    // bottom: steps past the end of the stream are harmless)
+    do {
+        stage_a(raw[0], p0set[0]); stage_b(A2, raw[1], p0set[1]); A2 = A1; A1 = A; advance();
+        stage_a(raw[1], p0set[1]); stage_b(A2, raw[2], p0set[2]); A2 = A1; A1 = A; advance();
+        stage_a(raw[2], p0set[2]); stage_b(A2, raw[0], p0set[0]); A2 = A1; A1 = A; advance();
+    } while (ok && (A.valid | A1.valid | A2.valid));
+    if (ok) {   // end of the list: a header with row -1 sends the consumer home
+        const int rs = rows_opened;
+        if (pc_wait_gt(flg + PC_ROWS_FREE, rs - 2, seen_free, flg)) {
+            if (lane == 0) *reinterpret_cast<int4*>(box + (rs & 1) * C::BOX_B) = make_int4(-1, 0, -1, 0);
+            pc_publish(flg + PC_ROWS_PUB, rs + 1);
+        }
+    }
+    pc_report(flg, err, lane);
+    if (__builtin_amdgcn_ballot_w64(bad_weight) != 0 && lane == 0) atomicOr(err, 2);
+    if (bad_keys && lane == 0) atomicOr(err, 4);
+    if (lossk) {
+        nume_k = wave_sum_f64(nume_k);
+        deno_k = wave_sum_f64(deno_k);
+        if (lane == 0) {
+            if (nume_k != 0.0) atomicAdd(p.loss, nume_k);
+            if (deno_k != 0.0) atomicAdd(p.loss + 1, deno_k);
+        }
+    }
+}
+
+// ---- consumer ------------------------------------------------------------------------------------------------------------------
+template <int T, bool BIG, bool LOSS>
+__device__ __forceinline__ void als_pc_consumer(const AlsParams& p, float* __restrict__ scratch, const float* ff_acc, char* pl, int* err, int lane) {
+    using C = AlsPc<T>;
+    constexpr int VD = C::VD, NT = C::NT;
+    const int half = lane >> 5, col = lane & 31;
+    const char* ring = pl;
+    const char* box = pl + C::NSLOT * C::SLOT_B + C::KEY_B;
+    float* pc = reinterpret_cast<float*>(pl + C::NSLOT * C::SLOT_B + C::KEY_B + 2 * C::BOX_B);
+    int* flg = reinterpret_cast<int*>(pl + C::PAIR_B - C::FLAG_B);
+    const float sI2 = p.split[2];
+    const bool lossk = LOSS && p.compute_loss && p.axis == 1;
+    double nume_k = 0.0, deno_k = 0.0;
+    int gseq = 0;
+    int seen_prod = 0, seen_pub = 0, seen_done = 0;
+    for (int rseq = 0;; ++rseq) {
+        if (!pc_wait_gt(flg + PC_ROWS_PUB, rseq, seen_pub, flg)) break;
+        const char* bx = box + (rseq & 1) * C::BOX_B;
+        const int4 hd = *reinterpret_cast<const int4*>(bx);
+        const int row = __builtin_amdgcn_readfirstlane(hd.x), n = __builtin_amdgcn_readfirstlane(hd.y), slot = __builtin_amdgcn_readfirstlane(hd.z);
+        if (row < 0) break;
+        const bool solve_here = slot < 0;
+        // the row at entry and FF p0 (als_rowff_kernel): wanted by the solve only -- the loads ride under the whole Gramian pass
+        float p0r[T], f0r[T];
+#pragma unroll
+        for (int b = 0; b < T; ++b) { p0r[b] = 0.f; f0r[b] = 0.f; }
+        if (solve_here) {
+            const float* Pu0 = p.P + static_cast<size_t>(row) * VD;
+            const float* Fu0 = p.F0 + static_cast<size_t>(row - p.start_x) * VD;
+#pragma unroll
+            for (int b = 0; b < T; ++b) { p0r[b] = Pu0[b * 32 + col]; f0r[b] = Fu0[b * 32 + col]; }
+        }
+        f32x16 acc[NT];
+        if (solve_here && !(p.debug & 2)) {   // M = FF + G: start from the FF tiles (accumulator layout, scaled by S^2)
+            const float* fl = ff_acc + lane * 4;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    const float4 v = *reinterpret_cast<const float4*>(fl + (t * 4 + e4) * 256);
+                    acc[t][4 * e4 + 0] = v.x; acc[t][4 * e4 + 1] = v.y; acc[t][4 * e4 + 2] = v.z; acc[t][4 * e4 + 3] = v.w;
+                }
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+        }
+        const int ng = (n + 15) >> 4;
+        u32x4 HA[T], LA[T], HB[T], LB[T];
+        auto read_slot = [&](int seq, u32x4 (&H)[T], u32x4 (&L)[T]) {
+            const char* sl = ring + (seq % C::NSLOT) * C::SLOT_B + lane * 16;
+#pragma unroll
+            for (int b = 0; b < T; ++b) {
+                L[b] = *reinterpret_cast<const u32x4*>(sl + (T + b) * 1024);
+                H[b] = *reinterpret_cast<const u32x4*>(sl + b * 1024);
+            }
+        };
+        auto mfmas = [&](const u32x4 (&H)[T], const u32x4 (&L)[T]) {
+            if (p.debug & 16) return;
+#pragma unroll
+            for (int pr = 0; pr < 3; ++pr) {   // small terms first: l h, h l, h h
+                int t = 0;
+#pragma unroll
+                for (int a = 0; a < T; ++a)
+#pragma unroll
+                    for (int b = a; b < T; ++b, ++t) {
+                        const u32x4 X = pr == 0 ? L[a] : H[a];
+                        const u32x4 Y = pr == 1 ? L[b] : H[b];
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, X), __builtin_bit_cast(f16x8_t, Y), acc[t], 0, 0, 0);
+                    }
+            }
+        };
+        bool ok = true;
+        if (ng > 0) {
+            if (!pc_wait_gt(flg + PC_PROD, gseq, seen_prod, flg)) break;
+            read_slot(gseq, HA, LA);
+            for (int g = 0;;) {
+                const bool more = g + 1 < ng;
+                if (more) {   // the next group's pieces are on their way from LDS while this group's matrix instructions issue
+                    if (!pc_wait_gt(flg + PC_PROD, gseq + 1, seen_prod, flg)) { ok = false; break; }
+                    read_slot(gseq + 1, HB, LB);
+                }
+                mfmas(HA, LA);
+                ++gseq; ++g;
+                if (!more) { pc_publish(flg + PC_CONS, gseq); break; }
+                pc_publish(flg + PC_CONS, gseq);   // slot gseq - 1 was read into registers before its matrix instructions issued
+                const bool more2 = g + 1 < ng;
+                if (more2) {
+                    if (!pc_wait_gt(flg + PC_PROD, gseq + 1, seen_prod, flg)) { ok = false; break; }
+                    read_slot(gseq + 1, HA, LA);
+                }
+                mfmas(HB, LB);
+                ++gseq; ++g;
+                pc_publish(flg + PC_CONS, gseq);
+                if (!more2) break;
+            }
+        }
+        if (!ok) break;
+        if (!pc_wait_gt(flg + PC_ROWS_DONE, rseq, seen_done, flg)) break;
+        float gs[T], g1s[T];
+        {
+            const float* hb = reinterpret_cast<const float*>(bx + 16);
+#pragma unroll
+            for (int b = 0; b < T; ++b) {
+                gs[b] = hb[b * 32 + col];
+                g1s[b] = LOSS ? hb[VD + b * 32 + col] : 0.f;
+            }
+        }
+        pc_publish(flg + PC_ROWS_FREE, rseq + 1);   // (waits for the reads above)
+        if (solve_here) {
+            float* Pu = p.P + static_cast<size_t>(row) * VD;
+            double nume = 0.0, deno = 0.0;
+            if (!(p.debug & 1)) {
+                wave_lds_sync();
+                if (half == 0) {
+#pragma unroll
+                    for (int b = 0; b < T; ++b) { pc[b * 32 + col] = p0r[b]; pc[VD + b * 32 + col] = 0.f; }
+                }
+                wave_lds_sync();
+                als_ialspp_inreg<T>(acc, gs, g1s, f0r, p, pc, pc + VD, pc + 2 * VD, lane, half, col, p.adaptive_reg ? static_cast<float>(n) : 1.0f, nume, deno, sI2);
+                wave_lds_sync();
+                for (int e = lane; e < VD; e += 64) Pu[e] = pc[e];
+            }
+            if (p.compute_loss && lane == 0) {
+                nume_k += nume;
+                deno_k += deno;
+            }
+        } else {   // chunk of a heavy row: the tiles, h and g1 are summed in the row's scratch slot (zeroed by the host) for als_solve_kernel
+            float* S = scratch + static_cast<size_t>(slot) * als_slot_floats(VD);
+            float* Sl = S + half * 4 * VD + col;
+            const float osc = p.out_scale * sI2, osg = p.out_scale;
+            int t = 0;
+#pragma unroll
+            for (int a = 0; a < T; ++a) {
+#pragma unroll
+                for (int b = a; b < T; ++b, ++t)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) atomic_add_f32(Sl + (a * 32 + (e & 3) + 8 * (e >> 2)) * VD + b * 32, acc[t][e] * osc);
+                if (half == 0) {
+                    float* gdst = S + VD * VD + a * 32 + col;
+                    atomic_add_f32(gdst, gs[a] * osg);
+                    if (lossk) atomic_add_f32(gdst + VD, g1s[a]);
+                }
+            }
+        }
+    }
+    pc_report(flg, err, lane);
+    if (p.compute_loss) {
+        nume_k = wave_sum_f64(nume_k);
+        deno_k = wave_sum_f64(deno_k);
+        if (lane == 0) {
+            if (nume_k != 0.0) atomicAdd(p.loss, nume_k);
+            if (deno_k != 0.0) atomicAdd(p.loss + 1, deno_k);
+        }
+    }
+}
+
+// One 512-thread workgroup per CU: four producer / consumer pairs.  err[0]: bit 0 a wait timed out, bit 1 a weight outside the f16
+// path reached the kernel; err[1]: workgroups whose pairs all sit on one SIMD each (placement statistic, not an error).
+template <int T, bool BIG, bool LOSS>
+__global__ __launch_bounds__(512, 2) void als_pc_kernel(AlsParams p, const AlsWork* __restrict__ work, int n_items, float* __restrict__ scratch,
+                                                        const float* __restrict__ Qi, const int* __restrict__ defer, int* __restrict__ err) {
+    extern __shared__ __attribute__((aligned(16))) char pc_lds[];
+    using C = AlsPc<T>;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float* ff_acc = reinterpret_cast<float*>(pc_lds);
+    int* role_tab = reinterpret_cast<int*>(pc_lds + C::FF_B + 4 * C::PAIR_B);   // [0..7] pair * 2 + role, [8..15] SIMD id of wave w
+    {
+        const float sS2 = p.split[1];
+        for (int idx = tid; idx < C::NT * 1024; idx += 512) {
+            const int t = idx >> 10, rem = idx & 1023, e4 = rem >> 8, ln = (rem >> 2) & 63, e3 = rem & 3;
+            const int a = als_tile_row<T>(t), b = als_tile_col<T>(t);
+            const int row = a * 32 + e3 + 8 * e4 + 4 * (ln >> 5), cc = b * 32 + (ln & 31);
+            ff_acc[idx] = sS2 * p.FF[row * C::VD + cc];
+        }
+    }
+    unsigned simd;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 4, 2)" : "=s"(simd));
+    if (lane == 0) role_tab[8 + wv] = static_cast<int>(simd);
+    if (tid < 64) reinterpret_cast<int*>(pc_lds + C::FF_B + (tid >> 4) * C::PAIR_B + C::PAIR_B - C::FLAG_B)[tid & 15] = 0;
+    __syncthreads();
+    if (tid == 0) {   // one consumer + one producer per SIMD where the placement allows, any pairing otherwise
+        int np = 0, same = 0;
+        unsigned used = 0;
+        for (int s = 0; s < 4; ++s) {
+            int first = -1;
+            for (int w = 0; w < 8; ++w)
+                if (role_tab[8 + w] == s) {
+                    if (first < 0) first = w;
+                    else {
+                        role_tab[first] = np * 2; role_tab[w] = np * 2 + 1;
+                        used |= (1u << first) | (1u << w);
+                        ++np; ++same; first = -1;
+                    }
+                }
+        }
+        int first = -1;
+        for (int w = 0; w < 8; ++w)
+            if (!((used >> w) & 1)) {
+                if (first < 0) first = w;
+                else { role_tab[first] = np * 2; role_tab[w] = np * 2 + 1; ++np; first = -1; }
+            }
+        if (same == 4) atomicAdd(err + 1, 1);
+    }
+    __syncthreads();
+    const int rl = __builtin_amdgcn_readfirstlane(role_tab[wv]);
+    char* pl = pc_lds + C::FF_B + (rl >> 1) * C::PAIR_B;
+    if (rl & 1) als_pc_producer<T, BIG, LOSS>(p, work, n_items, Qi, defer, pl, err, lane);
+    else als_pc_consumer<T, BIG, LOSS>(p, scratch, ff_acc, pl, err, lane);
+}
+
+}  // namespace bfh

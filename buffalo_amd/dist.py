@@ -17,25 +17,28 @@ The torch.distributed restatement of the exchange protocol that the gloo tests r
 import numpy as np
 
 
-def shard_bounds(indptr, world_size):
-    """Contiguous user ranges with ~equal nnz (degree distributions are heavy-tailed, so equal
-    row counts would not balance).  Returns world_size+1 row boundaries."""
+def shard_bounds(indptr, world_size, row_cost=0.0):
+    """Contiguous user ranges of ~equal COST, cost(row) = nnz(row) + row_cost (degree distributions are heavy-tailed, so equal
+    row counts would not balance; `row_cost` -- what a row costs beyond its entries, in entries -- is 0 for the SGD walks, whose
+    per-shard time follows the nnz to a few percent: profiles/r04_shard_times_all_ranks.txt).  Returns world_size+1 row boundaries."""
     indptr = np.asarray(indptr, dtype=np.int64)
     U = indptr.shape[0]
     nnz = int(indptr[-1]) if U else 0
+    cum = indptr.astype(np.float64) + row_cost * np.arange(1, U + 1, dtype=np.float64) if row_cost else indptr
+    total = float(cum[-1]) if U else 0.0
     bounds = [0]
     for r in range(1, world_size):
-        target = nnz * r // world_size
-        b = int(np.searchsorted(indptr, target, side="left")) + 1  # first row whose end offset >= target
+        target = (nnz * r // world_size) if not row_cost else total * r / world_size
+        b = int(np.searchsorted(cum, target, side="left")) + 1  # first row whose end offset >= target
         bounds.append(min(max(b, bounds[-1]), U))
     bounds.append(U)
     return bounds
 
 
-def shard_csr(indptr, keys, rank, world_size):
+def shard_csr(indptr, keys, rank, world_size, row_cost=0.0):
     """Rank-local CSR: rows [u0,u1) with indptr rebased to start at zero.
     Returns (u0, u1, local_indptr, local_keys, nnz_offset)."""
-    b = shard_bounds(indptr, world_size)
+    b = shard_bounds(indptr, world_size, row_cost)
     u0, u1 = b[rank], b[rank + 1]
     beg = 0 if u0 == 0 else int(indptr[u0 - 1])
     end = beg if u1 == u0 else int(indptr[u1 - 1])

@@ -1,7 +1,9 @@
 """ALS parity: HIP backend vs the CPU oracle, per half-epoch and over full epochs.
 
-Tolerance: max-abs error <= 1e-4 x max|value| for the factor matrices (three fp32 CG steps amplify
-summation-order differences; BASELINE.md states rtol 1e-4 for ALS), loss terms to 1e-4 relative."""
+Tolerance: the half-epoch ENVELOPE -- the HIP rows may sit no further from a float64 evaluation of the same recurrence than
+2.5 x the oracle's own distance from it (floor 5e-5; 10 x for the wide kernel, 128 < vdim <= 256): three fp32 CG steps on 32x32
+blocks amplify summation-order differences by the conditioning of the block, so a fixed max-abs bound would measure the
+problem, not the kernel.  Loss terms: 2e-4 relative (numerator), 1e-5 (denominator)."""
 import os
 
 import numpy as np
@@ -94,7 +96,7 @@ CASES = [
                           # a few entries 100x heavier than the rest (the test lowers the cut to 500) and a few negative ones: the split-f16 pass sends both kinds
                           # through the fp32 instruction (als_gram_kernel: fix_outliers)
                           (128, dict(optimizer="ialspp"), "outliers")])
-@pytest.mark.parametrize("design", ["inreg", "scratch", "fp32"])
+@pytest.mark.parametrize("design", ["inreg", "scratch", "fp32", "wave"])
 def test_half_epochs_match_oracle(oracle, d, kw, shape, design):
     """Every half-epoch starts from bit-identical factors (the GPU model is re-synchronised to the
     oracle's after each comparison), so differences are the kernels' own.  Truncated fp32 CG is
@@ -110,6 +112,8 @@ def test_half_epochs_match_oracle(oracle, d, kw, shape, design):
         pytest.skip("identical to 'inreg' unless the in-register iALS++ solve applies")
     if design == "fp32" and not (d == 128 and kw.get("block_size", 32) == 32):
         pytest.skip("'fp32' = the in-register solve with the fp32 matrix instruction instead of the split-f16 pass: d = 128 cases")
+    if design == "wave" and not (d in (64, 96, 128) and kw.get("block_size", 32) == 32 and kw.get("optimizer") == "ialspp"):
+        pytest.skip("'wave' = round 3's wave-per-row split-f16 kernel instead of the producer / consumer pairs: in-place iALS++ cases")
     if shape == "outliers":
         base = tiny_csr(U=320, I=280, density=0.2, seed=31, counts=True)
         v = base.vals.copy()
@@ -124,10 +128,12 @@ def test_half_epochs_match_oracle(oracle, d, kw, shape, design):
         csr = synth.generate(*synth.SHAPES["ml100k"], seed=7, vals="counts")  # row lengths 1..900: odd, > 64, > 128
     opt = als_opt(d=d, alpha=4.0, reg_u=0.2, reg_i=0.3, num_iters=2, **kw)
     o, obj, (P, Q), (Po, Qo) = _setup(oracle, csr, d, opt, scale=0.1)
-    # "inreg": iALS++ rows with block_size 32 are solved from the accumulator registers (the default);
+    # "inreg": iALS++ rows with block_size 32 are solved from the accumulator registers (the default: producer / consumer pairs,
+    # als_pc_kernel); "wave": the same with round 3's wave-per-row kernel; "fp32": that kernel with the fp32 matrix instruction;
     # "scratch": every row goes through the HBM scratch slot + dense-solve kernel
     obj.set_mode("als_inreg", int(design != "scratch"))
     obj.set_mode("als_split_f16", int(design != "fp32"))
+    obj.set_mode("als_pc", int(design != "wave"))
     if shape == "outliers":
         obj.set_mode("als_split_wcut", 500)   # alpha v = 4 * 2 * 100 and more: past the cut
     t = csr.transpose()
@@ -152,10 +158,13 @@ def test_half_epochs_match_oracle(oracle, d, kw, shape, design):
             # the explicit Gramian adds the rounding of an n-term fp32 sum per entry of M to what the matrix-free
             # reference recurrence sees; CG amplifies it with the conditioning of the 32x32 blocks, which grows
             # with d: the envelope is 2.5x the oracle's own error up to vdim 128 and 10x for the wide kernel
-            # "outliers": weights spanning 1 : 100 make single rows ill-conditioned enough that the three device designs land at
-            # 1.3x (scratch), 3.3x (fp32 instruction) and 5.5x (split-f16) of the oracle's distance on the SAME inputs
-            # (profiles/r03_als_split_f16.txt) -- the case is there to catch an entry lost on the side path (an O(0.1) error)
-            env = max((2.5 if _vdim(d) <= 128 and shape != "outliers" else 10) * e_or, 5e-5)
+            # "outliers": weights spanning 1 : 100 make single rows ill-conditioned enough that round 3's in-register designs land at
+            # 3.3x (fp32 instruction) and 5.5x (split-f16 with its fp32 side pass) of the oracle's distance where the scratch path
+            # lands at 1.3x on the SAME inputs (profiles/r03_als_split_f16.txt).  The default path now sends the rows that hold such
+            # weights through the scratch path (als_defer_scan_kernel) and is held to the 2.5x of every other case; the two
+            # non-default kernels keep the 10x they were measured at
+            loose = _vdim(d) > 128 or (shape == "outliers" and design in ("fp32", "wave"))
+            env = max((10 if loose else 2.5) * e_or, 5e-5)
             print("\nALS d=%d %s %s/%s it %d axis %d: err(hip,f64) %.3e  err(oracle,f64) %.3e  ratio %.2f  hip~oracle %.3e"
                   % (d, kw, shape, design, it, axis, e_hip, e_or, e_hip / max(e_or, 1e-30), e_pair))
             assert e_hip <= env, (it, axis, e_hip, e_or)
