@@ -1758,8 +1758,10 @@ struct AlsWide {
     static constexpr bool owns_row(int a) { return a == R0 || (TWO && a == R1); }
 };
 
-struct AlsWideLds {          // carved from dynamic LDS: vdim | W*32 | 32 | 32 | 8 floats
+struct AlsWideLds {          // carved from dynamic LDS: 3 vdim | W*32 | 32 | 32 | 8 floats
     float* pc;               // the row (current iterate)
+    float* dl;               // delta = p - p0 (zero in the blocks not solved yet)
+    float* hv;               // h = sum_k alpha v_k (q_k.p0 - 1) q_k, all blocks (formed by wave 0, which loads every block of the q rows)
     float* contrib;          // [W][32] column-product partials of the waves
     float* rowres;           // [32] row-product result of the diagonal tile's owner
     float* pvs;              // [32] CG direction
@@ -1779,7 +1781,14 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
     float* Pu = p.P + static_cast<size_t>(wk.row) * VD;
 
     f32x16 acc[NTW];
-    float gp0 = 0.f, gp1 = 0.f, g10 = 0.f, g11 = 0.f;   // g / g1 shares of rows R0, R1
+    float g10 = 0.f, g11 = 0.f;   // g1 = sum q shares of rows R0, R1 (loss only)
+    // Residual-first gradient (als.cc:292-296, like als_ialspp_inreg): every entry's q_k.p0 - 1 against the row AT ENTRY, summed as
+    // h = sum alpha v (q.p0 - 1) q.  The dot needs every block of the q row: wave 0 loads them all (R0 = 0), so it forms h for all T
+    // blocks and hands it over through LDS (the scratch slot for the chunks of a heavy row).  [Rounds 1-3 evaluated (M p) - g_w here:
+    // the same number, but once the model fits G p and g_w nearly cancel -- 10x envelope, profiles/r03_als_config3_warm_epoch.txt.]
+    float p0r[WV == 0 ? T : 1], hb[WV == 0 ? T : 1];
+#pragma unroll
+    for (int b = 0; b < (WV == 0 ? T : 1); ++b) { p0r[b] = WV == 0 ? Pu[b * 32 + col] : 0.f; hb[b] = 0.f; }
     {   // accumulators start from FF (+ the heavy row's summed chunk tiles when finalizing); zero for a chunk
         const float* Fl = p.FF + half * 4 * VD + col;
         const float* Sl = scratch + static_cast<size_t>(wk.slot >= 0 ? wk.slot : 0) * als_slot_floats(VD) + half * 4 * VD + col;
@@ -1829,15 +1838,21 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
             const float a0 = wgt * q[0];                       // block R0
 #pragma unroll
             for (int s = 0; s < C::N0; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, q[s], acc[s], 0, 0, 0);
-            gp0 += wgt * q[0];
             g10 += lo * q[0];
             if (TWO) {
                 const float a1 = wgt * q[R1 - R0];             // block R1
 #pragma unroll
                 for (int s = 0; s < C::N1; ++s)
                     acc[C::N0 + s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, q[R1 - R0 + s], acc[C::N0 + s], 0, 0, 0);
-                gp1 += wgt * q[R1 - R0];
                 g11 += lo * q[R1 - R0];
+            }
+            if constexpr (WV == 0) {   // NB == T here
+                float part = q[0] * p0r[0];
+#pragma unroll
+                for (int b = 1; b < T; ++b) part = __builtin_fmaf(q[b], p0r[b], part);
+                const float cial = __builtin_fmaf(wgt, half_sum(part, half), -wgt);   // alpha v (q.p0 - 1)
+#pragma unroll
+                for (int b = 0; b < T; ++b) hb[b] = __builtin_fmaf(cial, q[b], hb[b]);
             }
         };
         auto nnz_of = [&](int64_t ch) { return ch < nchunks ? static_cast<int>((n - ch * 64) < 64 ? (n - ch * 64) : 64) : 0; };
@@ -1888,8 +1903,11 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
         }
     }
     // the two halves hold the k-parities of the same element
-    gp0 += __shfl_xor(gp0, 32, 64); gp1 += __shfl_xor(gp1, 32, 64);
     g10 += __shfl_xor(g10, 32, 64); g11 += __shfl_xor(g11, 32, 64);
+    if constexpr (WV == 0) {
+#pragma unroll
+        for (int b = 0; b < T; ++b) hb[b] += __shfl_xor(hb[b], 32, 64);
+    }
 
     float* S = scratch + static_cast<size_t>(wk.slot >= 0 ? wk.slot : 0) * als_slot_floats(VD);
     if (partial) {   // add this chunk's tiles / vector shares into the (zeroed) slot
@@ -1901,34 +1919,43 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
             for (int e = 0; e < 16; ++e) atomic_add_f32(Sl + (a * 32 + (e & 3) + 8 * (e >> 2)) * VD + b * 32, acc[s][e]);
         }
         if (half == 0) {
-            atomic_add_f32(S + VD * VD + R0 * 32 + col, gp0);
-            if (lossk) atomic_add_f32(S + VD * VD + VD + R0 * 32 + col, g10);
-            if (TWO) {
-                atomic_add_f32(S + VD * VD + R1 * 32 + col, gp1);
-                if (lossk) atomic_add_f32(S + VD * VD + VD + R1 * 32 + col, g11);
+            if constexpr (WV == 0) {
+#pragma unroll
+                for (int b = 0; b < T; ++b) atomic_add_f32(S + VD * VD + b * 32 + col, hb[b]);
             }
+            if (lossk) atomic_add_f32(S + VD * VD + VD + R0 * 32 + col, g10);
+            if (TWO && lossk) atomic_add_f32(S + VD * VD + VD + R1 * 32 + col, g11);
         }
         return;
     }
-    if (finalize) {   // g, g1 were summed in the slot
-        gp0 = S[VD * VD + R0 * 32 + col];
+    if (finalize) {   // g1 was summed in the slot (h: below)
         g10 = lossk ? S[VD * VD + VD + R0 * 32 + col] : 0.f;
-        if (TWO) {
-            gp1 = S[VD * VD + R1 * 32 + col];
-            g11 = lossk ? S[VD * VD + VD + R1 * 32 + col] : 0.f;
-        }
+        if (TWO) g11 = lossk ? S[VD * VD + VD + R1 * 32 + col] : 0.f;
     }
 
     // ---------------- iALS++ across the W waves (als.cc:269-352, see als_ialspp_inreg) ----------------
-    for (int e = threadIdx.x; e < VD; e += 64 * W) L.pc[e] = Pu[e];
+    for (int e = threadIdx.x; e < VD; e += 64 * W) {
+        L.pc[e] = Pu[e];
+        L.dl[e] = 0.f;
+        if (finalize) L.hv[e] = S[VD * VD + e];
+    }
+    if constexpr (WV == 0) {
+        if (!finalize && half == 0) {
+#pragma unroll
+            for (int b = 0; b < T; ++b) L.hv[b * 32 + col] = hb[b];
+        }
+    }
+    // f0 = FF p0 of this wave's rows (als_rowff_kernel)
+    const float* Fu0 = p.F0 + static_cast<size_t>(wk.row - p.start_x) * VD;
+    const float f00 = Fu0[R0 * 32 + col], f01 = TWO ? Fu0[R1 * 32 + col] : 0.f;
     __syncthreads();
     // this wave's share of (M x)[32 blk + col] for x = pc: column products of its tiles in column blk go to
     // contrib[WV], the row products of row blk (if it owns it) to rowres; the caller sums after a barrier
-    auto block_partials = [&](auto blk_c) {
+    auto block_partials = [&](auto blk_c, const float* x) {
         constexpr int blk = decltype(blk_c)::value;
         float part = 0.f;
-        if constexpr (R0 <= blk) part += als_tile_colpart(acc[C::slot(R0, blk)], L.pc + R0 * 32, half);
-        if constexpr (TWO && R1 <= blk) part += als_tile_colpart(acc[C::slot(R1, blk)], L.pc + R1 * 32, half);
+        if constexpr (R0 <= blk) part += als_tile_colpart(acc[C::slot(R0, blk)], x + R0 * 32, half);
+        if constexpr (TWO && R1 <= blk) part += als_tile_colpart(acc[C::slot(R1, blk)], x + R1 * 32, half);
         part += __shfl_xor(part, 32, 64);
         if (half == 0) L.contrib[WV * 32 + col] = part;
         if constexpr (C::owns_row(blk)) {
@@ -1939,7 +1966,7 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
                 for (int e = 0; e < 16; ++e) z[e] = 0.f;
 #pragma unroll
                 for (int jb = blk + 1; jb < T; ++jb) {
-                    const float xv = L.pc[jb * 32 + col];
+                    const float xv = x[jb * 32 + col];
 #pragma unroll
                     for (int e = 0; e < 16; ++e) z[e] += acc[C::slot(blk, jb)][e] * xv;
                 }
@@ -1957,20 +1984,23 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
     };
     const float ada = p.adaptive_reg ? static_cast<float>(wk.kend - wk.kbeg) : 1.0f;
     (void)ada;
-    if (p.compute_loss) {   // als.cc:288-309 on the row at entry: reg*ada*|p|^2 (+ p^T M p - 2 p.(g_w + g_1) on the item side)
+    if (p.compute_loss) {   // als.cc:288-309 on the row at entry: reg*ada*|p|^2 and, on the item side, with g_w = G p0 - h:
+        // p FF p + [p G p - 2 p.(g_w + g_1)] = 2 p.f0 - p M p + 2 p.(h - g_1)   (als_ialspp_inreg)
         float pp = 0.f, pmp = 0.f, pg = 0.f;
         als_static_for<T>([&](auto blk_c) {
             constexpr int blk = decltype(blk_c)::value;
+            float mp = 0.f;
             if (p.axis == 1) {
-                block_partials(blk_c);
+                block_partials(blk_c, L.pc);
                 __syncthreads();
-                if (WV == 0) pmp += L.pc[blk * 32 + col] * block_sum();
+                mp = block_sum();
                 __syncthreads();
             }
             if constexpr (C::owns_row(blk)) {
                 const float pv = L.pc[blk * 32 + col];
                 pp += pv * pv;
-                pg += pv * (blk == R0 ? gp0 + g10 : gp1 + g11);
+                pmp += pv * (2.0f * (blk == R0 ? f00 : f01) - mp);
+                pg += pv * ((blk == R0 ? g10 : g11) - L.hv[blk * 32 + col]);
             }
         });
         pp = wave_sum(half == 0 ? pp : 0.f);
@@ -1987,12 +2017,11 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
     }
     als_static_for<T>([&](auto blk_c) {
         constexpr int blk = decltype(blk_c)::value;
-        block_partials(blk_c);
+        block_partials(blk_c, L.dl);   // (M delta)[blk]: delta is non-zero only in the blocks already solved
         __syncthreads();
-        if constexpr (C::owns_row(blk)) {   // this wave holds the diagonal tile and g_blk: gradient + 3 CG steps (als.cc:286-346)
+        if constexpr (C::owns_row(blk)) {   // this wave holds the diagonal tile: gradient of the block at the current row + 3 CG steps (als.cc:286-346)
             const float pblk = L.pc[blk * 32 + col];
-            const float gblk = blk == R0 ? gp0 : gp1;
-            const float bi = block_sum() - gblk + p.reg * pblk;
+            const float bi = (blk == R0 ? f00 : f01) + L.hv[blk * 32 + col] + block_sum() + p.reg * pblk;
             float xr = 0.f, rr = bi, pvr = bi;
             double rsold = static_cast<double>(wave_sum(half == 0 ? rr * rr : 0.f));
             if (rsold > static_cast<double>(p.cg_tol)) {
@@ -2013,7 +2042,10 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
                     rsold = rsnew;
                 }
             }
-            if (half == 0 && !(p.debug & 1)) L.pc[blk * 32 + col] = pblk - xr;
+            if (half == 0 && !(p.debug & 1)) {
+                L.pc[blk * 32 + col] = pblk - xr;
+                L.dl[blk * 32 + col] = -xr;
+            }
         }
         __syncthreads();
     });
@@ -2028,7 +2060,9 @@ __global__ __launch_bounds__(64 * ((T + 1) / 2), 2) void als_wide_kernel(AlsPara
     extern __shared__ __attribute__((aligned(16))) float lds[];
     AlsWideLds L;
     L.pc = lds;
-    L.contrib = lds + VD;
+    L.dl = lds + VD;
+    L.hv = lds + 2 * VD;
+    L.contrib = lds + 3 * VD;
     L.rowres = L.contrib + W * 32;
     L.pvs = L.rowres + 32;
     L.red = L.pvs + 32;
@@ -2058,7 +2092,7 @@ __global__ __launch_bounds__(64 * ((T + 1) / 2), 2) void als_wide_kernel(AlsPara
         }
     }
 }
-__host__ __device__ inline size_t als_wide_lds_bytes(int vdim) { return (static_cast<size_t>(vdim) + 4 * 32 + 32 + 32 + 8 + 4) * sizeof(float); }
+__host__ __device__ inline size_t als_wide_lds_bytes(int vdim) { return (3 * static_cast<size_t>(vdim) + 4 * 32 + 32 + 32 + 8 + 4) * sizeof(float); }
 
 struct AlsHeavy {
     int row, slot;
@@ -2572,6 +2606,18 @@ class AlsHandle : public HandleBase {
         else BFH_WIDE(8, ITEMS, N, FIN);           \
     } while (0)
             (void)blocks;
+            {   // FF p0 for every row of the call (the residual-first gradient starts from it, als_wide_item)
+                const size_t need0 = static_cast<size_t>(nrows) * vdim_;
+                if (rowff_.size() < need0) rowff_.resize(need0);
+                const int quads = (nrows + 3) / 4;
+                const int rb = std::max(1, std::min((quads + 3) / 4, num_cus_ * 8));
+                if (T == 5) hipLaunchKernelGGL(als_rowff_kernel<5>, dim3(rb), dim3(256), 0, stream, p.P, start_x, nrows, FF_.get(), rowff_.get());
+                else if (T == 6) hipLaunchKernelGGL(als_rowff_kernel<6>, dim3(rb), dim3(256), 0, stream, p.P, start_x, nrows, FF_.get(), rowff_.get());
+                else if (T == 7) hipLaunchKernelGGL(als_rowff_kernel<7>, dim3(rb), dim3(256), 0, stream, p.P, start_x, nrows, FF_.get(), rowff_.get());
+                else hipLaunchKernelGGL(als_rowff_kernel<8>, dim3(rb), dim3(256), 0, stream, p.P, start_x, nrows, FF_.get(), rowff_.get());
+                BFH_HIP(hipGetLastError());
+                p.F0 = rowff_.get();
+            }
             if (wl->n_work > 0) BFH_WIDE_T(wl->work.get(), wl->n_work, 0);
             BFH_HIP(hipGetLastError());
             if (wl->n_heavy) {   // heavy rows: FF + summed chunk tiles -> solve

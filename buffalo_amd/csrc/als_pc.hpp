@@ -32,7 +32,7 @@ struct AlsPc {
     static constexpr int NT = T * (T + 1) / 2;
     static constexpr int VD = 32 * T;
     static constexpr int NSLOT = 3;                        // ring depth per pair (groups of 16 entries)
-    static constexpr int NK = 3;                           // staged 64-entry key chunks per pair
+    static constexpr int NK = 2;                           // staged 64-entry key chunks per pair
     static constexpr int SLOT_B = 2 * T * 1024;            // H[0..T-1] | L[0..T-1], each 64 lanes x 16 B
     static constexpr int FF_B = NT * 4096;                 // the FF tiles in accumulator layout, scaled by S^2
     static constexpr int KEY_B = NK * 3 * 64 * 4;          // (row id, weight, S sqrt(weight)) x 64 entries
@@ -166,15 +166,24 @@ __device__ __forceinline__ void pc_split_pair(float q0, float s0, float q1, floa
     asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(q1), "v"(s1), "v"(h));
 }
 
-struct PcCursor {   // where a pipeline stage stands in the pair's stream of groups (all wave-uniform)
+struct PcChunk {   // where a pipeline stage stands in the pair's stream: one 64-entry chunk of one work item (all wave-uniform)
     int valid;
     int row, kbeg, n, slot;   // the work item
-    int g, ng;                // group inside the item, groups of the item
-    int cseq;                 // running number of the 64-entry chunk that holds group g (key staging buffer = cseq % NK)
+    int chunk, ng;            // chunk inside the item, groups (of 16 entries) of the item
     int rseq;                 // running number of the item (row box = rseq & 1)
+    int buf;                  // key staging buffer of the chunk (0 / 1)
 };
 
 // ---- producer ------------------------------------------------------------------------------------------------------------------
+// The stream of a pair is walked CHUNK by chunk (64 entries = 4 groups): everything that decides where the stream goes next -- the
+// work list, the row boundaries, the staging of a chunk's keys and weights -- runs once per chunk, and the four group steps inside
+// are straight-line code with compile-time sub-indices.  (A lone wave issues about one instruction every four cycles whatever
+// its kind, so the instruction COUNT of the loop is the producer's speed: the first version spent more issue slots on its
+// per-group cursor than on the arithmetic -- profiles/r04_als_pc_steps.txt.)
+// Four register sets hold the rows of four groups; step s loads group (chunk, s) into set s and prepares set (s + 1) % 4, loaded
+// three steps earlier.  Every vector-memory operation of a trip is issued unconditionally and in a fixed order (rows past an item's
+// end are row 0 with weight 0): the compiler joins control-flow paths by the FEWEST loads issued since the one it waits for, and
+// one path without loads turns every wait into vmcnt(0).
 template <int T, bool BIG, bool LOSS>
 __device__ __forceinline__ void als_pc_producer(const AlsParams& p, const AlsWork* __restrict__ work, int n_items, const float* __restrict__ Qi,
                                                 const int* __restrict__ defer, char* pl, int* err, int lane) {
@@ -185,11 +194,15 @@ __device__ __forceinline__ void als_pc_producer(const AlsParams& p, const AlsWor
     int* ks = reinterpret_cast<int*>(pl + C::NSLOT * C::SLOT_B);
     char* box = pl + C::NSLOT * C::SLOT_B + C::KEY_B;
     int* flg = reinterpret_cast<int*>(pl + C::PAIR_B - C::FLAG_B);
-    const float sS = p.split[0], wcut = p.split[3];
+    const float sS = p.split[0], wcut = p.split[3], alpha = p.alpha;
     const bool lossk = LOSS && p.compute_loss && p.axis == 1;
+    const int dbg = p.debug;
     double nume_k = 0.0, deno_k = 0.0;
     const char* qbase = reinterpret_cast<const char*>(Qi);
     const unsigned lane_off = static_cast<unsigned>(col) * (4u * T);
+    const int32_t* __restrict__ keys = p.keys;
+    const float* __restrict__ vals = p.vals;
+    const float* __restrict__ Pm = p.P;
 
     // ---- the work list, drawn in batches (same-address atomics serialise at ~12 ns: one draw per row would cost 1.7 ms per half-epoch).
     // The ticket of the NEXT batch is always under way while the current one [b_base, b_base + b_len) is worked through; the items
@@ -197,14 +210,10 @@ __device__ __forceinline__ void als_pc_producer(const AlsParams& p, const AlsWor
     // tracked with).
     int b_base = 0, b_len = 0, b_pos = 0;
     int tk_v = 0, tk_rows = 0;
+    const int batch_max = p.batch;
     auto draw = [&](int rows) {
         tk_rows = rows;
         if (lane == 0) tk_v = atomicAdd(p.ticket, rows);
-    };
-    auto rows_for = [&](int len) {
-        int fit = 1024 / (len > 0 ? len : 1);
-        fit = fit < 1 ? 1 : (fit > p.batch ? p.batch : fit);
-        return fit < 1 ? 1 : fit;
     };
     bool list_end = false;
     draw(1);
@@ -219,7 +228,10 @@ __device__ __forceinline__ void als_pc_producer(const AlsParams& p, const AlsWor
                 b_base = base; b_len = len; b_pos = 0;
                 if (len == 0) { list_end = true; return false; }
                 // the list is sorted longest first: nothing later is longer than the item at hand, so about 1024 entries per draw
-                draw(rows_for(work[base].kend - work[base].kbeg));
+                const int l0 = work[base].kend - work[base].kbeg;
+                int fit = 1024 / (l0 > 0 ? l0 : 1);
+                fit = fit < 1 ? 1 : (fit > batch_max ? batch_max : fit);
+                draw(fit);
             }
             const int idx = b_base + b_pos++;
             const AlsWork w = work[idx];
@@ -228,100 +240,74 @@ __device__ __forceinline__ void als_pc_producer(const AlsParams& p, const AlsWor
         }
     };
 
-    // ---- key chunks: fetched one chunk ahead into (pk_c, pk_v), weighted and staged in LDS when stage A enters the chunk.
-    // The fetch is issued on EVERY step (for the chunk stage A will enter next -- the same one for up to four steps; clamped
-    // addresses instead of predication), like the row and p0 loads below: every path through a step then issues the same vector-memory
-    // operations in the same order, which is what keeps the compiler's s_waitcnt counts exact instead of vmcnt(0).
+    // ---- key chunks: fetched one chunk ahead into (pk_c, pk_v), weighted and staged in LDS when stage A enters the chunk ----
     int pk_c = 0, pk_rseq = -1, pk_chunk = -1;
     float pk_v = 0.f;
     auto load_keys = [&](int kbeg, int n, int chunk, int rseq) {
         int kk = chunk * 64 + lane;
         kk = kk < n ? kk : n - 1;
         kk = kk < 0 ? 0 : kk;
-        pk_c = p.keys[kbeg + kk];
-        pk_v = p.vals[kbeg + kk];
+        pk_c = keys[kbeg + kk];
+        pk_v = vals[kbeg + kk];
         pk_rseq = rseq;
         pk_chunk = chunk;
     };
 
-    PcCursor A{}, A1{}, A2{};
-    int nx_valid = 0, nx_row = 0, nx_kbeg = 0, nx_n = 1, nx_slot = 0;
+    PcChunk CA{}, CB{};
+    int nx_valid = 0, nx_row = 0, nx_kbeg = 0, nx_n = 1, nx_slot = -1;
     auto fetch_next = [&]() {
         nx_valid = next_item(nx_row, nx_kbeg, nx_n, nx_slot) ? 1 : 0;
         if (!nx_valid) { nx_row = 0; nx_kbeg = 0; nx_n = 1; nx_slot = -1; }
     };
-    A.n = 1;
+    CA.n = 1;
     fetch_next();
     if (nx_valid) {
-        A.valid = 1; A.row = nx_row; A.kbeg = nx_kbeg; A.n = nx_n; A.slot = nx_slot;
-        A.g = 0; A.ng = (nx_n + 15) >> 4; A.cseq = 0; A.rseq = 0;
+        CA.valid = 1; CA.row = nx_row; CA.kbeg = nx_kbeg; CA.n = nx_n; CA.slot = nx_slot;
+        CA.chunk = 0; CA.ng = (nx_n + 15) >> 4; CA.rseq = 0; CA.buf = 0;
         fetch_next();
     }
-    load_keys(A.kbeg, A.n, 0, 0);
-    auto advance = [&]() {   // stage A moves to the next group of the stream
-        if (!A.valid) return;
-        if (A.g + 1 < A.ng) {
-            ++A.g;
-            if ((A.g & 3) == 0) ++A.cseq;
-            return;
-        }
-        if (!nx_valid) { A.valid = 0; A.row = 0; A.kbeg = 0; A.n = 1; A.g = 0; return; }
-        A.row = nx_row; A.kbeg = nx_kbeg; A.n = nx_n; A.slot = nx_slot;
-        A.g = 0; A.ng = (nx_n + 15) >> 4; ++A.cseq; ++A.rseq;
+    load_keys(CA.kbeg, CA.n, 0, 0);
+    auto advance = [&]() {   // stage A moves to the next chunk of the stream
+        CA.buf ^= 1;
+        if (!CA.valid) return;
+        if ((CA.chunk + 1) * 4 < CA.ng) { ++CA.chunk; return; }
+        if (!nx_valid) { CA.valid = 0; CA.row = 0; CA.kbeg = 0; CA.n = 1; CA.chunk = 0; CA.ng = 0; return; }
+        CA.row = nx_row; CA.kbeg = nx_kbeg; CA.n = nx_n; CA.slot = nx_slot;
+        CA.chunk = 0; CA.ng = (nx_n + 15) >> 4; ++CA.rseq;
         fetch_next();
     };
 
-    float raw[3][8][T];      // the rows of three groups: one being prepared, two on their way
-    float p0set[3][T];       // the row at entry (this lane's elements [32 b + col]) of the item a group opens
-#pragma unroll
-    for (int s3 = 0; s3 < 3; ++s3) {
-#pragma unroll
-        for (int b = 0; b < T; ++b) {
-            p0set[s3][b] = 0.f;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) raw[s3][r][b] = 0.f;
-        }
-    }
+    float raw[4][8][T];      // the rows of four groups: one being prepared, three on their way
+    float p0A[T];            // the row at entry (this lane's elements [32 b + col]) of stage A's item
     float p0cur[T], gpart[T], g1part[T];
 #pragma unroll
-    for (int b = 0; b < T; ++b) { p0cur[b] = 0.f; gpart[b] = 0.f; g1part[b] = 0.f; }
-    int gseq = 0;            // groups published
+    for (int b = 0; b < T; ++b) { p0A[b] = 0.f; p0cur[b] = 0.f; gpart[b] = 0.f; g1part[b] = 0.f; }
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int b = 0; b < T; ++b) raw[s4][r][b] = 0.f;
+    int gseq = 0;            // groups written to the ring
+    int gpub = 0;            // groups published
     int rows_opened = 0;
     int seen_cons = 0, seen_free = 0;
     bool ok = true, bad_keys = false, bad_weight = false;
 
-    auto stage_a = [&](float (&rw)[8][T], float (&p0s)[T]) {
-        int* kb = ks + (A.cseq % C::NK) * 192;
-        const int chunk = A.g >> 2;
-        if (A.valid && (A.g & 3) == 0) {   // a new 64-entry chunk: weigh and stage its keys (fetched on the previous steps)
-            if (!(pk_rseq == A.rseq && pk_chunk == chunk)) bad_keys = true;   // (cannot happen: every chunk is fetched ahead)
-            const bool in = chunk * 64 + lane < A.n;
-            const float ww = in ? p.alpha * pk_v : 0.f;     // padding lanes: row 0 of the other factor with weight 0
-            const float ss = (ww > 0.f && ww <= wcut) ? sS * __builtin_amdgcn_sqrtf(ww) : 0.f;
-            if (lossk && in) {   // constant and denominator of the loss (als_gram_kernel's header)
-                const double w = static_cast<double>(ww);
-                deno_k += w;
-                nume_k += 1.0 + w;
-            }
-            if (ww != 0.f && ss == 0.f) bad_weight = true;   // a weight the scan should have routed elsewhere
-            kb[lane] = in ? pk_c : 0;
-            kb[64 + lane] = __builtin_bit_cast(int, ww);
-            kb[128 + lane] = __builtin_bit_cast(int, ss);
-            wave_lds_sync();
+    // the flag store of a group is put off until the NEXT step's LDS reads have been waited for: the wait for the slot's eight
+    // 16-byte stores then costs nothing
+    auto flush_pub = [&]() {
+        if (gpub != gseq) {
+            gpub = gseq;
+            pc_publish(flg + PC_PROD, gseq);
         }
-        // the chunk stage A enters next: the following one of this item, else the first of the next item
-        if ((chunk + 1) * 64 < A.n) load_keys(A.kbeg, A.n, chunk + 1, A.rseq);
-        else load_keys(nx_kbeg, nx_n, 0, A.rseq + 1);
-        // The row at entry of stage A's item and the eight row loads, on every step (past the end of the list: row 0)
-        {
-            const float* Pu0 = p.P + static_cast<size_t>(A.row) * VD;
-#pragma unroll
-            for (int b = 0; b < T; ++b) p0s[b] = Pu0[b * 32 + col];
-        }
-        const int4 c0 = *reinterpret_cast<const int4*>(kb + 16 * (A.g & 3) + 8 * half);
-        const int4 c1 = *reinterpret_cast<const int4*>(kb + 16 * (A.g & 3) + 8 * half + 4);
-        const int keep = A.valid ? -1 : 0;
-        const int cid[8] = {c0.x & keep, c0.y & keep, c0.z & keep, c0.w & keep, c1.x & keep, c1.y & keep, c1.z & keep, c1.w & keep};
+    };
+
+    auto load_group = [&](const int* kbA, int sg, float (&rw)[8][T]) {
+        const int4 c0 = *reinterpret_cast<const int4*>(kbA + 16 * sg + 8 * half);
+        const int4 c1 = *reinterpret_cast<const int4*>(kbA + 16 * sg + 8 * half + 4);
+        const int cid[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        // (no run-time switch around these loads: a path without them would put the compiler's wait counts back to "everything")
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             using off_t = typename std::conditional<BIG, size_t, unsigned>::type;
@@ -330,67 +316,77 @@ __device__ __forceinline__ void als_pc_producer(const AlsParams& p, const AlsWor
         }
     };
 
-    // (The arithmetic of stage B runs on every step as well -- on row 0's data while the pipeline fills and drains -- and only the
-    // hand-off is conditional: a path that does not read the group's registers leaves their loads "pending" in the compiler's
-    // books, and the next load into them then waits for everything in flight.)
-    auto stage_b = [&](const PcCursor& Bc, float (&q)[8][T], const float (&p0s)[T]) {
-        const bool live = Bc.valid && ok;
-        char* bx = box + (Bc.rseq & 1) * C::BOX_B;
-        if (live && Bc.g == 0) {   // the item opens: its row at entry, fresh sums, the header for the consumer
-#pragma unroll
-            for (int b = 0; b < T; ++b) { p0cur[b] = p0s[b]; gpart[b] = 0.f; g1part[b] = 0.f; }
-            if (!pc_wait_gt(flg + PC_ROWS_FREE, Bc.rseq - 2, seen_free, flg)) { ok = false; return; }
-            if (lane == 0) *reinterpret_cast<int4*>(bx) = make_int4(Bc.row, Bc.n, Bc.slot, 0);
-            ++rows_opened;
-            pc_publish(flg + PC_ROWS_PUB, Bc.rseq + 1);
-        }
-        const int* kb = ks + (Bc.cseq % C::NK) * 192 + 16 * (Bc.g & 3) + 8 * half;
+    // group sg (compile-time) of chunk Cc: residuals, h, pieces -> ring slot
+    auto prep_group = [&](const PcChunk& Cc, int sg, float (&q)[8][T]) {
+        const int g = 4 * Cc.chunk + sg;
+        const bool live = Cc.valid && g < Cc.ng && ok;
+        if (!live) return;
+        char* bx = box + (Cc.rseq & 1) * C::BOX_B;
+        const int* kb = ks + Cc.buf * 192 + 16 * sg + 8 * half;
         const float4 w0 = *reinterpret_cast<const float4*>(kb + 64), w1 = *reinterpret_cast<const float4*>(kb + 64 + 4);
         const float4 s0 = *reinterpret_cast<const float4*>(kb + 128), s1 = *reinterpret_cast<const float4*>(kb + 128 + 4);
         const float wgt[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
         const float sw[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-        // als.cc:292-296: residual = Yui - 1 against the row at entry; laid out in stages over the eight entries so that the
-        // dependent chains run side by side
-        float y[8], yo[8];
+        if (sg == 0 && Cc.chunk == 0) {   // the item opens: its row at entry, fresh sums, the header for the consumer
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            y[r] = q[r][0] * p0cur[0];
-#pragma unroll
-            for (int b = 1; b < T; ++b) y[r] = __builtin_fmaf(q[r][b], p0cur[b], y[r]);
-        }
-#pragma unroll
-        for (int r = 0; r < 8; ++r) y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), 0x128, 0xf, 0xf, false));
-#pragma unroll
-        for (int r = 0; r < 8; ++r) y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), 0x124, 0xf, 0xf, false));
-#pragma unroll
-        for (int r = 0; r < 8; ++r) y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), 0x122, 0xf, 0xf, false));
-#pragma unroll
-        for (int r = 0; r < 8; ++r) y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), 0x121, 0xf, 0xf, false));
-#pragma unroll
-        for (int r = 0; r < 8; ++r) yo[r] = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, y[r]), 0x401F));
-        const int k0 = 16 * Bc.g + 8 * half;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const float cial = __builtin_fmaf(wgt[r], y[r] + yo[r], -wgt[r]);   // alpha v (q.p0 - 1)
-            const float one = (LOSS && lossk && k0 + r < Bc.n) ? 1.0f : 0.f;
-#pragma unroll
-            for (int b = 0; b < T; ++b) {
-                gpart[b] = __builtin_fmaf(cial, q[r][b], gpart[b]);
-                if (LOSS) g1part[b] = __builtin_fmaf(one, q[r][b], g1part[b]);
-            }
+            for (int b = 0; b < T; ++b) { p0cur[b] = p0A[b]; gpart[b] = 0.f; g1part[b] = 0.f; }
+            if (!pc_wait_gt(flg + PC_ROWS_FREE, Cc.rseq - 2, seen_free, flg)) { ok = false; return; }
+            if (lane == 0) *reinterpret_cast<int4*>(bx) = make_int4(Cc.row, Cc.n, Cc.slot, 0);
+            ++rows_opened;
+            pc_publish(flg + PC_ROWS_PUB, Cc.rseq + 1);
         }
         u32x4 H[T], L[T];
+        if (dbg & 32) {   // (timing probe: bit 32 drops the arithmetic)
 #pragma unroll
-        for (int b = 0; b < T; ++b)
+            for (int b = 0; b < T; ++b) { H[b] = u32x4{0u, 0u, 0u, 0u}; L[b] = H[b]; }
+        } else {
+            // als.cc:292-296: residual = Yui - 1 against the row at entry; laid out in stages over the eight entries so that the
+            // dependent chains run side by side
+            float y[8], yo[8];
 #pragma unroll
-            for (int j2 = 0; j2 < 4; ++j2) {
-                unsigned h_, l_;
-                pc_split_pair(q[2 * j2][b], sw[2 * j2], q[2 * j2 + 1][b], sw[2 * j2 + 1], h_, l_);
-                H[b][j2] = h_;
-                L[b][j2] = l_;
+            for (int r = 0; r < 8; ++r) {
+                y[r] = q[r][0] * p0cur[0];
+#pragma unroll
+                for (int b = 1; b < T; ++b) y[r] = __builtin_fmaf(q[r][b], p0cur[b], y[r]);
             }
-        if (!live) return;
-        if (!pc_wait_gt(flg + PC_CONS, gseq - C::NSLOT, seen_cons, flg)) { ok = false; return; }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), 0x128, 0xf, 0xf, false));
+#pragma unroll
+            for (int r = 0; r < 8; ++r) y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), 0x124, 0xf, 0xf, false));
+#pragma unroll
+            for (int r = 0; r < 8; ++r) y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), 0x122, 0xf, 0xf, false));
+#pragma unroll
+            for (int r = 0; r < 8; ++r) y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), 0x121, 0xf, 0xf, false));
+#pragma unroll
+            for (int r = 0; r < 8; ++r) yo[r] = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, y[r]), 0x401F));
+            // the previous group goes out HERE: its stores have drained behind the swizzles, and the wait costs nothing (placed before
+            // the dot products it exposes the latency of the weight reads: +0.1 ms per half-epoch, profiles/r04_als_pc_steps.txt)
+            flush_pub();
+            const int k0 = 16 * g + 8 * half;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float cial = __builtin_fmaf(wgt[r], y[r] + yo[r], -wgt[r]);   // alpha v (q.p0 - 1)
+                const float one = (LOSS && lossk && k0 + r < Cc.n) ? 1.0f : 0.f;
+#pragma unroll
+                for (int b = 0; b < T; ++b) {
+                    gpart[b] = __builtin_fmaf(cial, q[r][b], gpart[b]);
+                    if (LOSS) g1part[b] = __builtin_fmaf(one, q[r][b], g1part[b]);
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < T; ++b)
+#pragma unroll
+                for (int j2 = 0; j2 < 4; ++j2) {
+                    unsigned h_, l_;
+                    pc_split_pair(q[2 * j2][b], sw[2 * j2], q[2 * j2 + 1][b], sw[2 * j2 + 1], h_, l_);
+                    H[b][j2] = h_;
+                    L[b][j2] = l_;
+                }
+        }
+        if (seen_cons - (gseq - C::NSLOT) <= 0) {   // the ring looks full: whatever is still unpublished goes out before the wait
+            flush_pub();
+            if (!pc_wait_gt(flg + PC_CONS, gseq - C::NSLOT, seen_cons, flg)) { ok = false; return; }
+        }
         char* sl = ring + (gseq % C::NSLOT) * C::SLOT_B + lane * 16;
 #pragma unroll
         for (int b = 0; b < T; ++b) {
@@ -398,8 +394,7 @@ __device__ __forceinline__ void als_pc_producer(const AlsParams& p, const AlsWor
             *reinterpret_cast<u32x4*>(sl + (T + b) * 1024) = L[b];
         }
         ++gseq;
-        pc_publish(flg + PC_PROD, gseq);
-        if (Bc.g == Bc.ng - 1) {   // the item closes: h (and g1) for the consumer; the two halves hold the k-parities of the same element
+        if (g == Cc.ng - 1) {   // the item closes: h (and g1) for the consumer; the two halves hold the k-parities of the same element
             float* hb = reinterpret_cast<float*>(bx + 16);
 #pragma unroll
             for (int b = 0; b < T; ++b) {
@@ -410,20 +405,51 @@ __device__ __forceinline__ void als_pc_producer(const AlsParams& p, const AlsWor
                     if (LOSS) hb[VD + b * 32 + col] = g1s;
                 }
             }
-            pc_publish(flg + PC_ROWS_DONE, Bc.rseq + 1);
+            flush_pub();
+            pc_publish(flg + PC_ROWS_DONE, Cc.rseq + 1);
         }
     };
 
     // Everything fetched so far is waited for HERE, by reading it: whatever the loop header inherits as "in flight" from the code
     // before the loop, the compiler keeps waiting for on every trip.
     asm volatile("" ::"v"(pk_c), "v"(pk_v), "v"(tk_v));
-    // three register sets in rotation: step S loads into set S and prepares the set loaded two steps earlier (one exit, at the
-    // bottom: steps past the end of the stream are harmless)
     do {
-        stage_a(raw[0], p0set[0]); stage_b(A2, raw[1], p0set[1]); A2 = A1; A1 = A; advance();
-        stage_a(raw[1], p0set[1]); stage_b(A2, raw[2], p0set[2]); A2 = A1; A1 = A; advance();
-        stage_a(raw[2], p0set[2]); stage_b(A2, raw[0], p0set[0]); A2 = A1; A1 = A; advance();
-    } while (ok && (A.valid | A1.valid | A2.valid));
+        // ---- stage A enters chunk CA: weigh and stage its keys (fetched during the previous trip), fetch the next chunk's ----
+        int* kbA = ks + CA.buf * 192;
+        if (CA.valid) {
+            if (!(pk_rseq == CA.rseq && pk_chunk == CA.chunk)) bad_keys = true;   // (cannot happen: every chunk is fetched ahead)
+            const bool in = CA.chunk * 64 + lane < CA.n;
+            const float ww = in ? alpha * pk_v : 0.f;     // padding lanes: row 0 of the other factor with weight 0
+            const float ss = (ww > 0.f && ww <= wcut) ? sS * __builtin_amdgcn_sqrtf(ww) : 0.f;
+            if (lossk && in) {   // constant and denominator of the loss (als_gram_kernel's header)
+                const double w = static_cast<double>(ww);
+                deno_k += w;
+                nume_k += 1.0 + w;
+            }
+            if (ww != 0.f && ss == 0.f) bad_weight = true;   // a weight the scan should have routed elsewhere
+            kbA[lane] = in ? pk_c : 0;
+            kbA[64 + lane] = __builtin_bit_cast(int, ww);
+            kbA[128 + lane] = __builtin_bit_cast(int, ss);
+        } else {
+            kbA[lane] = 0;
+        }
+        wave_lds_sync();
+        if ((CA.chunk + 1) * 64 < CA.n) load_keys(CA.kbeg, CA.n, CA.chunk + 1, CA.rseq);
+        else load_keys(nx_kbeg, nx_n, 0, CA.rseq + 1);
+        {
+            const float* Pu0 = Pm + static_cast<size_t>(CA.row) * VD;
+#pragma unroll
+            for (int b = 0; b < T; ++b) p0A[b] = Pu0[b * 32 + col];
+        }
+        // ---- four steps: load group s of CA, prepare the group loaded three steps ago ----
+        load_group(kbA, 0, raw[0]); prep_group(CB, 1, raw[1]);
+        load_group(kbA, 1, raw[1]); prep_group(CB, 2, raw[2]);
+        load_group(kbA, 2, raw[2]); prep_group(CB, 3, raw[3]);
+        load_group(kbA, 3, raw[3]); prep_group(CA, 0, raw[0]);
+        CB = CA;
+        advance();
+    } while (ok && (CA.valid | CB.valid));
+    flush_pub();
     if (ok) {   // end of the list: a header with row -1 sends the consumer home
         const int rs = rows_opened;
         if (pc_wait_gt(flg + PC_ROWS_FREE, rs - 2, seen_free, flg)) {
@@ -502,10 +528,14 @@ __device__ __forceinline__ void als_pc_consumer(const AlsParams& p, float* __res
                 H[b] = *reinterpret_cast<const u32x4*>(sl + b * 1024);
             }
         };
-        auto mfmas = [&](const u32x4 (&H)[T], const u32x4 (&L)[T]) {
+        // part 0 = the l h and h l products (2 T(T+1)/2 instructions), part 1 = h h: the slot of the NEXT group is released between the
+        // two -- its pieces have landed in registers behind part 0, and the producer gets the slot back early (a release straight after
+        // the reads stalls the matrix pipe for an LDS round trip: measured +0.2 ms on the item half-epoch)
+        auto mfmas = [&](const u32x4 (&H)[T], const u32x4 (&L)[T], int part) {
             if (p.debug & 16) return;
 #pragma unroll
             for (int pr = 0; pr < 3; ++pr) {   // small terms first: l h, h l, h h
+                if ((pr < 2) != (part == 0)) continue;
                 int t = 0;
 #pragma unroll
                 for (int a = 0; a < T; ++a)
@@ -527,18 +557,22 @@ __device__ __forceinline__ void als_pc_consumer(const AlsParams& p, float* __res
                     if (!pc_wait_gt(flg + PC_PROD, gseq + 1, seen_prod, flg)) { ok = false; break; }
                     read_slot(gseq + 1, HB, LB);
                 }
-                mfmas(HA, LA);
+                mfmas(HA, LA, 0);
+                mfmas(HA, LA, 1);
+                // both slots read so far are released AFTER the group's matrix instructions: a release in their middle (or straight
+                // after the reads) was measured slower (+0.2 ms on the item half-epoch: the wait for the reads stalls the matrix pipe)
+                pc_publish(flg + PC_CONS, gseq + (more ? 2 : 1));
                 ++gseq; ++g;
-                if (!more) { pc_publish(flg + PC_CONS, gseq); break; }
-                pc_publish(flg + PC_CONS, gseq);   // slot gseq - 1 was read into registers before its matrix instructions issued
+                if (!more) break;
                 const bool more2 = g + 1 < ng;
                 if (more2) {
                     if (!pc_wait_gt(flg + PC_PROD, gseq + 1, seen_prod, flg)) { ok = false; break; }
                     read_slot(gseq + 1, HA, LA);
                 }
-                mfmas(HB, LB);
+                mfmas(HB, LB, 0);
+                mfmas(HB, LB, 1);
+                pc_publish(flg + PC_CONS, gseq + (more2 ? 2 : 1));
                 ++gseq; ++g;
-                pc_publish(flg + PC_CONS, gseq);
                 if (!more2) break;
             }
         }
@@ -652,6 +686,11 @@ __global__ __launch_bounds__(512, 2) void als_pc_kernel(AlsParams p, const AlsWo
     __syncthreads();
     const int rl = __builtin_amdgcn_readfirstlane(role_tab[wv]);
     char* pl = pc_lds + C::FF_B + (rl >> 1) * C::PAIR_B;
+    if (p.debug & 128) {   // (probe: static issue priority for the producers / 256: for the consumers)
+        if (rl & 1) __builtin_amdgcn_s_setprio(2);
+    } else if (p.debug & 256) {
+        if (!(rl & 1)) __builtin_amdgcn_s_setprio(2);
+    }
     if (rl & 1) als_pc_producer<T, BIG, LOSS>(p, work, n_items, Qi, defer, pl, err, lane);
     else als_pc_consumer<T, BIG, LOSS>(p, scratch, ff_acc, pl, err, lane);
 }

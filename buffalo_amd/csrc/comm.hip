@@ -144,10 +144,16 @@ Comm::Comm(int n_ranks, int rank, const char* id128, int dev) {
     BFH_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     if (std::memcmp(id128, kShmMagic, sizeof(kShmMagic)) == 0) {
         BFH_REQUIRE(n_ranks <= kShmMaxRanks, "shm transport: at most 16 ranks");
-        struct Guard {   // a throw below must not leak the mapping (the destructor of a half-built Comm never runs)
-            Shm*& p; bool armed = true;
-            ~Guard() { if (armed) { delete p; p = nullptr; } }
-        } guard{shm_};
+        struct Guard {   // a throw below must not leak the mapping, the segment's name or the stream (the destructor of a half-built Comm never runs)
+            Shm*& p; hipStream_t& st; bool armed = true, created = false;
+            ~Guard() {
+                if (!armed) return;
+                if (p && created && !p->name.empty()) shm_unlink(p->name.c_str());   // never counted in `attached`: ~Shm would not unlink it
+                delete p;
+                p = nullptr;
+                if (st) { (void)hipStreamDestroy(st); st = nullptr; }
+            }
+        } guard{shm_, stream};
         shm_ = new Shm();
         static const char* hex = "0123456789abcdef";
         shm_->name = "/bfh_";
@@ -157,7 +163,9 @@ Comm::Comm(int n_ranks, int rank, const char* id128, int dev) {
             shm_->name += hex[b & 15];
         }
         shm_->bytes = kShmHeader + static_cast<size_t>(n_ranks) * kShmSlot;
-        shm_->fd = shm_open(shm_->name.c_str(), O_CREAT | O_RDWR, 0600);
+        shm_->fd = shm_open(shm_->name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (shm_->fd >= 0) guard.created = true;
+        else shm_->fd = shm_open(shm_->name.c_str(), O_CREAT | O_RDWR, 0600);
         if (shm_->fd < 0 || ftruncate(shm_->fd, static_cast<off_t>(shm_->bytes)) != 0)   // a fresh segment reads as zeros: counters start at 0
             throw Error(BFH_ERR_HIP, "shm transport: cannot create " + shm_->name);
         void* m = mmap(nullptr, shm_->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, shm_->fd, 0);
@@ -165,6 +173,7 @@ Comm::Comm(int n_ranks, int rank, const char* id128, int dev) {
         shm_->base = static_cast<char*>(m);
         shm_->hdr = reinterpret_cast<ShmHeader*>(m);
         shm_->hdr->attached.fetch_add(1, std::memory_order_acq_rel);
+        guard.created = false;   // counted: from here ~Shm unlinks when the last rank leaves
         shm_->host.resize(kShmSlot);
         shm_->barrier(n_ranks);   // every rank is attached before the first collective
         guard.armed = false;
@@ -186,21 +195,39 @@ Comm::~Comm() {
     if (stream) (void)hipStreamDestroy(stream);
 }
 
-// rounds of at most one slot per rank: D2H into the rank's slot | barrier | sum the slots in rank order | barrier | H2D
+// rounds of at most one slot per rank: D2H into the rank's slot | barrier | sum the slots | barrier | H2D.
+// The sum runs in rank order, or -- BFH_COMM_SHM_ORDER=ring -- in the order a ring all-reduce produces: the round's elements are cut
+// into N segments, and segment c is accumulated starting at rank c + 1 and ending at rank c (reduce-scatter), then handed to everybody
+// (all-gather).  Different segments see different summation orders; every rank still receives the SAME bits, which is the property
+// the exchange protocol relies on (tests/test_comm_ranks_gpu.py holds the replicas to bit-identity under both orders).
 template <typename T>
 void Comm::shm_all_reduce(const T* send, T* recv, size_t count, hipStream_t s) {
     BFH_HIP(hipStreamSynchronize(s));
     const size_t per = kShmSlot / sizeof(T);
     T* out = reinterpret_cast<T*>(shm_->host.data());
+    static const bool ring = [] { const char* o = std::getenv("BFH_COMM_SHM_ORDER"); return o && std::string(o) == "ring"; }();
     for (size_t off = 0; off < count; off += per) {
         const size_t n = std::min(per, count - off);
         BFH_HIP(hipMemcpy(shm_->slot(rank_), send + off, n * sizeof(T), hipMemcpyDeviceToHost));
         shm_->barrier(size_);
-        const T* a = reinterpret_cast<const T*>(shm_->slot(0));
-        for (size_t i = 0; i < n; ++i) out[i] = a[i];
-        for (int r = 1; r < size_; ++r) {
-            const T* b = reinterpret_cast<const T*>(shm_->slot(r));
-            for (size_t i = 0; i < n; ++i) out[i] += b[i];
+        if (ring) {
+            const size_t seg = (n + size_ - 1) / size_;
+            for (int c = 0; c < size_; ++c) {
+                const size_t lo = std::min(n, c * seg), hi = std::min(n, (c + 1) * seg);
+                const T* a = reinterpret_cast<const T*>(shm_->slot((c + 1) % size_));
+                for (size_t i = lo; i < hi; ++i) out[i] = a[i];
+                for (int k = 2; k <= size_; ++k) {
+                    const T* b = reinterpret_cast<const T*>(shm_->slot((c + k) % size_));
+                    for (size_t i = lo; i < hi; ++i) out[i] += b[i];
+                }
+            }
+        } else {
+            const T* a = reinterpret_cast<const T*>(shm_->slot(0));
+            for (size_t i = 0; i < n; ++i) out[i] = a[i];
+            for (int r = 1; r < size_; ++r) {
+                const T* b = reinterpret_cast<const T*>(shm_->slot(r));
+                for (size_t i = 0; i < n; ++i) out[i] += b[i];
+            }
         }
         shm_->barrier(size_);
         BFH_HIP(hipMemcpy(recv + off, out, n * sizeof(T), hipMemcpyHostToDevice));

@@ -65,10 +65,13 @@ def rel(a, b):
 for m in ({"als_pc": 0}, {"als_pc": 1}):
     timing(m)
 if "--ablate" in sys.argv:   # results are wrong with these, timings only
-    for bits, what in ((1, "no block solve"), (16, "no matrix instructions"), (17, "neither"), (2, "no FF tiles")):
+    for bits, what in ((1, "no block solve"), (16, "no matrix instructions"), (17, "neither"), (17 + 32, "neither, producer without arithmetic"),
+                       (512, "matrix instructions free-running (not waiting for pieces)"), (512 + 1, "... and no solve")):
         print("als_debug %d (%s):" % (bits, what), end=" ")
         timing({"als_pc": 1, "als_debug": bits}, epochs=3)
 
+if "--timing-only" in sys.argv:
+    sys.exit(0)
 # the same warm state through both kernels
 P, Q, _ = synth.init_factors(U, I, D, seed=7)
 g = make(P, Q, {"als_pc": 0})

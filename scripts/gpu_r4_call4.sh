@@ -1,0 +1,6 @@
+#!/bin/bash
+# round 4, GPU call 4: chunk-granular producer (als_pc.hpp): parity tests, A/B timing + probes
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r4c4; mkdir -p $O
+timeout 900 python -m pytest tests/test_als_gpu.py -q -m gpu -x -k "half_epochs or empty_rows or two_rank or resident" -p no:cacheprovider > $O/als_tests.txt 2>&1; tail -6 $O/als_tests.txt | cut -c1-300
+timeout 600 python scripts/als_pc_ab.py --ablate --timing-only > $O/als_pc_ab.txt 2>&1; tail -9 $O/als_pc_ab.txt | cut -c1-300

@@ -95,7 +95,11 @@ CASES = [
                           (256, dict(optimizer="ialspp"), "heavy"),
                           # a few entries 100x heavier than the rest (the test lowers the cut to 500) and a few negative ones: the split-f16 pass sends both kinds
                           # through the fp32 instruction (als_gram_kernel: fix_outliers)
-                          (128, dict(optimizer="ialspp"), "outliers")])
+                          (128, dict(optimizer="ialspp"), "outliers"),
+                          # factor rows spanning 1e-4 .. 1 in scale and weights just below the cut: entries far below max|Q|
+                          # put the low f16 piece of the split pass into subnormals -- absolute accuracy only -- while the heaviest
+                          # weights the f16 path admits stretch its range from the other end
+                          (128, dict(optimizer="ialspp"), "scales")])
 @pytest.mark.parametrize("design", ["inreg", "scratch", "fp32", "wave"])
 def test_half_epochs_match_oracle(oracle, d, kw, shape, design):
     """Every half-epoch starts from bit-identical factors (the GPU model is re-synchronised to the
@@ -120,6 +124,8 @@ def test_half_epochs_match_oracle(oracle, d, kw, shape, design):
         v[::499] *= 100.0
         v[5::53] = -0.05
         csr = synth.CSR(base.num_users, base.num_items, base.indptr, base.keys, v)
+    elif shape == "scales":
+        csr = tiny_csr(U=320, I=280, density=0.2, seed=37, counts=True)
     elif shape == "tiny":
         csr = tiny_csr(U=320, I=280, density=0.06, seed=31, counts=True)   # every row shorter than a wave
     elif shape == "heavy":
@@ -136,6 +142,16 @@ def test_half_epochs_match_oracle(oracle, d, kw, shape, design):
     obj.set_mode("als_pc", int(design != "wave"))
     if shape == "outliers":
         obj.set_mode("als_split_wcut", 500)   # alpha v = 4 * 2 * 100 and more: past the cut
+    if shape == "scales":
+        rs = np.random.default_rng(41)
+        for X, Xo in ((P, Po), (Q, Qo)):
+            f = (10.0 ** rs.uniform(-4.0, 0.0, size=X.shape[0])).astype(np.float32)
+            f[rs.integers(0, X.shape[0])] = 1.0
+            X *= f[:, None]
+            Xo *= f[:, None]
+        obj.set_mode("als_split_wcut", int(np.ceil(4.0 * csr.vals.max())))   # the heaviest weight alpha v sits AT the cut: still on the f16 path
+        obj.initialize_model(P, Q)
+        obj.set_placeholder(csr.indptr, csr.transpose().indptr, csr.nnz + 1)
     t = csr.transpose()
     for it in range(2 if shape == "tiny" else 1):
         for axis, mat in ((0, csr), (1, t)):
@@ -209,7 +225,9 @@ def test_empty_rows_unchanged_q16(oracle):
 def test_resident_csr_and_deferred_writeback(oracle):
     csr = tiny_csr(U=50, I=40, density=0.25, seed=8, counts=True)
     d = 128
-    opt = als_opt(d=d, alpha=2.0, compute_loss_on_training=False)
+    # (regulariser 2: 50 x 40 with a dozen entries per row leaves the d = 128 systems to the regulariser; at the default 0.1 the two
+    #  fp32 evaluations of a free-running epoch differ by 5 % through conditioning alone, and the test is about residency, not that)
+    opt = als_opt(d=d, alpha=2.0, reg_u=2.0, reg_i=2.0, compute_loss_on_training=False)
     o, obj, (P, Q), (Po, Qo) = _setup(oracle, csr, d, opt)
     t = csr.transpose()
     obj.set_resident_csr(0, csr.indptr, csr.keys, csr.vals)
@@ -223,7 +241,7 @@ def test_resident_csr_and_deferred_writeback(oracle):
         assert obj.partial_update(0, mat.num_users, mat.indptr, None, None, axis) == (0.0, 0.0)
     assert np.array_equal(P, P_before)          # nothing written back yet
     obj.synchronize(True)
-    assert H.relerr(P[:, :d], Po) < 5e-2 and H.relerr(Q[:, :d], Qo) < 5e-2   # 50 x 40 toy at d=128: see envelope test
+    assert H.relerr(P[:, :d], Po) < 5e-3 and H.relerr(Q[:, :d], Qo) < 5e-3, (H.relerr(P[:, :d], Po), H.relerr(Q[:, :d], Qo))
 
 
 @pytest.mark.parametrize("optimizer", ["llt", "manual_cg"])
@@ -474,7 +492,7 @@ def test_config3_warm_epoch_matches_the_oracle_path(oracle):
     for q, a_, b_ in zip(qs, q_hip, q_or):
         assert a_ <= max(2.5 * b_, 2e-7), (q, a_, b_)
     assert n_hip <= 2.5 * n_or + 3, (n_hip, n_or)
-    assert e_hip.max() <= max(2.5 * e_or.max(), 5e-4), (e_hip.max(), e_or.max())
+    assert e_hip.max() <= max(2.5 * e_or.max(), 2e-4), (e_hip.max(), e_or.max())   # largest ever measured: 1.3e-4 (profiles/r03_als_split_rows.txt)
     users = np.random.default_rng(11).choice(U, 2000, replace=False)
 
     def top10(Pm, Qm):

@@ -26,8 +26,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_world(tmp_path, world, spec, timeout=240):
+def run_world(tmp_path, world, spec, timeout=240, order=None):
+    """`order="ring"`: the test transport sums every segment of a buffer in the rotated order a ring all-reduce produces
+    (csrc/comm.hip shm_all_reduce) instead of in rank order."""
+    os.makedirs(str(tmp_path), exist_ok=True)
     env = dict(os.environ, BFH_COMM_TRANSPORT="shm")
+    if order:
+        env["BFH_COMM_SHM_ORDER"] = order
     os.environ["BFH_COMM_TRANSPORT"] = "shm"
     try:
         from buffalo_amd.backend import Comm
@@ -174,15 +179,16 @@ def test_sgd_saturation_weights_are_the_same_on_every_rank(tmp_path):
     assert H.relerr(Qb, sQb) > 1e-4
 
 
-@pytest.mark.parametrize("modes,per_call", [({}, 1), (dict(comm_segments=3), 3)])
-def test_hogwild_item_major_two_ranks(tmp_path, modes, per_call):
-    """The throughput walk (item-major, per-XCD replicas) with its exchange blocking (default) and pipelined three deep:
-    replicas bit-identical after the flush, every call made its exchange points, and the two-rank model ranks as well as
-    the one-GPU model on a planted problem (local SGD with summed deltas, statistical parity: SURVEY 8(e))."""
+@pytest.mark.parametrize("modes,per_call,world", [({}, 1, 2), (dict(comm_segments=3), 3, 2), (dict(comm_segments=3), 3, 3), (dict(comm_segments=3), 3, 8),
+                                                  ({}, 1, 8)])
+def test_hogwild_item_major_n_ranks(tmp_path, modes, per_call, world):
+    """The throughput walk (item-major, per-XCD replicas) with its exchange blocking (default) and pipelined three deep, on 2, 3
+    and 8 ranks: replicas bit-identical after the flush, every call made its exchange points, and the N-rank model ranks as well
+    as the one-GPU model on a planted problem (local SGD with summed deltas, statistical parity: SURVEY 8(e))."""
     from buffalo_amd import synth
     spec = dict(scenario="sgd", kind="bpr", d=16, epochs=30, U=600, I=400, density=0.06, data_seed=7, lr=0.05, min_lr=0.01,
                 opt=dict(reg_u=0.01, reg_i=0.01, reg_j=0.01, reg_b=0.01), modes=modes)
-    ranks = run_world(tmp_path, 2, spec, timeout=400)
+    ranks = run_world(tmp_path, world, spec, timeout=400)
     assert all(spec["epochs"] * per_call <= int(r["exchanges"]) <= spec["epochs"] * (per_call + 1) for r in ranks), [int(r["exchanges"]) for r in ranks]
     P, Q, Qb = assemble(ranks)
     assert np.isfinite(P).all() and np.isfinite(Q).all() and np.isfinite(Qb).all()
@@ -196,9 +202,31 @@ def test_hogwild_item_major_two_ranks(tmp_path, modes, per_call):
         pos = s[rows, csr.keys].mean()
         return pos - s.mean()
     f2, f1 = fit(P, Q, Qb), fit(one["P"], one["Q"], one["Qb"])
-    assert f1 > 0 and f2 > 0.8 * f1, (f2, f1)
     n2, n1 = np.linalg.norm(Q), np.linalg.norm(one["Q"])
+    print("\nHogwild walk, %d ranks, %s: fit %.4f vs one GPU %.4f (ratio %.3f), |Q| ratio %.3f" % (world, modes or "blocking", f2, f1, f2 / f1, n2 / n1))
+    assert f1 > 0 and f2 > 0.8 * f1, (f2, f1)
     assert 0.7 < n2 / n1 < 1.4, (n2, n1)
+
+
+@pytest.mark.parametrize("world,modes", [(3, dict(sequential=1)), (8, dict(sequential=1)), (3, dict(comm_segments=3)), (8, {})])
+def test_replicas_stay_bit_identical_under_ring_order_sums(tmp_path, world, modes):
+    """RCCL's ring all-reduce does not sum in rank order: each segment of the buffer is accumulated around the ring from a different
+    starting rank, and every rank receives the same result.  The exchange protocol needs only the second half of that sentence.
+    With the test transport summing in ring order (BFH_COMM_SHM_ORDER=ring): the replicas are still bit-identical on every rank
+    (`assemble`), and the model differs from the rank-order run by fp32 summation order only (deterministic walk) / stays the
+    same model statistically (Hogwild walk)."""
+    spec = dict(scenario="sgd", kind="bpr", d=16, epochs=6, U=600, I=400, density=0.06, data_seed=7, lr=0.05, min_lr=0.01,
+                opt=dict(reg_u=0.01, reg_i=0.01, reg_j=0.01, reg_b=0.01), modes=modes)
+    ring = run_world(tmp_path / "ring", world, spec, timeout=400, order="ring")
+    Pr, Qr, Qbr = assemble(ring)                      # bit-identical replicas under ring-order sums
+    rank_order = run_world(tmp_path / "rank", world, spec, timeout=400)
+    Po, Qo, Qbo = assemble(rank_order)
+    e = max(H.relerr(Qr, Qo), H.relerr(Qbr, Qbo), H.relerr(Pr, Po))
+    print("\n%d ranks, %s: ring-order vs rank-order sums, model distance %.2e" % (world, modes, e))
+    if modes.get("sequential"):
+        assert 0 < e < 1e-4, e                        # not the same bits (the order did change), the same numbers
+    else:
+        assert e < 0.5, e                             # Hogwild: another legal interleaving of the same updates
 
 
 @pytest.mark.parametrize("world,optimizer,d", [(2, "manual_cg", 32), (3, "llt", 20), (2, "ialspp", 128)])
