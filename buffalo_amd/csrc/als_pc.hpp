@@ -38,7 +38,7 @@ struct AlsPc {
     static constexpr int KEY_B = NK * 3 * 64 * 4;          // (row id, weight, S sqrt(weight)) x 64 entries
     static constexpr int BOX_B = 16 + 2 * VD * 4;          // row header (row, n, slot, -) | h | g1
     static constexpr int VEC_B = (2 * VD + 64) * 4;        // the consumer's solve vectors: p | delta | 64 exchange floats
-    static constexpr int FLAG_B = 64;
+    static constexpr int FLAG_B = 128;                     // six counters | 16 floats of exchange space for the producer's lane reduction
     static constexpr int PAIR_B = NSLOT * SLOT_B + KEY_B + 2 * BOX_B + VEC_B + FLAG_B;
     static constexpr int ROLE_B = 64;
     static constexpr int LDS_B = FF_B + 4 * PAIR_B + ROLE_B;
@@ -166,6 +166,32 @@ __device__ __forceinline__ void pc_split_pair(float q0, float s0, float q1, floa
     asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(q1), "v"(s1), "v"(h));
 }
 
+template <int CTRL>
+__device__ __forceinline__ float pc_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// y[r], r = 0..7  ->  the sum of y[r] over the 32 lanes of this half-wave, all eight in every lane.  A butterfly costs 5 steps x 8
+// values = 40 instructions (+ 8 adds); here every step HALVES the number of values a lane carries on (lane bit 3 decides which four
+// of the eight it keeps and which it hands to its mirror lane, bit 2 which two of the four, bit 0 which one), so the tree costs
+// 12 + 6 + 3 + 1 + 2 instructions, and one LDS round trip hands all eight sums to every lane: 31 issue slots instead of 48 -- the
+// producer is bound by its instruction count.  `tmp`: 16 floats of LDS private to the wave.
+__device__ __forceinline__ void pc_sum8_over_half(float (&y)[8], float* tmp, int lane) {
+    const bool b3 = lane & 8, b2 = lane & 4, b0 = lane & 1;
+    float z[4], w[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) z[i] = (b3 ? y[i + 4] : y[i]) + pc_dpp<0x140>(b3 ? y[i] : y[i + 4]);        // row_mirror: lane ^ 15
+#pragma unroll
+    for (int i = 0; i < 2; ++i) w[i] = (b2 ? z[i + 2] : z[i]) + pc_dpp<0x141>(b2 ? z[i] : z[i + 2]);        // row_half_mirror: lane ^ 7
+    float v = (b0 ? w[1] : w[0]) + pc_dpp<0xB1>(b0 ? w[0] : w[1]);                                            // quad_perm [1,0,3,2]: lane ^ 1
+    v += pc_dpp<0x4E>(v);                                                                                     // quad_perm [2,3,0,1]: lane ^ 2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));          // the half's other 16-lane row
+    float* t8 = tmp + 8 * (lane >> 5);
+    t8[(lane & 1) + ((lane & 12) >> 1)] = v;   // this lane carries the sum of y[b0 + 2 b2 + 4 b3]
+    wave_lds_sync();
+    const float4 a = *reinterpret_cast<const float4*>(t8), b = *reinterpret_cast<const float4*>(t8 + 4);
+    y[0] = a.x; y[1] = a.y; y[2] = a.z; y[3] = a.w; y[4] = b.x; y[5] = b.y; y[6] = b.z; y[7] = b.w;
+}
+
 struct PcChunk {   // where a pipeline stage stands in the pair's stream: one 64-entry chunk of one work item (all wave-uniform)
     int valid;
     int row, kbeg, n, slot;   // the work item
@@ -194,6 +220,7 @@ __device__ __forceinline__ void als_pc_producer(const AlsParams& p, const AlsWor
     int* ks = reinterpret_cast<int*>(pl + C::NSLOT * C::SLOT_B);
     char* box = pl + C::NSLOT * C::SLOT_B + C::KEY_B;
     int* flg = reinterpret_cast<int*>(pl + C::PAIR_B - C::FLAG_B);
+    float* redtmp = reinterpret_cast<float*>(pl + C::PAIR_B - C::FLAG_B + 64);
     const float sS = p.split[0], wcut = p.split[3], alpha = p.alpha;
     const bool lossk = LOSS && p.compute_loss && p.axis == 1;
     const int dbg = p.debug;
@@ -310,9 +337,13 @@ __device__ __forceinline__ void als_pc_producer(const AlsParams& p, const AlsWor
         // (no run-time switch around these loads: a path without them would put the compiler's wait counts back to "everything")
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            using off_t = typename std::conditional<BIG, size_t, unsigned>::type;
-            const off_t voff = static_cast<off_t>(static_cast<unsigned>(cid[r])) * (4u * VD) + lane_off;
-            pc_load_row<T>(qbase + voff, rw[r]);
+            if constexpr (BIG) {
+                const size_t voff = static_cast<size_t>(static_cast<unsigned>(cid[r])) * (4u * VD) + lane_off;
+                pc_load_row<T>(qbase + voff, rw[r]);
+            } else {
+                const unsigned voff = static_cast<unsigned>(cid[r]) + lane_off;
+                pc_load_row<T>(qbase + voff, rw[r]);
+            }
         }
     };
 
@@ -342,30 +373,21 @@ __device__ __forceinline__ void als_pc_producer(const AlsParams& p, const AlsWor
         } else {
             // als.cc:292-296: residual = Yui - 1 against the row at entry; laid out in stages over the eight entries so that the
             // dependent chains run side by side
-            float y[8], yo[8];
+            float y[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 y[r] = q[r][0] * p0cur[0];
 #pragma unroll
                 for (int b = 1; b < T; ++b) y[r] = __builtin_fmaf(q[r][b], p0cur[b], y[r]);
             }
-#pragma unroll
-            for (int r = 0; r < 8; ++r) y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), 0x128, 0xf, 0xf, false));
-#pragma unroll
-            for (int r = 0; r < 8; ++r) y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), 0x124, 0xf, 0xf, false));
-#pragma unroll
-            for (int r = 0; r < 8; ++r) y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), 0x122, 0xf, 0xf, false));
-#pragma unroll
-            for (int r = 0; r < 8; ++r) y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), 0x121, 0xf, 0xf, false));
-#pragma unroll
-            for (int r = 0; r < 8; ++r) yo[r] = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, y[r]), 0x401F));
-            // the previous group goes out HERE: its stores have drained behind the swizzles, and the wait costs nothing (placed before
-            // the dot products it exposes the latency of the weight reads: +0.1 ms per half-epoch, profiles/r04_als_pc_steps.txt)
+            pc_sum8_over_half(y, redtmp, lane);
+            // the previous group goes out HERE: its stores have drained behind the reduction's LDS round trip, and the wait costs nothing
+            // (placed before the dot products it exposes the latency of the weight reads: +0.1 ms per half-epoch, profiles/r04_als_pc_steps.txt)
             flush_pub();
             const int k0 = 16 * g + 8 * half;
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                const float cial = __builtin_fmaf(wgt[r], y[r] + yo[r], -wgt[r]);   // alpha v (q.p0 - 1)
+                const float cial = __builtin_fmaf(wgt[r], y[r], -wgt[r]);   // alpha v (q.p0 - 1)
                 const float one = (LOSS && lossk && k0 + r < Cc.n) ? 1.0f : 0.f;
 #pragma unroll
                 for (int b = 0; b < T; ++b) {
@@ -427,7 +449,8 @@ __device__ __forceinline__ void als_pc_producer(const AlsParams& p, const AlsWor
                 nume_k += 1.0 + w;
             }
             if (ww != 0.f && ss == 0.f) bad_weight = true;   // a weight the scan should have routed elsewhere
-            kbA[lane] = in ? pk_c : 0;
+            // (the row's BYTE offset into the interleaved factor when that fits 32 bits: one instruction less per gathered row)
+            kbA[lane] = in ? (BIG ? pk_c : pk_c * (4 * VD)) : 0;
             kbA[64 + lane] = __builtin_bit_cast(int, ww);
             kbA[128 + lane] = __builtin_bit_cast(int, ss);
         } else {

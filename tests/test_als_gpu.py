@@ -172,15 +172,20 @@ def test_half_epochs_match_oracle(oracle, d, kw, shape, design):
             # partial_update wrote the updated rows back into the caller's arrays (als.cu:403)
             e_or, e_hip, e_pair = H.relerr(Xo, truth), H.relerr(X[:, :d], truth_hip), H.relerr(X[:, :d], Xo)
             # the explicit Gramian adds the rounding of an n-term fp32 sum per entry of M to what the matrix-free
-            # reference recurrence sees; CG amplifies it with the conditioning of the 32x32 blocks, which grows
-            # with d: the envelope is 2.5x the oracle's own error up to vdim 128 and 10x for the wide kernel
+            # reference recurrence sees; CG amplifies it with the conditioning of the 32x32 blocks: the envelope is
+            # 2.5x the oracle's own error (the wide kernel, 128 < vdim <= 256, was at 10x until it moved to the
+            # residual-first gradient in round 4)
             # "outliers": weights spanning 1 : 100 make single rows ill-conditioned enough that round 3's in-register designs land at
             # 3.3x (fp32 instruction) and 5.5x (split-f16 with its fp32 side pass) of the oracle's distance where the scratch path
             # lands at 1.3x on the SAME inputs (profiles/r03_als_split_f16.txt).  The default path now sends the rows that hold such
             # weights through the scratch path (als_defer_scan_kernel) and is held to the 2.5x of every other case; the two
             # non-default kernels keep the 10x they were measured at
-            loose = _vdim(d) > 128 or (shape == "outliers" and design in ("fp32", "wave"))
-            env = max((10 if loose else 2.5) * e_or, 5e-5)
+            loose = shape == "outliers" and design in ("fp32", "wave")
+            # the wide kernel (128 < vdim <= 256, fp32 matrix instruction across 3-4 waves): 20 of its 21 half-epochs sit at 0.2 .. 2.0x
+            # since it forms the gradient residual-first (round 4; 10x before), one -- d = 192, the cold first user half-epoch -- at
+            # 3.5x (profiles/r04_als_wide_residual_first.txt): 4x
+            factor = 10 if loose else (4.0 if _vdim(d) > 128 else 2.5)
+            env = max(factor * e_or, 5e-5)
             print("\nALS d=%d %s %s/%s it %d axis %d: err(hip,f64) %.3e  err(oracle,f64) %.3e  ratio %.2f  hip~oracle %.3e"
                   % (d, kw, shape, design, it, axis, e_hip, e_or, e_hip / max(e_or, 1e-30), e_pair))
             assert e_hip <= env, (it, axis, e_hip, e_or)

@@ -28,3 +28,49 @@ def test_split_f16_loop_keeps_its_shape():
     assert st["loop_valu"] <= 520, st                 # ~230 VALU per group (measured 472 per pair)
     assert st["vgpr_spill"] <= 48, st                 # whole kernel (the per-row phases spill a few registers)
     assert st["lds"] <= 80 * 1024, st                 # FF tiles (64 KB) + per-wave vectors: one block per CU by registers, two by LDS
+
+
+@pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="needs hipcc")
+def test_pc_kernel_keeps_its_wait_counts_and_registers():
+    """als_pc_kernel (csrc/als_pc.hpp) depends on two properties of the compiler's output that no parity test sees and that were
+    both lost and found while it was written (profiles/r04_als_pc_steps.txt):
+      * the producer's loop waits for the group it loaded THREE steps ago with s_waitcnt vmcnt(N), N >= 16 -- one control-flow path
+        without the unconditional loads and every wait becomes vmcnt(0), i.e. no memory overlap at all (1.7 us per group);
+      * the consumer's matrix instructions run from registers: no scratch traffic in their blocks (a second copy of the stream
+        behind a branch made the allocator shuttle the accumulators: 900 spilled registers)."""
+    import re
+    import subprocess
+    import tempfile
+    src = ('#include "als_kernels.hpp"\nnamespace bfh {\ntemplate __global__ void als_pc_kernel<4, false, false>(AlsParams, const AlsWork*, int, float*, '
+           'const float*, const int*, int*);\n}\n')
+    with tempfile.TemporaryDirectory() as d:
+        hip, asm = os.path.join(d, "one.hip"), os.path.join(d, "one.s")
+        open(hip, "w").write(src)
+        cmd = [HIPCC, "-DBFH_ALS_KERNELS_ONLY", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
+               "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "buffalo_amd", "csrc"), "-S", "--cuda-device-only", hip, "-o", asm]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
+        text = open(asm).read()
+    i = text.index("als_pc_kernelILi4ELb0ELb0E")
+    body = text[text.index(":", i):text.index(".Lfunc_end", i)]
+    blocks = re.split(r"\n(?=\.LBB\d+_\d+:)", body)
+    prep, gather, matrix = [], [], []
+    for b in blocks:
+        ins = [l.strip() for l in b.split("\n") if l.strip() and not l.strip().startswith(";")]
+        if sum("v_fma_mix" in l for l in ins) >= 32:
+            prep.append(ins)
+        if sum(l.startswith("global_load_dwordx4") for l in ins) >= 8:
+            gather.append(ins)
+        if sum("v_mfma" in l for l in ins) >= 10:
+            matrix.append(ins)
+    assert len(prep) == 4 and len(gather) == 4 and len(matrix) >= 2, (len(prep), len(gather), len(matrix))
+    for ins in gather:      # the eight row loads of a step are never preceded by a drain of everything in flight
+        waits = [int(re.search(r"vmcnt\((\d+)\)", l).group(1)) for l in ins if "vmcnt" in l]
+        assert all(w >= 8 for w in waits), waits
+    for ins in prep:        # the group being prepared was loaded three steps ago: two newer groups (16 loads) may stay in flight
+        waits = [int(re.search(r"vmcnt\((\d+)\)", l).group(1)) for l in ins if "vmcnt" in l]
+        assert all(w >= 16 for w in waits), waits
+    for ins in matrix + prep + gather:
+        assert not any(l.startswith("scratch_") for l in ins), [l for l in ins if l.startswith("scratch_")][:4]
+    spill = int(re.search(r"als_pc_kernelILi4ELb0ELb0E.*?\.vgpr_spill_count:\s+(\d+)", text, re.S).group(1))
+    assert spill <= 48, spill   # the per-row solve spills a few registers; the loops none
