@@ -178,7 +178,7 @@ def extra_als(csr, seed, epochs=5, cpu=True):
     alg_bytes = 2 * nnz * (4 * D + 8) + (U + I) * (8 * D + 8) + (U + I) * 4 * D     # SURVEY 8(d) B_als, both half-epochs
     out = {"config": "ALS iALS++ (block 32, 3 CG steps), ml20m-shaped synthetic (%d x %d, %d nnz, values 1+Poisson(1)), d=%d, f32, "
                      "rowwise + colwise CSR and factors resident in HBM" % (U, I, nnz, D),
-           "epoch_ms": dt * 1e3, "interactions_per_s": 2 * nnz / dt, "kernel": "als_gram_kernel (Gramian on the f16 matrix cores at fp32 accuracy + in-register block CG)",
+           "epoch_ms": dt * 1e3, "interactions_per_s": 2 * nnz / dt, "kernel": "als_pc_kernel (producer / consumer wave pairs: gather + residuals + f16 cut | Gramian on the f16 matrix cores at fp32 accuracy + in-register block CG)",
            "kernel_ms_per_epoch": kernel_s * 1e3, "gramian_ff_ms_per_epoch": st["aux_ms"] / epochs,
            "mfma": {"issued_TFLOPs": mfma_flop / kernel_s / 1e12, "peak_TFLOPs": MFMA_F16_PEAK_TF,
                     "frac": mfma_flop / kernel_s / 1e12 / MFMA_F16_PEAK_TF,
@@ -188,9 +188,10 @@ def extra_als(csr, seed, epochs=5, cpu=True):
                     # what a block-diagonal formulation would need, 4 nnz d bs + 2 (U + I) d^2 -- the "useful" flops
                     "useful_flop_per_epoch": 4 * nnz * D * 32 + 2 * (U + I) * D * D,
                     "useful_frac_of_fp32_peak": (4 * nnz * D * 32 + 2 * (U + I) * D * D) / kernel_s / 1e12 / MFMA_F32_PEAK_TF,
-                    "note": "the pass is VALU / latency bound at one wave per SIMD, not matrix-core bound: the same Gramian through "
-                            "v_mfma_f32_32x32x2_f32 (als_split_f16=0) needs %.1f ms of matrix-core time alone at its %.0f TFLOP/s peak"
-                            % (gram_flop / MFMA_F32_PEAK_TF / 1e9, MFMA_F32_PEAK_TF)},
+                    "note": "bound by instruction issue, not by the matrix cores: a VALU wave and a matrix wave on one SIMD serialise "
+                            "(profiles/r04_micro_simd_overlap.txt), so the producers' ~270 instructions per 16 entries add to the 30 matrix "
+                            "instructions; the same Gramian through v_mfma_f32_32x32x2_f32 (als_split_f16=0) needs %.1f ms of matrix-core "
+                            "time alone at its %.0f TFLOP/s peak" % (gram_flop / MFMA_F32_PEAK_TF / 1e9, MFMA_F32_PEAK_TF)},
            "hbm": {"algorithmic_bytes_per_epoch": alg_bytes, "achieved_GBps": alg_bytes / kernel_s / 1e9,
                    "frac": alg_bytes / kernel_s / 1e9 / HBM_PEAK_GBS}}
     del g

@@ -187,8 +187,10 @@ int bfh_als_synchronize(void* h, int device_to_host);
  *   events around every launch), "epoch";
  *   "als_split_f16"    (ALS, in-place iALS++ rows, d >= 64; default 1) the row Gramian through v_mfma_f32_32x32x16_f16 with every
  *                      operand cut into two round-to-nearest f16 pieces (fp32 accuracy, 5x fewer matrix-core cycles);
- *                      0 = v_mfma_f32_32x32x2_f32;  "als_split_wcut" weights alpha*v above this (default 32768) and negative ones
- *                      take the fp32 instruction inside that pass;  "als_inreg" 0 = every row through the scratch slot + als_solve_kernel. */
+ *                      0 = v_mfma_f32_32x32x2_f32;  "als_split_wcut": rows holding a weight alpha*v above this (default 32768) or a
+ *                      negative one go through the fp32 instruction + the dense-solve kernel (a scan of the weights, cached per
+ *                      chunk, finds them);  "als_pc" (default 1) producer / consumer wave pairs for those rows (csrc/als_pc.hpp),
+ *                      0 = round 3's wave-per-row kernel;  "als_inreg" 0 = every row through the scratch slot + als_solve_kernel. */
 int bfh_bpr_set_mode(void* h, const char* name, int64_t value);
 int bfh_warp_set_mode(void* h, const char* name, int64_t value);
 int bfh_als_set_mode(void* h, const char* name, int64_t value);

@@ -12,7 +12,7 @@ meta = {}
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if not any(t in k for t in ("bpr_item_major_kernel", "bpr_item_major_dual_kernel", "bpr_update_kernel", "grad_gather_kernel", "warp_update_kernel", "als_gram_kernel",
+        if not any(t in k for t in ("bpr_item_major_kernel", "bpr_item_major_dual_kernel", "bpr_update_kernel", "grad_gather_kernel", "warp_update_kernel", "als_gram_kernel", "als_pc_kernel",
                                     "xcd_merge_kernel", "bpr_presample_kernel")):
             continue
         per[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -34,13 +34,15 @@ out = {
              "under 'others'.",
     "others": {k[:90]: {n: sum(v) / len(v) for n, v in d.items()} for k, d in per.items() if k != dom},
 }
-als = [k for k in per if "als_gram_kernel" in k and "SQ_VALU_MFMA_BUSY_CYCLES" in per[k]]
+als = [k for k in per if ("als_pc_kernel" in k or "als_gram_kernel" in k) and "SQ_VALU_MFMA_BUSY_CYCLES" in per[k]]
+als.sort(key=lambda k: "als_pc_kernel" not in k)
 if als:   # MFMA utilisation of the ALS Gramian/solve kernel: matrix-pipe busy cycles over (kernel cycles x 1024 SIMDs).
     # GRBM_GUI_ACTIVE is reported summed over the 8 XCDs (71.4 M for a 3.9 ms launch at ~2.3 GHz), hence the / 8.
     a = {n: sum(v) / len(v) for n, v in per[als[0]].items()}
-    out["als_gram_kernel"] = {"counters_per_launch": a, **meta[als[0]],
-                              "mfma_busy_frac": a["SQ_VALU_MFMA_BUSY_CYCLES"] / (a.get("GRBM_GUI_ACTIVE", 0.0) / 8 * 1024) if a.get("GRBM_GUI_ACTIVE") else None,
-                              "mfma_instructions_per_launch": a["SQ_VALU_MFMA_BUSY_CYCLES"] / 64.0}
+    out["als_row_kernel"] = {"kernel": als[0][:80], "counters_per_launch": a, **meta[als[0]],
+                             "mfma_busy_frac": a["SQ_VALU_MFMA_BUSY_CYCLES"] / (a.get("GRBM_GUI_ACTIVE", 0.0) / 8 * 1024) if a.get("GRBM_GUI_ACTIVE") else None,
+                             # v_mfma_f32_32x32x16_f16 keeps the pipe busy 32 cycles (MI355X_MICROARCH.md: SQ_VALU_MFMA_BUSY_CYCLES = 32 x N for 32x32x16)
+                             "mfma_instructions_per_launch_if_32x32x16": a["SQ_VALU_MFMA_BUSY_CYCLES"] / 32.0}
 if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
     out["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
 json.dump(out, open(out_path, "w"), indent=1)
