@@ -63,6 +63,7 @@ def _sgd_sigs(pfx):
 
 SIGNATURES = {
     "bfh_version": (C.c_char_p, []),
+    "bfh_stats_size": (C.c_size_t, []),
     "bfh_last_error": (C.c_char_p, [_vp]),
     "bfh_device_count": (_i32, []),
     "bfh_bpr_update_triples": (_i32, [_vp, _i64, _pi32, _pi32, _pi32, _f64]),
@@ -181,6 +182,9 @@ def lib():
         fn = getattr(L, name)  # AttributeError here == ABI drift between header and library
         fn.restype = res
         fn.argtypes = args
+    if L.bfh_stats_size() != C.sizeof(Stats):   # bfh_*_get_stats writes the library's whole struct into OUR buffer
+        raise BuffaloHipError("bfh_stats is %d bytes in libbuffalo_hip.so and %d in buffalo_amd/_lib.py: rebuild / update the mirror"
+                              % (L.bfh_stats_size(), C.sizeof(Stats)))
     _lib = L
     return L
 

@@ -213,7 +213,8 @@ std::string Options::str(const std::string& k) const {
 
 extern "C" {
 
-const char* bfh_version(void) { return "buffalo_hip 0.1.0 (gfx950)"; }
+const char* bfh_version(void) { return "buffalo_hip 0.2.0 (gfx950)"; }
+size_t bfh_stats_size(void) { return sizeof(bfh_stats); }
 
 const char* bfh_last_error(const void* handle) {
     if (!handle) return bfh::g_create_error.c_str();

@@ -397,6 +397,7 @@ class EalsHandle : public AlsHandle {
         DevBuf<float> vals, vhat;
         DevBuf<int32_t> light, mid, heavy;   // row ids with <= EALS_LIGHT / <= EALS_HEAVY / more entries, the long ones longest first (empty rows are light: the regulariser still moves them)
         int n_light = 0, n_mid = 0, n_heavy = 0;
+        int64_t mid_longest = 0;
         int64_t longest = 0, heavy_entries = 0;   // sum of the heavy rows' lengths, each rounded up to 64
         DevBuf<int64_t> heavy_off;                // [n_heavy] scratch offset (entries) of every heavy row, in list order
         int64_t nnz = 0;
@@ -432,6 +433,7 @@ class EalsHandle : public AlsHandle {
             std::stable_sort(md.begin(), md.end(), longer);
             s.n_light = static_cast<int>(li.size());
             s.n_mid = static_cast<int>(md.size());
+            s.mid_longest = md.empty() ? 0 : indptr[md[0]] - (md[0] ? indptr[md[0] - 1] : 0);
             s.n_heavy = static_cast<int>(hv.size());
             s.light.resize(std::max<size_t>(1, li.size()));
             s.mid.resize(std::max<size_t>(1, md.size()));
@@ -541,7 +543,9 @@ class EalsHandle : public AlsHandle {
             pm.n_list = s.n_mid;
             pm.ticket = tickets3_.get() + 1;
             const int groups = std::min(s.n_mid, num_cus_ * 16);
-            const int64_t cap = EALS_HEAVY;
+            // slot = the longest mid row (the list is sorted longest first) rounded up to a wave, not the class bound EALS_HEAVY: mid rows
+            // may be as short as EALS_LIGHT + 1 entries, and 4,096 groups x 17 x EALS_HEAVY floats were 1.1 GB whatever the rows' lengths
+            const int64_t cap = std::min<int64_t>(EALS_HEAVY, ((s.mid_longest + 63) / 64) * 64);
             const size_t need = static_cast<size_t>(groups) * (1 + EALS_DB) * cap;
             if (scratch_m_.size() < need) scratch_m_.resize(need);
             BFH_HIP(hipStreamWaitEvent(side_stream_[0], side_go_, 0));

@@ -238,12 +238,13 @@ __global__ __launch_bounds__(256) void grad_gather_kernel(GatherParams g) {
                 if (it < static_cast<uint32_t>(g.Q_rows)) {
                     const int32_t idx = g.inc_idx[kk];
                     bool any = false;
-                    // one 8-byte gather carries the user and the coefficient (negative = rejected)
+                    // one 8-byte gather carries the user and the coefficient (negative = rejected: BPR / WARP coefficients are >= 0 by
+                    // construction -- sigmoid / log of a count; a NaN of a diverged model is NOT negative and propagates like in the reference)
                     const int64_t base = g.pos_list ? static_cast<int64_t>(idx) * g.num_neg : static_cast<int64_t>(idx);
                     const int slots = g.pos_list ? g.num_neg : 1;
                     for (int sl = 0; sl < slots; ++sl) {
                         const float2 v = g.uc[base + sl];
-                        if (v.y >= 0.f) {
+                        if (!(v.y < 0.f)) {
                             my_c += v.y;
                             my_u = __builtin_bit_cast(int, v.x);
                             any = true;
@@ -545,6 +546,8 @@ void SgdHandle::exchange_begin() {
     comm_->all_reduce_f32(S, xR_.get(), x_count(), comm_->comm_stream());
     t_ar_.end(ar, comm_->comm_stream());
     BFH_HIP(hipEventRecord(x_done_, comm_->comm_stream()));
+    x_p_num_neg_ = x_w_num_neg_;   // what exchange_finish weighs THIS exchange with (exchange_weights may be called for a later one meanwhile)
+    x_p_uniform_ = x_w_uniform_;
     x_pending_ = true;
     stats.exchanges += 1;
 }
@@ -555,11 +558,11 @@ void SgdHandle::exchange_finish(bool progressed) {
     BFH_HIP(hipStreamWaitEvent(stream, x_done_, 0));
     const int xk = t_xk_.begin(stream);
     if (x_gcnt_ready_) {
-        const double glob_triples = static_cast<double>(num_nnz_) * x_w_num_neg_;          // one epoch over all ranks
-        const double pos_scale = x_gcnt_total_ > 0 ? static_cast<double>(num_nnz_) / x_gcnt_total_ * x_w_num_neg_ : 0.0;   // counted keys -> the whole matrix
+        const double glob_triples = static_cast<double>(num_nnz_) * x_p_num_neg_;          // one epoch over all ranks
+        const double pos_scale = x_gcnt_total_ > 0 ? static_cast<double>(num_nnz_) / x_gcnt_total_ * x_p_num_neg_ : 0.0;   // counted keys -> the whole matrix
         hipLaunchKernelGGL(exchange_weight_kernel, dim3((Q_rows_ + 255) / 256), dim3(256), 0, stream, static_cast<const int*>(x_gcnt_.get()),
-                           x_w_uniform_ ? nullptr : static_cast<const int64_t*>(cum_.get()), cum_total_, Q_rows_, pos_scale, glob_triples,
-                           x_w_uniform_ ? 1.0 / Q_rows_ : 0.0, static_cast<const float*>(xR_.get() + x_scalars()), comm_stiffness_q_milli_ * 1e-3,
+                           x_p_uniform_ ? nullptr : static_cast<const int64_t*>(cum_.get()), cum_total_, Q_rows_, pos_scale, glob_triples,
+                           x_p_uniform_ ? 1.0 / Q_rows_ : 0.0, static_cast<const float*>(xR_.get() + x_scalars()), comm_stiffness_q_milli_ * 1e-3,
                            comm_stiffness_milli_ * 1e-3, comm_->size(), xW_.get(), xWb_.get());
     }
     hipLaunchKernelGGL(delta_finish_kernel, stream_grid(nq), dim3(256), 0, stream, Q_.get(), xZ_.get(), static_cast<const float*>(xS_.get()),

@@ -218,6 +218,8 @@ class SgdHandle : public HandleBase {
     double x_w_interval_ = 0, x_w_lr_ = 0;   // what exchange_weights announced for the exchange that begins next
     int x_w_num_neg_ = 1;
     bool x_w_uniform_ = true;
+    int x_p_num_neg_ = 1;           // ... of the exchange in flight (snapshot taken by exchange_begin)
+    bool x_p_uniform_ = true;
 
     EventTimer t_main_, t_opt_, t_aux_, t_xk_, t_ar_;   // dominant kernel, optimizer, everything else, exchange kernels, all-reduces
 };

@@ -67,6 +67,9 @@ typedef struct {
 } bfh_stats;
 
 const char* bfh_version(void);
+/* sizeof(bfh_stats) of THIS library: the struct grows at its end between versions, a caller built against an older header can check that
+ * its buffer is large enough before calling bfh_*_get_stats (which writes the whole struct). */
+size_t bfh_stats_size(void);
 /* Message of the last failure on `handle` (any bfh object), or of the last failed *_create when
  * handle is NULL.  Never returns NULL. */
 const char* bfh_last_error(const void* handle);
