@@ -222,6 +222,44 @@ def extra_als(csr, seed, epochs=5, cpu=True):
     return out
 
 
+def extra_als_wide(csr, seed, d, epochs=3):
+    """ALS at 128 < d <= 256 (iALS++, block 32) on the ML-20M shape: als_wide_kernel -- the row's tiles spread over ceil(T/2) waves,
+    fp32 matrix instruction, residual-first gradient."""
+    from buffalo_amd import ingest, synth
+    from buffalo_amd.backend import CyALS
+    U, I, nnz = csr.num_users, csr.num_items, csr.nnz
+    vals = (1 + np.random.default_rng(seed).poisson(1.0, size=nnz)).astype(np.float32)
+    col = ingest.coo_to_csr(csr.keys, csr.rows(), vals, I, U)
+    P, Q, _ = synth.init_factors(U, I, d, seed=seed)
+    g = CyALS()
+    path = _opt_file(dict(ALS_OPT, d=d))
+    assert g.init(path)
+    os.unlink(path)
+    g.initialize_model(P, Q)
+    g.set_resident_csr(0, csr.indptr, csr.keys, vals)
+    g.set_resident_csr(1, col["indptr"], col["key"], col["val"])
+    g.set_mode("als_writeback", 0)
+
+    def epoch():
+        g.precompute(0)
+        g.partial_update(0, U, csr.indptr, None, None, 0)
+        g.precompute(1)
+        g.partial_update(0, I, col["indptr"], None, None, 1)
+    epoch()
+    g.reset_stats()
+    t0 = time.perf_counter()
+    for _ in range(epochs):
+        epoch()
+    dt = (time.perf_counter() - t0) / epochs
+    st = g.stats()
+    T = d // 32
+    gram_flop = 2 * nnz * (T * (T + 1) // 2) * 2 * 32 * 32
+    kernel_s = st["kernel_ms"] / epochs * 1e-3
+    return {"config": "ALS iALS++ (block 32), ml20m-shaped synthetic, d=%d, f32: als_wide_kernel" % d, "epoch_ms": dt * 1e3,
+            "kernel_ms_per_epoch": kernel_s * 1e3, "interactions_per_s": 2 * nnz / dt,
+            "mfma_fp32_issued_TFLOPs": gram_flop / kernel_s / 1e12, "mfma_fp32_frac": gram_flop / kernel_s / 1e12 / MFMA_F32_PEAK_TF}
+
+
 def warp_epoch_row(st, nnz, d, U, I, wall_s, presample=4, chunk_runs=None):
     """One WARP epoch's numbers from the backend's counters.  Three byte figures, never mixed:
     * algorithmic (the reference formulation warp.cc:135-165): per accepted positive (8 + T) rows of 4d bytes + key,
@@ -405,7 +443,7 @@ def extra_warp_c5(seed, epochs=6, cpu=True):
     g.initialize_model(P, Q, Qb, nnz, True)
     g.set_resident_csr(indptr, keys)
     up_s = time.perf_counter() - t0
-    eps = _warp_epochs(g, U, indptr, nnz, d, I, epochs, until_T=3.0, max_epochs=18)
+    eps = _warp_epochs(g, U, indptr, nnz, d, I, epochs, until_T=3.0, max_epochs=12)
     out = _warp_summary(eps, {
         "config": "WARP adagrad, dot score, max_trials 500, configs[4]-shaped synthetic (%d x %d, %d nnz), d=%d, f32, ONE GPU, everything "
                   "resident in HBM" % (U, I, nnz, d),
@@ -814,6 +852,10 @@ def main():
                     extra[name] = fn(csr, args.seed, cpu=not args.no_cpu_baseline)
                 except Exception as e:   # the headline line is never lost to a secondary measurement
                     extra[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+            try:   # the top of the reference's own D-sweep (benchmark/README.md:97): d = 160, block 32 -> the wide ALS kernel (T = 5)
+                extra["als_ml20m_d160"] = extra_als_wide(csr, args.seed, 160)
+            except Exception as e:
+                extra["als_ml20m_d160"] = {"error": "%s: %s" % (type(e).__name__, e)}
             out["extra"] = extra
             # the driver's record keeps the scalars of `roofline` / `cpu_baseline` and drops nested objects: configs[2] (ALS) and
             # configs[4] (WARP) at BASELINE size, measured in this process, as flat keys
@@ -826,6 +868,9 @@ def main():
                 rf.update({"als_epoch_ms": a["epoch_ms"], "als_kernel_ms": a["kernel_ms_per_epoch"], "als_hbm_frac": a["hbm"]["frac"],
                            "als_hbm_frac_of_epoch": a["hbm"]["algorithmic_bytes_per_epoch"] / (a["epoch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                            "als_useful_mfma_frac": a["mfma"]["useful_frac_of_fp32_peak"], "als_issued_mfma_frac_f16": a["mfma"]["frac"]})
+            a160 = extra.get("als_ml20m_d160") or {}
+            if "epoch_ms" in a160:
+                rf.update({"als_d160_epoch_ms": a160["epoch_ms"], "als_d160_kernel_ms": a160["kernel_ms_per_epoch"]})
             w = extra.get("warp_ml20m_d256") or {}
             if "epoch_ms" in w:
                 rf.update({"warp_ml20m_epoch_ms": w["epoch_ms"], "warp_ml20m_T": w["mean_scored_negatives_T"],

@@ -2319,6 +2319,10 @@ class AlsHandle : public HandleBase {
         BFH_REQUIRE(model_, "precompute before initialize_model");
         BFH_REQUIRE(axis == 0 || axis == 1, "axis must be 0 or 1");
         gramian_of(axis == 0 ? Q_.get() : P_.get(), axis == 0 ? Q_rows_ : P_rows_);
+        // a new half-epoch: whatever was derived from the other factor (its interleaved copy, the split scale) is rebuilt by the next
+        // partial_update -- the factor may have been written through a device pointer handed out earlier (row exchange of a sharded
+        // run), which no version counter of this handle sees; the chunks of ONE half-epoch still share the copy
+        qi_side_ = -1;
     }
     // FF = F^T F for a device matrix [rows, vdim]
     void gramian_of(const float* F, int rows) {

@@ -73,3 +73,27 @@ def test_rejects_bad_arguments():
     for nq, nn in ((0, 1), (9, 1), (8, 0)):
         assert L.bfh_bpr_item_major_plan(nq, one.ctypes.data_as(p64), nn, 1, C.byref(sl), C.byref(sg), one.ctypes.data_as(p64),
                                          one.ctypes.data_as(p64)) != 0
+
+
+def test_shard_bounds_cost_model():
+    """`shard_bounds`: contiguous ranges of equal cost, cost(row) = nnz + row_cost.  row_cost = 0 is the nnz balance the SGD walks use
+    (every rank's shard timed: profiles/r04_shard_times_all_ranks.txt, slowest / mean <= 1.03); a per-row term moves the cuts towards
+    equal row counts."""
+    import numpy as np
+    from buffalo_amd.dist import shard_bounds, shard_csr
+    rng = np.random.default_rng(0)
+    deg = np.concatenate([rng.integers(200, 400, 500), rng.integers(1, 5, 5000)])     # heavy head, long light tail
+    indptr = np.cumsum(deg).astype(np.int64)
+    for world in (2, 4, 8):
+        b0 = shard_bounds(indptr, world)
+        assert b0[0] == 0 and b0[-1] == len(deg) and all(x <= y for x, y in zip(b0, b0[1:]))
+        nnz = [int(indptr[b - 1] - (indptr[a - 1] if a else 0)) if b > a else 0 for a, b in zip(b0, b0[1:])]
+        assert max(nnz) - min(nnz) <= 2 * deg.max(), nnz
+        b1 = shard_bounds(indptr, world, row_cost=1e6)                                  # rows dominate: equal row counts
+        rows = [b - a for a, b in zip(b1, b1[1:])]
+        assert max(rows) - min(rows) <= 2, rows
+        bm = shard_bounds(indptr, world, row_cost=50.0)
+        cost = [(int(indptr[b - 1] - (indptr[a - 1] if a else 0)) if b > a else 0) + 50.0 * (b - a) for a, b in zip(bm, bm[1:])]
+        assert max(cost) - min(cost) <= 2 * (deg.max() + 50), cost
+    u0, u1, ip, keys, off = shard_csr(indptr, np.arange(indptr[-1], dtype=np.int32), 1, 4, row_cost=50.0)
+    assert ip[-1] == keys.shape[0] and keys[0] == off
