@@ -2453,7 +2453,9 @@ class AlsHandle : public HandleBase {
             int blocks = (items + 3) / 4;                           // 4 independent waves per block, one work item each
             if (blocks > num_cus_ * 4) blocks = num_cus_ * 4;       // persistent: residency is set by the kernel's VGPR count
             // producer / consumer pairs (als_pc.hpp): the default for the in-place iALS++ rows at d = 64 / 96 / 128
-            bool use_pc = items > 0 && inreg && split_f16_ && pc_ && T >= 2 && T <= 4;
+            // (measured on the ML-20M shape, profiles/r04_als_pc_steps.txt: d = 128 4.53 vs 5.08 ms, d = 96 3.47 vs 3.95, d = 64 2.47 vs 2.06 --
+            //  at T = 2 round 3's kernel already runs two waves per SIMD, and the pairs only add their hand-off: "als_pc" = 2 forces them)
+            bool use_pc = items > 0 && inreg && split_f16_ && T <= 4 && (pc_ == 2 ? T >= 2 : (pc_ == 1 && T >= 3));
             if (use_pc) {
                 scan_deferred(*wl, p, items);
                 if (wl->n_def_rows > 4096 || wl->n_def * 4 > items) {
@@ -2850,7 +2852,7 @@ class AlsHandle : public HandleBase {
         else if (name == "als_debug") debug_ = static_cast<int>(v);
         else if (name == "als_split_wcut") split_wcut_ = static_cast<float>(v);   // weights above this take the fp32 side path (default 2^15; tests lower it)
         else if (name == "als_split_f16") split_f16_ = v != 0;             // 0: the in-place iALS++ rows keep the fp32 matrix instruction
-        else if (name == "als_pc") pc_ = v != 0;                           // 0: the wave-per-row split kernel (round 3) instead of the producer / consumer pairs
+        else if (name == "als_pc") { BFH_REQUIRE(v >= 0 && v <= 2, "als_pc must be 0, 1 or 2"); pc_ = static_cast<int>(v); }   // 0: round 3's wave-per-row split kernel; 1: producer / consumer pairs where they win (d = 96, 128); 2: also at d = 64
         else if (name == "als_inreg") no_inreg_ = v == 0;                 // 0: iALS++ rows go through the scratch + solve kernel instead of the in-register solve
         else if (name == "timing") timing = v != 0;
         else throw Error(BFH_ERR_INVALID, "unknown mode '" + name + "'");
@@ -2897,7 +2899,7 @@ class AlsHandle : public HandleBase {
     int debug_ = 0;
     bool no_inreg_ = false;
     bool split_f16_ = true;
-    bool pc_ = true;
+    int pc_ = 1;
     float split_wcut_ = 32768.0f;
     uint64_t fver_[2] = {1, 1};     // bumped whenever P (0) / Q (1) may have changed on the device
     uint64_t vals_ver_ = 1;         // bumped whenever confidence values were uploaded

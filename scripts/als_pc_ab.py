@@ -15,8 +15,8 @@ csr = bench.load_matrix("ml20m", 7)
 U, I, nnz = csr.num_users, csr.num_items, csr.nnz
 vals = (1 + np.random.default_rng(7).poisson(1.0, size=nnz)).astype(np.float32)
 col = ingest.coo_to_csr(csr.keys, csr.rows(), vals, I, U)
-D = bench.D
-OPT = bench.ALS_OPT
+D = int(os.environ.get("ALS_D", bench.D))                    # 64 / 96: the pc kernel at T = 2 / 3 (iALS++ has to be asked for below d = 128)
+OPT = dict(bench.ALS_OPT, d=D, optimizer="ialspp")
 
 
 def make(P, Q, modes):

@@ -139,7 +139,7 @@ def test_half_epochs_match_oracle(oracle, d, kw, shape, design):
     # "scratch": every row goes through the HBM scratch slot + dense-solve kernel
     obj.set_mode("als_inreg", int(design != "scratch"))
     obj.set_mode("als_split_f16", int(design != "fp32"))
-    obj.set_mode("als_pc", int(design != "wave"))
+    obj.set_mode("als_pc", 0 if design == "wave" else 2)   # 2: the pairs at d = 64 too (the default leaves T = 2 to the wave-per-row kernel, which is faster there)
     if shape == "outliers":
         obj.set_mode("als_split_wcut", 500)   # alpha v = 4 * 2 * 100 and more: past the cut
     if shape == "scales":
