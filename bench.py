@@ -885,6 +885,7 @@ def main():
                 if isinstance(tr, dict) and tr.get("hbm_bytes_per_epoch"):
                     dev_ms = last["trial_kernel_ms"] + last["sort_and_gather_ms"] + last["optimizer_ms"]
                     rf["warp_c5_traffic_frac"] = tr["hbm_bytes_per_epoch"] / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                    rf["warp_c5_traffic_T"] = tr.get("mean_scored_negatives_T")   # the T of the profiled epoch (compare with warp_c5_T)
                     rf["warp_c5_traffic_source"] = "profiles/warp_pmc_latest.json (counter bytes of an earlier run of this workload) over this run's device time"
             cb = out.get("cpu_baseline") or {}
             for name, key in (("als_ml20m_d128", "als"), ("warp_ml20m_d256", "warp_ml20m"), ("warp_c5_one_gpu", "warp_c5")):

@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/warp_prof
 rm -rf $O; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 for SH in ml20m c5; do
-  EP=4; [ $SH = c5 ] && EP=6
+  EP=4; [ $SH = c5 ] && EP=12
   CMD="python $R/scripts/run_warp.py shape=$SH epochs=$EP"
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$SH/stats -o p -- $CMD out=$O/${SH}_epochs.json > $O/${SH}_stats.log 2>&1
   timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/$SH/pmc_fetch -o p -- $CMD > $O/${SH}_fetch.log 2>&1
