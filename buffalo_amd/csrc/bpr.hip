@@ -578,7 +578,7 @@ __device__ __forceinline__ float f4_fma(float sc, float a, float b) { return sc 
 template <typename T>
 __global__ __launch_bounds__(256) void xcd_merge_kernel(T* __restrict__ S, T* __restrict__ rep, int64_t n, int64_t stride, float scale,
                                                          int write_replicas, const uint8_t* __restrict__ hot, int row_len, T* __restrict__ base,
-                                                         int only = 0) {
+                                                         int only = 0, const float* __restrict__ W = nullptr) {
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
         if (hot && (only ? hot[i / row_len] != only : hot[i / row_len] != 0)) continue;
         const T s_now = S[i];
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(256) void xcd_merge_kernel(T* __restrict__ S, T* __
         T acc = f4_sub(r[0], s0);
 #pragma unroll
         for (int x = 1; x < kXcdReplicas; ++x) acc = f4_add(acc, f4_sub(r[x], s0));
-        const T out = f4_fma(scale, acc, s_now);
+        const T out = f4_fma(W ? scale * W[i / row_len] : scale, acc, s_now);
         S[i] = out;
         if (write_replicas) {
 #pragma unroll
@@ -597,6 +597,39 @@ __global__ __launch_bounds__(256) void xcd_merge_kernel(T* __restrict__ S, T* __
             if (base) base[i] = out;
         }
     }
+}
+
+// Per-row weight of the merge's sum (the rule of exchange_weight_kernel, sgd_base.hip, applied between the XCDs of one GPU): a
+// replica row receives m steps between two merges; with curvature k each contracts the row towards its local equilibrium by
+// exp(-lr k), so n replicas that started from the same state combine like ONE run of n m steps when their summed deltas are scaled
+// by w = (1 - exp(-n x)) / (n (1 - exp(-x))), x = lr k m  (w -> 1: independent steps, SUM; w -> 1/n: n estimates of one move, MEAN).
+// Items: only the NEGATIVE steps of a row land in its replicas (the positive item lives in registers and is flushed into S).
+__device__ __forceinline__ double xcd_sat_weight(double x, int n) { return (n > 1 && x > 1e-9) ? -expm1(-n * x) / (n * -expm1(-x)) : 1.0; }
+__global__ void xcd_item_weight_kernel(const int64_t* __restrict__ cum, int64_t cum_total, int rows, double neg_steps, double neg_uniform, double lr,
+                                       double kq, double kb, int n, float* __restrict__ Wq, float* __restrict__ Wb) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    double pneg = neg_uniform;
+    if (cum) pneg = static_cast<double>(cum[i] - (i ? cum[i - 1] : 0)) / static_cast<double>(cum_total);
+    const double m = neg_steps * pneg / n;      // negative steps of row i per replica between two merges
+    Wq[i] = static_cast<float>(xcd_sat_weight(lr * kq * m, n));
+    Wb[i] = static_cast<float>(xcd_sat_weight(lr * kb * m, n));
+}
+// Users that have replicas: every step of the user lands in them, spread over n queues (im_keys_kernel's rule: all nq, or for
+// spread mode 3 the smallest power of two r with deg < heavy_deg * r).
+__global__ void xcd_user_weight_kernel(const int64_t* __restrict__ indptr, int first_row, int rows, double steps_per_entry, double lr, double kp, int nq,
+                                       int spread_mode, int64_t heavy_deg, float* __restrict__ Wp) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= rows) return;
+    const int g = first_row + u;
+    const int64_t deg = indptr[g] - (g ? indptr[g - 1] : 0);
+    int n = nq;
+    if (spread_mode == 3 && heavy_deg > 0) {
+        n = 2;
+        while (n < nq && deg >= heavy_deg * n) n <<= 1;
+        if (n > nq) n = nq;
+    }
+    Wp[g] = static_cast<float>(xcd_sat_weight(lr * kp * static_cast<double>(deg) * steps_per_entry / n, n));
 }
 
 // How often is every item row updated?  One int atomic per index (once per resident CSR).
@@ -833,8 +866,9 @@ class BprHandle : public SgdHandle {
         // so the rule is "fewer than 3072 users per queue".  Statistics (profiles/r02_gate_study_user_replicas.txt, whole matrix, 8 copies):
         // at the reference's lr the gate metrics stay inside the oracle pair's spread; at lr 0.05 the sum of eight deltas of a heavy
         // user overshoots (|P| 390 vs 430, one run in three diverging), so above lr 0.01 the owner form stays.
+        const float user_lr_max = im_user_lr_max_milli_ * 1e-3f;
         const bool p_rep = im_user_replicas_ > 0 ||
-                           (im_user_replicas_ < 0 && !im_single_wave_ && users_here < static_cast<int64_t>(nq) * 3072 && c.lr <= 0.01f);
+                           (im_user_replicas_ < 0 && !im_single_wave_ && users_here < static_cast<int64_t>(nq) * 3072 && c.lr <= user_lr_max);
         // Whole matrices keep one owner XCD per user -- except for the HEAVY users, the ones the collision rule below would put on
         // fp32 atomics (ML-20M shape: degree >= ~780, 2 % of the users, 17 % of the triples; `xcd_hot_tau = 0` showed those atomics
         // cost 8 % of the walk).  They alone get the replica treatment: their entries are spread over the queues, so a heavy user's
@@ -843,7 +877,7 @@ class BprHandle : public SgdHandle {
         const int64_t waves0 = im_resident_waves();
         const double inflight0 = (!im_prefetch() ? 0.25 : (c.fresh ? 0.5 : 2.0)) * (static_cast<double>(waves0) / nq) * (im_dual() ? 2.0 : 1.0);
         const double tau0 = xcd_hot_tau_ * 1e-3;
-        const bool p_hyb = !p_rep && im_user_hybrid_ && !im_single_wave_ && c.lr <= 0.01f && tau0 > 0.0 && inflight0 > 0.0 && nq > 1;
+        const bool p_hyb = !p_rep && im_user_hybrid_ && !im_single_wave_ && c.lr <= user_lr_max && tau0 > 0.0 && inflight0 > 0.0 && nq > 1;
         // degree from which the owner-share rule fires: deg * num_neg / (triples / nq) * inflight >= tau
         const int64_t heavy_deg = p_hyb ? std::max<int64_t>(1, static_cast<int64_t>(std::ceil(tau0 * (static_cast<double>(c.total) / nq) / (inflight0 * num_neg_)))) : 0;
         const int spread_mode = p_rep ? 1 : (p_hyb ? (im_user_hybrid_ >= 2 ? 3 : 2) : 0);
@@ -931,6 +965,23 @@ class BprHandle : public SgdHandle {
         BFH_HIP(hipMemsetAsync(im_hot_user_.get(), 0, im_hot_user_.bytes(), stream));
         hipLaunchKernelGGL(im_user_flags_kernel, dim3((next_x - start_x + 255) / 256), dim3(256), 0, stream, p.indptr, start_x, next_x - start_x,
                            static_cast<double>(num_neg_), triples / nq, triples, inflight, tau, spread_mode >= 2 ? 2 : spread_mode, heavy_deg, im_hot_user_.get());
+        BFH_HIP(hipGetLastError());
+        // ---- weights of the merges' sums (0 = plain sum) ----
+        const bool w_items = xcd_stiff_q_milli_ > 0 || xcd_stiff_b_milli_ > 0;
+        const bool w_users = xcd_stiff_p_milli_ > 0 && spread_mode != 0;
+        if (w_items) {
+            xcd_wq_.resize(static_cast<size_t>(Q_rows_));
+            xcd_wb_.resize(static_cast<size_t>(Q_rows_));
+            hipLaunchKernelGGL(xcd_item_weight_kernel, dim3((Q_rows_ + 255) / 256), dim3(256), 0, stream, uniform_ ? nullptr : p.cum_table, cum_total_, Q_rows_,
+                               triples / static_cast<double>(segments), uniform_ ? 1.0 / Q_rows_ : 0.0, static_cast<double>(c.lr), xcd_stiff_q_milli_ * 1e-3,
+                               xcd_stiff_b_milli_ * 1e-3, nq, xcd_wq_.get(), xcd_wb_.get());
+        }
+        if (w_users) {
+            xcd_wp_.resize(static_cast<size_t>(P_rows_));
+            hipLaunchKernelGGL(xcd_user_weight_kernel, dim3((next_x - start_x + 255) / 256), dim3(256), 0, stream, p.indptr, start_x, next_x - start_x,
+                               static_cast<double>(num_neg_) / static_cast<double>(segments), static_cast<double>(c.lr), xcd_stiff_p_milli_ * 1e-3, nq, spread_mode,
+                               heavy_deg, xcd_wp_.get());
+        }
         BFH_HIP(hipGetLastError());
         // ---- replicas of the item factors (+ the copy they started from) ----
         xcd_alloc(true);
@@ -1035,12 +1086,12 @@ class BprHandle : public SgdHandle {
             // multi-GPU: the other ranks' deltas of the previous exchange point land in Q before the replicas are folded in and
             // refreshed; this segment's own delta goes out behind the merge and travels while the next walk runs
             exchange_finish(true);
-            xcd_merge(sgm + 1 < segments, c.hot, true);
+            xcd_merge(sgm + 1 < segments, c.hot, true, w_items);
             if (p_any) {   // P <- P + sum_x (P_x - B) for the users that have replicas (flag 2); the others were updated in P itself
                 hipLaunchKernelGGL((xcd_merge_kernel<float4>), dim3(static_cast<unsigned>(std::min<int64_t>((up4 + 255) / 256, 8192))), dim3(256), 0, stream,
                                    reinterpret_cast<float4*>(P_.get()) + uoff4, reinterpret_cast<float4*>(repP_.get()) + uoff4, up4, np4, 1.0f,
                                    sgm + 1 < segments ? 1 : 0, static_cast<const uint8_t*>(im_hot_user_.get()) + start_x, vdim_ / 4,
-                                   reinterpret_cast<float4*>(repP_.get()) + kXcdReplicas * np4 + uoff4, 2);
+                                   reinterpret_cast<float4*>(repP_.get()) + kXcdReplicas * np4 + uoff4, 2, w_users ? xcd_wp_.get() + start_x : nullptr);
                 BFH_HIP(hipGetLastError());
             }
             t_aux_.end(slot, stream);
@@ -1079,16 +1130,16 @@ class BprHandle : public SgdHandle {
                            static_cast<const float*>(Qb_.get()), repQb_.get(), static_cast<int64_t>(Q_rows_), rep_bstride(), copies);
         BFH_HIP(hipGetLastError());
     }
-    void xcd_merge(bool write_replicas, const uint8_t* hot, bool with_base) {
+    void xcd_merge(bool write_replicas, const uint8_t* hot, bool with_base, bool weighted = false) {
         const int64_t nq4 = static_cast<int64_t>(Q_rows_) * vdim_ / 4;
         const float scale = xcd_merge_mean_ ? 1.0f / kXcdReplicas : 1.0f;
         float4* base4 = with_base ? reinterpret_cast<float4*>(repQ_.get()) + kXcdReplicas * nq4 : nullptr;
         float* baseb = with_base ? repQb_.get() + kXcdReplicas * rep_bstride() : nullptr;
         hipLaunchKernelGGL((xcd_merge_kernel<float4>), dim3(static_cast<unsigned>(std::min<int64_t>((nq4 + 255) / 256, 8192))), dim3(256), 0, stream,
                            reinterpret_cast<float4*>(Q_.get()), reinterpret_cast<float4*>(repQ_.get()), nq4, nq4, scale, write_replicas ? 1 : 0,
-                           hot, vdim_ / 4, base4);
+                           hot, vdim_ / 4, base4, 0, weighted ? xcd_wq_.get() : nullptr);
         hipLaunchKernelGGL((xcd_merge_kernel<float>), dim3((Q_rows_ + 255) / 256), dim3(256), 0, stream, Qb_.get(), repQb_.get(),
-                           static_cast<int64_t>(Q_rows_), rep_bstride(), scale, write_replicas ? 1 : 0, hot, 1, baseb);
+                           static_cast<int64_t>(Q_rows_), rep_bstride(), scale, write_replicas ? 1 : 0, hot, 1, baseb, 0, weighted ? xcd_wb_.get() : nullptr);
         BFH_HIP(hipGetLastError());
     }
     // hot-row flags for this call (policy 2); returns null when the split is disabled

@@ -941,6 +941,11 @@ void SgdHandle::set_mode(const std::string& name, int64_t v) {
     }
     else if (name == "xcd_sync_updates") { BFH_REQUIRE(v >= 1, "xcd_sync_updates must be positive"); xcd_sync_updates_ = v; }
     else if (name == "xcd_merge_mean") xcd_merge_mean_ = v != 0;
+    else if (name == "xcd_stiff_q" || name == "xcd_stiff_b" || name == "xcd_stiff_p") {
+        BFH_REQUIRE(v >= 0 && v <= 100000, name + " is a curvature in permille, 0 (plain sum) .. 100000");
+        (name == "xcd_stiff_q" ? xcd_stiff_q_milli_ : name == "xcd_stiff_b" ? xcd_stiff_b_milli_ : xcd_stiff_p_milli_) = static_cast<int>(v);
+    }
+    else if (name == "im_user_lr_max") { BFH_REQUIRE(v >= 0, "im_user_lr_max is a learning rate in permille >= 0"); im_user_lr_max_milli_ = static_cast<int>(v); }
     else if (name == "xcd_fresh") xcd_fresh_ = v != 0 ? 1 : 0;
     else if (name == "im_drift_budget") { BFH_REQUIRE(v >= 0, "im_drift_budget is a permille value >= 0"); im_drift_budget_milli_ = static_cast<int>(v); }
     else if (name == "im_blocks") { BFH_REQUIRE(v >= 0 && v <= 64, "im_blocks must be in [0,64] (0 = choose from the learning rate)"); im_blocks_ = static_cast<int>(v); }

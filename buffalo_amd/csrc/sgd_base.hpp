@@ -137,6 +137,10 @@ class SgdHandle : public HandleBase {
     // whether the merge sums (0) or averages (1) the replicas' deltas
     int64_t xcd_sync_updates_ = -1;   // default: 2^21 (policy 2), 2^23 (policy 3)
     int xcd_merge_mean_ = 0;
+    // policy 3: curvature (permille) the merge's per-row saturation weights assume for Q / Qb / the replicated P rows (xcd_item_weight_kernel); 0 = plain sum
+    int xcd_stiff_q_milli_ = 0, xcd_stiff_b_milli_ = 0, xcd_stiff_p_milli_ = 0;
+    int im_user_lr_max_milli_ = 10;   // learning rate (permille) up to which users get per-XCD replicas
+    DevBuf<float> xcd_wq_, xcd_wb_, xcd_wp_;
     int im_single_wave_ = 0, im_force_queues_ = 0;   // test hooks: one wave drains all queues in order; number of queues for that run
     int im_drain_only_ = 0;        // test hook: skip the owner-XCD launch, the atomic drain launch does everything
     DevBuf<int32_t> im_trace_;     // test hook ("im_trace" = capacity): table index of every triple of a single-wave call
