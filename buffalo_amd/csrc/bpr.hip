@@ -604,7 +604,12 @@ __global__ __launch_bounds__(256) void xcd_merge_kernel(T* __restrict__ S, T* __
 // exp(-lr k), so n replicas that started from the same state combine like ONE run of n m steps when their summed deltas are scaled
 // by w = (1 - exp(-n x)) / (n (1 - exp(-x))), x = lr k m  (w -> 1: independent steps, SUM; w -> 1/n: n estimates of one move, MEAN).
 // Items: only the NEGATIVE steps of a row land in its replicas (the positive item lives in registers and is flushed into S).
-__device__ __forceinline__ double xcd_sat_weight(double x, int n) { return (n > 1 && x > 1e-9) ? -expm1(-n * x) / (n * -expm1(-x)) : 1.0; }
+// m is an expectation; steps are whole: a row that saw at most one step over all replicas (n m <= 1) cannot have overshot, so the
+// saturation is counted from the second step on, x = lr k (m - 1/n) -- w = 1 exactly for the cold tail (and for conflict-free tests).
+__device__ __forceinline__ double xcd_sat_weight(double a, double m, int n) {
+    const double x = a * (m - 1.0 / n);
+    return (n > 1 && x > 1e-9) ? -expm1(-n * x) / (n * -expm1(-x)) : 1.0;
+}
 __global__ void xcd_item_weight_kernel(const int64_t* __restrict__ cum, int64_t cum_total, int rows, double neg_steps, double neg_uniform, double lr,
                                        double kq, double kb, int n, float* __restrict__ Wq, float* __restrict__ Wb) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -612,8 +617,8 @@ __global__ void xcd_item_weight_kernel(const int64_t* __restrict__ cum, int64_t 
     double pneg = neg_uniform;
     if (cum) pneg = static_cast<double>(cum[i] - (i ? cum[i - 1] : 0)) / static_cast<double>(cum_total);
     const double m = neg_steps * pneg / n;      // negative steps of row i per replica between two merges
-    Wq[i] = static_cast<float>(xcd_sat_weight(lr * kq * m, n));
-    Wb[i] = static_cast<float>(xcd_sat_weight(lr * kb * m, n));
+    Wq[i] = static_cast<float>(xcd_sat_weight(lr * kq, m, n));
+    Wb[i] = static_cast<float>(xcd_sat_weight(lr * kb, m, n));
 }
 // Users that have replicas: every step of the user lands in them, spread over n queues (im_keys_kernel's rule: all nq, or for
 // spread mode 3 the smallest power of two r with deg < heavy_deg * r).
@@ -629,7 +634,7 @@ __global__ void xcd_user_weight_kernel(const int64_t* __restrict__ indptr, int f
         while (n < nq && deg >= heavy_deg * n) n <<= 1;
         if (n > nq) n = nq;
     }
-    Wp[g] = static_cast<float>(xcd_sat_weight(lr * kp * static_cast<double>(deg) * steps_per_entry / n, n));
+    Wp[g] = static_cast<float>(xcd_sat_weight(lr * kp, static_cast<double>(deg) * steps_per_entry / n, n));
 }
 
 // How often is every item row updated?  One int atomic per index (once per resident CSR).
@@ -967,8 +972,9 @@ class BprHandle : public SgdHandle {
                            static_cast<double>(num_neg_), triples / nq, triples, inflight, tau, spread_mode >= 2 ? 2 : spread_mode, heavy_deg, im_hot_user_.get());
         BFH_HIP(hipGetLastError());
         // ---- weights of the merges' sums (0 = plain sum) ----
-        const bool w_items = xcd_stiff_q_milli_ > 0 || xcd_stiff_b_milli_ > 0;
-        const bool w_users = xcd_stiff_p_milli_ > 0 && spread_mode != 0;
+        // (not for the single-wave test hook: one wave takes every step there, in ONE replica, and the sum is already the sequential result)
+        const bool w_items = (xcd_stiff_q_milli_ > 0 || xcd_stiff_b_milli_ > 0) && !im_single_wave_;
+        const bool w_users = xcd_stiff_p_milli_ > 0 && spread_mode != 0 && !im_single_wave_;
         if (w_items) {
             xcd_wq_.resize(static_cast<size_t>(Q_rows_));
             xcd_wb_.resize(static_cast<size_t>(Q_rows_));

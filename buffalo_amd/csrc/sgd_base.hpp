@@ -137,9 +137,16 @@ class SgdHandle : public HandleBase {
     // whether the merge sums (0) or averages (1) the replicas' deltas
     int64_t xcd_sync_updates_ = -1;   // default: 2^21 (policy 2), 2^23 (policy 3)
     int xcd_merge_mean_ = 0;
-    // policy 3: curvature (permille) the merge's per-row saturation weights assume for Q / Qb / the replicated P rows (xcd_item_weight_kernel); 0 = plain sum
-    int xcd_stiff_q_milli_ = 0, xcd_stiff_b_milli_ = 0, xcd_stiff_p_milli_ = 0;
-    int im_user_lr_max_milli_ = 10;   // learning rate (permille) up to which users get per-XCD replicas
+    // policy 3: curvature (permille) the merge's per-row saturation weights assume for Q / Qb / the replicated P rows (xcd_item_weight_kernel); 0 = plain sum.
+    // Biases: 250 = the logistic loss's own curvature bound (1/4), the constant the multi-GPU exchange uses (comm_stiffness_milli_).  Measured at
+    // BASELINE scale against the threaded oracle pair (profiles/r04_bpr_merge_weights_study.txt): at the reference's lr |Qb| 93.04 -> 91.93 (oracles
+    // 90.21 / 92.06), sampled loss 0.2075 -> 0.2081 (oracles 0.2075 / 0.2084), kernel time unchanged; the factor rows sit far below saturation there
+    // (a weight on Q moves |Q| AWAY from the oracles, one on the replicated P rows changes nothing), and at lr 0.05 the drift rule has the item
+    // rows chip-wide, so no weight reaches them.
+    int xcd_stiff_q_milli_ = 0, xcd_stiff_b_milli_ = 250, xcd_stiff_p_milli_ = 0;
+    // learning rate (permille) up to which users get per-XCD replicas.  Above it (study at lr 0.05): plain sums end at |Qb| 109 against the oracles'
+    // 91.6; with xcd_stiff_p = 50 |P| 424 / |Qb| 95.5 against 428.7 / 94.8 for the owner form (oracle 430.6 / 91.6) for 6 % of the walk -- not taken.
+    int im_user_lr_max_milli_ = 10;
     DevBuf<float> xcd_wq_, xcd_wb_, xcd_wp_;
     int im_single_wave_ = 0, im_force_queues_ = 0;   // test hooks: one wave drains all queues in order; number of queues for that run
     int im_drain_only_ = 0;        // test hook: skip the owner-XCD launch, the atomic drain launch does everything

@@ -170,6 +170,12 @@ int bfh_als_synchronize(void* h, int device_to_host);
  *   "xcd_sync_updates" updates between two merges of the per-XCD replicas (default 2^23 for 3, 2^21 for 2);
  *   "xcd_merge_mean"   1 = average instead of sum the replicas' deltas;  "xcd_hot_tau" (permille) tolerated collision
  *                      probability of a plainly stored row, above it the row is updated with atomics;
+ *   "xcd_stiff_b", "xcd_stiff_q", "xcd_stiff_p"  (3, permille) curvature assumed by the merge's per-row saturation weights for the item
+ *                      biases (default 250 = the logistic loss's 1/4, the multi-GPU exchange's constant), the item factor rows and the
+ *                      replicated user rows (default 0 = plain sum): a row whose replicas each took m steps between two merges is merged
+ *                      with w = (1 - exp(-n x)) / (n (1 - exp(-x))), x = lr k (m - 1/n) (sum for cold rows -- exactly, up to one step per row -- mean for
+ *                      saturated ones);
+ *   "im_user_lr_max"   (3, permille, default 10) learning rate up to which "im_user_replicas" / "im_user_hybrid" apply;
  *   "im_max_stale"     (3) updates of one item row in flight unseen by the other waves, stated at lr 0.05 (scales 1/lr; default 16);
  *   "im_p_nt", "im_neg_limit"  (3) study knobs (non-temporal hint on the P rows; uniform negatives folded into the first rows
  *                      of Q): DESIGN.md 4.1 "what bounds it" -- not for training;

@@ -25,12 +25,15 @@ SETTINGS = json.loads(os.environ["SETTINGS"]) if "SETTINGS" in os.environ else [
             {"im_blocks": 16}, {"im_blocks": 2}, {"xcd_hot_tau": 30}, {"im_drift_budget": 250}, {"hogwild_atomic": 1}]
 rows = []
 for modes in SETTINGS:
-    for rep in range(3):
+    for rep in range(int(os.environ.get("REPS", "3"))):
         obj, P, Q, Qb = G._run_hip(csr, opt, epochs, modes)
         top = G._top10(P, Q, Qb, users)
         m = G._metrics(lambda: obj.compute_loss(eu, ep, en), P, Q, Qb)
         m["prec10"] = G._precision10(csr, top, users)
         m["overlap"] = 0.5 * (G._overlap(top, ref["top_a"]) + G._overlap(top, ref["top_b"]))
+        st = obj.stats()
+        m["kernel_ms_per_launch"] = st["kernel_ms"] / max(1, st["launches"])
+        m["aux_ms_per_epoch"] = st["aux_ms"] / epochs
         m["modes"] = modes
         rows.append(m)
         print(json.dumps(m), flush=True)

@@ -36,6 +36,12 @@ with the oracles 0.15 .. 0.38, |P| 430.1 (oracle 430.4 .. 430.6; 425.7 with the 
 default is 16), |Q| 110.9 vs 108.2, |Qb| 94.9 vs 91.5.  The norms are the sharp part of this case; loss, precision and
 overlap carry bounds as wide as the reference's own scatter.  The "bench" case (the reference's default lr) is tight on
 everything: thirty-odd HIP runs all gave loss 0.20718 .. 0.20723 against 0.2073 .. 0.2098 for the oracles.
+
+Round 4: the merge of the per-XCD replicas weighs the bias rows by the saturation rule of the multi-GPU exchange (`xcd_stiff_b` = 250,
+profiles/r04_bpr_merge_weights_study.txt): "bench" |Qb| 93.04 -> 91.93 against oracles 90.21 / 92.06, so its bound is now 2 % or ONE
+oracle-vs-oracle spread (was three).  The same study says why the lr-0.05 bounds on |Q| / |Qb| stay: at that learning rate the drift rule
+keeps every item row with >= 60 positives chip-wide (atomics), no weight reaches them (|Q| 110.39, |Qb| 94.80 for every weight tried), and
+with the rule relaxed the one-merge-late feedback diverges with or without weights.
 """
 import time
 
@@ -143,7 +149,7 @@ def _metrics(loss_fn, P, Q, Qb):
 CASES = {
     # name: (option overrides, epochs, oracle worker counts, {metric: (relative bound, multiple of the oracle-vs-oracle spread)},
     #        overlap slack)
-    "bench": (dict(lr=0.002, min_lr=0.0001), 3, (8, 64), {"loss": (0.01, 3.0), "P": (0.02, 3.0), "Q": (0.02, 3.0), "Qb": (0.02, 3.0),
+    "bench": (dict(lr=0.002, min_lr=0.0001), 3, (8, 64), {"loss": (0.01, 3.0), "P": (0.02, 3.0), "Q": (0.02, 3.0), "Qb": (0.02, 1.0),
                                                            "prec10": (0.03, 3.0)}, 0.10),
     "lr0.05": (dict(lr=0.05, min_lr=0.05), 24, (8, 16), {"loss": (0.09, 3.0), "P": (0.02, 3.0), "Q": (0.05, 3.0), "Qb": (0.07, 3.0),
                                                           "prec10": (0.30, 3.0)}, 0.45),

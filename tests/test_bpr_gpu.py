@@ -170,6 +170,10 @@ def test_triples_parallel_disjoint_rows(oracle):
     (128, dict(lr=0.005, min_lr=0.005), dict(xcd_hot_tau=500)),
     (128, dict(lr=0.005, min_lr=0.005, num_negative_samples=2), dict(xcd_hot_tau=500, im_dual=0, xcd_sync_updates=1024, im_user_hybrid=1)),
     (96, dict(lr=0.005, min_lr=0.005), dict(xcd_hot_tau=500, im_user_hybrid=0)),
+    # the merges' saturation weights (round 4; bias weight on by default): a row that saw at most one step is merged with weight 1 exactly
+    (128, dict(num_negative_samples=2), dict(xcd_stiff_q=1000, xcd_stiff_b=1000)),
+    (128, dict(lr=0.005, min_lr=0.005), dict(xcd_hot_tau=500, xcd_stiff_p=1000, xcd_stiff_q=250)),
+    (128, {}, dict(xcd_stiff_b=0)),
 ])
 def test_item_major_conflict_free(oracle, d, kw, modes):
     """hogwild_atomic=3 (item-major walk, users owned by XCDs, Q[i] in registers, Q[j] in per-XCD replicas):
