@@ -188,9 +188,9 @@ def extra_als(csr, seed, epochs=5, cpu=True):
                     # what a block-diagonal formulation would need, 4 nnz d bs + 2 (U + I) d^2 -- the "useful" flops
                     "useful_flop_per_epoch": 4 * nnz * D * 32 + 2 * (U + I) * D * D,
                     "useful_frac_of_fp32_peak": (4 * nnz * D * 32 + 2 * (U + I) * D * D) / kernel_s / 1e12 / MFMA_F32_PEAK_TF,
-                    "note": "bound by instruction issue, not by the matrix cores: a VALU wave and a matrix wave on one SIMD serialise "
-                            "(profiles/r04_micro_simd_overlap.txt), so the producers' ~270 instructions per 16 entries add to the 30 matrix "
-                            "instructions; the same Gramian through v_mfma_f32_32x32x2_f32 (als_split_f16=0) needs %.1f ms of matrix-core "
+                    "note": "not bound by the matrix cores: the gather skeleton alone is 2.5 ms per epoch (~8 TB/s out of L2 / Infinity Cache), the "
+                            "producers' arithmetic and the user half's per-row VALU work (block solve, handshakes) make up the rest "
+                            "(DESIGN 4.5, profiles/r04_micro_simd_overlap.txt); the same Gramian through v_mfma_f32_32x32x2_f32 (als_split_f16=0) needs %.1f ms of matrix-core "
                             "time alone at its %.0f TFLOP/s peak" % (gram_flop / MFMA_F32_PEAK_TF / 1e9, MFMA_F32_PEAK_TF)},
            "hbm": {"algorithmic_bytes_per_epoch": alg_bytes, "achieved_GBps": alg_bytes / kernel_s / 1e9,
                    "frac": alg_bytes / kernel_s / 1e9 / HBM_PEAK_GBS}}

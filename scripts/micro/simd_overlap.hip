@@ -2,7 +2,9 @@
 // workgroup per CU puts two waves on every SIMD (waves w and w + 4 share one: the dispatcher deals waves to SIMDs cyclically); waves
 // 0-3 issue v_mfma_f32_32x32x16_f16 back to back over 10 accumulators (the consumer's stream), waves 4-7 run independent fp32 FMA
 // chains (a producer-like stream: 8 chains, no memory).  Three timings: matrix waves alone, VALU waves alone, both.
-//   hipcc --offload-arch=gfx950 -O3 scripts/micro/simd_overlap.hip -o /tmp/simd_overlap && /tmp/simd_overlap
+//   hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize scripts/micro/simd_overlap.hip -o /tmp/simd_overlap && /tmp/simd_overlap
+// (without -fno-slp-vectorize the FMA chains below become v_pk_fma_f32, four dependent chains: a latency-bound stream whose time ADDS to the
+// matrix waves' -- the first reading of this program, corrected in profiles/r04_micro_simd_overlap.txt)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
