@@ -1,4 +1,5 @@
-// Follow-up to simd_overlap.hip (which showed: a VALU-only wave and a matrix-only wave on one SIMD take the SUM of their times).
+// Follow-up to simd_overlap.hip (whose first, packed-FMA build showed a VALU-only wave and a matrix-only wave taking the SUM of their times;
+// with plain VALU they overlap -- profiles/r04_micro_simd_overlap.txt).
 // Question for the next ALS design: when every wave carries its OWN mix -- a matrix instruction followed by a few
 // independent fp32 FMAs, the way round 3's fused row kernel issues them -- how much of the VALU work hides, with one such wave per
 // SIMD and with two?  A 512-thread workgroup per CU puts waves w and w + 4 on one SIMD.

@@ -1,5 +1,5 @@
-// Third micro-benchmark of the series (simd_overlap.hip: a VALU-only wave and a matrix-only wave on one SIMD take the SUM of their times;
-// simd_fused_pairs.hip: waves that each carry matrix + VALU work hide most of the VALU).  This one maps the ways a row's group of 16 entries
+// Third micro-benchmark of the series (simd_overlap.hip: a matrix-only wave beside a VALU-only wave; simd_fused_pairs.hip: waves that each
+// carry matrix + VALU work; results and their reading: profiles/r04_micro_simd_overlap.txt).  This one maps the ways a row's group of 16 entries
 // -- 30 x v_mfma_f32_32x32x16_f16 over 10 tiles and V independent fp32 FMAs standing in for gather + residuals + f16 cut -- can be dealt to
 // the two waves of a SIMD (waves w and w + 4 of a 512-thread workgroup).  Role 0 = waves 0-3: NT0 tiles, V0 FMAs spread behind its matrix
 // instructions; role 1 = waves 4-7: NT1 tiles, V1 FMAs (NT1 = 0: a plain FMA stream).  Printed: ns per group.
