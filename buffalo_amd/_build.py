@@ -10,7 +10,7 @@ LIB = os.path.join(HERE, "libbuffalo_hip.so")
 SOURCES = ["common.hip", "comm.hip", "sgd_base.hip", "bpr.hip", "warp.hip", "als.hip", "topk.hip", "ingest.hip", "sppmi.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall",
-         "-Wno-unused-function", "-Wno-unused-result"]
+         "-Wno-unused-function", "-Wno-unused-result"] + os.environ.get("BFH_EXTRA_FLAGS", "").split()   # e.g. -DBFH_WITH_ALS_SOLO (rebuild with --force)
 
 
 def _deps():

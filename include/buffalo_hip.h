@@ -199,7 +199,8 @@ int bfh_als_synchronize(void* h, int device_to_host);
  *                      0 = v_mfma_f32_32x32x2_f32;  "als_split_wcut": rows holding a weight alpha*v above this (default 32768) or a
  *                      negative one go through the fp32 instruction + the dense-solve kernel (a scan of the weights, cached per
  *                      chunk, finds them);  "als_pc" (default 1) producer / consumer wave pairs for those rows where they win (d = 96, 128;
- *                      csrc/als_pc.hpp), 2 = also at d = 64, 0 = round 3's wave-per-row kernel everywhere;  "als_inreg" 0 = every row through the scratch slot + als_solve_kernel. */
+ *                      csrc/als_pc.hpp), 2 = also at d = 64, 0 = round 3's wave-per-row kernel everywhere (3 = the experimental one-wave-per-row DMA kernel of
+ *                      csrc/als_solo.hpp at d = 128, only in a build with -DBFH_WITH_ALS_SOLO; the default build rejects it);  "als_inreg" 0 = every row through the scratch slot + als_solve_kernel. */
 int bfh_bpr_set_mode(void* h, const char* name, int64_t value);
 int bfh_warp_set_mode(void* h, const char* name, int64_t value);
 int bfh_als_set_mode(void* h, const char* name, int64_t value);

@@ -100,7 +100,7 @@ CASES = [
                           # put the low f16 piece of the split pass into subnormals -- absolute accuracy only -- while the heaviest
                           # weights the f16 path admits stretch its range from the other end
                           (128, dict(optimizer="ialspp"), "scales")])
-@pytest.mark.parametrize("design", ["inreg", "scratch", "fp32", "wave"])
+@pytest.mark.parametrize("design", ["inreg", "scratch", "fp32", "wave", "solo"])
 def test_half_epochs_match_oracle(oracle, d, kw, shape, design):
     """Every half-epoch starts from bit-identical factors (the GPU model is re-synchronised to the
     oracle's after each comparison), so differences are the kernels' own.  Truncated fp32 CG is
@@ -118,6 +118,8 @@ def test_half_epochs_match_oracle(oracle, d, kw, shape, design):
         pytest.skip("'fp32' = the in-register solve with the fp32 matrix instruction instead of the split-f16 pass: d = 128 cases")
     if design == "wave" and not (d in (64, 96, 128) and kw.get("block_size", 32) == 32 and kw.get("optimizer") == "ialspp"):
         pytest.skip("'wave' = round 3's wave-per-row split-f16 kernel instead of the producer / consumer pairs: in-place iALS++ cases")
+    if design == "solo" and not (d == 128 and kw.get("block_size", 32) == 32 and kw.get("optimizer") == "ialspp"):
+        pytest.skip("'solo' = als_solo_kernel (one wave per row, two per SIMD; als_pc = 3): in-place iALS++ cases at d = 128")
     if shape == "outliers":
         base = tiny_csr(U=320, I=280, density=0.2, seed=31, counts=True)
         v = base.vals.copy()
@@ -139,7 +141,13 @@ def test_half_epochs_match_oracle(oracle, d, kw, shape, design):
     # "scratch": every row goes through the HBM scratch slot + dense-solve kernel
     obj.set_mode("als_inreg", int(design != "scratch"))
     obj.set_mode("als_split_f16", int(design != "fp32"))
-    obj.set_mode("als_pc", 0 if design == "wave" else 2)   # 2: the pairs at d = 64 too (the default leaves T = 2 to the wave-per-row kernel, which is faster there)
+    if design == "solo":
+        try:
+            obj.set_mode("als_pc", 3)
+        except Exception as e:   # the default build does not carry the experimental kernel
+            pytest.skip("als_solo_kernel is not in this build (%s)" % str(e)[:80])
+    else:
+        obj.set_mode("als_pc", 0 if design == "wave" else 2)   # 2: the pairs at d = 64 too (the default leaves T = 2 to the wave-per-row kernel, which is faster there)
     if shape == "outliers":
         obj.set_mode("als_split_wcut", 500)   # alpha v = 4 * 2 * 100 and more: past the cut
     if shape == "scales":
@@ -180,7 +188,7 @@ def test_half_epochs_match_oracle(oracle, d, kw, shape, design):
             # lands at 1.3x on the SAME inputs (profiles/r03_als_split_f16.txt).  The default path now sends the rows that hold such
             # weights through the scratch path (als_defer_scan_kernel) and is held to the 2.5x of every other case; the two
             # non-default kernels keep the 10x they were measured at
-            loose = shape == "outliers" and design in ("fp32", "wave")
+            loose = shape == "outliers" and design in ("fp32", "wave")   # ("solo" routes the outliers through the scratch path like "inreg")
             # the wide kernel (128 < vdim <= 256, fp32 matrix instruction across 3-4 waves): 20 of its 21 half-epochs sit at 0.2 .. 2.0x
             # since it forms the gradient residual-first (round 4; 10x before), one -- d = 192, the cold first user half-epoch -- at
             # 3.5x (profiles/r04_als_wide_residual_first.txt): 4x
