@@ -2912,6 +2912,7 @@ class AlsHandle : public HandleBase {
         std::map<std::pair<int, int>, std::pair<int64_t, uint64_t>> chunks;   // auto-residency: row range -> (length, checksum)
     };
     void unpin_host() {
+        if (!pinned_.empty() && stream) (void)hipStreamSynchronize(stream);   // (see SgdHandle::unpin_host)
         for (void* q : pinned_) (void)hipHostUnregister(q);
         if (!pinned_.empty()) (void)hipGetLastError();
         pinned_.clear();

@@ -605,6 +605,9 @@ void SgdHandle::exchange_gradients() {
 
 // ------------------------------------------------------------------------------------------------
 void SgdHandle::unpin_host() {
+    // nothing of this handle may still be writing into a page-locked array when its registration goes (every entry point synchronises
+    // before it returns, so this costs nothing; it is the belt to that pair of braces)
+    if (!pinned_.empty() && stream) (void)hipStreamSynchronize(stream);
     for (auto& p : pinned_) (void)hipHostUnregister(p.first);
     if (!pinned_.empty()) (void)hipGetLastError();   // an array that was freed while pinned must not leave a sticky error behind
     pinned_.clear();
