@@ -1,7 +1,9 @@
-// als_solo_kernel -- the in-place iALS++ row update (als.cc:211-358, block_size 32, d = 96 / 128) with EVERY wave carrying a whole row:
+// als_solo_kernel -- the in-place iALS++ row update (als.cc:211-358, block_size 32, d = 128) with EVERY wave carrying a whole row:
 // gather, residuals, f16 cut, its own matrix instructions and the block solve.  Two waves of 256 registers per SIMD, no hand-off.
 // Included by als_kernels.hpp after als_pc.hpp (shares its helpers: pc_split_pair, pc_sum8_over_half, the interleaved factor copy, the
-// deferred-weight scan).  "als_pc" = 3 selects it.
+// deferred-weight scan).  EXPERIMENTAL: compiled only with -DBFH_WITH_ALS_SOLO (BFH_EXTRA_FLAGS), then "als_pc" = 3 selects it at d = 128;
+// first contact in profiles/r04_als_solo_first_contact.txt (user half -6 %, item half +4 % against the pairs; the d = 96 instantiation, 12-byte
+// DMA loads, aborted on its first launch and is not dispatched).
 //
 // Why (profiles/r04_micro_*.txt).  The pair kernel's user half sits 1.75 ms above the 0.95 ms its loads need: per row the
 // producer's and the consumer's VALU work share one VALU, the ring couples them to a third of a row, a quarter of the producer's steps is
