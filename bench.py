@@ -28,6 +28,7 @@ MFMA_F32_PEAK_TF = 157.3  # same guide: v_mfma_f32_32x32x2_f32, exact fp32 (the 
 MFMA_F16_PEAK_TF = 2500.0     # dense f16/bf16 (MI355X_MICROARCH.md)
 D = 128
 CPU_KIND = "port"
+CPU_WHAT_SHORT = "oracle/buffalo_oracle.cc: restatement of the reference CPU path, the reference's flags (-O3 -fopenmp -mavx2 -mfma)"
 CPU_WHAT = ("restatement of reference CPU path (oracle/buffalo_oracle.cc, compiled with the reference's flags "
             "-O3 -fopenmp -mavx2 -mfma; the reference's own C++ cannot be built here: Eigen/json11/spdlog submodules are empty)")
 
@@ -82,11 +83,11 @@ def cpu_baseline(csr, target_seconds=12.0):
     cores = os.cpu_count() or 1
     I = csr.num_items
 
-    def run(n_users, workers=cores):
+    def run(n_users, workers=cores, cls=None):
         nnz = int(csr.indptr[n_users - 1])
         opt = bpr_options(1, accelerator=False, num_workers=workers)
         P, Q, Qb = synth.init_factors(n_users, I, D, seed=7)
-        o = orc.OracleBPRMF()
+        o = (cls or orc.OracleBPRMF)()
         path = write_opt(opt)
         assert o.init(path)
         os.unlink(path)
@@ -114,11 +115,25 @@ def cpu_baseline(csr, target_seconds=12.0):
     nnz8, dt8 = run(min(csr.num_users, int(np.searchsorted(csr.indptr, want8)) + 1), workers=8)
     # the headline figure is the 8-worker one -- the reference's own benchmark setting, and the faster of the two (its job queue
     # is contended: all cores are SLOWER); the all-core run is kept beside it
-    return {"value": nnz8 / dt8, "unit": "updates/s", "cores": 8, "kind": CPU_KIND, "what": CPU_WHAT,
-            "sample": "first %d interactions (1 epoch) of the same matrix, 8 std::thread workers (the reference's benchmark setting, "
-                      "tests/algo/test_performance.py:53), %.1f s" % (nnz8, dt8),
-            "value_all_cores": nnz1 / dt1, "all_cores": cores,
-            "sample_all_cores": "first %d users (%d interactions, 1 epoch), %d workers, %.1f s" % (n_users, nnz1, cores, dt1)}
+    out = {"value": nnz8 / dt8, "unit": "updates/s", "cores": 8, "kind": CPU_KIND, "what": CPU_WHAT,
+           "sample": "first %d interactions (1 epoch) of the same matrix, 8 std::thread workers (the reference's benchmark setting, "
+                     "tests/algo/test_performance.py:53), %.1f s" % (nnz8, dt8),
+           "value_all_cores": nnz1 / dt1, "all_cores": cores,
+           "sample_all_cores": "first %d users (%d interactions, 1 epoch), %d workers, %.1f s" % (n_users, nnz1, cores, dt1)}
+    # the bracket: the reference's OWN algo.cc / bpr.cc compiled unmodified on stand-ins for Eigen / json11 / spdlog (oracle/_ref, built in
+    # the build container by __graft_entry__.build(); NOT the reference binary -- an Eigen expression evaluates as the stand-in reads it),
+    # same sample, same 8 workers
+    try:
+        from oracle import ref_sgd
+        if os.path.exists(ref_sgd._path("bpr")):
+            n8 = min(csr.num_users, int(np.searchsorted(csr.indptr, want8)) + 1)
+            nnz_r, dt_r = run(n8, workers=8, cls=ref_sgd.RefBPRMF)
+            out.update({"reference_on_stand_ins_value": nnz_r / dt_r, "reference_on_stand_ins_kind": "reference-on-stand-ins",
+                        "reference_on_stand_ins_sample": "lib/algo.cc + bpr.cc compiled unmodified on oracle/stand_in_3rd, first %d interactions, "
+                                                         "8 workers, %.1f s" % (nnz_r, dt_r)})
+    except Exception as e:
+        out["reference_on_stand_ins_error"] = "%s: %s" % (type(e).__name__, e)
+    return out
 
 
 ALS_OPT = {  # ALSOption defaults (/root/reference/buffalo/algo/options.py:66-86) at d=128 (=> iALS++, Q-13)
@@ -176,8 +191,9 @@ def extra_als(csr, seed, epochs=5, cpu=True):
     mfma_flop = 3 * gram_flop                                       # issued now: x = h + l in f16, the three products hh + hl + lh (als_gram_kernel<SPLIT>)
     kernel_s = st["kernel_ms"] / epochs * 1e-3
     alg_bytes = 2 * nnz * (4 * D + 8) + (U + I) * (8 * D + 8) + (U + I) * 4 * D     # SURVEY 8(d) B_als, both half-epochs
-    out = {"config": "ALS iALS++ (block 32, 3 CG steps), ml20m-shaped synthetic (%d x %d, %d nnz, values 1+Poisson(1)), d=%d, f32, "
-                     "rowwise + colwise CSR and factors resident in HBM" % (U, I, nnz, D),
+    out = {"config": "ALS iALS++ (block 32, 3 CG steps), ml20m-shaped synthetic (%d x %d, %d nnz, values 1+Poisson(1)), d=%d, Gramian in split-f16 "
+                     "(two f16 pieces per factor, ~22-bit products, fp32 accumulate; everything else f32), rowwise + colwise CSR and factors "
+                     "resident in HBM" % (U, I, nnz, D),
            "epoch_ms": dt * 1e3, "interactions_per_s": 2 * nnz / dt, "kernel": "als_pc_kernel (producer / consumer wave pairs: gather + residuals + f16 cut | Gramian on the f16 matrix cores at fp32 accuracy + in-register block CG)",
            "kernel_ms_per_epoch": kernel_s * 1e3, "gramian_ff_ms_per_epoch": st["aux_ms"] / epochs,
            "mfma": {"issued_TFLOPs": mfma_flop / kernel_s / 1e12, "peak_TFLOPs": MFMA_F16_PEAK_TF,
@@ -194,6 +210,11 @@ def extra_als(csr, seed, epochs=5, cpu=True):
                             "time alone at its %.0f TFLOP/s peak" % (gram_flop / MFMA_F32_PEAK_TF / 1e9, MFMA_F32_PEAK_TF)},
            "hbm": {"algorithmic_bytes_per_epoch": alg_bytes, "achieved_GBps": alg_bytes / kernel_s / 1e9,
                    "frac": alg_bytes / kernel_s / 1e9 / HBM_PEAK_GBS}}
+    if cpu:
+        try:
+            out["parity"] = als_parity_block(g, P, Q, csr, vals, col, epoch)
+        except Exception as e:
+            out["parity"] = {"error": "%s: %s" % (type(e).__name__, e)}
     del g
     if cpu:
         from oracle import oracle as orc
@@ -220,6 +241,62 @@ def extra_als(csr, seed, epochs=5, cpu=True):
                                "sample": "user half-epoch (precompute + partial_update, iALS++) over the first %d interactions of the same "
                                          "matrix, OpenMP %d threads, %.1f s" % (m1, cores, d1)}
     return out
+
+
+def als_parity_block(g, P, Q, csr, vals, col, epoch):
+    """configs[2] against the REFERENCE PATH in absolute numbers, in the bench line (the statement of
+    tests/test_als_gpu.py::test_config3_warm_epoch_matches_the_oracle_path, without the float64 envelopes): the model is warm (the timed
+    epochs), that state goes to the device handle and to the oracle, each runs ONE epoch, and the line carries
+      user_max / item_max : max |x_hip - x_oracle| over all rows, relative to the largest entry of the oracle's factor;
+      item_max_reorder    : the same distance between the oracle and ITSELF with every item row's entries in reverse order (a legal
+                            reordering of its fp32 sums; the item systems are ill-conditioned even warm) -- the yardstick for item_max;
+      top10_overlap(_reorder): mean overlap of 2,000 sampled users' top-10 lists, HIP model vs oracle model (oracle vs reordered oracle)."""
+    from oracle import oracle as orc
+    orc.build()
+    U, I = csr.num_users, csr.num_items
+    g.synchronize(True)
+    Po, Qo = P.copy(), Q.copy()
+    o = orc.OracleALS()
+    path = _opt_file(dict(ALS_OPT, accelerator=False, num_workers=os.cpu_count() or 16))
+    assert o.init(path)
+    os.unlink(path)
+    o.initialize_model(Po, Qo)
+    t0 = time.perf_counter()
+    o.precompute(0)
+    o.partial_update(0, U, csr.indptr, csr.keys, vals, 0)
+    Po_mid, Qw = Po.copy(), Qo.copy()
+    o.precompute(1)
+    o.partial_update(0, I, col["indptr"], col["key"], col["val"], 1)
+    ip = col["indptr"]
+    starts = np.concatenate([[0], ip[:-1]])
+    rid = np.repeat(np.arange(I), np.diff(np.concatenate([[0], ip])))
+    rev = (starts[rid] + (ip[rid] - 1 - np.arange(len(rid), dtype=np.int64))).astype(np.int64)
+    Pr, Qr = Po_mid.copy(), Qw.copy()
+    o2 = orc.OracleALS()
+    path = _opt_file(dict(ALS_OPT, accelerator=False, num_workers=os.cpu_count() or 16))
+    assert o2.init(path)
+    os.unlink(path)
+    o2.initialize_model(Pr, Qr)
+    o2.precompute(1)
+    o2.partial_update(0, I, ip, np.ascontiguousarray(col["key"][rev]), np.ascontiguousarray(col["val"][rev]), 1)
+    cpu_s = time.perf_counter() - t0
+    epoch()                                          # the device handle, one epoch from the same warm state
+    g.synchronize(True)
+
+    def dist(X, Xo):
+        return float(np.abs(X - Xo).max() / max(float(np.abs(Xo).max()), 1e-30))
+    users = np.random.default_rng(11).choice(U, 2000, replace=False)
+
+    def top10(Pm, Qm):
+        return np.argsort(-(Pm[users] @ Qm.T), axis=1)[:, :10]
+
+    def overlap(a, b):
+        return float(np.mean([len(set(x) & set(y)) / 10.0 for x, y in zip(a, b)]))
+    to = top10(Po, Qo)
+    return {"user_max": dist(P, Po), "item_max": dist(Q, Qo), "item_max_reorder": dist(Qr, Qo),
+            "top10_overlap": overlap(top10(P, Q), to), "top10_overlap_reorder": overlap(top10(Po_mid, Qr), to),
+            "what": "one epoch from the same warm state, HIP vs the oracle (restatement of als.cc:211-358) over ALL rows; *_reorder = the oracle "
+                    "against itself with the item rows' entries reversed; oracle time %.1f s" % cpu_s}
 
 
 def extra_als_wide(csr, seed, d, epochs=3):
@@ -285,7 +362,10 @@ def warp_epoch_row(st, nnz, d, U, I, wall_s, presample=4, chunk_runs=None):
     dev_all_s = dev_s + st["optimizer_ms"] * 1e-3
     return {"epoch_ms": wall_s * 1e3, "trial_kernel_ms": st["kernel_ms"], "sort_and_gather_ms": st["aux_ms"], "optimizer_ms": st["optimizer_ms"],
             "positives_per_s": nnz / wall_s, "mean_scored_negatives_T": scored / nnz, "candidate_rows_fetched_per_positive": loaded / nnz,
-            "accepted_frac": acc / nnz, "algorithmic_bytes": alg, "algorithmic_GBps": alg / dev_s / 1e9, "hbm_frac": alg / dev_s / 1e9 / HBM_PEAK_GBS,
+            "accepted_frac": acc / nnz, "algorithmic_bytes": alg, "algorithmic_GBps": alg / dev_s / 1e9,
+            # SURVEY 8(d)'s formula counts six gradient-row read-modify-writes per positive that the gather-by-item formulation never performs:
+            # this ratio can exceed 1 and is NOT a bandwidth fraction (that is counter_traffic / implemented_model_frac)
+            "survey_formula_bytes_over_peak": alg / dev_s / 1e9 / HBM_PEAK_GBS,
             "implemented_model_bytes": impl, "implemented_model_total": sum(impl.values()),
             "implemented_model_GBps": sum(impl.values()) / dev_all_s / 1e9,
             "implemented_model_frac": sum(impl.values()) / dev_all_s / 1e9 / HBM_PEAK_GBS,
@@ -353,7 +433,7 @@ def _warp_summary(eps, out):
     (T = 1, everything accepted -- the easy regime); by the third the trial loop rejects (T ~ 4 on the ML-20M shape)."""
     last = eps[-1]
     out.update({"epochs": eps, "quoted_epoch": len(eps) - 1, "epoch_ms": last["epoch_ms"], "positives_per_s": last["positives_per_s"],
-                "mean_scored_negatives_T": last["mean_scored_negatives_T"], "algorithmic_GBps": last["algorithmic_GBps"], "hbm_frac": last["hbm_frac"],
+                "mean_scored_negatives_T": last["mean_scored_negatives_T"], "algorithmic_GBps": last["algorithmic_GBps"], "survey_formula_bytes_over_peak": last["survey_formula_bytes_over_peak"],
                 "implemented_model_frac": last["implemented_model_frac"]})
     return out
 
@@ -390,20 +470,22 @@ def extra_warp(csr, seed, epochs=3, cpu=True):
     return out
 
 
-def warp_c5_inputs(skew=True):
+def warp_c5_inputs(skew=True, u0=0, u1=None, users=10_000_000):
     """BASELINE configs[4]'s shape for ONE GPU: 10 M users x 1 M items, 1 B interactions, d=256.  Every user has 100 items, one in
     each 10,000-wide band of the catalogue (sorted keys, no duplicates).  `skew`: the item inside a band is floor(10^4 x^3) for a
     hashed x in [0, 1) -- a popularity law (the head item of a band is chosen by 4.6 % of the users), so that there is something to
     rank and the trial loop leaves the T = 1 regime as it does on real data; without it (round 2's generator) every epoch accepts
     the first draw.  Factors signed N(0, 1/d^2) (Q-18), P tiled from 65,536 distinct rows to keep host generation to seconds.
     41.9 GB resident (P, Q, gradients, adagrad state, keys, row ids)."""
-    U5, I5, deg, d = 10_000_000, 1_000_000, 100, WARP_D
+    I5, deg, d = 1_000_000, 100, WARP_D
+    u1 = users if u1 is None else u1
+    U5 = u1 - u0                                   # this rank's users [u0, u1) of `users` (N > 1: --workload warp_c5)
     step = I5 // deg
     keys = np.empty((U5, deg), dtype=np.int32)
     band_hash = ((np.arange(deg, dtype=np.int64) * 104729) % step).astype(np.int32)
     band_base = np.arange(deg, dtype=np.int32) * step
-    for u0 in range(0, U5, 500_000):              # int32 throughout: ~11 s for the 10^9 keys on the host
-        u = np.arange(u0, min(U5, u0 + 500_000), dtype=np.int64)
+    for c0 in range(0, U5, 500_000):              # int32 throughout: ~11 s for the 10^9 keys on the host
+        u = np.arange(u0 + c0, u0 + min(U5, c0 + 500_000), dtype=np.int64)
         hu = ((u * 7919) % step).astype(np.int32)
         if skew:
             h = hu[:, None] + band_hash[None, :]
@@ -415,12 +497,12 @@ def warp_c5_inputs(skew=True):
         else:
             off = np.repeat(hu[:, None], deg, axis=1)
         off += band_base[None, :]
-        keys[u0:u0 + u.shape[0]] = off
+        keys[c0:c0 + u.shape[0]] = off
     keys = keys.reshape(-1)
     indptr = (np.arange(U5, dtype=np.int64) + 1) * deg
     rng = np.random.default_rng(7)
     base = (rng.normal(size=(65536, d)) / d).astype(np.float32)
-    P = np.ascontiguousarray(np.tile(base, (U5 // 65536 + 1, 1))[:U5])
+    P = np.ascontiguousarray(base[np.arange(u0, u1, dtype=np.int64) % 65536])
     Q = (rng.normal(size=(I5, d)) / d).astype(np.float32)
     Qb = np.zeros((I5, 1), np.float32)
     return indptr, keys, P, Q, Qb
@@ -619,50 +701,244 @@ def measured_stream_bandwidth(n_bytes=1 << 30, reps=20):
     return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=250)   # ~2.2 s timed region on one MI355X
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--shape", default="ml20m")
-    ap.add_argument("--seed", type=int, default=7)
-    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
-    ap.add_argument("--minibatches", type=int, default=1, help="all-reduce points per epoch (N>1)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the ALS / WARP secondary measurements (N=1)")
-    ap.add_argument("--mode", action="append", default=[], help="backend knob name=value (e.g. hogwild_atomic=0)")
-    args = ap.parse_args()
+# ------------------------------------------------------------------------------------------------------------------------------
+# The line.  The driver parses the LAST stdout line and keeps an 8 KB tail of stdout (round 4's 27 KB line was cut in the middle and
+# the round went unrecorded), so the last line is held under LINE_LIMIT: the contract's head keys, `config`, `roofline` and
+# `cpu_baseline` as FLAT scalars.  Everything else (per-epoch lists, byte models, per-kernel tables, the long descriptions) goes to
+# `bench_extra.json` (repo root and gpurun_out/) and to an EARLIER stdout line prefixed "BENCH_EXTRA ".
+LINE_LIMIT = 4096
+HEAD_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+# flat roofline keys the line can do without, first to go first (the contract's own keys are never dropped)
+ROOFLINE_OPTIONAL = ("warp_c5_traffic_source", "traffic_source", "warp_c5_sort_and_gather_ms", "warp_c5_trial_kernel_ms", "warp_c5_epochs_run",
+                     "warp_ml20m_implemented_model_frac", "warp_c5_implemented_model_frac", "strict_frac", "strict_bytes_per_update",
+                     "frac_incl_merge_kernels", "launches_per_step", "als_issued_mfma_frac_f16", "als_d160_kernel_ms", "copy_GBps")
 
-    import torch
-    import torch.distributed as dist
+
+def _short(v, n=200):
+    return v if not isinstance(v, str) or len(v) <= n else v[:n - 3] + "..."
+
+
+def _num(v):
+    if isinstance(v, bool) or not isinstance(v, float):
+        return v
+    if v != v or v in (float("inf"), float("-inf")):
+        return None
+    return float("%.6g" % v)
+
+
+def _flat(d, strlen=200):
+    """The scalar members of a dict (numbers rounded to 6 digits, strings cut): what the driver's record keeps."""
+    return {k: _num(_short(v, strlen)) for k, v in d.items() if v is None or isinstance(v, (bool, int, float, str))}
+
+
+def compact_line(out, extra_file="bench_extra.json", limit=LINE_LIMIT):
+    """The LAST stdout line from the full result: <= `limit` bytes, json.loads-able, head + config + flat roofline + flat cpu_baseline."""
+    line = {k: _num(out.get(k)) for k in HEAD_KEYS}
+    line["config"] = _flat(out.get("config") or {}, 360)
+    rf = _flat(out.get("roofline") or {})
+    st = (out.get("roofline") or {}).get("strict") or {}
+    if "frac" in st:
+        rf["strict_frac"], rf["strict_bytes_per_update"] = _num(st["frac"]), _num(st["bytes_per_update"])
+    line["roofline"] = rf
+    if out.get("cpu_baseline"):
+        line["cpu_baseline"] = _flat(dict(out["cpu_baseline"], what=CPU_WHAT_SHORT if out["cpu_baseline"].get("kind") == "port" else
+                                          out["cpu_baseline"].get("what", "")), 220)
+    if out.get("breakdown"):
+        line["breakdown"] = _flat(out["breakdown"], 120)
+    line["extra_file"] = extra_file
+    s = json.dumps(line)
+    for k in ROOFLINE_OPTIONAL:                       # never needed at today's size; the guard that keeps the driver's record whole
+        if len(s) <= limit:
+            break
+        line["roofline"].pop(k, None)
+        s = json.dumps(line)
+    if len(s) > limit:
+        for blk in ("config", "cpu_baseline", "breakdown"):
+            for k, v in list((line.get(blk) or {}).items()):
+                if isinstance(v, str):
+                    line[blk][k] = _short(v, 80)
+        s = json.dumps(line)
+    assert len(s) <= limit, "bench line is %d bytes (> %d)" % (len(s), limit)
+    return s
+
+
+def emit(out):
+    """Side file + the two stdout lines (extras first, the driver's line LAST)."""
+    extra = {k: v for k, v in out.items() if k not in HEAD_KEYS}
+    blob = json.dumps(dict({k: out.get(k) for k in HEAD_KEYS}, **extra))
+    for path in (os.path.join(ROOT, "bench_extra.json"), os.path.join(ROOT, "gpurun_out", "bench_extra.json")):
+        try:
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            with open(path, "w") as f:
+                f.write(blob)
+        except OSError:
+            pass
+    sys.stdout.write("BENCH_EXTRA " + blob + "\n")
+    sys.stdout.write(compact_line(out) + "\n")
+    sys.stdout.flush()
+
+
+def counter_traffic(name="pmc_latest.json", key="hbm_bytes_per_launch"):
+    """Counter bytes of the separate rocprofv3 --pmc passes (scripts/gpu_profile.sh -> scripts/pmc_summary.py).  The file is from an
+    EARLIER process: it is only used when it was taken on the kernel sources this process runs (`csrc_sha16` stamped by the summary
+    script = buffalo_amd._build.source_fingerprint() now); otherwise traffic is null and the reason is in `traffic_source`."""
+    from buffalo_amd import _build
+    path = os.path.join(ROOT, "profiles", name)
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None, "profiles/%s absent" % name
+    now = _build.source_fingerprint()
+    if d.get("csrc_sha16") != now:
+        return None, "profiles/%s was taken on other kernel sources (%s, now %s): not used" % (name, d.get("csrc_sha16"), now)
+    return d.get(key), "profiles/%s (rocprofv3 --pmc passes of this command on these sources, csrc %s)" % (name, now)
+
+
+class Ctx:
+    """One rank's view of the job: torch.distributed is the CONTROL plane only (rendezvous, barrier, max of the elapsed times -- gloo on
+    CPU tensors); the data plane is the library's own communicator (bfh_comm_*: RCCL over xGMI)."""
+
+    def __init__(self, args):
+        import torch
+        self.torch = torch
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+        assert self.world == args.gpus, "WORLD_SIZE (%d) != --gpus (%d)" % (self.world, args.gpus)
+        # test hooks (1-GPU boxes): BFH_DEVICE_OVERRIDE pins every rank to one device; BFH_COMM_TRANSPORT=shm selects the library's
+        # shared-memory test transport (RCCL refuses two ranks on one GPU) and with it gloo as the control plane
+        if "BFH_DEVICE_OVERRIDE" in os.environ:
+            self.local_rank = int(os.environ["BFH_DEVICE_OVERRIDE"])
+        torch.cuda.set_device(self.local_rank)
+        self.dist = None
+        self.comm_mode = "none"
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            backend = os.environ.get("BFH_DIST_BACKEND", "gloo" if os.environ.get("BFH_COMM_TRANSPORT") == "shm" else "nccl")
+            dist.init_process_group("cpu:gloo,cuda:nccl" if backend == "nccl" else backend)
+            self.dist = dist
+            self.comm_mode = os.environ.get("BFH_COMM", "library")   # BFH_COMM=torch: emergency path (bench-only), BPRMF workload
+
+    def barrier(self):
+        self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.all_reduce(self.torch.zeros(1))                # CPU tensor: a gloo barrier that never touches the data plane
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, x):
+        if self.dist is None:
+            return float(x)
+        t = self.torch.tensor([float(x)], dtype=self.torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def minmax(self, vals):
+        t = self.torch.tensor([float(v) for v in vals], dtype=self.torch.float64)
+        lo = t.clone()
+        if self.dist is not None:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            self.dist.all_reduce(lo, op=self.dist.ReduceOp.MIN)
+        return [float(v) for v in lo], [float(v) for v in t]
+
+    def make_comm(self):
+        """The library communicator of this rank (None + reason when it cannot be built: every rank takes the same path)."""
+        from buffalo_amd.backend import Comm
+        torch, dist = self.torch, self.dist
+        ok, note, comm = 1, None, None
+        try:
+            uid = torch.frombuffer(bytearray(Comm.unique_id() if self.rank == 0 else bytes(128)), dtype=torch.uint8).clone()
+            dist.broadcast(uid, src=0)                           # CPU tensor -> gloo
+            comm = Comm(self.world, self.rank, bytes(uid.numpy().tobytes()), self.local_rank)
+            comm.self_test()
+        except Exception as e:
+            ok, note = 0, "%s: %s" % (type(e).__name__, e)
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) != 1:
+            return None, "library communicator unavailable (%s)" % note
+        return comm, None
+
+    def transport(self):
+        return os.environ.get("BFH_COMM_TRANSPORT", "RCCL over xGMI")
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.all_reduce(self.torch.zeros(1))
+            self.dist.destroy_process_group()
+
+
+def timed_steps(ctx, step, steps, warmup, before_timing=None, after_steps=None):
+    """W untimed steps, then EXACTLY K steps bracketed by barrier + synchronize on both sides; the MAX over ranks."""
+    for _ in range(warmup):
+        step()
+    if before_timing is not None:
+        before_timing()
+    ctx.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    if after_steps is not None:
+        after_steps()
+    ctx.barrier()
+    return ctx.max_over_ranks(time.perf_counter() - t0)
+
+
+def extra_bpr_lr005(csr, seed, epochs=10):
+    """The reference's own BPRMF benchmark setting (/root/reference/benchmark/models.py:86-93): lr 0.05 decaying to min_lr 0.0001 over
+    num_iters 10, everything else the option defaults -- 10 epochs of the same walk on the same matrix, per-launch kernel time."""
+    from buffalo_amd import synth
+    from buffalo_amd.backend import CyBPR
+    U, I, nnz = csr.num_users, csr.num_items, csr.nnz
+    P, Q, Qb = synth.init_factors(U, I, D, seed=seed)
+    g = CyBPR()
+    path = write_opt(bpr_options(num_iters=epochs, seed=seed, lr=0.05, min_lr=0.0001))
+    assert g.init(path)
+    os.unlink(path)
+    g.sync_every_epoch = False
+    g.initialize_model(P, Q, Qb, nnz, True)
+    g.set_cumulative_table(np.zeros(I, np.int64), I)
+    g.set_resident_csr(csr.indptr, csr.keys)
+    per = []
+    t_all = time.perf_counter()
+    for _ in range(epochs):
+        g.reset_stats()
+        t0 = time.perf_counter()
+        g.add_jobs(0, U, csr.indptr, None)
+        g.update_parameters()
+        import torch
+        torch.cuda.synchronize()
+        st = g.stats()
+        per.append({"epoch_ms": (time.perf_counter() - t0) * 1e3, "kernel_ms_per_launch": st["kernel_ms"] / max(st["launches"], 1),
+                    "launches": st["launches"], "aux_ms": st["aux_ms"]})
+    wall = time.perf_counter() - t_all
+    g.synchronize(True)
+    bytes_per_launch = (24 * D + 20) * nnz / max(per[-1]["launches"], 1)
+    # epoch 1 carries the one-off plan build (sort of the entries by queue / block / item); the kernel figure is over epochs 2..
+    k = [p["kernel_ms_per_launch"] for p in per[1:]] or [per[0]["kernel_ms_per_launch"]]
+    kernel_ms = sum(k) / len(k)
+    out = {"config": "BPRMF sgd, lr 0.05 -> min_lr 0.0001 over %d epochs (benchmark/models.py:86-93), ml20m-shaped synthetic, d=%d" % (epochs, D),
+           "epochs": per, "kernel_ms_per_launch": kernel_ms, "kernel_ms_per_launch_first": per[0]["kernel_ms_per_launch"],
+           "kernel_ms_per_launch_max": max(p["kernel_ms_per_launch"] for p in per),
+           "frac": bytes_per_launch / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "epoch_ms_after_first": sum(p["epoch_ms"] for p in per[1:]) / max(len(per) - 1, 1),
+           "updates_per_s_after_first": nnz * max(len(per) - 1, 1) / max(sum(p["epoch_ms"] for p in per[1:]) * 1e-3, 1e-12),
+           "wall_s": wall, "finite": bool(np.isfinite(P).all() and np.isfinite(Q).all() and np.isfinite(Qb).all()),
+           "norm_P": float(np.linalg.norm(P)), "norm_Q": float(np.linalg.norm(Q)), "norm_Qb": float(np.linalg.norm(Qb))}
+    del g
+    return out
+
+
+def run_bpr(args, ctx):
+    """The headline: BASELINE configs[1] (N = 1) / configs[3] (N > 1) -- BPRMF sgd, ML-20M shape, d = 128."""
+    torch, dist = ctx.torch, ctx.dist
     from buffalo_amd import synth
     from buffalo_amd.backend import CyBPR
     from buffalo_amd.dist import shard_csr
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    # test hooks (1-GPU boxes): BFH_DEVICE_OVERRIDE pins every rank to one device, BFH_DIST_BACKEND=gloo
-    # replaces RCCL (which refuses two ranks on one GPU); the driver's runs set neither
-    if "BFH_DEVICE_OVERRIDE" in os.environ:
-        local_rank = int(os.environ["BFH_DEVICE_OVERRIDE"])
-    torch.cuda.set_device(local_rank)
-    comm_mode = "none"
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = os.environ.get("BFH_DIST_BACKEND", "nccl")
-        # torch.distributed is the control plane only (rendezvous, barrier, max of the elapsed times: gloo on CPU tensors);
-        # the data plane is the library's own communicator (bfh_comm_*: RCCL over xGMI).  Test hooks for one-GPU boxes:
-        # BFH_DIST_BACKEND=gloo + BFH_COMM_TRANSPORT=shm + BFH_DEVICE_OVERRIDE=0 run N ranks on one device through the
-        # library's shared-memory test transport (RCCL refuses two ranks on one GPU).  BFH_COMM=torch selects the emergency
-        # path below that all-reduces the backend's buffers through torch.distributed (bench-only; not the product).
-        if backend == "nccl":
-            dist.init_process_group("cpu:gloo,cuda:nccl")
-        else:
-            dist.init_process_group(backend)
-        comm_mode = os.environ.get("BFH_COMM", "library")
-    assert world == args.gpus, "WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus)
+    world, rank, local_rank = ctx.world, ctx.rank, ctx.local_rank
+    comm_mode = ctx.comm_mode
 
     csr = load_matrix(args.shape, args.seed)
     U, I, nnz = csr.num_users, csr.num_items, csr.nnz
@@ -678,6 +954,8 @@ def main():
 
     steps, warmup = args.steps, args.warmup
     opt = bpr_options(num_iters=steps + warmup, seed=args.seed)
+    if args.lr is not None:
+        opt["lr"] = args.lr
     P, Q, Qb = synth.init_factors(U, I, D, seed=args.seed)
     P = np.ascontiguousarray(P[u0:u1])
 
@@ -701,22 +979,12 @@ def main():
     obj.set_shard(nnz_off, world)
     comm, comm_note = None, None
     if comm_mode == "library":
-        from buffalo_amd.backend import Comm
-        ok = 1
-        try:
-            uid = torch.frombuffer(bytearray(Comm.unique_id() if rank == 0 else bytes(128)), dtype=torch.uint8).clone()
-            dist.broadcast(uid, src=0)                       # CPU tensor -> gloo
-            comm = Comm(world, rank, bytes(uid.numpy().tobytes()), local_rank)
-            comm.self_test()
-        except Exception as e:                                # every rank must take the same path
-            ok, comm_note = 0, "%s: %s" % (type(e).__name__, e)
-        flag = torch.tensor([ok], dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 1:
+        comm, comm_note = ctx.make_comm()
+        if comm is not None:
             obj.set_comm(comm)
         else:
-            comm, comm_mode = None, "torch"
-            comm_note = "library communicator unavailable (%s): fell back to torch.distributed" % comm_note
+            comm_mode = "torch"
+            comm_note += ": fell back to torch.distributed"
     fallback = None
     if world > 1 and comm_mode == "torch":
         # emergency path (the library's communicator could not be built on this node): the blocking delta all-reduce
@@ -741,163 +1009,348 @@ def main():
                 torch.cuda.current_stream().synchronize()
         obj.update_parameters()
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.all_reduce(torch.zeros(1))                  # CPU tensor: a gloo barrier that never touches the data plane
-        torch.cuda.synchronize()
-
-    for _ in range(warmup):
-        step()
-    obj.reset_stats()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    if comm is not None:
-        obj.comm_flush()                                     # the exchange still in flight belongs to the timed region
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # the exchange still in flight belongs to the timed region
+    elapsed = timed_steps(ctx, step, steps, warmup, before_timing=obj.reset_stats,
+                          after_steps=(obj.comm_flush if comm is not None else None))
     st = obj.stats()
     breakdown = None
     if world > 1:
         # per step, the slowest rank of each: where a scaling run's time goes (device times from HIP events inside the library)
-        b = torch.tensor([st["kernel_ms"], st["aux_ms"], st["exchange_kernel_ms"], st["allreduce_ms"], float(local_nnz)], dtype=torch.float64)
-        lo = b.clone()
-        dist.all_reduce(b, op=dist.ReduceOp.MAX)
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        lo, hi = ctx.minmax([st["kernel_ms"], st["aux_ms"], st["exchange_kernel_ms"], st["allreduce_ms"], float(local_nnz)])
         k = 1.0 / max(steps, 1)
-        breakdown = {"walk_kernel_ms": float(b[0]) * k, "sort_merge_presample_ms": float(b[1]) * k, "exchange_kernel_ms": float(b[2]) * k,
-                     "allreduce_ms": float(b[3]) * k, "what": "max over ranks, per step; allreduce_ms = the collective on the stream it ran on, "
+        breakdown = {"walk_kernel_ms": hi[0] * k, "sort_merge_presample_ms": hi[1] * k, "exchange_kernel_ms": hi[2] * k,
+                     "allreduce_ms": hi[3] * k, "what": "max over ranks, per step; allreduce_ms = the collective on the stream it ran on, "
                      "incl. the wait for the slowest rank (blocking exchanges only)",
-                     "walk_kernel_ms_min_rank": float(lo[0]) * k, "shard_nnz_min_max": [int(lo[4]), int(b[4])]}
-
-    if rank == 0:
-        updates = float(total_nnz) * opt["num_negative_samples"] * steps
-        # roofline of the dominant kernel (bpr_update_kernel), HIP events on the backend's stream
-        bytes_per_update = 24 * D + 20            # read+write P_u, Q_i, Q_j, 2 biases, key
-        kernel_ms = st["kernel_ms"] / max(st["launches"], 1)
-        alg_bytes = bytes_per_update * (st["samples"] / max(st["launches"], 1))
-        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        # PMC counters need rocprofv3: `traffic` is the per-launch figure of the latest separate --pmc passes of this same
-        # command (scripts/gpu_profile.sh -> scripts/pmc_summary.py -> profiles/pmc_latest.json), not of this process
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        # the library's own rule for the two-triples-per-wave walk (bfh_bpr_set_mode "im_dual"): vdim <= 128 and >= 6144 users per queue
-        dual_walk = hog == "3" and knobs.get("im_dual", "-1") != "0" and (knobs.get("im_dual", "-1") == "1" or n_local_users >= 8 * 6144)
-        out = {
-            "metric": "BPRMF training throughput (interactions/s), ML-20M-shaped synthetic, d=128",
-            "value": updates / elapsed, "unit": "updates/s", "n_gpus": world, "steps": steps, "warmup": warmup,
-            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BPRMF sgd, %s-shaped synthetic (%d x %d, %d nnz%s), d=%d, 1 negative/positive, "
-                                   "uniform sampling + verify_neg, CSR + factors resident in HBM"
-                                   % (args.shape, U, I, nnz, "" if args.scaling == "strong" or world == 1 else " per GPU", D),
-                       "parallelism": "1 GPU" if world == 1 else "dp%d: users sharded, Q replicated, %.1f delta all-reduce/epoch (%s)"
-                                      % (world, (st["exchanges"] / max(steps, 1)) if comm is not None else args.minibatches,
-                                         ("inside the library, transport %s" % os.environ.get("BFH_COMM_TRANSPORT", "RCCL over xGMI")) if comm is not None
-                                         else (comm_note or "EMERGENCY PATH through torch.distributed")),
-                       "hogwild": {"0": "write-through (sc1) racy stores on item rows", "1": "fp32 atomics on item rows",
-                                   "2": "per-XCD item-factor replicas (plain stores through the XCD's L2, merged by the delta rule "
-                                        "%.1f times per epoch); popular rows stay chip-wide on fp32 atomics"
-                                        % (st["merges"] / max(steps, 1)),
-                                   "3": "item-major walk%s: users owned by XCDs (plain stores through the owner's L2), the positive "
-                                        "item row in registers with bounded-staleness atomic flushes, negatives in per-XCD replicas "
-                                        "merged by the delta rule %.1f times per epoch"
-                                        % (", two triples per wave" if dual_walk else "", st["merges"] / max(steps, 1))}[hog]},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": "profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)",
-                         "kernel": ("bpr_item_major_dual_kernel" if dual_walk else "bpr_item_major_kernel") if hog == "3" else "bpr_update_kernel",
-                         "kernel_ms": kernel_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         # SURVEY.md section 8(d)'s stricter variant, reported alongside: one side's row is read and written once per
-                         # run of its triples instead of once per triple (16 d + 20 + 8 d / mean degree bytes per update)
-                         "strict": {"bytes_per_update": 16 * D + 20 + 8 * D / (nnz / U),
-                                    "achieved": achieved * (16 * D + 20 + 8 * D / (nnz / U)) / bytes_per_update,
-                                    "frac": achieved * (16 * D + 20 + 8 * D / (nnz / U)) / bytes_per_update / HBM_PEAK_GBS},
-                         "launches_per_step": st["launches"] / max(steps, 1),
-                         # the same bytes over ALL device time of a step (update launches + replica broadcast / merge kernels)
-                         "frac_incl_merge_kernels": (bytes_per_update * st["samples"] / max((st["kernel_ms"] + st["aux_ms"]) * 1e-3, 1e-12)
-                                                     / 1e9 / HBM_PEAK_GBS)},
-            "epoch_ms": elapsed / steps * 1e3,
-        }
-        if breakdown is not None:
-            out["breakdown"] = breakdown
-        if world == 1:
-            try:   # the same box's HBM under a trivial kernel, next to the 8 TB/s the fraction is quoted against
-                m = measured_stream_bandwidth()
-                m["frac_of_triad"] = achieved / m["triad_GBps"] if m["triad_GBps"] > 0 else None
-                out["roofline"]["measured_stream"] = m
-            except Exception as e:
-                out["roofline"]["measured_stream"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(csr)
-        if world == 1 and not args.no_extra:
-            del obj
-            extra = {}
-            for name, fn in (("als_ml20m_d128", extra_als), ("warp_ml20m_d256", extra_warp),
-                             ("warp_c5_one_gpu", lambda _csr, seed, cpu: extra_warp_c5(seed, cpu=cpu)), ("topk_ml20m_d128_k100", extra_topk),
-                             ("sppmi_ml20m_stream_w5", extra_sppmi), ("coo_to_csr_ml20m", extra_ingest)):
-                try:
-                    extra[name] = fn(csr, args.seed, cpu=not args.no_cpu_baseline)
-                except Exception as e:   # the headline line is never lost to a secondary measurement
-                    extra[name] = {"error": "%s: %s" % (type(e).__name__, e)}
-            try:   # the top of the reference's own D-sweep (benchmark/README.md:97): d = 160, block 32 -> the wide ALS kernel (T = 5)
-                extra["als_ml20m_d160"] = extra_als_wide(csr, args.seed, 160)
-            except Exception as e:
-                extra["als_ml20m_d160"] = {"error": "%s: %s" % (type(e).__name__, e)}
-            out["extra"] = extra
-            # the driver's record keeps the scalars of `roofline` / `cpu_baseline` and drops nested objects: configs[2] (ALS) and
-            # configs[4] (WARP) at BASELINE size, measured in this process, as flat keys
-            rf = out["roofline"]
-            ms = rf.get("measured_stream") or {}
-            if "triad_GBps" in ms:
-                rf["triad_GBps"], rf["frac_of_triad"] = ms["triad_GBps"], ms.get("frac_of_triad")
-            a = extra.get("als_ml20m_d128") or {}
-            if "epoch_ms" in a:
-                rf.update({"als_epoch_ms": a["epoch_ms"], "als_kernel_ms": a["kernel_ms_per_epoch"], "als_hbm_frac": a["hbm"]["frac"],
-                           "als_hbm_frac_of_epoch": a["hbm"]["algorithmic_bytes_per_epoch"] / (a["epoch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                           "als_useful_mfma_frac": a["mfma"]["useful_frac_of_fp32_peak"], "als_issued_mfma_frac_f16": a["mfma"]["frac"]})
-            a160 = extra.get("als_ml20m_d160") or {}
-            if "epoch_ms" in a160:
-                rf.update({"als_d160_epoch_ms": a160["epoch_ms"], "als_d160_kernel_ms": a160["kernel_ms_per_epoch"]})
-            w = extra.get("warp_ml20m_d256") or {}
-            if "epoch_ms" in w:
-                rf.update({"warp_ml20m_epoch_ms": w["epoch_ms"], "warp_ml20m_T": w["mean_scored_negatives_T"],
-                           "warp_ml20m_implemented_model_frac": w["implemented_model_frac"]})
-            c5 = extra.get("warp_c5_one_gpu") or {}
-            if "epoch_ms" in c5:
-                last = c5["epochs"][-1]
-                rf.update({"warp_c5_epoch_ms": c5["epoch_ms"], "warp_c5_T": c5["mean_scored_negatives_T"], "warp_c5_accepted_frac": last["accepted_frac"],
-                           "warp_c5_epochs_run": len(c5["epochs"]), "warp_c5_implemented_model_frac": c5["implemented_model_frac"],
-                           "warp_c5_sort_and_gather_ms": last["sort_and_gather_ms"], "warp_c5_trial_kernel_ms": last["trial_kernel_ms"]})
-                tr = c5.get("counter_traffic") or {}
-                if isinstance(tr, dict) and tr.get("hbm_bytes_per_epoch"):
-                    dev_ms = last["trial_kernel_ms"] + last["sort_and_gather_ms"] + last["optimizer_ms"]
-                    rf["warp_c5_traffic_frac"] = tr["hbm_bytes_per_epoch"] / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-                    rf["warp_c5_traffic_T"] = tr.get("mean_scored_negatives_T")   # the T of the profiled epoch (compare with warp_c5_T)
-                    rf["warp_c5_traffic_source"] = "profiles/warp_pmc_latest.json (counter bytes of an earlier run of this workload) over this run's device time"
-            cb = out.get("cpu_baseline") or {}
-            for name, key in (("als_ml20m_d128", "als"), ("warp_ml20m_d256", "warp_ml20m"), ("warp_c5_one_gpu", "warp_c5")):
-                v = (extra.get(name) or {}).get("cpu_baseline") or {}
-                if "value" in v and cb:
-                    cb["%s_value" % key], cb["%s_unit" % key] = v["value"], v["unit"]
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.all_reduce(torch.zeros(1))
+                     "walk_kernel_ms_min_rank": lo[0] * k, "shard_nnz_min": int(lo[4]), "shard_nnz_max": int(hi[4])}
+    if rank != 0:
         del obj
-        comm = None
-        dist.destroy_process_group()
+        return None
+
+    updates = float(total_nnz) * opt["num_negative_samples"] * steps
+    # roofline of the dominant kernel, HIP events on the backend's stream
+    bytes_per_update = 24 * D + 20            # read+write P_u, Q_i, Q_j, 2 biases, key
+    kernel_ms = st["kernel_ms"] / max(st["launches"], 1)
+    alg_bytes = bytes_per_update * (st["samples"] / max(st["launches"], 1))
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    traffic, traffic_source = counter_traffic()
+    # the library's own rule for the two-triples-per-wave walk (bfh_bpr_set_mode "im_dual"): vdim <= 128 and >= 6144 users per queue
+    dual_walk = hog == "3" and knobs.get("im_dual", "-1") != "0" and (knobs.get("im_dual", "-1") == "1" or n_local_users >= 8 * 6144)
+    strict_b = 16 * D + 20 + 8 * D / (nnz / U)
+    out = {
+        "metric": "BPRMF training throughput (interactions/s), ML-20M-shaped synthetic, d=128",
+        "value": updates / elapsed, "unit": "updates/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BPRMF sgd lr %g -> min_lr %g over %d epochs, %d negative/positive, %s-shaped synthetic (%d x %d, %d nnz%s), d=%d, "
+                               "uniform sampling + verify_neg, reg 0.025, CSR + factors resident in HBM"
+                               % (opt["lr"], opt["min_lr"], steps + warmup, opt["num_negative_samples"], args.shape, U, I, nnz,
+                                  "" if args.scaling == "strong" or world == 1 else " per GPU", D),
+                   "lr": opt["lr"], "min_lr": opt["min_lr"], "num_negative_samples": opt["num_negative_samples"], "optimizer": "sgd",
+                   "parallelism": "1 GPU" if world == 1 else "dp%d: users sharded, Q replicated, %.1f delta all-reduce/epoch (%s)"
+                                  % (world, (st["exchanges"] / max(steps, 1)) if comm is not None else args.minibatches,
+                                     ("inside the library, transport %s" % ctx.transport()) if comm is not None
+                                     else (comm_note or "EMERGENCY PATH through torch.distributed")),
+                   "hogwild": {"0": "write-through (sc1) racy stores on item rows", "1": "fp32 atomics on item rows",
+                               "2": "per-XCD item-factor replicas (plain stores through the XCD's L2, merged by the delta rule "
+                                    "%.1f times per epoch); popular rows stay chip-wide on fp32 atomics"
+                                    % (st["merges"] / max(steps, 1)),
+                               "3": "item-major walk%s: users owned by XCDs (plain stores through the owner's L2), the positive "
+                                    "item row in registers with bounded-staleness atomic flushes, negatives in per-XCD replicas "
+                                    "merged by the delta rule %.1f times per epoch"
+                                    % (", two triples per wave" if dual_walk else "", st["merges"] / max(steps, 1))}[hog]},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                     "kernel": ("bpr_item_major_dual_kernel" if dual_walk else "bpr_item_major_kernel") if hog == "3" else "bpr_update_kernel",
+                     "kernel_ms": kernel_ms,
+                     "algorithmic_bytes_per_launch": alg_bytes,
+                     # SURVEY.md section 8(d)'s stricter variant, reported alongside: one side's row is read and written once per
+                     # run of its triples instead of once per triple (16 d + 20 + 8 d / mean degree bytes per update)
+                     "strict": {"bytes_per_update": strict_b, "achieved": achieved * strict_b / bytes_per_update,
+                                "frac": achieved * strict_b / bytes_per_update / HBM_PEAK_GBS},
+                     "launches_per_step": st["launches"] / max(steps, 1),
+                     # the same bytes over ALL device time of a step (update launches + replica broadcast / merge kernels)
+                     "frac_incl_merge_kernels": (bytes_per_update * st["samples"] / max((st["kernel_ms"] + st["aux_ms"]) * 1e-3, 1e-12)
+                                                 / 1e9 / HBM_PEAK_GBS)},
+        "epoch_ms": elapsed / steps * 1e3,
+    }
+    if traffic:
+        out["roofline"]["traffic_frac"] = traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    if breakdown is not None:
+        out["breakdown"] = breakdown
+    if world == 1:
+        try:   # the same box's HBM under a trivial kernel, next to the 8 TB/s the fraction is quoted against
+            m = measured_stream_bandwidth()
+            m["frac_of_triad"] = achieved / m["triad_GBps"] if m["triad_GBps"] > 0 else None
+            out["roofline"]["measured_stream"] = m
+            out["roofline"]["triad_GBps"], out["roofline"]["frac_of_triad"] = m["triad_GBps"], m["frac_of_triad"]
+        except Exception as e:
+            out["roofline"]["measured_stream"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    del obj
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(csr)
+    if world == 1 and not args.no_extra:
+        out["extra"] = run_extras(args, csr, out)
+    return out
+
+
+def run_extras(args, csr, out):
+    """N = 1, after the timed region, in the same process: the other inner loops north_star names (ALS configs[2], WARP at configs[4]'s
+    size and d), the BPRMF walk at the reference benchmark's learning rate, and the section-8(f) neighbours.  Their headline scalars
+    are copied into `roofline` / `cpu_baseline` as flat keys -- the part of the line the driver's record keeps."""
+    cpu = not args.no_cpu_baseline
+    extra = {}
+    for name, fn in (("bpr_lr005", lambda c, seed, cpu: extra_bpr_lr005(c, seed)),
+                     ("als_ml20m_d128", extra_als), ("warp_ml20m_d256", extra_warp),
+                     ("warp_c5_one_gpu", lambda _csr, seed, cpu: extra_warp_c5(seed, cpu=cpu)), ("topk_ml20m_d128_k100", extra_topk),
+                     ("sppmi_ml20m_stream_w5", extra_sppmi), ("coo_to_csr_ml20m", extra_ingest),
+                     # the top of the reference's own D-sweep (benchmark/README.md:97): d = 160, block 32 -> the wide ALS kernel (T = 5)
+                     ("als_ml20m_d160", lambda c, seed, cpu: extra_als_wide(c, seed, 160))):
+        if args.only_extra and name not in args.only_extra:
+            continue
+        try:
+            extra[name] = fn(csr, args.seed, cpu=cpu)
+        except Exception as e:   # the headline line is never lost to a secondary measurement
+            extra[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+    rf = out["roofline"]
+    b = extra.get("bpr_lr005") or {}
+    if "kernel_ms_per_launch" in b:
+        rf.update({"bpr_lr005_kernel_ms": b["kernel_ms_per_launch"], "bpr_lr005_frac": b["frac"], "bpr_lr005_kernel_ms_max": b["kernel_ms_per_launch_max"],
+                   "bpr_lr005_updates_per_s": b["updates_per_s_after_first"]})
+    a = extra.get("als_ml20m_d128") or {}
+    if "epoch_ms" in a:
+        rf.update({"als_epoch_ms": a["epoch_ms"], "als_kernel_ms": a["kernel_ms_per_epoch"], "als_hbm_frac": a["hbm"]["frac"],
+                   "als_hbm_frac_of_epoch": a["hbm"]["algorithmic_bytes_per_epoch"] / (a["epoch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                   "als_issued_mfma_frac_f16": a["mfma"]["frac"], "als_useful_mfma_frac": a["mfma"]["useful_frac_of_fp32_peak"],
+                   "als_arith": "split-f16"})
+        for k, v in (a.get("parity") or {}).items():
+            rf["als_" + k] = v
+    a160 = extra.get("als_ml20m_d160") or {}
+    if "epoch_ms" in a160:
+        rf.update({"als_d160_epoch_ms": a160["epoch_ms"], "als_d160_kernel_ms": a160["kernel_ms_per_epoch"]})
+    w = extra.get("warp_ml20m_d256") or {}
+    if "epoch_ms" in w:
+        rf.update({"warp_ml20m_epoch_ms": w["epoch_ms"], "warp_ml20m_T": w["mean_scored_negatives_T"],
+                   "warp_ml20m_implemented_model_frac": w["implemented_model_frac"]})
+    c5 = extra.get("warp_c5_one_gpu") or {}
+    if "epoch_ms" in c5:
+        last = c5["epochs"][-1]
+        rf.update({"warp_c5_epoch_ms": c5["epoch_ms"], "warp_c5_T": c5["mean_scored_negatives_T"], "warp_c5_accepted_frac": last["accepted_frac"],
+                   "warp_c5_epochs_run": len(c5["epochs"]), "warp_c5_implemented_model_frac": c5["implemented_model_frac"],
+                   "warp_c5_sort_and_gather_ms": last["sort_and_gather_ms"], "warp_c5_trial_kernel_ms": last["trial_kernel_ms"]})
+        tr = c5.get("counter_traffic") or {}
+        if isinstance(tr, dict) and tr.get("hbm_bytes_per_epoch"):
+            dev_ms = last["trial_kernel_ms"] + last["sort_and_gather_ms"] + last["optimizer_ms"]
+            rf["warp_c5_traffic_frac"] = tr["hbm_bytes_per_epoch"] / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            rf["warp_c5_traffic_T"] = tr.get("mean_scored_negatives_T")   # the T of the profiled epoch (compare with warp_c5_T)
+            rf["warp_c5_traffic_source"] = "profiles/warp_pmc_latest.json (counter bytes of an earlier run) over this run's device time"
+    cb = out.get("cpu_baseline") or {}
+    for name, key in (("als_ml20m_d128", "als"), ("warp_ml20m_d256", "warp_ml20m"), ("warp_c5_one_gpu", "warp_c5")):
+        v = (extra.get(name) or {}).get("cpu_baseline") or {}
+        if "value" in v and cb:
+            cb["%s_value" % key], cb["%s_unit" % key] = v["value"], v["unit"]
+    return extra
+
+
+def run_warp_c5(args, ctx):
+    """BASELINE configs[4]: WARP on 10 M x 1 M / 1 B nnz, d = 256, USER-SHARDED over the ranks (contiguous user ranges -- every user has
+    100 positives, so equal row counts are nnz-balanced), Q | Qb replicated, ONE grouped all-reduce of the item-side gradients per
+    update_parameters inside the library (csrc/sgd_base.hip; warp.cc:103-201 has no multi-device form).  A step = one epoch."""
+    from buffalo_amd.backend import CyWARP
+    world, rank = ctx.world, ctx.rank
+    U5, I5, deg, d = 10_000_000, 1_000_000, 100, WARP_D
+    if args.c5_users:
+        U5 = args.c5_users
+    u0, u1 = U5 * rank // world, U5 * (rank + 1) // world
+    indptr, keys, P, Q, Qb = warp_c5_inputs(u0=u0, u1=u1, users=U5)
+    total_nnz = U5 * deg
+    g = CyWARP()
+    g.set_device(ctx.local_rank)
+    path = _opt_file(dict(WARP_OPT, num_iters=args.steps + args.warmup))
+    assert g.init(path)
+    os.unlink(path)
+    g.sync_every_epoch = False
+    g.initialize_model(P, Q, Qb, total_nnz, True)
+    g.set_resident_csr(indptr, keys)
+    g.set_shard(u0 * deg, world)
+    comm = None
+    if world > 1:
+        comm, note = ctx.make_comm()
+        assert comm is not None, note          # no emergency path for this workload
+        g.set_comm(comm)
+    n_local = u1 - u0
+
+    def step():
+        g.add_jobs(0, n_local, indptr, None)
+        g.update_parameters()
+
+    elapsed = timed_steps(ctx, step, args.steps, args.warmup, before_timing=g.reset_stats)
+    st = g.stats()
+    lo, hi = ctx.minmax([st["kernel_ms"], st["aux_ms"], st["optimizer_ms"], st.get("allreduce_ms", 0.0), float(st["scored_negatives"]), float(st["accepted"])])
+    tot_scored = st["scored_negatives"]
+    if ctx.dist is not None:
+        t = ctx.torch.tensor([float(st["scored_negatives"]), float(st["accepted"]), float(st.get("loaded_rows", 0))], dtype=ctx.torch.float64)
+        ctx.dist.all_reduce(t)
+        tot_scored, tot_acc, tot_loaded = (float(x) for x in t)
+    else:
+        tot_acc, tot_loaded = float(st["accepted"]), float(st.get("loaded_rows", 0))
+    del g
+    if rank != 0:
+        return None
+    K = max(args.steps, 1)
+    row = 4 * d
+    positives = float(total_nnz) * args.steps
+    alg = (8 * tot_acc + 2 * (positives - tot_acc) + tot_scored) * row + 4 * positives        # SURVEY 8(d), all steps, all ranks
+    dev_ms = (hi[0] + hi[1]) / K                                                             # slowest rank's trial + sort/gather kernels per step
+    tr = _warp_counter_traffic("c5") or {}
+    out = {"metric": "WARP training throughput (positives/s), configs[4]-shaped synthetic (10M x 1M, 1B nnz), d=256",
+           "value": positives / elapsed, "unit": "positives/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "WARP adagrad lr %g, dot score, max_trials %d, threshold %g, %d x %d, %d nnz (100 per user, popularity-skewed bands), d=%d, "
+                                  "everything resident in HBM" % (WARP_OPT["lr"], WARP_OPT["max_trials"], WARP_OPT["threshold"], U5, I5, total_nnz, d),
+                      "lr": WARP_OPT["lr"], "optimizer": "adagrad",
+                      "parallelism": "1 GPU" if world == 1 else "dp%d: users sharded (%d per rank), Q | Qb replicated, one grouped gradient all-reduce per "
+                                     "epoch inside the library, transport %s" % (world, n_local, ctx.transport())},
+           "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                        # SURVEY 8(d)'s formula counts six gradient-row read-modify-writes per positive that the gather-by-item formulation never
+                        # performs, so this figure can exceed the peak: it is the contract's number, NOT evidence of bandwidth -- see traffic_frac
+                        "achieved": alg / K / world / (dev_ms * 1e-3) / 1e9, "frac": alg / K / world / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "achieved_is": "SURVEY 8(d) algorithmic bytes per rank and step over the slowest rank's trial + sort + gather kernel time",
+                        "kernel": "warp_update_kernel + grad_gather_kernel", "kernel_ms": dev_ms, "trial_kernel_ms": hi[0] / K, "sort_and_gather_ms": hi[1] / K,
+                        "optimizer_ms": hi[2] / K, "allreduce_ms": hi[3] / K, "mean_scored_negatives_T": tot_scored / positives,
+                        "accepted_frac": tot_acc / positives, "candidate_rows_fetched_per_positive": tot_loaded / positives,
+                        "traffic": (tr.get("hbm_bytes_per_epoch") if world == 1 else None),
+                        "traffic_source": "profiles/warp_pmc_latest.json (rocprofv3 --pmc passes of an earlier one-GPU run of this workload)"},
+           "breakdown": {"trial_kernel_ms_min_rank": lo[0] / K, "trial_kernel_ms": hi[0] / K, "sort_and_gather_ms": hi[1] / K, "optimizer_ms": hi[2] / K,
+                         "allreduce_ms": hi[3] / K, "what": "per step; max over ranks unless named min"}}
+    if world == 1 and tr.get("hbm_bytes_per_epoch"):
+        out["roofline"]["traffic_frac"] = tr["hbm_bytes_per_epoch"] / ((hi[0] + hi[1] + hi[2]) / K * 1e-3) / 1e9 / HBM_PEAK_GBS
+    if world == 1 and not args.no_cpu_baseline:
+        n100 = max(1, (u1 - u0) // 100)
+        out["cpu_baseline"] = _warp_cpu_baseline(indptr[:n100], keys[:int(indptr[n100 - 1])], I5, d, args.seed, seconds=10.0)
+        out["cpu_baseline"]["sample"] += "; the first 1/100 of the users against the full item table"
+    return out
+
+
+def run_als(args, ctx):
+    """BASELINE configs[2] over N ranks: ALS (iALS++ at d = 128) on the ML-20M shape; the rows of a half-epoch sharded nnz-balanced, both factor
+    matrices and both CSR orientations replicated, the solved row blocks published after each half-epoch (bfh_als_publish_rows).  A step = one epoch."""
+    from buffalo_amd import ingest, synth
+    from buffalo_amd.backend import CyALS
+    from buffalo_amd.dist import CommDataParallelALS
+    world, rank = ctx.world, ctx.rank
+    csr = load_matrix(args.shape, args.seed)
+    U, I, nnz = csr.num_users, csr.num_items, csr.nnz
+    vals = (1 + np.random.default_rng(args.seed).poisson(1.0, size=nnz)).astype(np.float32)
+    col = ingest.coo_to_csr(csr.keys, csr.rows(), vals, I, U)
+    P, Q, _ = synth.init_factors(U, I, D, seed=args.seed)
+    g = CyALS()
+    g.set_device(ctx.local_rank)
+    path = _opt_file(ALS_OPT)
+    assert g.init(path)
+    os.unlink(path)
+    g.initialize_model(P, Q)
+    g.set_resident_csr(0, csr.indptr, csr.keys, vals)
+    g.set_resident_csr(1, col["indptr"], col["key"], col["val"])
+    g.set_mode("als_writeback", 0)
+    if world > 1:
+        comm, note = ctx.make_comm()
+        assert comm is not None, note
+        g.set_comm(comm)
+        dp = CommDataParallelALS(g, comm, (csr.indptr, col["indptr"]), U, I)
+        step = dp.epoch
+    else:
+        def step():
+            g.precompute(0)
+            g.partial_update(0, U, csr.indptr, None, None, 0)
+            g.precompute(1)
+            g.partial_update(0, I, col["indptr"], None, None, 1)
+    elapsed = timed_steps(ctx, step, args.steps, args.warmup, before_timing=g.reset_stats)
+    st = g.stats()
+    lo, hi = ctx.minmax([st["kernel_ms"], st["aux_ms"]])
+    del g
+    if rank != 0:
+        return None
+    K = max(args.steps, 1)
+    alg_bytes = 2 * nnz * (4 * D + 8) + (U + I) * (8 * D + 8) + (U + I) * 4 * D     # SURVEY 8(d) B_als, both half-epochs, whole job
+    kernel_s = hi[0] / K * 1e-3
+    return {"metric": "ALS training throughput (interactions/s), ML-20M-shaped synthetic, d=128 (iALS++)",
+            "value": 2.0 * nnz * args.steps / elapsed, "unit": "interactions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32 (split-f16 Gramian)",
+            "data": "synthetic",
+            "config": {"workload": "ALS iALS++ (block 32, 3 CG steps, alpha 8, reg 0.1), %s-shaped synthetic (%d x %d, %d nnz, values 1+Poisson(1)), d=%d, "
+                                   "Gramian: split-f16 (~22-bit products, fp32 accumulate)" % (args.shape, U, I, nnz, D),
+                       "parallelism": "1 GPU" if world == 1 else "dp%d: rows of each half-epoch sharded nnz-balanced, factors replicated, solved rows "
+                                      "published per half-epoch inside the library, transport %s" % (world, ctx.transport())},
+            "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": alg_bytes / world / kernel_s / 1e9,
+                         "frac": alg_bytes / world / kernel_s / 1e9 / HBM_PEAK_GBS, "kernel": "als_pc_kernel", "kernel_ms": hi[0] / K,
+                         "kernel_ms_min_rank": lo[0] / K, "aux_ms": hi[1] / K, "traffic": None,
+                         "achieved_is": "SURVEY 8(d) B_als per rank over the slowest rank's row-kernel time per epoch"}}
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without a launcher: N ranks of this file (one per GPU), rendezvous on 127.0.0.1; rank 0 prints the line.
+    (The driver's `python -m torch.distributed.run ... bench.py --gpus N` sets WORLD_SIZE and never gets here.)"""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            r = p.poll()
+            if r is None:
+                continue
+            live.remove(p)
+            if r != 0 and rc == 0:
+                rc = r
+                for q in live:              # a rank died: the others would wait in a collective forever (exact PIDs, never a pattern)
+                    q.terminate()
+    return rc
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None, help="default 250 (bpr: ~2.1 s timed region on one MI355X), 20 (als), 5 (warp_c5)")
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=["bpr", "warp_c5", "als"], default="bpr",
+                    help="bpr = the headline (configs[1] / configs[3]); warp_c5 = configs[4], user-sharded; als = configs[2], rows sharded")
+    ap.add_argument("--shape", default="ml20m")
+    ap.add_argument("--seed", type=int, default=7)
+    ap.add_argument("--lr", type=float, default=None, help="BPRMF learning rate (default: the option default 0.002)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--minibatches", type=int, default=1, help="all-reduce points per epoch (N>1)")
+    ap.add_argument("--c5-users", type=int, default=0, help="warp_c5: number of users instead of 10 M (tests on shared boxes)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurements (N=1)")
+    ap.add_argument("--only-extra", action="append", default=[], help="run only these extras (name as in bench_extra.json's `extra`)")
+    ap.add_argument("--mode", action="append", default=[], help="backend knob name=value (e.g. hogwild_atomic=0)")
+    return ap.parse_args(argv)
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, argv))
+    if args.steps is None:
+        args.steps = {"bpr": 250, "als": 20, "warp_c5": 5}[args.workload]
+    ctx = Ctx(args)
+    out = {"bpr": run_bpr, "warp_c5": run_warp_c5, "als": run_als}[args.workload](args, ctx)
+    if ctx.rank == 0:
+        emit(out)
+    ctx.close()
 
 
 if __name__ == "__main__":

@@ -13,6 +13,34 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-ato
          "-Wno-unused-function", "-Wno-unused-result"] + os.environ.get("BFH_EXTRA_FLAGS", "").split()   # e.g. -DBFH_WITH_ALS_SOLO (rebuild with --force)
 
 
+FLAGS_STAMP = os.path.join(CSRC, ".build_flags")
+
+
+def source_fingerprint():
+    """16 hex digits over the kernel sources (csrc/*.hip, *.hpp + the public header) and the compile flags: what a profile taken by an
+    earlier process must match to be quoted by a later one (bench.py `roofline.traffic`; stamped by scripts/pmc_summary.py)."""
+    import hashlib
+    h = hashlib.sha256()
+    names = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".h")))
+    for f in names + [os.path.join("..", "..", "include", "buffalo_hip.h")]:
+        path = os.path.join(CSRC, f)
+        if os.path.exists(path):
+            h.update(f.encode())
+            with open(path, "rb") as fh:
+                h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
+def _flags_changed():
+    """BFH_EXTRA_FLAGS changes the compiled code (-DBFH_TEST_TRANSPORT, ...): objects built with other flags are stale."""
+    try:
+        with open(FLAGS_STAMP) as f:
+            return f.read() != " ".join(FLAGS)
+    except OSError:
+        return bool(os.environ.get("BFH_EXTRA_FLAGS", "").split())      # no stamp = a default build
+
+
 def _deps():
     return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))] + \
            [os.path.join(HERE, "..", "include", "buffalo_hip.h")]
@@ -28,6 +56,7 @@ def _stale(out, srcs):
 def build(force=False, verbose=False):
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     deps = _deps()
+    force = force or (_flags_changed() and os.access(CSRC, os.W_OK))
     objs, jobs = [], []
     for s in srcs:
         src = os.path.join(CSRC, s)
@@ -49,6 +78,9 @@ def build(force=False, verbose=False):
             for err in ex.map(run, jobs):
                 if verbose and err.strip():
                     print(err, file=sys.stderr)
+    if jobs:
+        with open(FLAGS_STAMP, "w") as f:
+            f.write(" ".join(FLAGS))
     if jobs or _stale(LIB, objs):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"])   # librccl is dlopen'ed (comm.hip)
     return LIB

@@ -4,7 +4,11 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from buffalo_amd import _build  # noqa: E402
 
 root, out_path = sys.argv[1], sys.argv[2]
 per = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -22,6 +26,7 @@ bpr = [k for k in per if "bpr_item_major_kernel" in k or "bpr_item_major_dual_ke
 dom = max(bpr, key=lambda k: sum(per[k].get("FETCH_SIZE", [0.0])))
 c = {n: sum(v) / len(v) for n, v in per[dom].items()}
 out = {
+    "csrc_sha16": _build.source_fingerprint(),       # bench.py quotes `traffic` from this file only when it runs the same kernel sources
     "command": "rocprofv3 --kernel-trace --pmc <COUNTER> --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra "
                "(scripts/gpu_profile.sh; the MFMA-utilisation pass keeps the extras)",
     "kernel": dom, "launches_seen": {n: len(v) for n, v in per[dom].items()}, "counters_per_launch": c, **meta[dom],

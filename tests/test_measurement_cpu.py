@@ -70,5 +70,95 @@ def test_warp_epoch_row_byte_figures():
     assert r["mean_scored_negatives_T"] == 2.5 and r["candidate_rows_fetched_per_positive"] == 3.0 and r["accepted_frac"] == 0.9
     m = r["implemented_model_bytes"]
     assert m["trial_kernel"] >= (nnz + 3000) * row and m["gather"] >= 2 * 900 * row and m["optimizer"] == (U + I) * 6 * row
-    assert abs(r["hbm_frac"] - r["algorithmic_bytes"] / 3e-3 / 1e9 / bench.HBM_PEAK_GBS) < 1e-12   # over trial + sort + gathers
+    assert abs(r["survey_formula_bytes_over_peak"] - r["algorithmic_bytes"] / 3e-3 / 1e9 / bench.HBM_PEAK_GBS) < 1e-12   # over trial + sort + gathers
     assert r["implemented_model_total"] == sum(m.values())
+
+
+def test_bench_last_line_is_compact_and_keeps_the_contract():
+    """BENCH_r04.json.parsed was null: the 27 KB line did not fit the driver's 8 KB stdout tail.  The line-assembly code run on that very
+    line (profiles/r04_bench_n1_default_250_steps.json, a real full result) must give <= 4096 bytes that json.loads back with the
+    contract's head keys, the flat roofline (frac, kernel_ms, the ALS / WARP keys) and the flat cpu_baseline."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_n1_default_250_steps.json")))
+    assert len(json.dumps(full)) > 20000                                   # the canned input is the oversized one
+    full["config"].update({"lr": 0.002, "min_lr": 0.0001, "num_negative_samples": 1})
+    full["roofline"].update({"bpr_lr005_kernel_ms": 5.1, "bpr_lr005_frac": 0.76, "als_user_max": 1.2e-4, "als_item_max": 1.7e-2,
+                             "als_item_max_reorder": 2.4e-2, "als_top10_overlap": 0.9755, "als_top10_overlap_reorder": 0.9757,
+                             "traffic_frac": 0.62})
+    full["cpu_baseline"].update({"reference_on_stand_ins_value": 5.9e6, "reference_on_stand_ins_kind": "reference-on-stand-ins"})
+    s = bench.compact_line(full)
+    assert len(s) <= bench.LINE_LIMIT and "\n" not in s
+    line = json.loads(s)
+    for k in bench.HEAD_KEYS:
+        assert k in line, k
+    assert line["value"] == float("%.6g" % full["value"]) and line["n_gpus"] == 1 and line["higher_is_better"] is True
+    rf, cb = line["roofline"], line["cpu_baseline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "als_epoch_ms", "als_kernel_ms", "als_hbm_frac",
+              "warp_c5_epoch_ms", "warp_c5_T", "warp_ml20m_epoch_ms", "bpr_lr005_kernel_ms", "bpr_lr005_frac", "als_user_max", "als_top10_overlap",
+              "triad_GBps", "frac_of_triad"):
+        assert k in rf, k
+    assert all(not isinstance(v, (dict, list)) for v in rf.values()) and all(not isinstance(v, (dict, list)) for v in cb.values())
+    assert abs(rf["frac"] - full["roofline"]["frac"]) < 1e-5 and abs(rf["achieved"] / rf["peak"] - rf["frac"]) < 1e-5
+    for k in ("value", "unit", "cores", "kind", "sample", "als_value", "warp_c5_value", "reference_on_stand_ins_value"):
+        assert k in cb, k
+    assert line["config"]["lr"] == 0.002 and "workload" in line["config"]
+    # a pathological result (every string long, hundreds of flat keys) still fits: optional keys go first, the contract's keys never
+    fat = json.loads(json.dumps(full))
+    fat["roofline"].update({"zz_%d" % i: 1.0 / (i + 1) for i in range(40)})
+    fat["config"]["workload"] = "x" * 3000
+    fat["cpu_baseline"]["sample"] = "y" * 3000
+    s2 = bench.compact_line(fat)
+    assert len(s2) <= bench.LINE_LIMIT
+    l2 = json.loads(s2)
+    assert "frac" in l2["roofline"] and "value" in l2["cpu_baseline"] and l2["value"] == line["value"]
+
+
+def test_bench_counter_traffic_is_refused_from_other_sources(tmp_path, monkeypatch):
+    """`roofline.traffic` comes from a file an EARLIER process wrote: it is quoted only when that process ran these kernel sources."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    from buffalo_amd import _build
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    (prof / "pmc_latest.json").write_text(json.dumps({"hbm_bytes_per_launch": 2.0e10, "csrc_sha16": "0123456789abcdef"}))
+    v, why = bench.counter_traffic()
+    assert v is None and "other kernel sources" in why
+    (prof / "pmc_latest.json").write_text(json.dumps({"hbm_bytes_per_launch": 2.0e10, "csrc_sha16": _build.source_fingerprint()}))
+    v, why = bench.counter_traffic()
+    assert v == 2.0e10
+    (prof / "pmc_latest.json").unlink()
+    assert bench.counter_traffic()[0] is None
+
+
+def test_bench_self_launch_sets_the_rendezvous(monkeypatch):
+    """`python bench.py --gpus N` without a launcher starts N ranks of itself with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set
+    (the driver's torchrun form sets WORLD_SIZE and never takes this branch); a dying rank takes the others down and its code is returned."""
+    sys.path.insert(0, ROOT)
+    import subprocess
+    import bench
+    seen = []
+
+    class P:
+        def __init__(self, cmd, env=None, stdout=None):
+            seen.append((cmd, env, stdout))
+            self.rc = 3 if env["RANK"] == "1" else None
+            self.terminated = False
+
+        def poll(self):
+            return self.rc
+
+        def terminate(self):
+            self.terminated, self.rc = True, -15
+    monkeypatch.setattr(subprocess, "Popen", P)
+    args = bench.parse_args(["--gpus", "4", "--workload", "warp_c5"])
+    rc = bench.self_launch(args, ["--gpus", "4", "--workload", "warp_c5"])
+    assert rc == 3 and len(seen) == 4
+    ports = {e["MASTER_PORT"] for _, e, _ in seen}
+    assert len(ports) == 1 and all(e["MASTER_ADDR"] == "127.0.0.1" and e["WORLD_SIZE"] == "4" for _, e, _ in seen)
+    assert [e["RANK"] for _, e, _ in seen] == ["0", "1", "2", "3"] == [e["LOCAL_RANK"] for _, e, _ in seen]
+    assert all(c[-4:] == ["--gpus", "4", "--workload", "warp_c5"] and c[1].endswith("bench.py") for c, _, _ in seen)
+    assert seen[0][2] is None and seen[1][2] is not None                 # rank 0 owns stdout
