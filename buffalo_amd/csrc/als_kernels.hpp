@@ -2460,7 +2460,11 @@ class AlsHandle : public HandleBase {
             //  at T = 2 round 3's kernel already runs two waves per SIMD, and the pairs only add their hand-off: "als_pc" = 2 forces them)
             bool use_pc = items > 0 && inreg && split_f16_ && T <= 4 && (pc_ >= 2 ? T >= 2 : (pc_ == 1 && T >= 3));   // 3: als_solo_kernel (one wave per row, two per SIMD)
             if (use_pc) {
+                float* const before = scratch_.get();
                 scan_deferred(*wl, p, items);
+                // the scan may GROW scratch_ (a new buffer, neither copied nor zeroed): the heavy rows' slots zeroed above are then gone
+                if (scratch_.get() != before && wl->n_heavy)
+                    BFH_HIP(hipMemsetAsync(scratch_.get(), 0, static_cast<size_t>(wl->n_heavy) * als_slot_floats(vdim_) * sizeof(float), stream));
                 if (wl->n_def_rows > 4096 || wl->n_def * 4 > items) {
                     // weights mostly outside the f16 path (negative confidences, ...): every row of the call takes the route the flagged
                     // ones would take -- fp32 instruction, scratch slot, dense-solve kernel (the branch below)

@@ -13,7 +13,8 @@ import bench  # noqa: E402
 import test_bpr_gate_gpu as G  # noqa: E402
 
 case = os.environ.get("CASE", "lr0.05")
-kw, default_epochs = {"lr0.05": (dict(lr=0.05, min_lr=0.05), 24), "bench": (dict(lr=0.002, min_lr=0.0001), 3)}[case]
+kw, default_epochs = {"lr0.05": (dict(lr=0.05, min_lr=0.05), 24), "bench": (dict(lr=0.002, min_lr=0.0001), 3),
+                      "refbench": (dict(lr=0.05, min_lr=0.0001), 10)}[case]
 ref = np.load(os.path.join(ROOT, "scripts", "data", "gate_%s_oracle.npz" % case.replace(".", "")))
 users = ref["users"]
 csr = G._csr()

@@ -16,7 +16,9 @@ import test_bpr_gate_gpu as G  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 
 case = sys.argv[1] if len(sys.argv) > 1 else "lr0.05"
-kw, epochs, workers = {"lr0.05": (dict(lr=0.05, min_lr=0.05), 24, (8, 16)), "bench": (dict(lr=0.002, min_lr=0.0001), 3, (8, 16))}[case]
+kw, epochs, workers = {"lr0.05": (dict(lr=0.05, min_lr=0.05), 24, (8, 16)), "bench": (dict(lr=0.002, min_lr=0.0001), 3, (8, 16)),
+                       # the reference's own BPRMF benchmark setting (benchmark/models.py:86-93): lr 0.05 decaying to min_lr 0.0001 over 10 iterations
+                       "refbench": (dict(lr=0.05, min_lr=0.0001), 10, (8, 16))}[case]
 csr = G._csr()
 users = np.random.default_rng(1).choice(csr.num_users, 2000, replace=False)
 eu, ep, en = G._eval_set(csr)

@@ -96,6 +96,9 @@ CASES = [
                           # a few entries 100x heavier than the rest (the test lowers the cut to 500) and a few negative ones: the split-f16 pass sends both kinds
                           # through the fp32 instruction (als_gram_kernel: fix_outliers)
                           (128, dict(optimizer="ialspp"), "outliers"),
+                          # both at once: rows cut into chunks summed in scratch slots AND rows deferred for their weights -- the scan
+                          # of the deferred rows grows the scratch buffer after the heavy rows' slots were zeroed
+                          (128, dict(optimizer="ialspp"), "heavy_outliers"),
                           # factor rows spanning 1e-4 .. 1 in scale and weights just below the cut: entries far below max|Q|
                           # put the low f16 piece of the split pass into subnormals -- absolute accuracy only -- while the heaviest
                           # weights the f16 path admits stretch its range from the other end
@@ -120,12 +123,22 @@ def test_half_epochs_match_oracle(oracle, d, kw, shape, design):
         pytest.skip("'wave' = round 3's wave-per-row split-f16 kernel instead of the producer / consumer pairs: in-place iALS++ cases")
     if design == "solo" and not (d == 128 and kw.get("block_size", 32) == 32 and kw.get("optimizer") == "ialspp"):
         pytest.skip("'solo' = als_solo_kernel (one wave per row, two per SIMD; als_pc = 3): in-place iALS++ cases at d = 128")
+    if shape == "heavy_outliers" and design != "inreg":
+        pytest.skip("the heavy + deferred rows case is about the default path's scratch slots")
     if shape == "outliers":
         base = tiny_csr(U=320, I=280, density=0.2, seed=31, counts=True)
         v = base.vals.copy()
         v[::499] *= 100.0
         v[5::53] = -0.05
         csr = synth.CSR(base.num_users, base.num_items, base.indptr, base.keys, v)
+    elif shape == "heavy_outliers":
+        rs = np.random.default_rng(5)                                       # 12 item rows of ~4170 nnz (heavy on axis 1) beside 288 light ones
+        M = np.concatenate([rs.random((4300, 12)) < 0.97, rs.random((4300, 288)) < 0.05], axis=1)
+        r, c = np.nonzero(M)
+        v = (1 + rs.poisson(1.0, size=c.shape[0])).astype(np.float32)
+        v[::4999] *= 100.0                                                  # ~22 entries past the (lowered) cut: deferred rows on both axes,
+        v[7::6007] = -0.05                                                  # few enough that the call stays on the pairs (n_def * 4 <= items)
+        csr = synth.CSR(4300, 300, np.cumsum(np.bincount(r, minlength=4300), dtype=np.int64), c.astype(np.int32), v)
     elif shape == "scales":
         csr = tiny_csr(U=320, I=280, density=0.2, seed=37, counts=True)
     elif shape == "tiny":
@@ -148,7 +161,7 @@ def test_half_epochs_match_oracle(oracle, d, kw, shape, design):
             pytest.skip("als_solo_kernel is not in this build (%s)" % str(e)[:80])
     else:
         obj.set_mode("als_pc", 0 if design == "wave" else 2)   # 2: the pairs at d = 64 too (the default leaves T = 2 to the wave-per-row kernel, which is faster there)
-    if shape == "outliers":
+    if shape in ("outliers", "heavy_outliers"):
         obj.set_mode("als_split_wcut", 500)   # alpha v = 4 * 2 * 100 and more: past the cut
     if shape == "scales":
         rs = np.random.default_rng(41)
