@@ -2260,7 +2260,7 @@ class AlsHandle : public HandleBase {
         hostP_ = P; hostQ_ = Q; P_rows_ = P_rows; Q_rows_ = Q_rows;
         const size_t np = static_cast<size_t>(P_rows) * vdim_, nq = static_cast<size_t>(Q_rows) * vdim_;
         unpin_host();
-        if (pin_host_) {   // the updated rows go back into these arrays after every partial_update (als.cu:403): page-lock them
+        if (pin_host_) {   // opt-in ("pin_host" = 1): page-lock the caller's arrays; the default goes through the library's own pinned ring
             for (auto pr : {std::make_pair(static_cast<void*>(P), np * sizeof(float)), std::make_pair(static_cast<void*>(Q), nq * sizeof(float))}) {
                 if (pr.second < (size_t(1) << 20)) continue;   // small arrays share heap pages with other objects: see SgdHandle::initialize_model
                 if (hipHostRegister(pr.first, pr.second, hipHostRegisterDefault) == hipSuccess) pinned_.push_back(pr.first);
@@ -2692,14 +2692,13 @@ class AlsHandle : public HandleBase {
         t_main_.end(slot, stream);
         double l[2] = {0, 0};
         if (compute_loss_) BFH_HIP(hipMemcpyAsync(l, loss_.get(), 2 * sizeof(double), hipMemcpyDeviceToHost, stream));
+        int pe[2] = {0, 0};
+        if (pc_launched) BFH_HIP(hipMemcpyAsync(pe, pc_err_.get(), 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
         if (writeback_) {  // als.cu:403: updated rows go back to the caller's array
             float* hostF = axis == 0 ? hostP_ : hostQ_;
             const size_t off = static_cast<size_t>(start_x) * vdim_, cnt = static_cast<size_t>(nrows) * vdim_;
-            BFH_HIP(hipMemcpyAsync(hostF + off, p.P + off, cnt * sizeof(float), hipMemcpyDeviceToHost, stream));
-            stats.d2h_bytes += static_cast<double>(cnt * sizeof(float));
+            copy_out(hostF + off, p.P + off, cnt * sizeof(float));
         }
-        int pe[2] = {0, 0};
-        if (pc_launched) BFH_HIP(hipMemcpyAsync(pe, pc_err_.get(), 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
         BFH_HIP(hipStreamSynchronize(stream));
         ++fver_[axis];   // the side just solved changed
         stats.kernel_ms += t_main_.drain();
@@ -2837,9 +2836,8 @@ class AlsHandle : public HandleBase {
         BFH_REQUIRE(model_, "synchronize before initialize_model");
         const size_t np = static_cast<size_t>(P_rows_) * vdim_, nq = static_cast<size_t>(Q_rows_) * vdim_;
         if (d2h) {
-            BFH_HIP(hipMemcpyAsync(hostP_, P_.get(), np * sizeof(float), hipMemcpyDeviceToHost, stream));
-            BFH_HIP(hipMemcpyAsync(hostQ_, Q_.get(), nq * sizeof(float), hipMemcpyDeviceToHost, stream));
-            stats.d2h_bytes += static_cast<double>((np + nq) * sizeof(float));
+            copy_out(hostP_, P_.get(), np * sizeof(float));
+            copy_out(hostQ_, Q_.get(), nq * sizeof(float));
         } else {
             BFH_HIP(hipMemcpyAsync(P_.get(), hostP_, np * sizeof(float), hipMemcpyHostToDevice, stream));
             BFH_HIP(hipMemcpyAsync(Q_.get(), hostQ_, nq * sizeof(float), hipMemcpyHostToDevice, stream));
@@ -2915,6 +2913,15 @@ class AlsHandle : public HandleBase {
         bool resident = false;
         std::map<std::pair<int, int>, std::pair<int64_t, uint64_t>> chunks;   // auto-residency: row range -> (length, checksum)
     };
+    // device -> the caller's array: through the library's own pinned ring (HostStager, common.hpp) unless the caller asked for its arrays
+    // to be registered ("pin_host" = 1); an array that is no longer mapped is an error, not a fault
+    void copy_out(void* dst, const void* src_dev, size_t bytes) {
+        if (!host_range_mapped(dst, bytes)) throw Error(BFH_ERR_INVALID, "the caller's factor array is no longer mapped (freed while the model still writes to it?)");
+        if (!pinned_.empty()) BFH_HIP(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, stream));
+        else stager_.d2h(dst, src_dev, bytes, stream, device);
+        stats.d2h_bytes += static_cast<double>(bytes);
+    }
+    HostStager stager_;
     void unpin_host() {
         if (!pinned_.empty() && stream) (void)hipStreamSynchronize(stream);   // (see SgdHandle::unpin_host)
         for (void* q : pinned_) (void)hipHostUnregister(q);
@@ -2922,7 +2929,7 @@ class AlsHandle : public HandleBase {
         pinned_.clear();
     }
     std::vector<void*> pinned_;
-    bool auto_resident_ = true, pin_host_ = true;
+    bool auto_resident_ = true, pin_host_ = false;   // pin_host: opt-in since round 5 (HostStager, common.hpp)
 
     Options opt_;
     bool inited_ = false, model_ = false, placeholder_ = false, writeback_ = true;

@@ -1,11 +1,80 @@
 // Options (JSON) reader + ABI odds and ends.
 #include "common.hpp"
 
+#include <sys/mman.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <cerrno>
 #include <thread>
 
 namespace bfh {
 
 thread_local std::string g_create_error;
+
+bool host_range_mapped(const void* p, size_t bytes) {
+    if (!p || !bytes) return p != nullptr;
+    const uintptr_t page = static_cast<uintptr_t>(sysconf(_SC_PAGESIZE));
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p), first = a & ~(page - 1), last = (a + bytes - 1) & ~(page - 1);
+    unsigned char vec = 0;
+    for (uintptr_t q : {first, last})
+        if (mincore(reinterpret_cast<void*>(q), page, &vec) != 0 && errno == ENOMEM) return false;
+    return true;
+}
+
+HostStager::~HostStager() {
+    for (auto& e : ev_)
+        if (e) (void)hipEventDestroy(e);
+    if (ring_) (void)hipHostFree(ring_);
+}
+
+void HostStager::d2h(void* dst, const void* src_dev, size_t bytes, hipStream_t s, int device) {
+    if (!bytes) return;
+    if (bytes < kChunk / 4) {   // small: the runtime's own staged copy of pageable memory
+        BFH_HIP(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, s));
+        BFH_HIP(hipStreamSynchronize(s));
+        return;
+    }
+    if (!ring_) {
+        BFH_HIP(hipHostMalloc(reinterpret_cast<void**>(&ring_), kSlots * kChunk, hipHostMallocDefault));
+        for (auto& e : ev_) BFH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    const int64_t n_chunks = static_cast<int64_t>((bytes + kChunk - 1) / kChunk);
+    const int workers = static_cast<int>(std::min<int64_t>({4, n_chunks, std::max(1u, std::thread::hardware_concurrency())}));
+    std::atomic<int64_t> issued{0};            // chunks whose DMA and event are in the stream
+    std::atomic<int64_t> drained[kSlots];      // per ring slot: 1 + the last chunk copied out of it
+    for (auto& d : drained) d.store(0);
+    std::atomic<int> failed{0};
+    char* const out = static_cast<char*>(dst);
+    auto work = [&](int t) {
+        (void)hipSetDevice(device);
+        for (int64_t k = t; k < n_chunks; k += workers) {
+            while (issued.load(std::memory_order_acquire) <= k && !failed.load()) std::this_thread::yield();
+            if (failed.load()) return;
+            const int slot = static_cast<int>(k % kSlots);
+            if (hipEventSynchronize(ev_[slot]) != hipSuccess) { failed.store(1); return; }
+            const size_t off = static_cast<size_t>(k) * kChunk, n = std::min(kChunk, bytes - off);
+            std::memcpy(out + off, ring_ + static_cast<size_t>(slot) * kChunk, n);
+            drained[slot].store(k + 1, std::memory_order_release);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < workers; ++t) th.emplace_back(work, t);
+    hipError_t err = hipSuccess;
+    for (int64_t k = 0; k < n_chunks && err == hipSuccess && !failed.load(); ++k) {
+        const int slot = static_cast<int>(k % kSlots);
+        while (k >= kSlots && drained[slot].load(std::memory_order_acquire) < k - kSlots + 1 && !failed.load()) std::this_thread::yield();
+        const size_t off = static_cast<size_t>(k) * kChunk, n = std::min(kChunk, bytes - off);
+        err = hipMemcpyAsync(ring_ + static_cast<size_t>(slot) * kChunk, static_cast<const char*>(src_dev) + off, n, hipMemcpyDeviceToHost, s);
+        if (err == hipSuccess) err = hipEventRecord(ev_[slot], s);
+        if (err != hipSuccess) failed.store(1);
+        else issued.store(k + 1, std::memory_order_release);
+    }
+    for (auto& x : th) x.join();
+    if (err != hipSuccess) BFH_HIP(err);
+    BFH_REQUIRE(!failed.load(), "device -> host staging copy failed");
+    BFH_HIP(hipStreamSynchronize(s));
+}
 
 uint64_t content_signature(const int32_t* keys, int64_t n) {
     const int64_t per_thread = int64_t(1) << 20;   // below ~4 MB a second thread costs more than it hashes

@@ -177,6 +177,33 @@ class EventTimer {
     size_t used_ = 0;
 };
 
+// Device -> caller memory WITHOUT page-locking the caller's arrays (round 5).  Until round 4 the factor arrays were hipHostRegister'ed for
+// the life of a model; a registration of memory the library does not own is only as sound as the allocator behind it -- glibc raises its mmap
+// threshold after the first large free, so later 1 .. 32 MB numpy arrays sit in the brk heap beside unrelated objects, a registered range then
+// covers pages other allocations come and go in, and the runtime's bookkeeping of such a range (re-validation after the process unmaps, trims or
+// migrates part of it) is outside the library's control.  Now the DMA lands in a ring of pinned buffers the LIBRARY owns (hipHostMalloc) and worker
+// threads copy every chunk on to its destination while the next chunks travel; "pin_host" = 1 brings the registration back for callers who
+// guarantee page-exclusive, long-lived arrays.
+class HostStager {
+ public:
+    HostStager() = default;
+    HostStager(const HostStager&) = delete;
+    HostStager& operator=(const HostStager&) = delete;
+    ~HostStager();
+    // returns when dst[0, bytes) holds the device bytes; the stream is idle afterwards
+    void d2h(void* dst, const void* src_dev, size_t bytes, hipStream_t s, int device);
+
+ private:
+    static constexpr int kSlots = 8;
+    static constexpr size_t kChunk = size_t(4) << 20;
+    char* ring_ = nullptr;
+    hipEvent_t ev_[kSlots] = {};
+};
+
+// true when the first and the last page of [p, p + bytes) are mapped in this process (mincore): a caller array that was unmapped behind the
+// library's back (freed while the handle still owes it a copy) is reported as an error instead of a fault
+bool host_range_mapped(const void* p, size_t bytes);
+
 static inline int vdim_of(int d) { return ((d + 31) / 32) * 32; }  // bpr.cu:266-267, als.cu:251-252
 
 // Auto-residency of chunks the caller hands over on every call (the reference's call pattern, cuda/_bpr.pyx:60-74, _als.pyx:52-67):

@@ -676,7 +676,7 @@ void SgdHandle::initialize_model(float* P, int P_rows, float* Q, float* Qb, int 
     if (!set_gpu) return;  // bpr.cu:293-298: only record host pointers
     const size_t np = static_cast<size_t>(P_rows) * vdim_, nq = static_cast<size_t>(Q_rows) * vdim_;
     unpin_host();
-    if (pin_host_) {   // best effort: a refusal (already registered, exotic memory) just leaves the copies pageable
+    if (pin_host_) {   // opt-in ("pin_host" = 1; the default copies back through the library's own pinned ring, HostStager).  Best effort: a refusal just leaves the copies pageable
         // only arrays of a MiB or more: those sit in pages of their own (malloc hands them out by mmap); a small array shares its
         // pages with whatever else lives on the heap -- including arrays another handle has registered -- and overlapping
         // registrations have aborted inside the runtime (seen once in tests/test_errors_gpu.py, on 1.5 KB factors)
@@ -865,8 +865,19 @@ void SgdHandle::synchronize(bool device_to_host, bool force) {
     const size_t np = static_cast<size_t>(P_rows_) * vdim_, nq = static_cast<size_t>(Q_rows_) * vdim_;
     const hipMemcpyKind kind = device_to_host ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice;
     if (device_to_host) {
-        BFH_HIP(hipMemcpyAsync(hostP_, P_.get(), np * sizeof(float), kind, stream));
-        BFH_HIP(hipMemcpyAsync(hostQ_, Q_.get(), nq * sizeof(float), kind, stream));
+        // through the library's own pinned ring (HostStager, common.hpp) unless the caller asked for its arrays to be registered
+        // ("pin_host" = 1); an array that is no longer mapped is an error, not a fault
+        for (auto& c : {std::make_pair(static_cast<void*>(hostP_), np * sizeof(float)), std::make_pair(static_cast<void*>(hostQ_), nq * sizeof(float)),
+                        std::make_pair(static_cast<void*>(hostQb_), static_cast<size_t>(Q_rows_) * sizeof(float))})
+            if (!host_range_mapped(c.first, c.second))
+                throw Error(BFH_ERR_INVALID, "the caller's factor array is no longer mapped (freed while the model still owes it a copy?)");
+        if (!pinned_.empty()) {
+            BFH_HIP(hipMemcpyAsync(hostP_, P_.get(), np * sizeof(float), kind, stream));
+            BFH_HIP(hipMemcpyAsync(hostQ_, Q_.get(), nq * sizeof(float), kind, stream));
+        } else {
+            stager_.d2h(hostP_, P_.get(), np * sizeof(float), stream, device);
+            stager_.d2h(hostQ_, Q_.get(), nq * sizeof(float), stream, device);
+        }
         BFH_HIP(hipMemcpyAsync(hostQb_, Qb_.get(), Q_rows_ * sizeof(float), kind, stream));
         stats.d2h_bytes += static_cast<double>((np + nq + Q_rows_) * sizeof(float));
     } else {

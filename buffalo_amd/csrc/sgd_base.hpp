@@ -173,7 +173,8 @@ class SgdHandle : public HandleBase {
     // buffer -- is served from its copy in HBM (and keeps its item-major regrouping); lazy_sync: synchronize(device_to_host)
     // only marks the host arrays stale, the copy happens on synchronize(2) / destroy (default off = the reference behaviour);
     // pin_host: the caller's factor arrays are page-locked for the duration of the model (D2H at PCIe rate)
-    int auto_resident_ = 1, lazy_sync_ = 0, pin_host_ = 1;
+    int auto_resident_ = 1, lazy_sync_ = 0, pin_host_ = 0;   // pin_host: opt-in since round 5 (the default copies back through HostStager)
+    HostStager stager_;
     bool host_stale_ = false;
     struct ChunkSig { int64_t n; uint64_t sig; };
     std::map<std::pair<int, int>, ChunkSig> chunks_;

@@ -117,24 +117,33 @@ if "bpr_adagrad" in which:
     print("bpr_adagrad", out["bpr_adagrad"], flush=True)
 
 if "bpr_pcie" in which:
-    # drop-in call pattern of the reference: host keys handed over every epoch + P,Q,Qb copied back
-    P, Q, Qb = synth.init_factors(U, I, 128, seed=7)
-    g = CyBPR()
-    assert g.init(write_opt(bpr_options(10)))
-    g.initialize_model(P, Q, Qb, nnz)
-    g.set_cumulative_table(np.zeros(I, np.int64), I)
-    g.set_placeholder(csr.indptr, nnz + 1)
-    g.initialize_model(P, Q, Qb, nnz, True)
-    g.add_jobs(0, U, csr.indptr, csr.keys)
-    g.update_parameters()
-    t0 = time.perf_counter()
-    for _ in range(3):
+    # drop-in call pattern of the reference: host keys handed over every epoch + P,Q,Qb copied back.  pin_host = 0 (default since round 5): the
+    # copy-back goes through the library's own pinned ring (HostStager); pin_host = 1: the caller's arrays are registered (the default until round 4)
+    for pin in (0, 1):
+        P, Q, Qb = synth.init_factors(U, I, 128, seed=7)
+        g = CyBPR()
+        assert g.init(write_opt(bpr_options(10)))
+        g.set_mode("pin_host", pin)
+        g.initialize_model(P, Q, Qb, nnz)
+        g.set_cumulative_table(np.zeros(I, np.int64), I)
+        g.set_placeholder(csr.indptr, nnz + 1)
+        g.initialize_model(P, Q, Qb, nnz, True)
         g.add_jobs(0, U, csr.indptr, csr.keys)
-        g.update_parameters()          # device optimizer step + D2H of P,Q,Qb (sync_every_epoch=True)
-    dt = (time.perf_counter() - t0) / 3
-    out["bpr_host_buffers_every_epoch"] = {"epoch_ms": dt * 1e3, "updates_per_s": nnz / dt,
-                                           "note": "80 MB keys H2D (pageable numpy) + fill_rows + kernel + 85 MB D2H per epoch"}
-    print("bpr_pcie", out["bpr_host_buffers_every_epoch"], flush=True)
+        g.update_parameters()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            g.add_jobs(0, U, csr.indptr, csr.keys)
+            g.update_parameters()          # device optimizer step + D2H of P,Q,Qb (sync_every_epoch=True)
+        dt = (time.perf_counter() - t0) / 3
+        t0 = time.perf_counter()
+        for _ in range(3):
+            g.synchronize(True)
+        ds = (time.perf_counter() - t0) / 3
+        out["bpr_host_buffers_every_epoch_pin_host_%d" % pin] = {"epoch_ms": dt * 1e3, "updates_per_s": nnz / dt, "copy_back_ms": ds * 1e3,
+                                                                  "copy_back_GBps": (U + I) * 128 * 4 / ds / 1e9,
+                                                                  "note": "80 MB keys H2D (pageable numpy) + fill_rows + kernel + 85 MB D2H per epoch"}
+        print("bpr_pcie pin_host=%d" % pin, out["bpr_host_buffers_every_epoch_pin_host_%d" % pin], flush=True)
+        del g
 
 if "als_pcie" in which:
     # the reference's call pattern for ALS: keys / vals handed over on every partial_update, updated rows written back every call

@@ -140,3 +140,54 @@ def test_topk_argument_checks():
     assert (ok >= -1).all()
     empty = np.empty((0, 3), np.int32), np.empty((0, 3), np.float32)
     eng.dot_topn(np.array([], np.int32), P, Q, tc.NO_BIAS, empty[0], empty[1], tc.EMPTY_POOL, 3)        # zero queries: no-op
+
+
+@pytest.mark.parametrize("pin", [0, 1])
+def test_freed_caller_arrays_are_an_exception_not_a_fault(pin):
+    """The backend stores raw host pointers and writes the model back into them (bpr.cu:334-336).  With `lazy_sync` = 1 the copy is
+    owed until flush / destroy; if the caller's arrays are gone by then (here: unmapped -- large numpy arrays are private mmaps) the
+    library has to say so (BFH_ERR_INVALID from the mincore probe in front of every device -> caller copy), not fault.  `pin` = 1:
+    the same with the arrays registered (`pin_host`, opt-in since round 5; the default copies back through the library's own pinned ring)."""
+    import gc
+    import mmap
+    from buffalo_amd._lib import BuffaloHipError
+    d, U, I = 128, 6000, 5000
+    csr = tiny_csr(U=U, I=I, density=0.002, seed=3)
+    obj = _bpr(bpr_opt(d=d, lr=0.01, min_lr=0.01, num_iters=2))
+    obj.set_mode("lazy_sync", 1)
+    obj.set_mode("pin_host", pin)
+    obj.sync_every_epoch = True
+    # page-aligned private mappings the test can unmap for sure (numpy would hand a freed array back to malloc, which may keep the pages)
+    maps = [mmap.mmap(-1, n * 4) for n in (U * d, I * d, I)]
+    P, Q, Qb = (np.frombuffer(m, dtype=np.float32).reshape(shape) for m, shape in zip(maps, ((U, d), (I, d), (I, 1))))
+    rng = np.random.default_rng(1)
+    P[:], Q[:], Qb[:] = rng.normal(scale=0.1, size=P.shape), rng.normal(scale=0.1, size=Q.shape), 0
+    obj.initialize_model(P, Q, Qb, csr.nnz, True)
+    obj.set_cumulative_table(np.zeros(I, np.int64), I)
+    obj.set_placeholder(csr.indptr, csr.nnz + 1)
+    obj.add_jobs(0, U, csr.indptr, csr.keys)
+    obj.update_parameters()                     # lazy: the arrays are now stale, the copy is owed
+    P0 = P.copy()
+    obj.flush_host()                            # while the arrays live: the copy arrives
+    assert not np.array_equal(P, P0) and np.isfinite(P).all()
+    obj.add_jobs(0, U, csr.indptr, csr.keys)
+    obj.update_parameters()
+    obj._keep.clear()                           # what a C caller can do: free the arrays while the handle still owes them a copy
+    del P, Q, Qb, P0
+    gc.collect()
+    for m in maps:
+        m.close()                               # munmap
+    with pytest.raises(BuffaloHipError, match="no longer mapped"):
+        obj.flush_host()
+    # the handle is still usable with new arrays (initialize_model drops the debt to the old ones: it cannot be paid)
+    P2, Q2, Qb2 = rng.normal(scale=0.1, size=(U, d)).astype(np.float32), rng.normal(scale=0.1, size=(I, d)).astype(np.float32), np.zeros((I, 1), np.float32)
+    try:
+        obj.initialize_model(P2, Q2, Qb2, csr.nnz, True)
+    except BuffaloHipError as e:                # the owed copy is attempted first and refused: the second call starts clean
+        assert "no longer mapped" in str(e)
+        obj.initialize_model(P2, Q2, Qb2, csr.nnz, True)
+    obj.add_jobs(0, U, csr.indptr, csr.keys)
+    obj.update_parameters()
+    obj.flush_host()
+    assert np.isfinite(P2).all()
+    del obj
