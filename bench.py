@@ -1342,6 +1342,8 @@ def parse_args(argv=None):
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
+    if os.environ.get("BFH_COMM_TRANSPORT") == "shm":      # one-GPU rehearsal of --gpus N: the shared-memory TEST transport lives in
+        os.environ.setdefault("BFH_LIBRARY", "test")       # libbuffalo_hip_test.so only (buffalo_amd/_lib.py); the ranks inherit the choice
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args, argv))
     if args.steps is None:

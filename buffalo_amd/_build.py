@@ -7,6 +7,9 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbuffalo_hip.so")
+# the same library with the shared-memory TEST transport of csrc/comm_test_transport.hpp compiled in (-DBFH_TEST_TRANSPORT: comm.hip alone differs).
+# Only the N-ranks-on-one-GPU tests load it (BFH_LIBRARY=test, buffalo_amd/_lib.py); the product library refuses BFH_COMM_TRANSPORT=shm.
+LIB_TEST = os.path.join(HERE, "libbuffalo_hip_test.so")
 SOURCES = ["common.hip", "comm.hip", "sgd_base.hip", "bpr.hip", "warp.hip", "als.hip", "topk.hip", "ingest.hip", "sppmi.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall",
@@ -64,6 +67,10 @@ def build(force=False, verbose=False):
         objs.append(obj)
         if force or _stale(obj, [src] + deps):
             jobs.append([HIPCC] + FLAGS + ["-c", src, "-o", obj])
+    comm_test = os.path.join(CSRC, "comm_test.o")
+    if force or _stale(comm_test, [os.path.join(CSRC, "comm.hip")] + deps):
+        jobs.append([HIPCC] + FLAGS + ["-DBFH_TEST_TRANSPORT", "-c", os.path.join(CSRC, "comm.hip"), "-o", comm_test])
+    objs_test = [comm_test if o.endswith(os.sep + "comm.o") else o for o in objs]
 
     def run(cmd):
         if verbose:
@@ -83,6 +90,8 @@ def build(force=False, verbose=False):
             f.write(" ".join(FLAGS))
     if jobs or _stale(LIB, objs):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"])   # librccl is dlopen'ed (comm.hip)
+    if jobs or _stale(LIB_TEST, objs_test):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_TEST] + objs_test + ["-ldl", "-lrt"])
     return LIB
 
 

@@ -8,7 +8,9 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbuffalo_hip.so")
+# BFH_LIBRARY=test selects libbuffalo_hip_test.so: the same objects + the shared-memory TEST transport (csrc/comm_test_transport.hpp) that lets
+# N processes share one GPU -- tests and one-GPU rehearsals of bench.py --gpus N only; the product library does not contain it
+LIB_PATH = os.path.join(_HERE, "libbuffalo_hip_test.so" if os.environ.get("BFH_LIBRARY") == "test" else "libbuffalo_hip.so")
 HEADER_PATH = os.path.join(_HERE, "..", "include", "buffalo_hip.h")
 
 

@@ -46,7 +46,11 @@ struct AlsPc {
 };
 // flag words of a pair (ints at the end of its LDS block)
 enum { PC_PROD = 0, PC_CONS = 1, PC_ROWS_PUB = 2, PC_ROWS_DONE = 3, PC_ROWS_FREE = 4, PC_ABORT = 5 };
-constexpr int PC_SPIN_LIMIT = 1 << 21;   // polls before a wait gives up (each >= ~100 cycles: tenths of a second)
+// A wait gives up after PC_WAIT_TICKS of the constant 100 MHz clock (s_memrealtime) -- 20 s of WALL CLOCK, not a poll count (until round 5:
+// 2^21 polls, tenths of a second -- a wave slowed or preempted by a profiler / debugger / a second process on the device turned a
+// legitimate wait into BFH_ERR_HIP with rows already overwritten in place).  After that error the factors of the call's rows are
+// undefined: re-upload them (bfh_als_initialize_model) before the next call.
+constexpr unsigned long long PC_WAIT_TICKS = 2000000000ull;
 
 // Qi[row][T col + b] = Q[row][32 b + col]  and  part[block] = max |Q| over the block's share (the split pass's scale,
 // als_split_scale_kernel): one pass over the other factor per half-epoch
@@ -120,12 +124,15 @@ __device__ __forceinline__ void pc_publish(int* flag, int v) {
 // counters only grow, so a wait the cached value already satisfies costs no LDS round trip
 __device__ __forceinline__ bool pc_wait_gt(int* flag, int v, int& seen, int* flg) {
     if (seen - v > 0) return true;
+    unsigned long long t0 = 0;
     for (int it = 0;; ++it) {
         seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         if (seen - v > 0) break;
-        if ((it & 63) == 63) {
+        if ((it & 1023) == 1023) {
             const int ab = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flg + PC_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-            if (ab != 0 || it > PC_SPIN_LIMIT) {   // (no global memory operation in here: the caller reports the time-out after its loop)
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            if (t0 == 0) t0 = now;
+            if (ab != 0 || now - t0 > PC_WAIT_TICKS) {   // (no global memory operation in here: the caller reports the time-out after its loop)
                 if (ab == 0) __hip_atomic_store(flg + PC_ABORT, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 return false;
             }

@@ -973,8 +973,11 @@ class BprHandle : public SgdHandle {
         BFH_HIP(hipGetLastError());
         // ---- weights of the merges' sums (0 = plain sum) ----
         // (not for the single-wave test hook: one wave takes every step there, in ONE replica, and the sum is already the sequential result)
-        const bool w_items = (xcd_stiff_q_milli_ > 0 || xcd_stiff_b_milli_ > 0) && !im_single_wave_;
-        const bool w_users = xcd_stiff_p_milli_ > 0 && spread_mode != 0 && !im_single_wave_;
+        // ... nor with "xcd_merge_mean": the mean already scales the sum by 1 / n, and a saturation weight (between 1 / n and 1) on top of it
+        // would damp the rows twice.  The weight of n replicas assumes the merge sums exactly those: nq <= kXcdReplicas
+        BFH_REQUIRE(nq <= kXcdReplicas, "hogwild_atomic=3: more queues than per-XCD replicas");
+        const bool w_items = (xcd_stiff_q_milli_ > 0 || xcd_stiff_b_milli_ > 0) && !im_single_wave_ && !xcd_merge_mean_;
+        const bool w_users = xcd_stiff_p_milli_ > 0 && spread_mode != 0 && !im_single_wave_ && !xcd_merge_mean_;
         if (w_items) {
             xcd_wq_.resize(static_cast<size_t>(Q_rows_));
             xcd_wb_.resize(static_cast<size_t>(Q_rows_));

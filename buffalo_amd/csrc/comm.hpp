@@ -3,7 +3,8 @@
 // (dlopen by SONAME, so a process that already loaded RCCL -- e.g. through torch -- shares that copy); a single-GPU
 // user never loads it.
 //
-// TEST TRANSPORT (environment BFH_COMM_TRANSPORT=shm, read when the id is made and when the communicator is built): RCCL
+// TEST TRANSPORT (csrc/comm_test_transport.hpp, compiled ONLY into libbuffalo_hip_test.so with -DBFH_TEST_TRANSPORT since round 5; there the
+// environment knob BFH_COMM_TRANSPORT=shm is read when the id is made and when the communicator is built; the product library refuses it): RCCL
 // refuses two ranks on one device, so on a one-GPU box the exchange code of the handles could only ever see a world of one.
 // With the knob the same Comm interface runs over a POSIX shared-memory segment: every collective waits for its stream,
 // stages the operands through host slots (one per rank), sums them IN RANK ORDER -- the same arithmetic on every rank --
@@ -38,6 +39,8 @@ class Comm : public HandleBase {
     struct Shm;
     Shm* shm_ = nullptr;
     template <typename T> void shm_all_reduce(const T* send, T* recv, size_t count, hipStream_t s);
+    bool shm_attach(int n_ranks, const char* id128);          // true: `id128` names a test-transport segment and this rank is attached to it
+    void shm_broadcast(void* buf, size_t bytes, int root, hipStream_t s);
 };
 
 }  // namespace bfh

@@ -67,3 +67,25 @@ def test_binding_argument_checks(built):
         _arr(np.zeros(3, np.float32), np.float32, 2, "P")
     with pytest.raises(ValueError):
         _arr(np.zeros((4, 4), np.float32)[:, ::2], np.float32, 2, "P")
+
+
+def test_the_product_library_does_not_contain_the_test_transport():
+    """The shared-memory transport that lets N test processes share one GPU (csrc/comm_test_transport.hpp) is compiled with
+    -DBFH_TEST_TRANSPORT into libbuffalo_hip_test.so only: the product library neither imports shm_open nor carries the transport's strings,
+    and exports exactly the same C ABI."""
+    import subprocess
+    from buffalo_amd import _build
+    _build.build()
+
+    def nm(path, *flags):
+        return subprocess.run(["nm", "-D"] + list(flags) + [path], capture_output=True, text=True, check=True).stdout
+    prod, test = _build.LIB, _build.LIB_TEST
+    assert os.path.exists(prod) and os.path.exists(test)
+    assert "shm_open" not in nm(prod, "--undefined-only") and "shm_open" in nm(test, "--undefined-only")
+    with open(prod, "rb") as f:
+        blob = f.read()
+    assert b"shm transport:" not in blob and b"TEST transport is not part of libbuffalo_hip.so" in blob
+
+    def exported(path):
+        return {ln.split()[-1] for ln in nm(path, "--defined-only").splitlines() if ln.split() and ln.split()[-1].startswith("bfh_")}
+    assert exported(prod) == exported(test) and len(exported(prod)) > 50

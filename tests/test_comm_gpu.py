@@ -153,3 +153,18 @@ def test_als_publish_rows_one_rank_world(comm, oracle):
         outs.append((P, Q))
     np.testing.assert_array_equal(outs[0][0], outs[1][0])
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
+
+
+def test_the_product_library_refuses_the_test_transport(monkeypatch):
+    """BFH_COMM_TRANSPORT=shm is the knob of libbuffalo_hip_test.so (tests/test_comm_ranks_gpu.py); the product library this process loaded
+    says so instead of silently building an RCCL communicator -- and an id made by the test library is refused too."""
+    import os
+    from buffalo_amd._lib import BuffaloHipError
+    from buffalo_amd.backend import Comm
+    monkeypatch.setenv("BFH_COMM_TRANSPORT", "shm")
+    with pytest.raises(BuffaloHipError, match="TEST transport"):
+        Comm.unique_id()
+    monkeypatch.delenv("BFH_COMM_TRANSPORT")
+    uid = (b"BFHSHM1\x00" + os.urandom(16)).ljust(128, b"\x00")
+    with pytest.raises(BuffaloHipError, match="TEST transport"):
+        Comm(1, 0, uid, 0)

@@ -30,15 +30,12 @@ def run_world(tmp_path, world, spec, timeout=240, order=None):
     """`order="ring"`: the test transport sums every segment of a buffer in the rotated order a ring all-reduce produces
     (csrc/comm.hip shm_all_reduce) instead of in rank order."""
     os.makedirs(str(tmp_path), exist_ok=True)
-    env = dict(os.environ, BFH_COMM_TRANSPORT="shm")
+    # the ranks load libbuffalo_hip_test.so (BFH_LIBRARY=test): the product library this process has loaded does not contain the test
+    # transport (csrc/comm_test_transport.hpp, -DBFH_TEST_TRANSPORT) and refuses the knob
+    env = dict(os.environ, BFH_COMM_TRANSPORT="shm", BFH_LIBRARY="test")
     if order:
         env["BFH_COMM_SHM_ORDER"] = order
-    os.environ["BFH_COMM_TRANSPORT"] = "shm"
-    try:
-        from buffalo_amd.backend import Comm
-        uid = Comm.unique_id().hex()
-    finally:
-        del os.environ["BFH_COMM_TRANSPORT"]
+    uid = (b"BFHSHM1\x00" + os.urandom(16)).ljust(128, b"\x00").hex()   # what bfh_comm_unique_id makes there: magic + 16 random bytes
     procs, outs = [], []
     for r in range(world):
         out = str(tmp_path / ("rank%d.npz" % r))

@@ -53,6 +53,58 @@ def test_train_and_validate(algo):
     assert len(top) == 3 and all(len(v) == 5 for v in top.values())
 
 
+@pytest.mark.parametrize("algo", ["ALS", "BPRMF"])
+def test_train_and_validate_through_the_compiled_binding(algo, monkeypatch):
+    """The same front run with `self.obj` = the COMPILED Cython class of integration/buffalo/algo/hip instead of the
+    ctypes mirror: what stock buffalo does after the two-line change of INTEGRATION.md section 3.  The two bindings drive one library: same
+    seeds, same arrays in -> the same model out, bit for bit."""
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(os.path.dirname(here), "integration"))
+    import build_binding
+    if not os.path.exists(os.path.join(os.path.dirname(here), "integration", "buffalo", "algo", "hip", "_bpr.pyx")):
+        pytest.skip("integration/ is not in this snapshot")
+    try:
+        build_binding.build()
+    except ImportError as e:        # no Cython on this box and no prebuilt extension
+        pytest.skip("the compiled binding is not built here (%s)" % e)
+    CyBPR, CyALS, _ = build_binding.import_binding()
+    import buffalo_front.algo as A
+    import buffalo_front.algo.als as als_mod
+    import buffalo_front.algo.bpr as bpr_mod
+
+    def run(compiled):
+        np.random.seed(7)
+        if algo == "ALS":
+            opt = A.ALSOption().get_default_option()
+            opt.update(d=20, num_iters=4, validation={"topk": 10}, random_seed=7)
+            if compiled:
+                monkeypatch.setattr(als_mod, "CyALS", CyALS)
+            m = A.ALS(opt, data_opt=_data())
+        else:
+            opt = A.BPRMFOption().get_default_option()
+            opt.update(d=20, num_iters=20, lr=0.05, min_lr=0.01, reg_u=0.01, reg_i=0.01, reg_j=0.01, reg_b=0.01, validation={"topk": 10},
+                       evaluation_period=10, random_seed=7)
+            if compiled:
+                monkeypatch.setattr(bpr_mod, "CyBPR", CyBPR)
+            m = A.BPRMF(opt, data_opt=_data())
+        if algo == "BPRMF":
+            m.obj.set_mode("sequential", 1)         # the deterministic walk: two runs are comparable number for number
+        m.initialize()
+        m.train()
+        assert type(m.obj).__module__ == ("buffalo.algo.hip._%s" % ("als" if algo == "ALS" else "bpr") if compiled else "buffalo_amd.backend")
+        res = m.get_validation_results()
+        monkeypatch.undo()
+        return m.P.copy(), m.Q.copy(), res
+    Pc, Qc, res_c = run(True)
+    Pm, Qm, res_m = run(False)
+    assert np.isfinite(Pc).all() and res_c["ndcg"] > 0.03, res_c
+    np.testing.assert_array_equal(Pc, Pm)
+    np.testing.assert_array_equal(Qc, Qm)
+    assert res_c == res_m
+
+
 def test_accelerator_false_is_refused():
     import buffalo_front.algo as A
     opt = A.BPRMFOption().get_default_option()
