@@ -673,6 +673,51 @@ def extra_ingest(csr, seed, cpu=True):
     return out
 
 
+def extra_text_ingest(csr, seed, cpu=True, lines=2_000_000):
+    """SURVEY.md section 8 f.2, the step BEFORE the arrays exist: the working text file of buffalo's data creation ("row col val" lines, 1-based,
+    data/mm.py:175-234) -> rowwise group, parse included (bfh_text_to_csr = fileio.hpp:263-420 on the device), beside the reference's own
+    compiled builder on the SAME file.  A 2 M-line sample of the matrix's records in shuffled order (writing 20 M lines of text from Python
+    would take longer than the rest of this run)."""
+    import tempfile
+    from buffalo_amd import ingest
+    rng = np.random.default_rng(seed)
+    n = min(lines, csr.nnz)
+    pick = rng.choice(csr.nnz, n, replace=False)
+    rows, cols = csr.rows()[pick].astype(np.int64) + 1, csr.keys[pick].astype(np.int64) + 1
+    stars = (1 + (pick % 10)) * 0.5                                   # half-star ratings 0.5 .. 5.0
+    text = ("\n".join("%d %d %s" % t for t in zip(rows.tolist(), cols.tolist(), stars.tolist())) + "\n").encode()
+    ingest.text_to_csr(text, n, csr.num_users, csr.num_items, 1)
+    t0 = time.perf_counter()
+    g, st = ingest.text_to_csr(text, n, csr.num_users, csr.num_items, 1, with_stats=True)
+    dt = time.perf_counter() - t0
+    want = ingest.coo_to_csr((rows - 1).astype(np.int32), (cols - 1).astype(np.int32), stars.astype(np.float32), csr.num_users, csr.num_items)
+    out = {"config": "%d text lines (%d bytes) 'row col val' -> rowwise group of %d x %d: host bytes in -> host (indptr, key, val) out" % (n, len(text), csr.num_users, csr.num_items),
+           "lines": n, "bytes": len(text), "device_ms_incl_upload": st["kernel_ms"], "wall_ms": dt * 1e3, "lines_per_s_wall": n / dt,
+           "lines_reparsed_on_host": st["merges"],
+           "identical_to_the_array_path": bool(np.array_equal(g["indptr"], want["indptr"]) and np.array_equal(g["key"], want["key"]) and np.array_equal(g["val"], want["val"]))}
+    if cpu:
+        try:
+            from oracle import ref_fileio as rf
+            if os.path.exists(rf._LIB_PATH):
+                workers = os.cpu_count() or 1
+                with tempfile.TemporaryDirectory() as d:
+                    src = os.path.join(d, "working.txt")
+                    with open(src, "wb") as f:
+                        f.write(text)
+                    t0 = time.perf_counter()
+                    nf = rf.lib().ref_sort_and_compressed_binarization(src.encode(), d.encode(), n, csr.num_users, 1, workers)
+                    dr = time.perf_counter() - t0
+                    assert nf == workers + 1
+                    ok = bool(np.array_equal(np.fromfile(os.path.join(d, "indptr.bin"), dtype=np.int64), g["indptr"]))
+                out["cpu_baseline"] = {"value": n / dr, "unit": "lines/s", "cores": workers, "kind": "reference",
+                                       "what": "the reference's own buffalo/data/fileio.hpp compiled from its source (oracle/_ref): "
+                                               "_sort_and_compressed_binarization on the same file (parse, stable sort, indptr, binary chunks)",
+                                       "sample": "%d lines, %d workers, %.2f s" % (n, workers, dr), "same_indptr_as_device": ok}
+        except Exception as e:
+            out["cpu_baseline_reference_error"] = "%s: %s" % (type(e).__name__, e)
+    return out
+
+
 def measured_stream_bandwidth(n_bytes=1 << 30, reps=20):
     """What this box's HBM delivers to a trivial kernel ("always also report the fraction of measured
     triad bandwidth"): STREAM triad a = b + s * c (two reads + one write per element) and a plain copy over 1 GiB fp32 arrays,
@@ -1102,7 +1147,7 @@ def run_extras(args, csr, out):
     for name, fn in (("bpr_lr005", lambda c, seed, cpu: extra_bpr_lr005(c, seed)),
                      ("als_ml20m_d128", extra_als), ("warp_ml20m_d256", extra_warp),
                      ("warp_c5_one_gpu", lambda _csr, seed, cpu: extra_warp_c5(seed, cpu=cpu)), ("topk_ml20m_d128_k100", extra_topk),
-                     ("sppmi_ml20m_stream_w5", extra_sppmi), ("coo_to_csr_ml20m", extra_ingest),
+                     ("sppmi_ml20m_stream_w5", extra_sppmi), ("coo_to_csr_ml20m", extra_ingest), ("text_to_csr_2m_lines", extra_text_ingest),
                      # the top of the reference's own D-sweep (benchmark/README.md:97): d = 160, block 32 -> the wide ALS kernel (T = 5)
                      ("als_ml20m_d160", lambda c, seed, cpu: extra_als_wide(c, seed, 160))):
         if args.only_extra and name not in args.only_extra:

@@ -117,6 +117,8 @@ SIGNATURES = {
     "bfh_cfr_get_stats": (_i32, [_vp, C.POINTER(Stats)]),
     "bfh_cfr_reset_stats": (_i32, [_vp]),
     "bfh_coo_to_csr": (_i32, [_pi32, _pi32, _pf, _i64, _i32, _i32, C.POINTER(_i64), _pi32, _pf, C.POINTER(Stats)]),
+    "bfh_parse_triples": (_i32, [C.c_char_p, _i64, _i64, _pi32, _pi32, _pf, C.POINTER(Stats)]),
+    "bfh_text_to_csr": (_i32, [C.c_char_p, _i64, _i64, _i32, _i32, _i32, C.POINTER(_i64), _pi32, _pf, C.POINTER(Stats)]),
     "bfh_sppmi_create": (_vp, []),
     "bfh_sppmi_destroy": (None, [_vp]),
     "bfh_sppmi_build": (_i32, [_vp, _pi64, _pi32, _i32, _i32, _i32, _i32, _pi64, _pi64]),

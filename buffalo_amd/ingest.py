@@ -34,6 +34,47 @@ def coo_to_csr(major, minor, vals, num_major, num_minor, with_stats=False):
     return (g, st.as_dict()) if with_stats else g
 
 
+def _text_bytes(text):
+    if isinstance(text, (bytes, bytearray, memoryview)):
+        return bytes(text) if not isinstance(text, bytes) else text
+    if isinstance(text, np.ndarray) and text.dtype == np.uint8:
+        return text.tobytes()
+    raise TypeError("text must be bytes (the working file's content) or a uint8 array")
+
+
+def parse_triples(text, total_lines, with_stats=False):
+    """The first `total_lines` lines of buffalo's working text file ("row col val", 1-based ids: data/mm.py:175-234) as the reference's
+    sscanf(line, "%d %d %f") reads them (fileio.hpp:300-303), parsed on the device (`bfh_parse_triples`).  Returns (rows, cols, vals) with the
+    ids still 1-based; stats["merges"] = lines the device handed back to sscanf."""
+    buf = _text_bytes(text)
+    n = int(total_lines)
+    rows, cols, vals = np.empty(n, np.int32), np.empty(n, np.int32), np.empty(n, np.float32)
+    st = Stats()
+    L = lib()
+    rc = L.bfh_parse_triples(buf, len(buf), n, rows.ctypes.data_as(C.POINTER(C.c_int32)), cols.ctypes.data_as(C.POINTER(C.c_int32)),
+                             vals.ctypes.data_as(C.POINTER(C.c_float)), C.byref(st))
+    if rc < 0:
+        raise BuffaloHipError((L.bfh_last_error(None) or b"bfh_parse_triples failed").decode())
+    return ((rows, cols, vals), st.as_dict()) if with_stats else (rows, cols, vals)
+
+
+def text_to_csr(text, total_lines, num_major, num_minor, sort_key, with_stats=False):
+    """Working text file -> the `rowwise` (sort_key 1) / `colwise` (sort_key 2) group, everything between the bytes and the group on the device
+    (`bfh_text_to_csr` = fileio.hpp:263-420: parse, stable sort by (major, minor), END offsets, 0-based minors)."""
+    buf = _text_bytes(text)
+    n = int(total_lines)
+    indptr = np.empty(int(num_major), dtype=np.int64)
+    key, val = np.empty(n, dtype=np.int32), np.empty(n, dtype=np.float32)
+    st = Stats()
+    L = lib()
+    rc = L.bfh_text_to_csr(buf, len(buf), n, int(num_major), int(num_minor), int(sort_key), indptr.ctypes.data_as(C.POINTER(C.c_int64)),
+                           key.ctypes.data_as(C.POINTER(C.c_int32)), val.ctypes.data_as(C.POINTER(C.c_float)), C.byref(st))
+    if rc < 0:
+        raise BuffaloHipError((L.bfh_last_error(None) or b"bfh_text_to_csr failed").decode())
+    g = {"indptr": indptr, "key": key, "val": val}
+    return (g, st.as_dict()) if with_stats else g
+
+
 def build_sppmi(indptr, items, num_items, windows, k, with_stats=False):
     """SPPMI group of a stream: `indptr` = END offsets [num_users] over the 0-based `items` of the users' sequences,
     `windows` / `k` = the reference's data.sppmi options (stream.py:34-36).  Returns {"indptr": int64 END offsets

@@ -329,6 +329,17 @@ int bfh_topk_reset_stats(void* h);
 int bfh_coo_to_csr(const int32_t* major, const int32_t* minor, const float* vals, int64_t nnz, int num_major,
                    int num_minor, int64_t* indptr, int32_t* out_minor, float* out_vals, bfh_stats* stats);
 
+/* The working TEXT file of buffalo's data creation parsed on the device (buffalo/data/fileio.hpp:263-330; the file is what
+ * buffalo/data/mm.py:175-234 writes: the MatrixMarket body, one "row col val" line per entry, 1-based ids).
+ * bfh_parse_triples: the first `total_lines` lines as the reference's sscanf(line, "%d %d %f") reads them (ids stay 1-based) --
+ * bit-identical: what the device cannot guarantee to round like strtof is re-parsed on the host with that very call
+ * (stats->merges = number of such lines, 0 on ordinary rating files).
+ * bfh_text_to_csr: the same followed by _sort_and_compressed_binarization (:328-420) on the device; sort_key 1 = rowwise
+ * (major = row), 2 = colwise (major = col); outputs as bfh_coo_to_csr (0-based minors, END offsets). */
+int bfh_parse_triples(const char* text, int64_t bytes, int64_t total_lines, int32_t* rows, int32_t* cols, float* vals, bfh_stats* stats);
+int bfh_text_to_csr(const char* text, int64_t bytes, int64_t total_lines, int num_major, int num_minor, int sort_key,
+                    int64_t* indptr, int32_t* out_minor, float* out_vals, bfh_stats* stats);
+
 /* ------------------------------------------------------------------------------------------------
  * CFR / CoFactor   (CCFR: include/buffalo/algo_impl/cfr/cfr.hpp:19-45, lib/algo_impl/cfr/cfr.cc;
  * SURVEY.md section 8(f) rank 4) -- the three row updates run on the ALS Gramian / dense-solve kernels.

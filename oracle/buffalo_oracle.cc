@@ -1779,6 +1779,26 @@ double orc_cfr_partial_update_item(void* hp, int s, int n, const int64_t* ipu, c
 double orc_cfr_partial_update_context(void* hp, int s, int n, const int64_t* indptr, const int32_t* keys, const float* vals) {
     return static_cast<CFR*>(((Handle*)hp)->als)->partial_update_context(s, n, indptr, keys, vals);
 }
+// fileio.hpp:280-310 restated for a buffer in memory: the file's lines in order (std::getline: split at '\n', an unterminated last line
+// counts), each through the reference's own sscanf(line, "%d %d %f"), the first `total_lines` of them.  Returns the number of lines found.
+int64_t orc_parse_triples(const char* text, int64_t bytes, int64_t total_lines, int32_t* rows, int32_t* cols, float* vals) {
+    int64_t k = 0, beg = 0;
+    std::string line;
+    while (beg < bytes) {
+        const char* nlp = static_cast<const char*>(memchr(text + beg, '\n', static_cast<size_t>(bytes - beg)));
+        const int64_t end = nlp ? nlp - text : bytes;
+        if (k < total_lines) {
+            line.assign(text + beg, text + end);
+            int r = 0, c = 0;
+            float v = 0.f;
+            sscanf(line.c_str(), "%d %d %f", &r, &c, &v);
+            rows[k] = r; cols[k] = c; vals[k] = v;
+        }
+        ++k;
+        beg = end + 1;
+    }
+    return k;
+}
 void orc_coo_to_csr(const int32_t* major, const int32_t* minor, const float* vals, int64_t nnz, int num_major, int64_t* indptr,
                     int32_t* out_minor, float* out_vals) {
     std::vector<int64_t> order(nnz);

@@ -379,6 +379,19 @@ def coo_to_csr(major, minor, vals, num_major, num_minor=None):
     return {"indptr": indptr, "key": key, "val": val}
 
 
+def parse_triples(text, total_lines):
+    """fileio.hpp:280-310 on the oracle: the first `total_lines` lines of the working text file through sscanf("%d %d %f"); ids stay 1-based."""
+    buf = bytes(text)
+    n = int(total_lines)
+    rows, cols, vals = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.float32)
+    L = lib()
+    L.orc_parse_triples.restype = C.c_int64
+    L.orc_parse_triples.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_float)]
+    found = L.orc_parse_triples(buf, len(buf), n, _p(rows, C.c_int32), _p(cols, C.c_int32), _p(vals, C.c_float))
+    assert found >= n, (found, n)
+    return rows, cols, vals
+
+
 def build_sppmi(indptr, items, num_items, windows, k):
     """stream.py:257-267 + fileio.hpp:109-254 + stream.py:169-195 on the oracle: the SPPMI group (indptr, key, val) of a stream
     given as END-offset `indptr` [num_users] over 0-based `items`; same return layout as buffalo_amd.ingest.build_sppmi."""

@@ -114,3 +114,35 @@ def test_psort_restatement_is_what_sort_does(tmp_path):
     rf._psort_first_field(str(a), 2)
     rf._psort_python(str(b), 2)
     assert a.read_text() == b.read_text()
+
+
+def test_oracle_text_parse_is_the_reference_s_parse(tmp_path):
+    """oracle.parse_triples (the checker of bfh_parse_triples / bfh_text_to_csr) against the reference's own compiled fileio.hpp on the SAME text
+    file: decimal values in every shape, near-ties of the float rounding, specials, CR / tab / double-space separators, with and without the
+    final newline.  The reference's keep-order mode (sort_key -1) hands back (col - 1, val) per line and an indptr that is a function of the rows."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import text_cases
+    from oracle import oracle as orc
+    from oracle import ref_fileio as rf
+    if not rf.available():
+        pytest.skip("oracle/_ref/libbuffalo_fileio_ref.so is not built and /root/reference is absent")
+    orc.build()
+    for seed, n in ((1, 401), (2, 1000)):
+        rng = np.random.default_rng(seed)
+        text, n_lines = text_cases.make_text(rng, n, num_rows=60, num_cols=90, sorted_rows=True)
+        rows, cols, vals = orc.parse_triples(text, n_lines)
+        src = tmp_path / ("w%d.txt" % seed)
+        src.write_bytes(text)
+        d = tmp_path / ("out%d" % seed)
+        d.mkdir()
+        workers = 3
+        nfiles = rf.lib().ref_sort_and_compressed_binarization(str(src).encode(), str(d).encode(), n_lines, 60, -1, workers)
+        assert nfiles == workers + 1
+        rec = np.dtype([("i", "<i4"), ("v", "<f4")])
+        data = np.concatenate([np.fromfile(str(d / ("chunk%d.bin" % i)), dtype=rec) for i in range(workers)])
+        assert data.shape[0] == n_lines
+        np.testing.assert_array_equal(data["i"], cols - 1)
+        np.testing.assert_array_equal(data["v"].view(np.uint32), vals.view(np.uint32))          # bit for bit, NaN payloads included
+        indptr = np.fromfile(str(d / "indptr.bin"), dtype=np.int64)
+        np.testing.assert_array_equal(indptr, np.cumsum(np.bincount(rows - 1, minlength=60)))
