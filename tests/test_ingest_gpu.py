@@ -94,7 +94,7 @@ def test_text_parse_is_sscanf_bit_for_bit(oracle, seed, n):
     np.testing.assert_array_equal(v.view(np.uint32), vo.view(np.uint32))
     assert st["samples"] == lines
     if n >= 1000:
-        assert 0 < st["merges"] < 0.35 * lines      # the specials and near-ties of text_cases went the host way, the ordinary values did not
+        assert 0 < st["merges"] < 0.5 * lines       # the specials, near-ties and 17-digit reprs of text_cases went the host way (a third of ITS lines), the ordinary values did not
     # fewer lines asked for than the file holds: the first ones (fileio.hpp:312-320); more: an error (its assert)
     if n > 10:
         r2, c2, v2 = parse_triples(text, lines - 7)
