@@ -53,6 +53,7 @@ struct AlsParams {
     const float* split;    // als_gram_kernel<SPLIT>: {S, S^2, 1/S^2, weight cut} written by als_split_scale_kernel (device-side, no host round trip)
     int accumulate;        // add into the row's (zeroed) slot instead of overwriting it: two passes build one system
     float ff_scale;        // the solve kernel's M = ff_scale * FF + slot
+    const float* Qi;       // als_wide_kernel<SPLIT>: the block-interleaved copy of Q (als_interleave_stats_kernel: Qi[row][T col + b] = Q[row][32 b + col])
 };
 
 template <int K>
@@ -940,6 +941,16 @@ __device__ __forceinline__ void als_split_f16(float x0, float x1, unsigned& h, u
     l = __builtin_bit_cast(unsigned, ll);
 }
 
+// The same cut with the scaling folded in (als_pc.hpp's pc_split_pair, als_wide_kernel<SPLIT>): (q0 s0, q1 s1) -> packed f16 pairs h (the
+// product rounded to nearest ONCE, inside the fused operation) and l (the remainder q s - h, exact in the fused multiply-add, rounded the same
+// way) -- four v_fma_mix{lo,hi}_f16 per pair where the form above takes seven instructions with its multiplies.
+__device__ __forceinline__ void als_split_pair_mix(float q0, float s0, float q1, float s1, unsigned& h, unsigned& l) {
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(q0), "v"(s0));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(q1), "v"(s1));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l) : "v"(q0), "v"(s0), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(q1), "v"(s1), "v"(h));
+}
+
 // Scale of the split pass (als_gram_kernel<SPLIT>), decided on the device from ONE fixed-order reduction, qmax = max |Q| over the
 // other factor matrix -- nothing that depends on how the rows are chunked or sharded, so every chunking and every rank of a
 // sharded run works with the same numbers:
@@ -1767,6 +1778,10 @@ struct AlsWide {
     static constexpr bool owns_row(int a) { return a == R0 || (TWO && a == R1); }
 };
 
+__host__ __device__ inline size_t als_wide_ring_offset_floats(int vdim) {
+    const size_t upto = 3 * static_cast<size_t>(vdim) + 4 * 32 + 32 + 32 + 8 + 4 + static_cast<size_t>(vdim);   // ... | g_1
+    return (upto + 3) & ~size_t(3);
+}
 struct AlsWideLds {          // carved from dynamic LDS: 3 vdim | W*32 | 32 | 32 | 8 floats
     float* pc;               // the row (current iterate)
     float* dl;               // delta = p - p0 (zero in the blocks not solved yet)
@@ -1775,14 +1790,28 @@ struct AlsWideLds {          // carved from dynamic LDS: 3 vdim | W*32 | 32 | 32
     float* rowres;           // [32] row-product result of the diagonal tile's owner
     float* pvs;              // [32] CG direction
     float* red;              // [8] loss partials
+    float* g1v;              // SPLIT: [vdim] g_1 = sum q of the row (loss only), formed by the producer
+    u32x4* ring;             // SPLIT: two slots of one group of 16 entries: [16][vdim] fp32 rows + 16 scales S sqrt(alpha v)
 };
 
-template <int T, int WV, bool BIG>
+// SPLIT (round 5, "als_wide_split"): the Gramian through the f16 matrix cores at fp32 accuracy, with the rows gathered ONCE per block.  The fp32
+// pass has every wave load the blocks of the q rows it needs itself -- 14 block loads per row at T = 5 where the row has 5: the first split-f16
+// version of this kernel kept that and was bound by exactly this traffic (10.0 ms per ML-20M epoch at d = 160, 72 GB out of L2 / Infinity
+// Cache; four waves with two row sets each: 11.1).  Now a block carries one more wave, the PRODUCER (wave W): it gathers the 16 rows of a
+// group, forms every entry's residual and h (it holds p0), cuts x = S sqrt(alpha v) q into the f16 pieces h + l for all T blocks and parks
+// them in one of two LDS slots (T x 2 KB each); the W consumer waves read the pieces of the blocks their tiles need (conflict-free 16-byte
+// reads) and issue l h + h l + h h per tile.  One block barrier per group: the producer fills slot (g + 1) & 1 while the consumers drain
+// slot g & 1.  The accumulators hold S^2 G during the pass and come back (x 1 / S^2, + the FF tile) behind it.  Calls with weights outside
+// the f16 path (als_defer_scan_kernel) keep the fp32 instantiation.
+template <int T, int WV, bool BIG, bool SPLIT = false>
 __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork& wk, bool finalize, float* __restrict__ scratch, const AlsWideLds& L,
                                               int lane, int half, int col, double& nume_k, double& deno_k) {
-    using C = AlsWide<T, WV>;
-    constexpr int NTW = C::NTW, NB = C::NB, R0 = C::R0, R1 = C::R1, VD = 32 * T, W = C::W;
-    constexpr bool TWO = C::TWO;
+    constexpr bool PROD = SPLIT && WV == (T + 1) / 2;     // the producer wave: no tiles
+    using C = AlsWide<T, PROD ? 0 : WV>;
+    constexpr int NTW = PROD ? 1 : C::NTW, NB = C::NB, R0 = C::R0, R1 = C::R1, VD = 32 * T, W = C::W;
+    constexpr bool TWO = C::TWO && !PROD;
+    // the wave that forms the per-entry residual and h (it needs EVERY block of the q rows): wave 0, which loads them all anyway; SPLIT: the producer
+    constexpr bool HWAVE = SPLIT ? PROD : (WV == 0);
     constexpr int UP = 4;
     constexpr unsigned row_bytes = VD * 4u;
     const bool lossk = p.compute_loss && p.axis == 1;
@@ -1795,10 +1824,13 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
     // h = sum alpha v (q.p0 - 1) q.  The dot needs every block of the q row: wave 0 loads them all (R0 = 0), so it forms h for all T
     // blocks and hands it over through LDS (the scratch slot for the chunks of a heavy row).  [Rounds 1-3 evaluated (M p) - g_w here:
     // the same number, but once the model fits G p and g_w nearly cancel -- 10x envelope, profiles/r03_als_config3_warm_epoch.txt.]
-    float p0r[WV == 0 ? T : 1], hb[WV == 0 ? T : 1];
+    float p0r[HWAVE ? T : 1], hb[HWAVE ? T : 1];
 #pragma unroll
-    for (int b = 0; b < (WV == 0 ? T : 1); ++b) { p0r[b] = WV == 0 ? Pu[b * 32 + col] : 0.f; hb[b] = 0.f; }
-    {   // accumulators start from FF (+ the heavy row's summed chunk tiles when finalizing); zero for a chunk
+    for (int b = 0; b < (HWAVE ? T : 1); ++b) { p0r[b] = HWAVE ? Pu[b * 32 + col] : 0.f; hb[b] = 0.f; }
+    float g1all[(SPLIT && PROD) ? T : 1];   // SPLIT: the consumers never see q -- g_1 = sum q (loss only) is formed by the producer for every block
+#pragma unroll
+    for (int b = 0; b < ((SPLIT && PROD) ? T : 1); ++b) g1all[b] = 0.f;
+    if constexpr (!PROD) {   // accumulators start from FF (+ the heavy row's summed chunk tiles when finalizing); zero for a chunk (SPLIT: FF joins behind the pass)
         const float* Fl = p.FF + half * 4 * VD + col;
         const float* Sl = scratch + static_cast<size_t>(wk.slot >= 0 ? wk.slot : 0) * als_slot_floats(VD) + half * 4 * VD + col;
         asm volatile("" : "+v"(Fl));
@@ -1808,7 +1840,7 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int off = (a * 32 + (e & 3) + 8 * (e >> 2)) * VD + b * 32;
-                acc[s][e] = partial ? 0.f : Fl[off] + (finalize ? Sl[off] : 0.f);
+                acc[s][e] = (partial || (SPLIT && !finalize)) ? 0.f : Fl[off] + (finalize ? Sl[off] : 0.f);
             }
         }
     }
@@ -1823,7 +1855,7 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
             if (kk < n) {
                 cc = p.keys[wk.kbeg + kk];
                 vvv = p.vals[wk.kbeg + kk];
-                if (lossk && WV == 0) {
+                if (lossk && HWAVE) {
                     const double w = static_cast<double>(vvv * p.alpha);
                     deno_k += w;
                     nume_k += 1.0 + w;
@@ -1855,7 +1887,7 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
                     acc[C::N0 + s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, q[R1 - R0 + s], acc[C::N0 + s], 0, 0, 0);
                 g11 += lo * q[R1 - R0];
             }
-            if constexpr (WV == 0) {   // NB == T here
+            if constexpr (HWAVE) {   // NB == T here (fp32 pass: wave 0)
                 float part = q[0] * p0r[0];
 #pragma unroll
                 for (int b = 1; b < T; ++b) part = __builtin_fmaf(q[b], p0r[b], part);
@@ -1864,76 +1896,305 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
                 for (int b = 0; b < T; ++b) hb[b] = __builtin_fmaf(cial, q[b], hb[b]);
             }
         };
-        auto nnz_of = [&](int64_t ch) { return ch < nchunks ? static_cast<int>((n - ch * 64) < 64 ? (n - ch * 64) : 64) : 0; };
-        auto groups_of = [&](int64_t ch) { return (nnz_of(ch) >> 1) / UP; };
-        int myc, myc_n;
-        float myv, myv_n;
-        fetch_keys(0, myc, myv);
-        fetch_keys(1, myc_n, myv_n);
-        float qa[UP][NB], va[UP];
-        if (groups_of(0) > 0) {
+        if constexpr (SPLIT) {
+            const float sS = p.split[0], sI2 = p.split[2], wcut = p.split[3];
+            // wave-uniform loop state in SGPRs (the work item came through a vector load; a 64-bit counter in VGPRs is what gets spilled)
+            const int n32 = __builtin_amdgcn_readfirstlane(static_cast<int>(n));
+            const int ngroups = (p.debug & 16) ? 0 : (n32 + 15) >> 4;     // the last group is padded with weight-0 entries of row 0 ("als_debug" bit 16: timing study, no pass)
+            float* const ringf = reinterpret_cast<float*>(L.ring);   // two slots of [16 entries][vdim] fp32 rows + 16 scales
+            constexpr int SLOTF = 16 * VD + 16;
+            if constexpr (PROD) {
+                const int bsel = 32 * half;          // lane (col, half) works on the entries 16 g + 8 half + r, r = 0 .. 7, of a chunk
+                // rows come from the block-interleaved copy (Qi[row][T col + b]): a lane's T elements of an entry are contiguous -- T / 4 + 1 load
+                // instructions per entry instead of T, which keeps three sets of rows under the 63 loads the hardware counter can track (with one
+                // dword per block and entry, two sets were already more than it counts: the waits then drained the prefetch)
+                const char* qb0 = reinterpret_cast<const char*>(p.Qi);
+                typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+                int myc, myc_n;
+                float myw, myw_n, mys, mys_n;
+                auto fetch = [&](int64_t chunk, int& cc, float& ww, float& ss) {
+                    float vvv;
+                    fetch_keys(chunk, cc, vvv);
+                    ww = p.alpha * vvv;
+                    ss = (ww > 0.f && ww <= wcut) ? sS * __builtin_amdgcn_sqrtf(ww) : 0.f;   // (the host sends calls with other weights to the fp32 kernel)
+                };
+                fetch(0, myc, myw, mys);
+                fetch(1, myc_n, myw_n, mys_n);
+                // three sets of rows: while group pg is prepared from one, the rows of pg + 1 and pg + 2 are landing in the others and those of
+                // pg + 3 leave into the one just consumed
+                float qA[8][T], qB[8][T], qC[8][T];
+                // the row ids of a group's entries, lane (col, half) <- entries 16 g + 8 half + r: all eight exchanges issued back to back (left to the
+                // compiler each exchange was followed by its wait and its load -- 24 serialised LDS round trips per group, 1.7 us of the 2.2 a group took)
+                auto group_ids = [&](int (&cid)[8], int src_c, int g) {
 #pragma unroll
-            for (int uu = 0; uu < UP; ++uu) load_pair(myc, myv, uu, qa[uu], va[uu]);
-        }
-        for (int64_t ch = 0; ch < nchunks; ++ch) {
-            const int npairs = (nnz_of(ch) + 1) >> 1;
-            const int ngroups = groups_of(ch);
-            for (int gidx = 0; gidx < ngroups; ++gidx) {   // same pipelining as als_gram_kernel
-                float qb[UP][NB], vb[UP];
-                const bool here = gidx + 1 < ngroups;
-                const int src_c = here ? myc : myc_n;
-                const float src_v = here ? myv : myv_n;
-                const int pr0 = here ? (gidx + 1) * UP : 0;
+                    for (int r = 0; r < 8; ++r) cid[r] = __builtin_amdgcn_ds_bpermute(bsel + 64 * g + 4 * r, src_c);
+                };
+                auto load_group = [&](float (&q)[8][T], const int (&cid)[8]) {
 #pragma unroll
-                for (int uu = 0; uu < UP; ++uu) load_pair(src_c, src_v, pr0 + uu, qb[uu], vb[uu]);
+                    for (int r = 0; r < 8; ++r) {
+                        using off_t = typename std::conditional<BIG, size_t, unsigned>::type;
+                        const off_t voff = static_cast<off_t>(static_cast<unsigned>(cid[r])) * row_bytes + static_cast<unsigned>(col) * (4u * T);
+                        const char* q_ = qb0 + voff;
 #pragma unroll
-                for (int uu = 0; uu < UP; ++uu) consume(qa[uu], va[uu], 1.0f);
+                        for (int b4 = 0; b4 + 4 <= T; b4 += 4) {
+                            const f4u v4 = *reinterpret_cast<const f4u*>(q_ + 4 * b4);
+                            q[r][b4] = v4[0]; q[r][b4 + 1] = v4[1]; q[r][b4 + 2] = v4[2]; q[r][b4 + 3] = v4[3];
+                        }
 #pragma unroll
-                for (int uu = 0; uu < UP; ++uu) {
-                    va[uu] = vb[uu];
-#pragma unroll
-                    for (int b = 0; b < NB; ++b) qa[uu][b] = qb[uu][b];
+                        for (int b = T & ~3; b < T; ++b) q[r][b] = *reinterpret_cast<const float*>(q_ + 4 * b);
+                    }
+                };
+                {
+                    int c0[8], c1[8], c2[8];
+                    group_ids(c0, myc, 0);
+                    group_ids(c1, myc, 1);   // (past the row's end: padding keys, row 0 with weight 0)
+                    group_ids(c2, myc, 2);
+                    load_group(qA, c0);
+                    load_group(qB, c1);
+                    load_group(qC, c2);
                 }
+                // group pg: residual + h + g_1 from the rows, the pieces of all T blocks into `slot`, then the rows of group pg + 2 into the set
+                // keys of chunk 2, in flight since before the first preparation (see the commit in `prepare`)
+                int pend_c = 0;
+                float pend_v = 0.f;
+                bool pend_in = false;
+                auto prepare = [&](float (&q)[8][T], int pg, int slot) {
+                    const int g = pg & 3;
+                    // the chunk after next: its keys are fetched on EVERY preparation (one control-flow path: the compiler counts the loads in flight
+                    // exactly; a conditional fetch turns the waits into vmcnt(0)) and USED one preparation later -- the commit below reads what the
+                    // previous preparation asked for (the same chunk: a commit happens at a chunk's fourth group), never its own request, whose
+                    // memory round trip would otherwise be paid in full by every group (measured: 1.7 us per group with everything else switched off)
+                    const int nc = pend_c;
+                    const float nv = pend_v;
+                    const bool kin = pend_in;
+                    {
+                        const int64_t kk = static_cast<int64_t>(((pg + 2) >> 2) + 1) * 64 + lane;   // (asked for one preparation ahead of its use)
+                        pend_in = kk < n;
+                        pend_c = pend_in ? p.keys[wk.kbeg + kk] : 0;
+                        pend_v = pend_in ? p.vals[wk.kbeg + kk] : 0.f;
+                    }
+                    float wgt[8], sw[8], y[8];
+                    int cid[8];   // the rows of group pg + 3 (the keys of a chunk's groups 1, 2, 3 + 3 sit in the next chunk)
+                    group_ids(cid, g < 1 ? myc : myc_n, (g + 3) & 3);
 #pragma unroll
-                for (int i = 0; i < UP * NTW; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x006, 2, 0);
-                    if (i % 2 == 0 && i / 2 < UP * NB) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    for (int r = 0; r < 8; ++r) wgt[r] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bsel + 64 * g + 4 * r, __builtin_bit_cast(int, myw)));
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) sw[r] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bsel + 64 * g + 4 * r, __builtin_bit_cast(int, mys)));
+                    __builtin_amdgcn_sched_barrier(0);   // (the 24 exchanges stay together, ahead of everything that waits on one of them)
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        y[r] = q[r][0] * p0r[0];
+#pragma unroll
+                        for (int b = 1; b < T; ++b) y[r] = __builtin_fmaf(q[r][b], p0r[b], y[r]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), 0x128, 0xf, 0xf, false));
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), 0x124, 0xf, 0xf, false));
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), 0x122, 0xf, 0xf, false));
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), 0x121, 0xf, 0xf, false));
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        const float yo = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, y[r]), 0x401F));
+                        const float cial = __builtin_fmaf(wgt[r], y[r] + yo, -wgt[r]);   // alpha v (q.p0 - 1)
+#pragma unroll
+                        for (int b = 0; b < T; ++b) hb[b] = __builtin_fmaf(cial, q[r][b], hb[b]);
+                    }
+                    if (lossk) {   // g_1 = sum q over the real entries (wave-uniform branch)
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            const float one = (pg * 16 + 8 * half + r < n32) ? 1.0f : 0.f;
+#pragma unroll
+                            for (int b = 0; b < T; ++b) g1all[b] = __builtin_fmaf(one, q[r][b], g1all[b]);
+                        }
+                    }
+                    // the group's rows (fp32) and scales into the slot: [entry 8 half + r][block][col], then the 16 scales -- the consumers cut the
+                    // blocks they need themselves (in parallel on their own SIMDs; cutting all T blocks here made this wave the bottleneck: 11.8 ms)
+                    float* const dst = ringf + slot * SLOTF + (8 * half) * VD + col;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r)
+#pragma unroll
+                        for (int b = 0; b < T; ++b) dst[r * VD + b * 32] = q[r][b];
+                    if (col == 0) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) ringf[slot * SLOTF + 16 * VD + 8 * half + r] = sw[r];
+                    }
+                    // the rows of group pg + 3 leave into the set just consumed
+                    load_group(q, cid);
+                    {   // commit the keys fetched at the top of this preparation when it ends a chunk
+                        const bool adv = g == 3;   // the next group opens a new 64-entry chunk
+                        if (lossk && adv && kin) {
+                            const double w = static_cast<double>(nv * p.alpha);
+                            deno_k += w;
+                            nume_k += 1.0 + w;
+                        }
+                        const float nw = p.alpha * nv;
+                        const float ns = (nw > 0.f && nw <= wcut) ? sS * __builtin_amdgcn_sqrtf(nw) : 0.f;
+                        myc = adv ? myc_n : myc; myw = adv ? myw_n : myw; mys = adv ? mys_n : mys;
+                        myc_n = adv ? nc : myc_n; myw_n = adv ? nw : myw_n; mys_n = adv ? ns : mys_n;
+                    }
+                };
+                prepare(qA, 0, 0);
+                __syncthreads();                      // slot 0 is ready
+                for (int jg = 0; jg < ngroups;) {     // while the consumers drain slot jg & 1: group jg + 1 (past the end: a padding group nobody reads)
+                    prepare(qB, jg + 1, (jg + 1) & 1);
+                    __syncthreads();
+                    if (++jg >= ngroups) break;
+                    prepare(qC, jg + 1, (jg + 1) & 1);
+                    __syncthreads();
+                    if (++jg >= ngroups) break;
+                    prepare(qA, jg + 1, (jg + 1) & 1);
+                    __syncthreads();
+                    ++jg;
+                }
+            } else {
+                __syncthreads();                      // slot 0 is ready
+                for (int jg = 0; jg < ngroups; ++jg) {
+                    const float* const src = ringf + (jg & 1) * SLOTF + (8 * half) * VD + R0 * 32 + col;
+                    const float* const ssw = ringf + (jg & 1) * SLOTF + 16 * VD + 8 * half;
+                    float qv[8][NB], sw[8];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        sw[r] = ssw[r];
+#pragma unroll
+                        for (int b = 0; b < NB; ++b) qv[r][b] = src[r * VD + b * 32];
+                    }
+                    u32x4 H[NB], Lo[NB];
+#pragma unroll
+                    for (int b = 0; b < NB; ++b)
+#pragma unroll
+                        for (int j2 = 0; j2 < 4; ++j2) {
+                            unsigned h_, l_;
+                            als_split_pair_mix(qv[2 * j2][b], sw[2 * j2], qv[2 * j2 + 1][b], sw[2 * j2 + 1], h_, l_);
+                            H[b][j2] = h_;
+                            Lo[b][j2] = l_;
+                        }
+#pragma unroll
+                    for (int pr = 0; pr < 3; ++pr) {   // small terms first: l h, h l, h h
+#pragma unroll
+                        for (int sidx = 0; sidx < C::N0; ++sidx) {
+                            const u32x4 X = pr == 0 ? Lo[0] : H[0];
+                            const u32x4 Y = pr == 1 ? Lo[sidx] : H[sidx];
+                            acc[sidx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, X), __builtin_bit_cast(f16x8_t, Y), acc[sidx], 0, 0, 0);
+                        }
+                        if constexpr (TWO) {
+#pragma unroll
+                            for (int sidx = 0; sidx < C::N1; ++sidx) {
+                                const u32x4 X = pr == 0 ? Lo[R1 - R0] : H[R1 - R0];
+                                const u32x4 Y = pr == 1 ? Lo[R1 - R0 + sidx] : H[R1 - R0 + sidx];
+                                acc[C::N0 + sidx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, X), __builtin_bit_cast(f16x8_t, Y), acc[C::N0 + sidx], 0, 0, 0);
+                            }
+                        }
+                    }
+                    __syncthreads();                  // the slot may be refilled; the next one is ready
+                }
+                // back to M's units, and (whole rows) the FF tiles join -- one wave-uniform branch around two straight loops (a per-element
+                // select around the load compiles into hundreds of two-instruction blocks with a spill reload each)
+                if (partial) {
+#pragma unroll
+                    for (int sidx = 0; sidx < NTW; ++sidx)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[sidx][e] *= sI2;
+                } else {
+                    const float* Fl2 = p.FF + half * 4 * VD + col;
+                    asm volatile("" : "+v"(Fl2));
+#pragma unroll
+                    for (int sidx = 0; sidx < NTW; ++sidx) {
+                        const int a = sidx < C::N0 ? R0 : R1, b = sidx < C::N0 ? R0 + sidx : R1 + (sidx - C::N0);
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[sidx][e] = __builtin_fmaf(acc[sidx][e], sI2, Fl2[(a * 32 + (e & 3) + 8 * (e >> 2)) * VD + b * 32]);
+                    }
                 }
             }
-            for (int pr = ngroups * UP; pr < npairs; ++pr) {
-                float q1[NB], v1;
-                load_pair(myc, myv, pr, q1, v1);
-                consume(q1, v1, (ch * 64 + 2 * pr + half < n) ? 1.0f : 0.f);
+        } else {
+            auto nnz_of = [&](int64_t ch) { return ch < nchunks ? static_cast<int>((n - ch * 64) < 64 ? (n - ch * 64) : 64) : 0; };
+            auto groups_of = [&](int64_t ch) { return (nnz_of(ch) >> 1) / UP; };
+            int myc, myc_n;
+            float myv, myv_n;
+            fetch_keys(0, myc, myv);
+            fetch_keys(1, myc_n, myv_n);
+            float qa[UP][NB], va[UP];
+            if (groups_of(0) > 0) {
+    #pragma unroll
+                for (int uu = 0; uu < UP; ++uu) load_pair(myc, myv, uu, qa[uu], va[uu]);
             }
-            myc = myc_n;
-            myv = myv_n;
-            fetch_keys(ch + 2, myc_n, myv_n);
+            for (int64_t ch = 0; ch < nchunks; ++ch) {
+                const int npairs = (nnz_of(ch) + 1) >> 1;
+                const int ngroups = groups_of(ch);
+                for (int gidx = 0; gidx < ngroups; ++gidx) {   // same pipelining as als_gram_kernel
+                    float qb[UP][NB], vb[UP];
+                    const bool here = gidx + 1 < ngroups;
+                    const int src_c = here ? myc : myc_n;
+                    const float src_v = here ? myv : myv_n;
+                    const int pr0 = here ? (gidx + 1) * UP : 0;
+    #pragma unroll
+                    for (int uu = 0; uu < UP; ++uu) load_pair(src_c, src_v, pr0 + uu, qb[uu], vb[uu]);
+    #pragma unroll
+                    for (int uu = 0; uu < UP; ++uu) consume(qa[uu], va[uu], 1.0f);
+    #pragma unroll
+                    for (int uu = 0; uu < UP; ++uu) {
+                        va[uu] = vb[uu];
+    #pragma unroll
+                        for (int b = 0; b < NB; ++b) qa[uu][b] = qb[uu][b];
+                    }
+    #pragma unroll
+                    for (int i = 0; i < UP * NTW; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x006, 2, 0);
+                        if (i % 2 == 0 && i / 2 < UP * NB) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+                }
+                for (int pr = ngroups * UP; pr < npairs; ++pr) {
+                    float q1[NB], v1;
+                    load_pair(myc, myv, pr, q1, v1);
+                    consume(q1, v1, (ch * 64 + 2 * pr + half < n) ? 1.0f : 0.f);
+                }
+                myc = myc_n;
+                myv = myv_n;
+                fetch_keys(ch + 2, myc_n, myv_n);
+            }
         }
     }
     // the two halves hold the k-parities of the same element
     g10 += __shfl_xor(g10, 32, 64); g11 += __shfl_xor(g11, 32, 64);
-    if constexpr (WV == 0) {
+    if constexpr (HWAVE) {
 #pragma unroll
         for (int b = 0; b < T; ++b) hb[b] += __shfl_xor(hb[b], 32, 64);
+    }
+    if constexpr (SPLIT && PROD) {
+#pragma unroll
+        for (int b = 0; b < T; ++b) g1all[b] += __shfl_xor(g1all[b], 32, 64);
     }
 
     float* S = scratch + static_cast<size_t>(wk.slot >= 0 ? wk.slot : 0) * als_slot_floats(VD);
     if (partial) {   // add this chunk's tiles / vector shares into the (zeroed) slot
-        float* Sl = S + half * 4 * VD + col;
+        if constexpr (!PROD) {
+            float* Sl = S + half * 4 * VD + col;
 #pragma unroll
-        for (int s = 0; s < NTW; ++s) {
-            const int a = s < C::N0 ? R0 : R1, b = s < C::N0 ? R0 + s : R1 + (s - C::N0);
+            for (int s = 0; s < NTW; ++s) {
+                const int a = s < C::N0 ? R0 : R1, b = s < C::N0 ? R0 + s : R1 + (s - C::N0);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) atomic_add_f32(Sl + (a * 32 + (e & 3) + 8 * (e >> 2)) * VD + b * 32, acc[s][e]);
+                for (int e = 0; e < 16; ++e) atomic_add_f32(Sl + (a * 32 + (e & 3) + 8 * (e >> 2)) * VD + b * 32, acc[s][e]);
+            }
         }
         if (half == 0) {
-            if constexpr (WV == 0) {
+            if constexpr (HWAVE) {
 #pragma unroll
                 for (int b = 0; b < T; ++b) atomic_add_f32(S + VD * VD + b * 32 + col, hb[b]);
             }
-            if (lossk) atomic_add_f32(S + VD * VD + VD + R0 * 32 + col, g10);
-            if (TWO && lossk) atomic_add_f32(S + VD * VD + VD + R1 * 32 + col, g11);
+            if constexpr (SPLIT) {
+                if constexpr (PROD) {
+                    if (lossk) {
+#pragma unroll
+                        for (int b = 0; b < T; ++b) atomic_add_f32(S + VD * VD + VD + b * 32 + col, g1all[b]);
+                    }
+                }
+            } else {
+                if (lossk) atomic_add_f32(S + VD * VD + VD + R0 * 32 + col, g10);
+                if (TWO && lossk) atomic_add_f32(S + VD * VD + VD + R1 * 32 + col, g11);
+            }
         }
         return;
     }
@@ -1943,33 +2204,46 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
     }
 
     // ---------------- iALS++ across the W waves (als.cc:269-352, see als_ialspp_inreg) ----------------
-    for (int e = threadIdx.x; e < VD; e += 64 * W) {
+    for (int e = threadIdx.x; e < VD; e += 64 * (W + (SPLIT ? 1 : 0))) {
         L.pc[e] = Pu[e];
         L.dl[e] = 0.f;
         if (finalize) L.hv[e] = S[VD * VD + e];
     }
-    if constexpr (WV == 0) {
+    if constexpr (HWAVE) {
         if (!finalize && half == 0) {
 #pragma unroll
             for (int b = 0; b < T; ++b) L.hv[b * 32 + col] = hb[b];
         }
     }
+    if constexpr (SPLIT && PROD) {   // g_1 of every block for the waves that own the rows (loss only)
+        if (!finalize && half == 0 && lossk) {
+#pragma unroll
+            for (int b = 0; b < T; ++b) L.g1v[b * 32 + col] = g1all[b];
+        }
+    }
     // f0 = FF p0 of this wave's rows (als_rowff_kernel)
     const float* Fu0 = p.F0 + static_cast<size_t>(wk.row - p.start_x) * VD;
-    const float f00 = Fu0[R0 * 32 + col], f01 = TWO ? Fu0[R1 * 32 + col] : 0.f;
+    const float f00 = PROD ? 0.f : Fu0[R0 * 32 + col], f01 = TWO ? Fu0[R1 * 32 + col] : 0.f;
     __syncthreads();
+    if constexpr (SPLIT && !PROD) {
+        if (!finalize && lossk) { g10 = L.g1v[R0 * 32 + col]; if (TWO) g11 = L.g1v[R1 * 32 + col]; }
+    }
     // this wave's share of (M x)[32 blk + col] for x = pc: column products of its tiles in column blk go to
     // contrib[WV], the row products of row blk (if it owns it) to rowres; the caller sums after a barrier
-    auto block_partials = [&](auto blk_c, const float* x) {
+    // DELTA: x is delta = p - p0, which is non-zero only in the blocks ALREADY solved (< blk): the tiles whose operand block is >= blk multiply
+    // exact zeros and are skipped -- all of the row products, and the column products of the wave's own rows >= blk (round 5: a third of the row end)
+    auto block_partials = [&](auto blk_c, const float* x, auto delta_c) {
         constexpr int blk = decltype(blk_c)::value;
+        constexpr bool DELTA = decltype(delta_c)::value;
+        if constexpr (PROD) return;   // the producer holds no tiles: it only keeps the block's barriers company
         float part = 0.f;
-        if constexpr (R0 <= blk) part += als_tile_colpart(acc[C::slot(R0, blk)], x + R0 * 32, half);
-        if constexpr (TWO && R1 <= blk) part += als_tile_colpart(acc[C::slot(R1, blk)], x + R1 * 32, half);
+        if constexpr (DELTA ? (R0 < blk) : (R0 <= blk)) part += als_tile_colpart(acc[C::slot(R0, blk)], x + R0 * 32, half);
+        if constexpr (TWO && (DELTA ? (R1 < blk) : (R1 <= blk))) part += als_tile_colpart(acc[C::slot(R1, blk)], x + R1 * 32, half);
         part += __shfl_xor(part, 32, 64);
         if (half == 0) L.contrib[WV * 32 + col] = part;
-        if constexpr (C::owns_row(blk)) {
+        if constexpr (!PROD && C::owns_row(blk)) {
             float y = 0.f;
-            if constexpr (blk < T - 1) {
+            if constexpr (blk < T - 1 && !DELTA) {
                 float z[16];
 #pragma unroll
                 for (int e = 0; e < 16; ++e) z[e] = 0.f;
@@ -2000,12 +2274,12 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
             constexpr int blk = decltype(blk_c)::value;
             float mp = 0.f;
             if (p.axis == 1) {
-                block_partials(blk_c, L.pc);
+                block_partials(blk_c, L.pc, std::false_type{});
                 __syncthreads();
                 mp = block_sum();
                 __syncthreads();
             }
-            if constexpr (C::owns_row(blk)) {
+            if constexpr (!PROD && C::owns_row(blk)) {
                 const float pv = L.pc[blk * 32 + col];
                 pp += pv * pv;
                 pmp += pv * (2.0f * (blk == R0 ? f00 : f01) - mp);
@@ -2020,17 +2294,19 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
             nume_k += static_cast<double>(ada * p.reg * pp);
             if (p.axis == 1) {
                 nume_k += static_cast<double>(pmp) - 2.0 * static_cast<double>(pg);
-                if (WV == 0) deno_k += static_cast<double>(p.op_rows);
+                if (HWAVE) deno_k += static_cast<double>(p.op_rows);
             }
         }
     }
     als_static_for<T>([&](auto blk_c) {
         constexpr int blk = decltype(blk_c)::value;
-        block_partials(blk_c, L.dl);   // (M delta)[blk]: delta is non-zero only in the blocks already solved
-        __syncthreads();
-        if constexpr (C::owns_row(blk)) {   // this wave holds the diagonal tile: gradient of the block at the current row + 3 CG steps (als.cc:286-346)
+        if constexpr (blk > 0) {   // (M delta)[blk]: delta is non-zero only in the blocks already solved -- nothing at all for the first block
+            block_partials(blk_c, L.dl, std::true_type{});
+            __syncthreads();
+        }
+        if constexpr (!PROD && C::owns_row(blk)) {   // this wave holds the diagonal tile: gradient of the block at the current row + 3 CG steps (als.cc:286-346)
             const float pblk = L.pc[blk * 32 + col];
-            const float bi = (blk == R0 ? f00 : f01) + L.hv[blk * 32 + col] + block_sum() + p.reg * pblk;
+            const float bi = (blk == R0 ? f00 : f01) + L.hv[blk * 32 + col] + (blk > 0 ? block_sum() : 0.f) + p.reg * pblk;
             float xr = 0.f, rr = bi, pvr = bi;
             double rsold = static_cast<double>(wave_sum(half == 0 ? rr * rr : 0.f));
             if (rsold > static_cast<double>(p.cg_tol)) {
@@ -2058,13 +2334,13 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
         }
         __syncthreads();
     });
-    for (int e = threadIdx.x; e < VD; e += 64 * W) Pu[e] = L.pc[e];
+    for (int e = threadIdx.x; e < VD; e += 64 * (W + (SPLIT ? 1 : 0))) Pu[e] = L.pc[e];
     __syncthreads();
 }
 
-template <int T, bool BIG>
-__global__ __launch_bounds__(64 * ((T + 1) / 2), 2) void als_wide_kernel(AlsParams p, const AlsWork* __restrict__ work, int n_items,
-                                                                         float* __restrict__ scratch, int finalize) {
+template <int T, bool BIG, bool SPLIT = false>
+__global__ __launch_bounds__((64 * ((T + 1) / 2 + (SPLIT ? 1 : 0))), 2) void als_wide_kernel(AlsParams p, const AlsWork* __restrict__ work, int n_items,
+                                                                                            float* __restrict__ scratch, int finalize) {
     constexpr int W = (T + 1) / 2, VD = 32 * T;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     AlsWideLds L;
@@ -2076,6 +2352,8 @@ __global__ __launch_bounds__(64 * ((T + 1) / 2), 2) void als_wide_kernel(AlsPara
     L.pvs = L.rowres + 32;
     L.red = L.pvs + 32;
     int* s_item = reinterpret_cast<int*>(L.red + 8);
+    L.g1v = L.red + 12;
+    L.ring = reinterpret_cast<u32x4*>(lds + als_wide_ring_offset_floats(VD));
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5, col = lane & 31;
@@ -2087,10 +2365,15 @@ __global__ __launch_bounds__(64 * ((T + 1) / 2), 2) void als_wide_kernel(AlsPara
         const int item = *s_item;
         if (item >= n_items) break;
         const AlsWork wk = work[item];
-        if (wv == 0) als_wide_item<T, 0, BIG>(p, wk, finalize != 0, scratch, L, lane, half, col, nume_k, deno_k);
-        else if (wv == 1) als_wide_item<T, 1, BIG>(p, wk, finalize != 0, scratch, L, lane, half, col, nume_k, deno_k);
-        else if (wv == 2) als_wide_item<T, 2, BIG>(p, wk, finalize != 0, scratch, L, lane, half, col, nume_k, deno_k);
-        else als_wide_item<T, (W > 3 ? 3 : 0), BIG>(p, wk, finalize != 0, scratch, L, lane, half, col, nume_k, deno_k);
+        // SPLIT: the roles (W consumers with different tile counts + the producer) ROTATE over a block's waves from row to row -- the tiles live in
+        // registers only inside a row -- so that every SIMD sees the same mix of work whatever the placement of the waves (with fixed roles both
+        // blocks of a CU had their producer on the same SIMD, whose VALU then bounded the pass: 6.0 ms of 9.6 at d = 160)
+        const int role = SPLIT ? (wv + item) % (W + 1) : wv;
+        if (SPLIT && role == W) als_wide_item<T, W, BIG, SPLIT>(p, wk, finalize != 0, scratch, L, lane, half, col, nume_k, deno_k);   // the producer
+        else if (role == 0) als_wide_item<T, 0, BIG, SPLIT>(p, wk, finalize != 0, scratch, L, lane, half, col, nume_k, deno_k);
+        else if (role == 1) als_wide_item<T, 1, BIG, SPLIT>(p, wk, finalize != 0, scratch, L, lane, half, col, nume_k, deno_k);
+        else if (role == 2) als_wide_item<T, 2, BIG, SPLIT>(p, wk, finalize != 0, scratch, L, lane, half, col, nume_k, deno_k);
+        else als_wide_item<T, (W > 3 ? 3 : 0), BIG, SPLIT>(p, wk, finalize != 0, scratch, L, lane, half, col, nume_k, deno_k);
     }
     if (p.compute_loss) {
         nume_k = wave_sum_f64(nume_k);
@@ -2101,7 +2384,11 @@ __global__ __launch_bounds__(64 * ((T + 1) / 2), 2) void als_wide_kernel(AlsPara
         }
     }
 }
-__host__ __device__ inline size_t als_wide_lds_bytes(int vdim) { return (3 * static_cast<size_t>(vdim) + 4 * 32 + 32 + 32 + 8 + 4) * sizeof(float); }
+// dynamic LDS: 3 vdim | 4 x 32 contrib | 32 | 32 | 8 loss | 4 (ticket) | [SPLIT: vdim g_1, then -- 16-byte aligned -- the two slots of pieces]
+__host__ __device__ inline size_t als_wide_lds_bytes(int vdim, bool split = false) {
+    const size_t base = 3 * static_cast<size_t>(vdim) + 4 * 32 + 32 + 32 + 8 + 4;
+    return (split ? als_wide_ring_offset_floats(vdim) + 2 * (16 * static_cast<size_t>(vdim) + 16) : base) * sizeof(float);
+}
 
 struct AlsHeavy {
     int row, slot;
@@ -2641,14 +2928,47 @@ class AlsHandle : public HandleBase {
             const int T = vdim_ / 32;
             const size_t lds = als_wide_lds_bytes(vdim_);
             int blocks = std::min(wl->n_work, num_cus_ * 2);
+            // "als_wide_split" (default on, T = 5 i.e. vdim 160 -- the top of the reference's own D sweep): the Gramian through the f16 matrix cores at fp32
+            // accuracy, rows gathered once per block by a producer wave (als_wide_item<SPLIT>).  T = 6 compiles and runs (2.3x faster) but one
+            // ill-conditioned tiny case lands at 5.9x the oracle's distance from float64 against 3.4x for the fp32 instruction and the 4x bound: left off
+            // for calls whose weights all fit the f16 path; als_defer_scan_kernel says so (cached per chunk while the values do not change)
+            bool wsplit = wide_split_ && split_f16_ && T == 5 && wl->n_work > 0;
+            if (wsplit) {
+                scan_deferred(*wl, p, wl->n_work);
+                if (wl->n_def > 0) wsplit = false;
+                else if (wl->n_heavy)   // (the scan may have grown scratch_: the heavy rows' slots zeroed above are then gone)
+                    BFH_HIP(hipMemsetAsync(scratch_.get(), 0, static_cast<size_t>(wl->n_heavy) * als_slot_floats(vdim_) * sizeof(float), stream));
+            }
+            if (wsplit) {   // the scale of the split pass, decided on the device (als_gram_kernel's rule), together with the block-interleaved copy of
+                // the other factor the producers gather from; both are kept while that factor does not change (the chunks of one half-epoch share them)
+                if (split_out_.size() < 4) { split_part_.resize(ALS_STAT_BLOCKS); split_out_.resize(4); }
+                const int oside = axis == 0 ? 1 : 0;
+                const size_t nq = static_cast<size_t>(p.op_rows) * vdim_;
+                if (qi_.size() < nq) { qi_.resize(nq); qi_side_ = -1; }
+                if (qi_side_ != oside || qi_ver_ != fver_[oside] || qi_wcut_ != split_wcut_) {
+                    hipLaunchKernelGGL(als_interleave_stats_kernel<5>, dim3(ALS_STAT_BLOCKS), dim3(256), 0, stream, p.Q, static_cast<size_t>(p.op_rows), qi_.get(), split_part_.get());
+                    hipLaunchKernelGGL(als_split_scale_kernel, dim3(1), dim3(64), 0, stream, split_part_.get(), ALS_STAT_BLOCKS, split_wcut_, split_out_.get());
+                    BFH_HIP(hipGetLastError());
+                    qi_side_ = oside; qi_ver_ = fver_[oside]; qi_wcut_ = split_wcut_;
+                }
+                p.split = split_out_.get();
+                p.Qi = qi_.get();
+            }
+#define BFH_WIDE_L(TT, BG, SP, ITEMS, N, FIN)                                                                                    \
+    hipLaunchKernelGGL((als_wide_kernel<TT, BG, SP>), dim3(std::max(1, std::min(N, num_cus_ * 2))), dim3(64 * ((TT + 1) / 2 + (SP ? 1 : 0))), als_wide_lds_bytes(vdim_, SP), stream, p, ITEMS, N, scratch_.get(), FIN)
 #define BFH_WIDE(TT, ITEMS, N, FIN)                                                                                              \
     do {                                                                                                                         \
-        if (big) hipLaunchKernelGGL((als_wide_kernel<TT, true>), dim3(std::max(1, std::min(N, num_cus_ * 2))), dim3(64 * ((TT + 1) / 2)), lds, stream, p, ITEMS, N, scratch_.get(), FIN); \
-        else hipLaunchKernelGGL((als_wide_kernel<TT, false>), dim3(std::max(1, std::min(N, num_cus_ * 2))), dim3(64 * ((TT + 1) / 2)), lds, stream, p, ITEMS, N, scratch_.get(), FIN);   \
+        if (big) BFH_WIDE_L(TT, true, false, ITEMS, N, FIN);                                                                     \
+        else BFH_WIDE_L(TT, false, false, ITEMS, N, FIN);                                                                        \
+    } while (0)
+#define BFH_WIDE_S(TT, ITEMS, N, FIN)                                                                                            \
+    do {                                                                                                                         \
+        if (big) BFH_WIDE_L(TT, true, true, ITEMS, N, FIN);                                                                      \
+        else BFH_WIDE_L(TT, false, true, ITEMS, N, FIN);                                                                         \
     } while (0)
 #define BFH_WIDE_T(ITEMS, N, FIN)                  \
     do {                                           \
-        if (T == 5) BFH_WIDE(5, ITEMS, N, FIN);    \
+        if (T == 5) { if (wsplit) BFH_WIDE_S(5, ITEMS, N, FIN); else BFH_WIDE(5, ITEMS, N, FIN); }    \
         else if (T == 6) BFH_WIDE(6, ITEMS, N, FIN); \
         else if (T == 7) BFH_WIDE(7, ITEMS, N, FIN); \
         else BFH_WIDE(8, ITEMS, N, FIN);           \
@@ -2674,7 +2994,9 @@ class AlsHandle : public HandleBase {
                 BFH_HIP(hipGetLastError());
             }
 #undef BFH_WIDE_T
+#undef BFH_WIDE_S
 #undef BFH_WIDE
+#undef BFH_WIDE_L
         } else if (code_ == 8) {
             const int bs = block_size_ < d_ ? block_size_ : d_;
             const int KB = (bs + 63) / 64;
@@ -2889,6 +3211,7 @@ class AlsHandle : public HandleBase {
         else if (name == "auto_resident") auto_resident_ = v != 0;
         else if (name == "pin_host") pin_host_ = v != 0;
         else if (name == "als_v1") force_v1_ = v != 0;
+        else if (name == "als_wide_split") wide_split_ = v != 0;         // 128 < vdim <= 192: 1 = split-f16 Gramian in als_wide_kernel (default), 0 = the fp32 instruction
         else if (name == "als_debug") debug_ = static_cast<int>(v);
         else if (name == "als_split_wcut") split_wcut_ = static_cast<float>(v);   // weights above this take the fp32 side path (default 2^15; tests lower it)
         else if (name == "als_split_f16") split_f16_ = v != 0;             // 0: the in-place iALS++ rows keep the fp32 matrix instruction
@@ -2953,6 +3276,7 @@ class AlsHandle : public HandleBase {
     DevBuf<int> ticket_;
     Axis ax_[2];
     bool force_v1_ = false;
+    bool wide_split_ = true;
     int debug_ = 0;
     bool no_inreg_ = false;
     bool split_f16_ = true;
