@@ -2318,12 +2318,14 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
                     ap += __shfl_xor(ap, 32, 64);
                     ap += p.reg * pvr;
                     const float pap = wave_sum(half == 0 ? pvr * ap : 0.f);
-                    const float step_size = static_cast<float>(rsold / static_cast<double>(pap));
+                    // als.cc:328: double / float rounded to float.  Both operands hold float values, and a quotient of two floats taken in double
+                    // and rounded to float IS the correctly rounded float quotient (53 >= 2 * 24 + 2): one fp32 division, same bits (als_ialspp_inreg)
+                    const float step_size = static_cast<float>(rsold) / pap;
                     xr += step_size * pvr;
                     rr -= step_size * ap;
                     const double rsnew = static_cast<double>(wave_sum(half == 0 ? rr * rr : 0.f));
                     if (rsnew < static_cast<double>(p.cg_tol)) break;
-                    pvr = rr + static_cast<float>(rsnew / rsold) * pvr;
+                    pvr = rr + (static_cast<float>(rsnew) / static_cast<float>(rsold)) * pvr;
                     rsold = rsnew;
                 }
             }
