@@ -151,8 +151,17 @@ CASES = {
     #        overlap slack)
     "bench": (dict(lr=0.002, min_lr=0.0001), 3, (8, 64), {"loss": (0.01, 3.0), "P": (0.02, 3.0), "Q": (0.02, 3.0), "Qb": (0.02, 1.0),
                                                            "prec10": (0.03, 3.0)}, 0.10),
-    "lr0.05": (dict(lr=0.05, min_lr=0.05), 24, (8, 16), {"loss": (0.09, 3.0), "P": (0.02, 3.0), "Q": (0.05, 3.0), "Qb": (0.07, 3.0),
+    # round 5: |Q| / |Qb| bounds 5 % / 7 % -> 3 % / 5 %: the walk sits at +2.0 % / +3.6 % on every box since round 2 (110.37 .. 110.42 vs 108.24; 94.8 .. 94.95 vs
+    # 91.57) -- a systematic offset of the schedule, which round 5's attempt to remove the atomics did not touch (it diverged: DESIGN 4.1)
+    "lr0.05": (dict(lr=0.05, min_lr=0.05), 24, (8, 16), {"loss": (0.09, 3.0), "P": (0.02, 3.0), "Q": (0.03, 3.0), "Qb": (0.05, 3.0),
                                                           "prec10": (0.30, 3.0)}, 0.45),
+    # the reference's OWN BPRMF benchmark setting (benchmark/models.py:86-93): lr 0.05 decaying to 0.0001 over 10 iterations.  The run ends inside the
+    # growth transient of the factors (they double per epoch while the lr lasts; any parallel schedule grows ~1.85x where 8 threads grow 2.05x, see
+    # above), so the norms at the end differ by the epoch the walk trails -- measured (profiles/r05_bpr_drift_study.txt): loss 0.1976 vs 0.1924 / 0.1924,
+    # |P| 8.71 vs 10.13 / 9.28, |Q| 4.98 vs 5.53 / 5.05, |Qb| 147.6 vs 183.0 / 183.0, precision@10 0.728 vs 0.769 / 0.747, overlap 0.65 vs 0.80.
+    # Bounds = those distances with a margin; the case is here so that the setting the reference publishes its numbers with is RUN against the oracle.
+    "refbench": (dict(lr=0.05, min_lr=0.0001), 10, (8, 16), {"loss": (0.04, 3.0), "P": (0.15, 3.0), "Q": (0.12, 3.0), "Qb": (0.25, 3.0),
+                                                              "prec10": (0.08, 3.0)}, 0.22),
 }
 
 
