@@ -1150,7 +1150,7 @@ def run_extras(args, csr, out):
                      ("sppmi_ml20m_stream_w5", extra_sppmi), ("coo_to_csr_ml20m", extra_ingest), ("text_to_csr_2m_lines", extra_text_ingest),
                      # the top of the reference's own D-sweep (benchmark/README.md:97): d = 160, block 32 -> the wide ALS kernel (T = 5)
                      ("als_ml20m_d160", lambda c, seed, cpu: extra_als_wide(c, seed, 160))):
-        if args.only_extra and name not in args.only_extra:
+        if (args.only_extra and name not in args.only_extra) or name in args.skip_extra:
             continue
         try:
             extra[name] = fn(csr, args.seed, cpu=cpu)
@@ -1380,6 +1380,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurements (N=1)")
     ap.add_argument("--only-extra", action="append", default=[], help="run only these extras (name as in bench_extra.json's `extra`)")
+    ap.add_argument("--skip-extra", action="append", default=[], help="leave these extras out (scripts/gpu_profile.sh: the BPRMF lr-0.05 extra launches the "
+                                                                     "headline kernel under other settings, which would mix into its per-kernel average)")
     ap.add_argument("--mode", action="append", default=[], help="backend knob name=value (e.g. hogwild_atomic=0)")
     return ap.parse_args(argv)
 

@@ -159,8 +159,10 @@ CASES = {
     # growth transient of the factors (they double per epoch while the lr lasts; any parallel schedule grows ~1.85x where 8 threads grow 2.05x, see
     # above), so the norms at the end differ by the epoch the walk trails -- measured (profiles/r05_bpr_drift_study.txt): loss 0.1976 vs 0.1924 / 0.1924,
     # |P| 8.71 vs 10.13 / 9.28, |Q| 4.98 vs 5.53 / 5.05, |Qb| 147.6 vs 183.0 / 183.0, precision@10 0.728 vs 0.769 / 0.747, overlap 0.65 vs 0.80.
-    # Bounds = those distances with a margin; the case is here so that the setting the reference publishes its numbers with is RUN against the oracle.
-    "refbench": (dict(lr=0.05, min_lr=0.0001), 10, (8, 16), {"loss": (0.04, 3.0), "P": (0.15, 3.0), "Q": (0.12, 3.0), "Qb": (0.25, 3.0),
+    # On the GPU box's 256 cores the oracle pair itself lands elsewhere (|P| 10.55 / 10.48, |Q| 5.77 / 5.74, precision@10 0.730 / 0.692, a~b overlap 0.60;
+    # the walk: 8.80, 5.03, 0.728, 0.55 -- profiles/r05_gpu_tests.txt).  Bounds = those distances with a margin; the case is here so that the setting the
+    # reference publishes its numbers with is RUN against the oracle, and so that a change of the walk that moves these numbers is seen.
+    "refbench": (dict(lr=0.05, min_lr=0.0001), 10, (8, 16), {"loss": (0.04, 3.0), "P": (0.20, 3.0), "Q": (0.16, 3.0), "Qb": (0.25, 3.0),
                                                               "prec10": (0.08, 3.0)}, 0.22),
 }
 
