@@ -1810,8 +1810,10 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
     using C = AlsWide<T, PROD ? 0 : WV>;
     constexpr int NTW = PROD ? 1 : C::NTW, NB = C::NB, R0 = C::R0, R1 = C::R1, VD = 32 * T, W = C::W;
     constexpr bool TWO = C::TWO && !PROD;
-    // the wave that forms the per-entry residual and h (it needs EVERY block of the q rows): wave 0, which loads them all anyway; SPLIT: the producer
-    constexpr bool HWAVE = SPLIT ? PROD : (WV == 0);
+    // the wave that forms the per-entry residual and h (it needs EVERY block of the q rows): wave 0, which loads them all anyway; SPLIT: the LAST
+    // consumer (the middle tile row(s): fewest tiles), which reads the blocks below its own from the slot as well -- on the producer that chain was a
+    // quarter of an iteration nothing else in the block could overlap
+    constexpr bool HWAVE = SPLIT ? (!PROD && WV == (T + 1) / 2 - 1) : (WV == 0);
     constexpr int UP = 4;
     constexpr unsigned row_bytes = VD * 4u;
     const bool lossk = p.compute_loss && p.axis == 1;
@@ -1827,9 +1829,9 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
     float p0r[HWAVE ? T : 1], hb[HWAVE ? T : 1];
 #pragma unroll
     for (int b = 0; b < (HWAVE ? T : 1); ++b) { p0r[b] = HWAVE ? Pu[b * 32 + col] : 0.f; hb[b] = 0.f; }
-    float g1all[(SPLIT && PROD) ? T : 1];   // SPLIT: the consumers never see q -- g_1 = sum q (loss only) is formed by the producer for every block
+    float g1all[(SPLIT && HWAVE) ? T : 1];   // SPLIT: g_1 = sum q (loss only) is formed for every block by the wave that reads every block
 #pragma unroll
-    for (int b = 0; b < ((SPLIT && PROD) ? T : 1); ++b) g1all[b] = 0.f;
+    for (int b = 0; b < ((SPLIT && HWAVE) ? T : 1); ++b) g1all[b] = 0.f;
     if constexpr (!PROD) {   // accumulators start from FF (+ the heavy row's summed chunk tiles when finalizing); zero for a chunk (SPLIT: FF joins behind the pass)
         const float* Fl = p.FF + half * 4 * VD + col;
         const float* Sl = scratch + static_cast<size_t>(wk.slot >= 0 ? wk.slot : 0) * als_slot_floats(VD) + half * 4 * VD + col;
@@ -1855,7 +1857,7 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
             if (kk < n) {
                 cc = p.keys[wk.kbeg + kk];
                 vvv = p.vals[wk.kbeg + kk];
-                if (lossk && HWAVE) {
+                if (lossk && (SPLIT ? PROD : HWAVE)) {   // once per entry: by the wave that walks the keys
                     const double w = static_cast<double>(vvv * p.alpha);
                     deno_k += w;
                     nume_k += 1.0 + w;
@@ -1901,8 +1903,8 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
             // wave-uniform loop state in SGPRs (the work item came through a vector load; a 64-bit counter in VGPRs is what gets spilled)
             const int n32 = __builtin_amdgcn_readfirstlane(static_cast<int>(n));
             const int ngroups = (p.debug & 16) ? 0 : (n32 + 15) >> 4;     // the last group is padded with weight-0 entries of row 0 ("als_debug" bit 16: timing study, no pass)
-            float* const ringf = reinterpret_cast<float*>(L.ring);   // two slots of [16 entries][vdim] fp32 rows + 16 scales
-            constexpr int SLOTF = 16 * VD + 16;
+            float* const ringf = reinterpret_cast<float*>(L.ring);   // two slots of [16 entries][vdim] fp32 rows + 16 scales S sqrt(alpha v) + 16 weights alpha v
+            constexpr int SLOTF = 16 * VD + 32;
             if constexpr (PROD) {
                 const int bsel = 32 * half;          // lane (col, half) works on the entries 16 g + 8 half + r, r = 0 .. 7, of a chunk
                 // rows come from the block-interleaved copy (Qi[row][T col + b]): a lane's T elements of an entry are contiguous -- T / 4 + 1 load
@@ -1973,7 +1975,7 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
                         pend_c = pend_in ? p.keys[wk.kbeg + kk] : 0;
                         pend_v = pend_in ? p.vals[wk.kbeg + kk] : 0.f;
                     }
-                    float wgt[8], sw[8], y[8];
+                    float wgt[8], sw[8];
                     int cid[8];   // the rows of group pg + 3 (the keys of a chunk's groups 1, 2, 3 + 3 sit in the next chunk)
                     group_ids(cid, g < 1 ? myc : myc_n, (g + 3) & 3);
 #pragma unroll
@@ -1981,35 +1983,6 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
 #pragma unroll
                     for (int r = 0; r < 8; ++r) sw[r] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bsel + 64 * g + 4 * r, __builtin_bit_cast(int, mys)));
                     __builtin_amdgcn_sched_barrier(0);   // (the 24 exchanges stay together, ahead of everything that waits on one of them)
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        y[r] = q[r][0] * p0r[0];
-#pragma unroll
-                        for (int b = 1; b < T; ++b) y[r] = __builtin_fmaf(q[r][b], p0r[b], y[r]);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), 0x128, 0xf, 0xf, false));
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), 0x124, 0xf, 0xf, false));
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), 0x122, 0xf, 0xf, false));
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), 0x121, 0xf, 0xf, false));
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        const float yo = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, y[r]), 0x401F));
-                        const float cial = __builtin_fmaf(wgt[r], y[r] + yo, -wgt[r]);   // alpha v (q.p0 - 1)
-#pragma unroll
-                        for (int b = 0; b < T; ++b) hb[b] = __builtin_fmaf(cial, q[r][b], hb[b]);
-                    }
-                    if (lossk) {   // g_1 = sum q over the real entries (wave-uniform branch)
-#pragma unroll
-                        for (int r = 0; r < 8; ++r) {
-                            const float one = (pg * 16 + 8 * half + r < n32) ? 1.0f : 0.f;
-#pragma unroll
-                            for (int b = 0; b < T; ++b) g1all[b] = __builtin_fmaf(one, q[r][b], g1all[b]);
-                        }
-                    }
                     // the group's rows (fp32) and scales into the slot: [entry 8 half + r][block][col], then the 16 scales -- the consumers cut the
                     // blocks they need themselves (in parallel on their own SIMDs; cutting all T blocks here made this wave the bottleneck: 11.8 ms)
                     float* const dst = ringf + slot * SLOTF + (8 * half) * VD + col;
@@ -2019,7 +1992,10 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
                         for (int b = 0; b < T; ++b) dst[r * VD + b * 32] = q[r][b];
                     if (col == 0) {
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) ringf[slot * SLOTF + 16 * VD + 8 * half + r] = sw[r];
+                        for (int r = 0; r < 8; ++r) {
+                            ringf[slot * SLOTF + 16 * VD + 8 * half + r] = sw[r];
+                            ringf[slot * SLOTF + 16 * VD + 16 + 8 * half + r] = wgt[r];   // alpha v: the residual's weight (last consumer)
+                        }
                     }
                     // the rows of group pg + 3 leave into the set just consumed
                     load_group(q, cid);
@@ -2052,14 +2028,48 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
             } else {
                 __syncthreads();                      // slot 0 is ready
                 for (int jg = 0; jg < ngroups; ++jg) {
-                    const float* const src = ringf + (jg & 1) * SLOTF + (8 * half) * VD + R0 * 32 + col;
+                    constexpr int QB0 = HWAVE ? 0 : R0, NQ = T - QB0, PO = R0 - QB0;   // blocks read from the slot, index of block R0 among them
+                    const float* const src = ringf + (jg & 1) * SLOTF + (8 * half) * VD + QB0 * 32 + col;
                     const float* const ssw = ringf + (jg & 1) * SLOTF + 16 * VD + 8 * half;
-                    float qv[8][NB], sw[8];
+                    float qv[8][NQ], sw[8];
 #pragma unroll
                     for (int r = 0; r < 8; ++r) {
                         sw[r] = ssw[r];
 #pragma unroll
-                        for (int b = 0; b < NB; ++b) qv[r][b] = src[r * VD + b * 32];
+                        for (int b = 0; b < NQ; ++b) qv[r][b] = src[r * VD + b * 32];
+                    }
+                    if constexpr (HWAVE) {   // the residual q.p0 - 1 of every entry, h and (loss) g_1 -- NQ == T here; the eight chains side by side
+                        float wgt[8], y[8];
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            wgt[r] = ssw[16 + r];
+                            y[r] = qv[r][0] * p0r[0];
+#pragma unroll
+                            for (int b = 1; b < T; ++b) y[r] = __builtin_fmaf(qv[r][b], p0r[b], y[r]);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), 0x128, 0xf, 0xf, false));
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), 0x124, 0xf, 0xf, false));
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), 0x122, 0xf, 0xf, false));
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), 0x121, 0xf, 0xf, false));
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            const float yo = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, y[r]), 0x401F));
+                            const float cial = __builtin_fmaf(wgt[r], y[r] + yo, -wgt[r]);   // alpha v (q.p0 - 1)
+#pragma unroll
+                            for (int b = 0; b < T; ++b) hb[b] = __builtin_fmaf(cial, qv[r][b], hb[b]);
+                        }
+                        if (lossk) {   // g_1 = sum q over the real entries (wave-uniform branch)
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) {
+                                const float one = (jg * 16 + 8 * half + r < n32) ? 1.0f : 0.f;
+#pragma unroll
+                                for (int b = 0; b < T; ++b) g1all[b] = __builtin_fmaf(one, qv[r][b], g1all[b]);
+                            }
+                        }
                     }
                     u32x4 H[NB], Lo[NB];
 #pragma unroll
@@ -2067,7 +2077,7 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
 #pragma unroll
                         for (int j2 = 0; j2 < 4; ++j2) {
                             unsigned h_, l_;
-                            als_split_pair_mix(qv[2 * j2][b], sw[2 * j2], qv[2 * j2 + 1][b], sw[2 * j2 + 1], h_, l_);
+                            als_split_pair_mix(qv[2 * j2][PO + b], sw[2 * j2], qv[2 * j2 + 1][PO + b], sw[2 * j2 + 1], h_, l_);
                             H[b][j2] = h_;
                             Lo[b][j2] = l_;
                         }
@@ -2163,7 +2173,7 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
 #pragma unroll
         for (int b = 0; b < T; ++b) hb[b] += __shfl_xor(hb[b], 32, 64);
     }
-    if constexpr (SPLIT && PROD) {
+    if constexpr (SPLIT && HWAVE) {
 #pragma unroll
         for (int b = 0; b < T; ++b) g1all[b] += __shfl_xor(g1all[b], 32, 64);
     }
@@ -2185,7 +2195,7 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
                 for (int b = 0; b < T; ++b) atomic_add_f32(S + VD * VD + b * 32 + col, hb[b]);
             }
             if constexpr (SPLIT) {
-                if constexpr (PROD) {
+                if constexpr (HWAVE) {
                     if (lossk) {
 #pragma unroll
                         for (int b = 0; b < T; ++b) atomic_add_f32(S + VD * VD + VD + b * 32 + col, g1all[b]);
@@ -2215,7 +2225,7 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
             for (int b = 0; b < T; ++b) L.hv[b * 32 + col] = hb[b];
         }
     }
-    if constexpr (SPLIT && PROD) {   // g_1 of every block for the waves that own the rows (loss only)
+    if constexpr (SPLIT && HWAVE) {   // g_1 of every block for the waves that own the rows (loss only)
         if (!finalize && half == 0 && lossk) {
 #pragma unroll
             for (int b = 0; b < T; ++b) L.g1v[b * 32 + col] = g1all[b];
@@ -2389,7 +2399,7 @@ __global__ __launch_bounds__((64 * ((T + 1) / 2 + (SPLIT ? 1 : 0))), 2) void als
 // dynamic LDS: 3 vdim | 4 x 32 contrib | 32 | 32 | 8 loss | 4 (ticket) | [SPLIT: vdim g_1, then -- 16-byte aligned -- the two slots of pieces]
 __host__ __device__ inline size_t als_wide_lds_bytes(int vdim, bool split = false) {
     const size_t base = 3 * static_cast<size_t>(vdim) + 4 * 32 + 32 + 32 + 8 + 4;
-    return (split ? als_wide_ring_offset_floats(vdim) + 2 * (16 * static_cast<size_t>(vdim) + 16) : base) * sizeof(float);
+    return (split ? als_wide_ring_offset_floats(vdim) + 2 * (16 * static_cast<size_t>(vdim) + 32) : base) * sizeof(float);
 }
 
 struct AlsHeavy {
