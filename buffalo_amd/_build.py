@@ -13,7 +13,7 @@ LIB_TEST = os.path.join(HERE, "libbuffalo_hip_test.so")
 SOURCES = ["common.hip", "comm.hip", "sgd_base.hip", "bpr.hip", "warp.hip", "als.hip", "topk.hip", "ingest.hip", "sppmi.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall",
-         "-Wno-unused-function", "-Wno-unused-result"] + os.environ.get("BFH_EXTRA_FLAGS", "").split()   # e.g. -DBFH_WITH_ALS_SOLO (rebuild with --force)
+         "-Wno-unused-function", "-Wno-unused-result"] + os.environ.get("BFH_EXTRA_FLAGS", "").split()   # extra -D switches for experiments (rebuild with --force)
 
 
 FLAGS_STAMP = os.path.join(CSRC, ".build_flags")

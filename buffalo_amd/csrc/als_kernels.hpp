@@ -2506,9 +2506,6 @@ __global__ __launch_bounds__(256) void als_solve_kernel(AlsParams p, const AlsHe
 
 }  // namespace bfh
 #include "als_pc.hpp"
-#ifdef BFH_WITH_ALS_SOLO   // experimental kernel of round 4 (als_solo.hpp), not part of the default build: BFH_EXTRA_FLAGS=-DBFH_WITH_ALS_SOLO
-#include "als_solo.hpp"
-#endif
 namespace bfh {
 
 // ------------------------------------------------------------------------------------------------
@@ -2766,7 +2763,7 @@ class AlsHandle : public HandleBase {
             // producer / consumer pairs (als_pc.hpp): the default for the in-place iALS++ rows at d = 64 / 96 / 128
             // (measured on the ML-20M shape, profiles/r04_als_pc_steps.txt: d = 128 4.53 vs 5.08 ms, d = 96 3.47 vs 3.95, d = 64 2.47 vs 2.06 --
             //  at T = 2 round 3's kernel already runs two waves per SIMD, and the pairs only add their hand-off: "als_pc" = 2 forces them)
-            bool use_pc = items > 0 && inreg && split_f16_ && T <= 4 && (pc_ >= 2 ? T >= 2 : (pc_ == 1 && T >= 3));   // 3: als_solo_kernel (one wave per row, two per SIMD)
+            bool use_pc = items > 0 && inreg && split_f16_ && T <= 4 && (pc_ >= 2 ? T >= 2 : (pc_ == 1 && T >= 3));
             if (use_pc) {
                 float* const before = scratch_.get();
                 scan_deferred(*wl, p, items);
@@ -2832,40 +2829,14 @@ class AlsHandle : public HandleBase {
         hipLaunchKernelGGL((als_pc_kernel<TT, BG, LS>), dim3(pblocks), dim3(512), AlsPc<TT>::LDS_B, stream, p, wl->work.get(), items, scratch_.get(), \
                            qi_.get(), wl->defer.get(), pc_err_.get());                                                              \
     } while (0)
-#ifdef BFH_WITH_ALS_SOLO
-#define BFH_SOLO(TT, BG, LS)                                                                                                        \
-    do {                                                                                                                            \
-        const int sblocks = std::max(1, std::min((items + 7) / 8, num_cus_));                                                       \
-        BFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(als_solo_kernel<TT, BG, LS>), hipFuncAttributeMaxDynamicSharedMemorySize, AlsSolo<TT>::LDS_B)); \
-        hipLaunchKernelGGL((als_solo_kernel<TT, BG, LS>), dim3(sblocks), dim3(512), AlsSolo<TT>::LDS_B, stream, p, wl->work.get(), items, scratch_.get(), \
-                           qi_.get(), wl->defer.get(), pc_err_.get());                                                              \
-    } while (0)
-#endif
 #define BFH_PC_T(TT)                                 \
     do {                                             \
         if (big) { if (lk) BFH_PC(TT, true, true); else BFH_PC(TT, true, false); }     \
         else { if (lk) BFH_PC(TT, false, true); else BFH_PC(TT, false, false); }       \
     } while (0)
-#ifdef BFH_WITH_ALS_SOLO
-#define BFH_SOLO_T(TT)                               \
-    do {                                             \
-        if (big) { if (lk) BFH_SOLO(TT, true, true); else BFH_SOLO(TT, true, false); }     \
-        else { if (lk) BFH_SOLO(TT, false, true); else BFH_SOLO(TT, false, false); }       \
-    } while (0)
-#endif
-                // "als_pc" = 3: als_solo_kernel (one wave per row, two per SIMD, als_solo.hpp) at d = 128.  (Its d = 96 instantiation -- 12-byte
-                // DMA loads -- aborted on first contact, profiles/r04_als_solo_first_contact.txt, and is not dispatched: the pairs take d = 96.)
-#ifdef BFH_WITH_ALS_SOLO
-                if (pc_ == 3 && T == 4) BFH_SOLO_T(4);
-                else
-#endif
                 if (T == 2) BFH_PC_T(2);
                 else if (T == 3) BFH_PC_T(3);
                 else BFH_PC_T(4);
-#ifdef BFH_WITH_ALS_SOLO
-#undef BFH_SOLO_T
-#undef BFH_SOLO
-#endif
 #undef BFH_PC_T
 #undef BFH_PC
                 BFH_HIP(hipGetLastError());
@@ -3228,13 +3199,9 @@ class AlsHandle : public HandleBase {
         else if (name == "als_split_wcut") split_wcut_ = static_cast<float>(v);   // weights above this take the fp32 side path (default 2^15; tests lower it)
         else if (name == "als_split_f16") split_f16_ = v != 0;             // 0: the in-place iALS++ rows keep the fp32 matrix instruction
         else if (name == "als_pc") {
-#ifdef BFH_WITH_ALS_SOLO
-            BFH_REQUIRE(v >= 0 && v <= 3, "als_pc must be 0, 1, 2 or 3");
-#else
-            BFH_REQUIRE(v >= 0 && v <= 2, "als_pc must be 0, 1 or 2 (3 = als_solo_kernel needs a build with -DBFH_WITH_ALS_SOLO)");
-#endif
+            BFH_REQUIRE(v >= 0 && v <= 2, "als_pc must be 0, 1 or 2");
             pc_ = static_cast<int>(v);
-        }   // 0: round 3's wave-per-row split kernel; 1: producer / consumer pairs where they win (d = 96, 128); 2: also at d = 64; 3: als_solo_kernel at d = 128 (pairs elsewhere)
+        }   // 0: round 3's wave-per-row split kernel; 1: producer / consumer pairs where they win (d = 96, 128); 2: also at d = 64
         else if (name == "als_inreg") no_inreg_ = v == 0;                 // 0: iALS++ rows go through the scratch + solve kernel instead of the in-register solve
         else if (name == "timing") timing = v != 0;
         else throw Error(BFH_ERR_INVALID, "unknown mode '" + name + "'");

@@ -62,12 +62,7 @@ def rel(a, b):
     return float(np.abs(a - b).max() / np.abs(b).max())
 
 
-SOLO = True   # als_pc = 3 (als_solo_kernel, d = 128) exists only in a build with -DBFH_WITH_ALS_SOLO
-try:
-    _g = CyALS(); _p = bench._opt_file(OPT); assert _g.init(_p); os.unlink(_p); _g.set_mode("als_pc", 3); del _g
-except Exception:
-    SOLO = False
-for m in ({"als_pc": 0}, {"als_pc": 1}) + (({"als_pc": 3}, {"als_pc": 1}, {"als_pc": 3}) if SOLO else ()):
+for m in ({"als_pc": 0}, {"als_pc": 1}):
     timing(m)
 if "--ablate" in sys.argv:   # results are wrong with these, timings only
     for bits, what in ((1, "no block solve"), (16, "no matrix instructions"), (17, "neither"), (17 + 32, "neither, producer without arithmetic"),
@@ -86,7 +81,7 @@ g.synchronize(True)
 Pw, Qw = P.copy(), Q.copy()
 del g
 out = {}
-for name, m in (("wave", {"als_pc": 0}), ("pc", {"als_pc": 1})) + ((("solo", {"als_pc": 3}),) if SOLO else ()):
+for name, m in (("wave", {"als_pc": 0}), ("pc", {"als_pc": 1})):
     P1, Q1 = Pw.copy(), Qw.copy()
     g = make(P1, Q1, m)
     half(g, 0)
@@ -97,5 +92,3 @@ for name, m in (("wave", {"als_pc": 0}), ("pc", {"als_pc": 1})) + ((("solo", {"a
     out[name] = (Pmid, Q1.copy())
     del g
 print("one epoch from the same warm state, producer/consumer vs wave-per-row: P max-rel %.3e   Q max-rel %.3e" % (rel(out["pc"][0], out["wave"][0]), rel(out["pc"][1], out["wave"][1])), flush=True)
-if SOLO:
-    print("one epoch from the same warm state, solo vs wave-per-row:              P max-rel %.3e   Q max-rel %.3e" % (rel(out["solo"][0], out["wave"][0]), rel(out["solo"][1], out["wave"][1])), flush=True)

@@ -110,7 +110,7 @@ CASES = [
                           (160, dict(optimizer="ialspp"), "ml100k"), (160, dict(optimizer="ialspp"), "heavy"),
                           (160, dict(optimizer="ialspp"), "outliers"), (160, dict(optimizer="ialspp"), "scales"),
                           (192, dict(optimizer="ialspp"), "ml100k"), (192, dict(optimizer="ialspp"), "heavy")])
-@pytest.mark.parametrize("design", ["inreg", "scratch", "fp32", "wave", "solo"])
+@pytest.mark.parametrize("design", ["inreg", "scratch", "fp32", "wave"])
 def test_half_epochs_match_oracle(oracle, d, kw, shape, design):
     """Every half-epoch starts from bit-identical factors (the GPU model is re-synchronised to the
     oracle's after each comparison), so differences are the kernels' own.  Truncated fp32 CG is
@@ -129,8 +129,6 @@ def test_half_epochs_match_oracle(oracle, d, kw, shape, design):
         pytest.skip("'fp32' = the in-register solve with the fp32 matrix instruction instead of the split-f16 pass: d = 128 cases (d = 160 / 192: als_wide_split 0)")
     if design == "wave" and not (d in (64, 96, 128) and kw.get("block_size", 32) == 32 and kw.get("optimizer") == "ialspp"):
         pytest.skip("'wave' = round 3's wave-per-row split-f16 kernel instead of the producer / consumer pairs: in-place iALS++ cases")
-    if design == "solo" and not (d == 128 and kw.get("block_size", 32) == 32 and kw.get("optimizer") == "ialspp"):
-        pytest.skip("'solo' = als_solo_kernel (one wave per row, two per SIMD; als_pc = 3): in-place iALS++ cases at d = 128")
     if shape == "heavy_outliers" and design != "inreg":
         pytest.skip("the heavy + deferred rows case is about the default path's scratch slots")
     if shape == "outliers":
@@ -164,13 +162,7 @@ def test_half_epochs_match_oracle(oracle, d, kw, shape, design):
     obj.set_mode("als_split_f16", int(design != "fp32" or wsplit))
     if wsplit:
         obj.set_mode("als_wide_split", int(design != "fp32"))
-    if design == "solo":
-        try:
-            obj.set_mode("als_pc", 3)
-        except Exception as e:   # the default build does not carry the experimental kernel
-            pytest.skip("als_solo_kernel is not in this build (%s)" % str(e)[:80])
-    else:
-        obj.set_mode("als_pc", 0 if design == "wave" else 2)   # 2: the pairs at d = 64 too (the default leaves T = 2 to the wave-per-row kernel, which is faster there)
+    obj.set_mode("als_pc", 0 if design == "wave" else 2)   # 2: the pairs at d = 64 too (the default leaves T = 2 to the wave-per-row kernel, which is faster there)
     if shape in ("outliers", "heavy_outliers"):
         obj.set_mode("als_split_wcut", 500)   # alpha v = 4 * 2 * 100 and more: past the cut
     if shape == "scales":
@@ -211,7 +203,7 @@ def test_half_epochs_match_oracle(oracle, d, kw, shape, design):
             # lands at 1.3x on the SAME inputs (profiles/r03_als_split_f16.txt).  The default path now sends the rows that hold such
             # weights through the scratch path (als_defer_scan_kernel) and is held to the 2.5x of every other case; the two
             # non-default kernels keep the 10x they were measured at
-            loose = shape == "outliers" and design in ("fp32", "wave")   # ("solo" routes the outliers through the scratch path like "inreg")
+            loose = shape == "outliers" and design in ("fp32", "wave")
             # the wide kernel (128 < vdim <= 256, fp32 matrix instruction across 3-4 waves): 20 of its 21 half-epochs sit at 0.2 .. 2.0x
             # since it forms the gradient residual-first (round 4; 10x before), one -- d = 192, the cold first user half-epoch -- at
             # 3.5x (profiles/r04_als_wide_residual_first.txt): 4x

@@ -74,45 +74,3 @@ def test_pc_kernel_keeps_its_wait_counts_and_registers():
         assert not any(l.startswith("scratch_") for l in ins), [l for l in ins if l.startswith("scratch_")][:4]
     spill = int(re.search(r"als_pc_kernelILi4ELb0ELb0E.*?\.vgpr_spill_count:\s+(\d+)", text, re.S).group(1))
     assert spill <= 48, spill   # the per-row solve spills a few registers; the loops none
-
-
-@pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="needs hipcc")
-def test_solo_kernel_hot_blocks_stay_clean():
-    """als_solo_kernel (csrc/als_solo.hpp, experimental: compiled with -DBFH_WITH_ALS_SOLO) lives on three properties of the compiler's
-    output (profiles/r04_als_solo_first_contact.txt): its rows travel by global_load_lds issued as inline assembly (eight per group, all in
-    one block of the loop), the block that holds the f16 cut and the 30 matrix instructions touches no scratch memory and contains no
-    compiler-generated wait on vector memory (hipcc would put a vmcnt(0) in front of the first ds_read if it knew of the DMA loads), and
-    the whole thing fits 256 registers."""
-    import re
-    import subprocess
-    import tempfile
-    src = ('#include "als_kernels.hpp"\nnamespace bfh {\ntemplate __global__ void als_solo_kernel<4, false, false>(AlsParams, const AlsWork*, int, float*, '
-           'const float*, const int*, int*);\n}\n')
-    with tempfile.TemporaryDirectory() as d:
-        hip, asm = os.path.join(d, "one.hip"), os.path.join(d, "one.s")
-        open(hip, "w").write(src)
-        cmd = [HIPCC, "-DBFH_ALS_KERNELS_ONLY", "-DBFH_WITH_ALS_SOLO", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
-               "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "buffalo_amd", "csrc"), "-S", "--cuda-device-only", hip, "-o", asm]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        assert r.returncode == 0, r.stderr[-3000:]
-        text = open(asm).read()
-    i = text.index("als_solo_kernelILi4ELb0ELb0E")
-    body = text[text.index(":", i):text.index(".Lfunc_end", i)]
-    blocks = re.split(r"\n(?=\.LBB\d+_\d+:)", body)
-    compute, dma = [], []
-    for b in blocks:
-        ins = [l.strip() for l in b.split("\n") if l.strip() and not l.strip().startswith(";")]
-        if sum("v_mfma" in l for l in ins) >= 30:
-            compute.append(ins)
-        if sum(l.startswith("global_load_lds_dwordx4") for l in ins) >= 8:
-            dma.append(ins)
-    assert len(compute) == 1 and len(dma) == 2, (len(compute), len(dma))      # the loop's and the prologue's row loads; ONE matrix stream
-    ins = compute[0]
-    assert sum("v_fma_mix" in l for l in ins) == 64, sum("v_fma_mix" in l for l in ins)
-    assert not any(l.startswith("scratch_") for l in ins)
-    assert not any("vmcnt" in l for l in ins), [l for l in ins if "vmcnt" in l]
-    for ins in dma:
-        assert not any(l.startswith("scratch_") for l in ins[:ins.index(next(l for l in ins if l.startswith("global_load_lds_dwordx4")))])
-    vg = int(re.search(r"als_solo_kernelILi4ELb0ELb0E.*?\.vgpr_count:\s+(\d+)", text, re.S).group(1))
-    spill = int(re.search(r"als_solo_kernelILi4ELb0ELb0E.*?\.vgpr_spill_count:\s+(\d+)", text, re.S).group(1))
-    assert vg <= 256 and spill <= 32, (vg, spill)   # the per-row solve spills a few registers; the loop none
