@@ -1803,6 +1803,17 @@ struct AlsWideLds {          // carved from dynamic LDS: 3 vdim | W*32 | 32 | 32
 // reads) and issue l h + h l + h h per tile.  One block barrier per group: the producer fills slot (g + 1) & 1 while the consumers drain
 // slot g & 1.  The accumulators hold S^2 G during the pass and come back (x 1 / S^2, + the FF tile) behind it.  Calls with weights outside
 // the f16 path (als_defer_scan_kernel) keep the fp32 instantiation.
+typedef __attribute__((address_space(1))) float AlsGlobalF;   // a pointer the optimiser lost track of (asm launder) is a FLAT pointer until told otherwise
+
+// The lane id from the hardware, opaque to the optimiser: als_wide_item<SPLIT> runs at three blocks per CU (168 registers), where every
+// lane constant the compiler hoists out of the row loop (col * 4, thread * 4, ...) is spilled across the pass and reloaded from scratch before
+// each of its ~100 uses in the row end -- +12 us per row, the whole gain of the third block.  Re-deriving them behind the pass costs 2 instructions.
+__device__ __forceinline__ int als_fresh_lane() {
+    int x;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(x));
+    return x;
+}
+
 template <int T, int WV, bool BIG, bool SPLIT = false>
 __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork& wk, bool finalize, float* __restrict__ scratch, const AlsWideLds& L,
                                               int lane, int half, int col, double& nume_k, double& deno_k) {
@@ -1833,17 +1844,33 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
 #pragma unroll
     for (int b = 0; b < ((SPLIT && HWAVE) ? T : 1); ++b) g1all[b] = 0.f;
     if constexpr (!PROD) {   // accumulators start from FF (+ the heavy row's summed chunk tiles when finalizing); zero for a chunk (SPLIT: FF joins behind the pass)
-        const float* Fl = p.FF + half * 4 * VD + col;
+        const float* Fl_ = p.FF + half * 4 * VD + col;
         const float* Sl = scratch + static_cast<size_t>(wk.slot >= 0 ? wk.slot : 0) * als_slot_floats(VD) + half * 4 * VD + col;
-        asm volatile("" : "+v"(Fl));
-#pragma unroll
-        for (int s = 0; s < NTW; ++s) {
+        asm volatile("" : "+v"(Fl_));   // (the address arithmetic stays inside the row loop; the cast says "global" again: flat loads otherwise)
+        const AlsGlobalF* Fl = (const AlsGlobalF*)Fl_;
+        // three straight loops behind wave-uniform branches (a per-element select around a load compiles into one two-instruction block per element
+        // with its own wait: 96 taken branches per row and wave on the split path, where the tiles start from zero)
+        auto tile_off = [&](int s, int e) {
             const int a = s < C::N0 ? R0 : R1, b = s < C::N0 ? R0 + s : R1 + (s - C::N0);
+            return (a * 32 + (e & 3) + 8 * (e >> 2)) * VD + b * 32;
+        };
+        if (partial || (SPLIT && !finalize)) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int off = (a * 32 + (e & 3) + 8 * (e >> 2)) * VD + b * 32;
-                acc[s][e] = (partial || (SPLIT && !finalize)) ? 0.f : Fl[off] + (finalize ? Sl[off] : 0.f);
+            for (int s = 0; s < NTW; ++s)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[s][e] = 0.f;
+        } else if (finalize) {   // (heavy rows only: a tile at a time, the loads of all NTW at once would not fit the registers)
+#pragma unroll
+            for (int s = 0; s < NTW; ++s) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[s][e] = Fl[tile_off(s, e)] + Sl[tile_off(s, e)];
+                __builtin_amdgcn_sched_barrier(0);
             }
+        } else {
+#pragma unroll
+            for (int s = 0; s < NTW; ++s)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[s][e] = Fl[tile_off(s, e)];
         }
     }
     if (!finalize) {
@@ -1961,6 +1988,9 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
                 float pend_v = 0.f;
                 bool pend_in = false;
                 auto prepare = [&](float (&q)[8][T], int pg, int slot) {
+#ifdef BFH_ALS_WIDE_STUDY   // (BFH_EXTRA_FLAGS=-DBFH_ALS_WIDE_STUDY: the two branches cost the default build 150 spilled registers and 1 ms per epoch)
+                    if (p.debug & 64) return;   // timing study: the producer only keeps the barriers company (results are wrong)
+#endif
                     const int g = pg & 3;
                     // the chunk after next: its keys are fetched on EVERY preparation (one control-flow path: the compiler counts the loads in flight
                     // exactly; a conditional fetch turns the waits into vmcnt(0)) and USED one preparation later -- the commit below reads what the
@@ -2028,6 +2058,9 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
             } else {
                 __syncthreads();                      // slot 0 is ready
                 for (int jg = 0; jg < ngroups; ++jg) {
+#ifdef BFH_ALS_WIDE_STUDY
+                    if (p.debug & 32) { __syncthreads(); continue; }   // timing study: the consumers only keep the barriers company (results are wrong)
+#endif
                     constexpr int QB0 = HWAVE ? 0 : R0, NQ = T - QB0, PO = R0 - QB0;   // blocks read from the slot, index of block R0 among them
                     const float* const src = ringf + (jg & 1) * SLOTF + (8 * half) * VD + QB0 * 32 + col;
                     const float* const ssw = ringf + (jg & 1) * SLOTF + 16 * VD + 8 * half;
@@ -2108,8 +2141,9 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
 #pragma unroll
                         for (int e = 0; e < 16; ++e) acc[sidx][e] *= sI2;
                 } else {
-                    const float* Fl2 = p.FF + half * 4 * VD + col;
-                    asm volatile("" : "+v"(Fl2));
+                    const float* Fl2_ = p.FF + half * 4 * VD + col;
+                    asm volatile("" : "+v"(Fl2_));
+                    const AlsGlobalF* Fl2 = (const AlsGlobalF*)Fl2_;
 #pragma unroll
                     for (int sidx = 0; sidx < NTW; ++sidx) {
                         const int a = sidx < C::N0 ? R0 : R1, b = sidx < C::N0 ? R0 + sidx : R1 + (sidx - C::N0);
@@ -2167,6 +2201,13 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
             }
         }
     }
+    int tid = threadIdx.x;
+    if constexpr (SPLIT) {   // the row end works on lane constants made HERE (als_fresh_lane)
+        lane = als_fresh_lane();
+        half = lane >> 5;
+        col = lane & 31;
+        tid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 64 + lane;
+    }
     // the two halves hold the k-parities of the same element
     g10 += __shfl_xor(g10, 32, 64); g11 += __shfl_xor(g11, 32, 64);
     if constexpr (HWAVE) {
@@ -2214,7 +2255,7 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
     }
 
     // ---------------- iALS++ across the W waves (als.cc:269-352, see als_ialspp_inreg) ----------------
-    for (int e = threadIdx.x; e < VD; e += 64 * (W + (SPLIT ? 1 : 0))) {
+    for (int e = tid; e < VD; e += 64 * (W + (SPLIT ? 1 : 0))) {
         L.pc[e] = Pu[e];
         L.dl[e] = 0.f;
         if (finalize) L.hv[e] = S[VD * VD + e];
@@ -2346,12 +2387,12 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
         }
         __syncthreads();
     });
-    for (int e = threadIdx.x; e < VD; e += 64 * (W + (SPLIT ? 1 : 0))) Pu[e] = L.pc[e];
+    for (int e = tid; e < VD; e += 64 * (W + (SPLIT ? 1 : 0))) Pu[e] = L.pc[e];
     __syncthreads();
 }
 
 template <int T, bool BIG, bool SPLIT = false>
-__global__ __launch_bounds__((64 * ((T + 1) / 2 + (SPLIT ? 1 : 0))), 2) void als_wide_kernel(AlsParams p, const AlsWork* __restrict__ work, int n_items,
+__global__ __launch_bounds__((64 * ((T + 1) / 2 + (SPLIT ? 1 : 0))), (SPLIT ? 3 : 2)) void als_wide_kernel(AlsParams p, const AlsWork* __restrict__ work, int n_items,
                                                                                             float* __restrict__ scratch, int finalize) {
     constexpr int W = (T + 1) / 2, VD = 32 * T;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -2938,7 +2979,7 @@ class AlsHandle : public HandleBase {
                 p.Qi = qi_.get();
             }
 #define BFH_WIDE_L(TT, BG, SP, ITEMS, N, FIN)                                                                                    \
-    hipLaunchKernelGGL((als_wide_kernel<TT, BG, SP>), dim3(std::max(1, std::min(N, num_cus_ * 2))), dim3(64 * ((TT + 1) / 2 + (SP ? 1 : 0))), als_wide_lds_bytes(vdim_, SP), stream, p, ITEMS, N, scratch_.get(), FIN)
+    hipLaunchKernelGGL((als_wide_kernel<TT, BG, SP>), dim3(std::max(1, std::min(N, num_cus_ * (SP ? 3 : 2)))), dim3(64 * ((TT + 1) / 2 + (SP ? 1 : 0))), als_wide_lds_bytes(vdim_, SP), stream, p, ITEMS, N, scratch_.get(), FIN)
 #define BFH_WIDE(TT, ITEMS, N, FIN)                                                                                              \
     do {                                                                                                                         \
         if (big) BFH_WIDE_L(TT, true, false, ITEMS, N, FIN);                                                                     \

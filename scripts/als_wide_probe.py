@@ -7,12 +7,16 @@ sys.path.insert(0, ROOT)
 import bench
 from buffalo_amd import ingest, synth
 from buffalo_amd.backend import CyALS
-d = int(sys.argv[1]) if len(sys.argv) > 1 else 160
+d = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 160
 csr = bench.load_matrix("ml20m", 7)
 U, I, nnz = csr.num_users, csr.num_items, csr.nnz
 vals = (1 + np.random.default_rng(7).poisson(1.0, size=nnz)).astype(np.float32)
 col = ingest.coo_to_csr(csr.keys, csr.rows(), vals, I, U)
-for name, modes in (("split", {}), ("split, no pass", {"als_debug": 16}), ("fp32", {"als_wide_split": 0})):
+CASES = (("split", {}), ("split, no pass", {"als_debug": 16}), ("fp32", {"als_wide_split": 0}))
+if "--study" in sys.argv:   # "als_debug" bits 32 / 64: consumers / producer reduced to the barriers (timing only)
+    CASES = (("split", {}), ("split, no pass", {"als_debug": 16}), ("consumers idle", {"als_debug": 32}), ("producer idle", {"als_debug": 64}),
+             ("both idle", {"als_debug": 96}))
+for name, modes in CASES:
     P, Q, _ = synth.init_factors(U, I, d, seed=7)
     g = CyALS()
     assert g.init(bench.write_opt(dict(bench.ALS_OPT, d=d)))
