@@ -13,6 +13,10 @@ U, I, nnz = csr.num_users, csr.num_items, csr.nnz
 vals = (1 + np.random.default_rng(7).poisson(1.0, size=nnz)).astype(np.float32)
 col = ingest.coo_to_csr(csr.keys, csr.rows(), vals, I, U)
 CASES = (("split", {}), ("split, no pass", {"als_debug": 16}), ("fp32", {"als_wide_split": 0}))
+if "--split-only" in sys.argv:   # one line: the library in place (a variant build copied over it)
+    CASES = (("split", {}),)
+if "--grid" in sys.argv:         # "als_debug" 1024 (an experiment's host-side switch, not in the tree: profiles/r05_als_wide_d160.txt): two blocks per CU with the three-block binary
+    CASES = (("split", {}), ("split, 2 blocks/CU", {"als_debug": 1024}), ("split, no pass", {"als_debug": 16}), ("split, no pass, 2 blocks/CU", {"als_debug": 1040}))
 if "--study" in sys.argv:   # "als_debug" bits 32 / 64: consumers / producer reduced to the barriers (timing only)
     CASES = (("split", {}), ("split, no pass", {"als_debug": 16}), ("consumers idle", {"als_debug": 32}), ("producer idle", {"als_debug": 64}),
              ("both idle", {"als_debug": 96}))
