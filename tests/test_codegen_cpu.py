@@ -74,3 +74,51 @@ def test_pc_kernel_keeps_its_wait_counts_and_registers():
         assert not any(l.startswith("scratch_") for l in ins), [l for l in ins if l.startswith("scratch_")][:4]
     spill = int(re.search(r"als_pc_kernelILi4ELb0ELb0E.*?\.vgpr_spill_count:\s+(\d+)", text, re.S).group(1))
     assert spill <= 48, spill   # the per-row solve spills a few registers; the loops none
+
+
+@pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="needs hipcc")
+def test_wide_split_kernel_fits_three_blocks_per_cu():
+    """als_wide_kernel<5, ., SPLIT> (d = 160) runs at three blocks per CU, which it owes to properties of the compiler's output that no parity
+    test sees (profiles/r05_als_wide_d160.txt): 168 registers; the matrix loops of the three consumer roles (18 / 18 / 9 instructions per
+    group) and the producer's store blocks free of scratch traffic; no flat loads (a pointer laundered through an asm statement is a FLAT pointer
+    until it is cast back: the FF tiles were read that way); the spills that remain sit in per-row code and stay few -- the row end lost 1.7 ms
+    per epoch when every lane constant was reloaded from scratch before each use (als_fresh_lane)."""
+    import re
+    import subprocess
+    import tempfile
+    src = ('#include "als_kernels.hpp"\nnamespace bfh {\ntemplate __global__ void als_wide_kernel<5, false, true>(AlsParams, const AlsWork*, int, float*, int);\n}\n')
+    with tempfile.TemporaryDirectory() as d:
+        hip, asm = os.path.join(d, "one.hip"), os.path.join(d, "one.s")
+        open(hip, "w").write(src)
+        cmd = [HIPCC, "-DBFH_ALS_KERNELS_ONLY", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
+               "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "buffalo_amd", "csrc"), "-S", "--cuda-device-only", hip, "-o", asm]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
+        text = open(asm).read()
+    name = "als_wide_kernelILi5ELb0ELb1E"
+    i = text.index(name)
+    body = text[text.index(":", i):text.index(".Lfunc_end", i)]
+    meta = text[text.index("amdhsa.kernels"):]
+    vg = int(re.search(name + r".*?\.vgpr_count:\s+(\d+)", meta, re.S).group(1))
+    spill = int(re.search(name + r".*?\.vgpr_spill_count:\s+(\d+)", meta, re.S).group(1))
+    assert vg <= 168, vg              # three waves per SIMD
+    assert spill <= 260, spill        # (226 when written; 350 - 450 cost the row end 1 - 1.5 ms per epoch)
+    assert "flat_load" not in body
+    blocks = re.split(r"\n(?=\.LBB\d+_\d+:)", body)
+    mfma, stores, scratch_total = [], 0, 0
+    for b in blocks:
+        ins = [l.strip() for l in b.split("\n") if l.strip() and not l.strip().startswith(";") and not l.strip().startswith(".")]
+        n_scr = sum(l.startswith("scratch_") for l in ins)
+        scratch_total += n_scr
+        n_mf = sum("v_mfma" in l for l in ins)
+        if n_mf:
+            mfma.append(n_mf)
+            assert n_scr <= 2, (n_mf, n_scr)     # (the 9-instruction role reloads two lane constants per group; the 18s none)
+            if n_mf == 18:
+                assert n_scr == 0
+        if sum(l.startswith("ds_write") for l in ins) >= 20:      # the producer's slot stores
+            stores += 1
+            assert n_scr <= 2, n_scr
+    assert sorted(mfma) == [9, 18, 18, 18] or sorted(mfma) == [9, 18, 18], mfma   # l h + h l + h h per tile: rows {0, 4}, {1, 3} (6 tiles each), {2} (3)
+    assert stores >= 3, stores        # one per row set of the producer's pipeline
+    assert scratch_total <= 230, scratch_total
