@@ -74,9 +74,11 @@ def load_matrix(shape_name, seed):
     return csr
 
 
-def cpu_baseline(csr, target_seconds=12.0):
+def cpu_baseline(csr, target_seconds=12.0, all_cores=False):
     """The oracle (restatement of the reference CPU path, reference's compile flags) timed on this
-    box's host cores over a bounded prefix of the same workload."""
+    box's host cores over a bounded prefix of the same workload.  `all_cores` (--cpu-all-cores): additionally one worker per host core -- on the
+    256-core GPU box that is the reference's contended job queue at HALF the 8-worker rate for 6 s of the default run; measured once
+    (BENCH_r05.json: 3.38 M/s against 7.40 M/s), off by default since round 6."""
     from oracle import oracle as orc
     from buffalo_amd import synth
     orc.build()
@@ -103,11 +105,6 @@ def cpu_baseline(csr, target_seconds=12.0):
         return nnz, dt
 
     probe_users = int(np.searchsorted(csr.indptr, 300000)) + 1
-    nnz0, dt0 = run(probe_users)
-    rate0 = nnz0 / dt0
-    want = int(min(csr.nnz, max(nnz0, rate0 * target_seconds)))
-    n_users = min(csr.num_users, int(np.searchsorted(csr.indptr, want)) + 1)
-    nnz1, dt1 = run(n_users)
     # the reference's own benchmark setting is 8 workers (tests/algo/test_performance.py:53): same port, sized by its own probe
     # (the job queue of the CPU path is contended, so fewer workers can be FASTER than all cores)
     nnz_p, dt_p = run(probe_users, workers=8)
@@ -117,9 +114,14 @@ def cpu_baseline(csr, target_seconds=12.0):
     # is contended: all cores are SLOWER); the all-core run is kept beside it
     out = {"value": nnz8 / dt8, "unit": "updates/s", "cores": 8, "kind": CPU_KIND, "what": CPU_WHAT,
            "sample": "first %d interactions (1 epoch) of the same matrix, 8 std::thread workers (the reference's benchmark setting, "
-                     "tests/algo/test_performance.py:53), %.1f s" % (nnz8, dt8),
-           "value_all_cores": nnz1 / dt1, "all_cores": cores,
-           "sample_all_cores": "first %d users (%d interactions, 1 epoch), %d workers, %.1f s" % (n_users, nnz1, cores, dt1)}
+                     "tests/algo/test_performance.py:53), %.1f s" % (nnz8, dt8)}
+    if all_cores:
+        nnz0, dt0 = run(probe_users)
+        want = int(min(csr.nnz, max(nnz0, nnz0 / dt0 * target_seconds)))
+        n_users = min(csr.num_users, int(np.searchsorted(csr.indptr, want)) + 1)
+        nnz1, dt1 = run(n_users)
+        out.update({"value_all_cores": nnz1 / dt1, "all_cores": cores,
+                    "sample_all_cores": "first %d users (%d interactions, 1 epoch), %d workers, %.1f s" % (n_users, nnz1, cores, dt1)})
     # the bracket: the reference's OWN algo.cc / bpr.cc compiled unmodified on stand-ins for Eigen / json11 / spdlog (oracle/_ref, built in
     # the build container by __graft_entry__.build(); NOT the reference binary -- an Eigen expression evaluates as the stand-in reads it),
     # same sample, same 8 workers
@@ -790,6 +792,9 @@ def compact_line(out, extra_file="bench_extra.json", limit=LINE_LIMIT):
                                           out["cpu_baseline"].get("what", "")), 220)
     if out.get("breakdown"):
         line["breakdown"] = _flat(out["breakdown"], 120)
+    for k in ("rccl_ranks", "transport"):             # N > 1: what the live communicator reports (bfh_comm_size / bfh_comm_transport)
+        if k in out:
+            line[k] = out[k]
     line["extra_file"] = extra_file
     s = json.dumps(line)
     for k in ROOFLINE_OPTIONAL:                       # never needed at today's size; the guard that keeps the driver's record whole
@@ -858,14 +863,13 @@ class Ctx:
             self.local_rank = int(os.environ["BFH_DEVICE_OVERRIDE"])
         torch.cuda.set_device(self.local_rank)
         self.dist = None
-        self.comm_mode = "none"
+        self.comm = None
         if self.world > 1:
             import torch.distributed as dist
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             backend = os.environ.get("BFH_DIST_BACKEND", "gloo" if os.environ.get("BFH_COMM_TRANSPORT") == "shm" else "nccl")
             dist.init_process_group("cpu:gloo,cuda:nccl" if backend == "nccl" else backend)
             self.dist = dist
-            self.comm_mode = os.environ.get("BFH_COMM", "library")   # BFH_COMM=torch: emergency path (bench-only), BPRMF workload
 
     def barrier(self):
         self.torch.cuda.synchronize()
@@ -889,7 +893,8 @@ class Ctx:
         return [float(v) for v in lo], [float(v) for v in t]
 
     def make_comm(self):
-        """The library communicator of this rank (None + reason when it cannot be built: every rank takes the same path)."""
+        """The library communicator of this rank.  There is NO other data plane: a node on which it cannot be built fails the run on every
+        rank (a line the library did not produce is worth nothing) -- the reason goes to stderr."""
         from buffalo_amd.backend import Comm
         torch, dist = self.torch, self.dist
         ok, note, comm = 1, None, None
@@ -898,16 +903,26 @@ class Ctx:
             dist.broadcast(uid, src=0)                           # CPU tensor -> gloo
             comm = Comm(self.world, self.rank, bytes(uid.numpy().tobytes()), self.local_rank)
             comm.self_test()
+            assert comm.size() == self.world, "the communicator reports %d ranks, WORLD_SIZE is %d" % (comm.size(), self.world)
         except Exception as e:
             ok, note = 0, "%s: %s" % (type(e).__name__, e)
         flag = torch.tensor([ok], dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)               # every rank takes the same decision
         if int(flag.item()) != 1:
-            return None, "library communicator unavailable (%s)" % note
-        return comm, None
+            raise RuntimeError("rank %d: the library communicator (bfh_comm_create: RCCL) could not be built on every rank -- %s"
+                               % (self.rank, note or "another rank failed"))
+        self.comm = comm
+        return comm
 
     def transport(self):
-        return os.environ.get("BFH_COMM_TRANSPORT", "RCCL over xGMI")
+        """What the live communicator says it runs on ("rccl 2.x.y"; the one-GPU rehearsal: "shm-test")."""
+        return self.comm.transport() if self.comm is not None else "none"
+
+    def comm_keys(self):
+        """Top-level scalars of every N > 1 line: the proof that the data plane saw N ranks (bfh_comm_size = ncclCommCount of the live communicator)."""
+        if self.comm is None:
+            return {}
+        return {"rccl_ranks": self.comm.size(), "transport": self.comm.transport()}
 
     def close(self):
         if self.dist is not None:
@@ -983,7 +998,6 @@ def run_bpr(args, ctx):
     from buffalo_amd.backend import CyBPR
     from buffalo_amd.dist import shard_csr
     world, rank, local_rank = ctx.world, ctx.rank, ctx.local_rank
-    comm_mode = ctx.comm_mode
 
     csr = load_matrix(args.shape, args.seed)
     U, I, nnz = csr.num_users, csr.num_items, csr.nnz
@@ -1022,36 +1036,15 @@ def run_bpr(args, ctx):
     obj.set_cumulative_table(np.zeros(I, np.int64), I)
     obj.set_resident_csr(ip, keys)        # inputs resident in HBM before the timed region starts
     obj.set_shard(nnz_off, world)
-    comm, comm_note = None, None
-    if comm_mode == "library":
-        comm, comm_note = ctx.make_comm()
-        if comm is not None:
-            obj.set_comm(comm)
-        else:
-            comm_mode = "torch"
-            comm_note += ": fell back to torch.distributed"
-    fallback = None
-    if world > 1 and comm_mode == "torch":
-        # emergency path (the library's communicator could not be built on this node): the blocking delta all-reduce
-        # T <- Z + sum_r (T_r - Z) on the backend's Q / Qb through torch.distributed.  Not the product path; labelled in `config`.
-        tq, tb = obj.device_tensor("Q", (I, D)), obj.device_tensor("Qb", (I,))
-        fallback = [(t, torch.empty_like(t)) for t in (tq, tb)]
+    comm = None
+    if world > 1:
+        comm = ctx.make_comm()                 # raises on every rank when RCCL is unavailable: no torch.distributed data path
+        obj.set_comm(comm)
     edges = np.linspace(0, n_local_users, (args.minibatches if world > 1 else 1) + 1).astype(int)
 
     def step():
         for a, b in zip(edges[:-1], edges[1:]):
-            if fallback is not None:
-                for t, z in fallback:
-                    z.copy_(t)
-                torch.cuda.current_stream().synchronize()
             obj.add_jobs(int(a), int(b), ip, None)          # an empty chunk still enters the call's collectives
-            if fallback is not None:
-                torch.cuda.synchronize()
-                for t, z in fallback:
-                    t.sub_(z)
-                    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-                    t.add_(z)
-                torch.cuda.current_stream().synchronize()
         obj.update_parameters()
 
     # the exchange still in flight belongs to the timed region
@@ -1091,10 +1084,8 @@ def run_bpr(args, ctx):
                                % (opt["lr"], opt["min_lr"], steps + warmup, opt["num_negative_samples"], args.shape, U, I, nnz,
                                   "" if args.scaling == "strong" or world == 1 else " per GPU", D),
                    "lr": opt["lr"], "min_lr": opt["min_lr"], "num_negative_samples": opt["num_negative_samples"], "optimizer": "sgd",
-                   "parallelism": "1 GPU" if world == 1 else "dp%d: users sharded, Q replicated, %.1f delta all-reduce/epoch (%s)"
-                                  % (world, (st["exchanges"] / max(steps, 1)) if comm is not None else args.minibatches,
-                                     ("inside the library, transport %s" % ctx.transport()) if comm is not None
-                                     else (comm_note or "EMERGENCY PATH through torch.distributed")),
+                   "parallelism": "1 GPU" if world == 1 else "dp%d: users sharded, Q replicated, %.1f delta all-reduce/epoch (inside the library, transport %s)"
+                                  % (world, st["exchanges"] / max(steps, 1), ctx.transport()),
                    "hogwild": {"0": "write-through (sc1) racy stores on item rows", "1": "fp32 atomics on item rows",
                                "2": "per-XCD item-factor replicas (plain stores through the XCD's L2, merged by the delta rule "
                                     "%.1f times per epoch); popular rows stay chip-wide on fp32 atomics"
@@ -1118,6 +1109,7 @@ def run_bpr(args, ctx):
                                                  / 1e9 / HBM_PEAK_GBS)},
         "epoch_ms": elapsed / steps * 1e3,
     }
+    out.update(ctx.comm_keys())
     if traffic:
         out["roofline"]["traffic_frac"] = traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
     if breakdown is not None:
@@ -1132,7 +1124,7 @@ def run_bpr(args, ctx):
             out["roofline"]["measured_stream"] = {"error": "%s: %s" % (type(e).__name__, e)}
     del obj
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(csr)
+        out["cpu_baseline"] = cpu_baseline(csr, all_cores=args.cpu_all_cores)
     if world == 1 and not args.no_extra:
         out["extra"] = run_extras(args, csr, out)
     return out
@@ -1219,8 +1211,7 @@ def run_warp_c5(args, ctx):
     g.set_shard(u0 * deg, world)
     comm = None
     if world > 1:
-        comm, note = ctx.make_comm()
-        assert comm is not None, note          # no emergency path for this workload
+        comm = ctx.make_comm()
         g.set_comm(comm)
     n_local = u1 - u0
 
@@ -1267,6 +1258,7 @@ def run_warp_c5(args, ctx):
                         "traffic_source": "profiles/warp_pmc_latest.json (rocprofv3 --pmc passes of an earlier one-GPU run of this workload)"},
            "breakdown": {"trial_kernel_ms_min_rank": lo[0] / K, "trial_kernel_ms": hi[0] / K, "sort_and_gather_ms": hi[1] / K, "optimizer_ms": hi[2] / K,
                          "allreduce_ms": hi[3] / K, "what": "per step; max over ranks unless named min"}}
+    out.update(ctx.comm_keys())
     if world == 1 and tr.get("hbm_bytes_per_epoch"):
         out["roofline"]["traffic_frac"] = tr["hbm_bytes_per_epoch"] / ((hi[0] + hi[1] + hi[2]) / K * 1e-3) / 1e9 / HBM_PEAK_GBS
     if world == 1 and not args.no_cpu_baseline:
@@ -1298,8 +1290,7 @@ def run_als(args, ctx):
     g.set_resident_csr(1, col["indptr"], col["key"], col["val"])
     g.set_mode("als_writeback", 0)
     if world > 1:
-        comm, note = ctx.make_comm()
-        assert comm is not None, note
+        comm = ctx.make_comm()
         g.set_comm(comm)
         dp = CommDataParallelALS(g, comm, (csr.indptr, col["indptr"]), U, I)
         step = dp.epoch
@@ -1318,7 +1309,8 @@ def run_als(args, ctx):
     K = max(args.steps, 1)
     alg_bytes = 2 * nnz * (4 * D + 8) + (U + I) * (8 * D + 8) + (U + I) * 4 * D     # SURVEY 8(d) B_als, both half-epochs, whole job
     kernel_s = hi[0] / K * 1e-3
-    return {"metric": "ALS training throughput (interactions/s), ML-20M-shaped synthetic, d=128 (iALS++)",
+    return {**ctx.comm_keys(),
+            "metric": "ALS training throughput (interactions/s), ML-20M-shaped synthetic, d=128 (iALS++)",
             "value": 2.0 * nnz * args.steps / elapsed, "unit": "interactions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32 (split-f16 Gramian)",
             "data": "synthetic",
@@ -1378,6 +1370,7 @@ def parse_args(argv=None):
     ap.add_argument("--minibatches", type=int, default=1, help="all-reduce points per epoch (N>1)")
     ap.add_argument("--c5-users", type=int, default=0, help="warp_c5: number of users instead of 10 M (tests on shared boxes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-all-cores", action="store_true", help="also time the oracle with one worker per host core (6 s on the 256-core box; off by default)")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurements (N=1)")
     ap.add_argument("--only-extra", action="append", default=[], help="run only these extras (name as in bench_extra.json's `extra`)")
     ap.add_argument("--skip-extra", action="append", default=[], help="leave these extras out (scripts/gpu_profile.sh: the BPRMF lr-0.05 extra launches the "

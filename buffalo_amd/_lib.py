@@ -75,6 +75,7 @@ SIGNATURES = {
     "bfh_comm_destroy": (None, [_vp]),
     "bfh_comm_rank": (_i32, [_vp]),
     "bfh_comm_size": (_i32, [_vp]),
+    "bfh_comm_transport": (_i32, [_vp, C.c_char_p, C.c_size_t]),
     "bfh_comm_self_test": (_i32, [_vp]),
     "bfh_comm_all_reduce_f64": (_i32, [_vp, _pf64, _i32]),
     "bfh_als_set_comm": (_i32, [_vp, _vp]),

@@ -73,6 +73,19 @@ class Comm:
     def self_test(self):
         check(self._h, self._L.bfh_comm_self_test(self._h))
 
+    def size(self):
+        """Ranks the LIVE communicator reports (ncclCommCount) -- not the number it was asked for."""
+        n = self._L.bfh_comm_size(self._h)
+        if n < 0:
+            check(self._h, n)
+        return int(n)
+
+    def transport(self):
+        """"rccl <version>", or "shm-test" for libbuffalo_hip_test.so's shared-memory transport."""
+        buf = C.create_string_buffer(64)
+        check(self._h, self._L.bfh_comm_transport(self._h, buf, 64))
+        return buf.value.decode()
+
     def all_reduce(self, values):
         """Sum of a small list of host doubles over the ranks (loss sums)."""
         arr = (C.c_double * len(values))(*[float(v) for v in values])

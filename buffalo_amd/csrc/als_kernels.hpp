@@ -2958,10 +2958,14 @@ class AlsHandle : public HandleBase {
             // for calls whose weights all fit the f16 path; als_defer_scan_kernel says so (cached per chunk while the values do not change)
             bool wsplit = wide_split_ && split_f16_ && T == 5 && wl->n_work > 0;
             if (wsplit) {
+                float* const before = scratch_.get();
                 scan_deferred(*wl, p, wl->n_work);
-                if (wl->n_def > 0) wsplit = false;
-                else if (wl->n_heavy)   // (the scan may have grown scratch_: the heavy rows' slots zeroed above are then gone)
+                // the scan may GROW scratch_ (a new buffer, neither copied nor zeroed): the heavy rows' slots zeroed above are then gone -- whichever
+                // instantiation runs below (round 5 re-zeroed them only when no item was deferred: a call with heavy rows AND weights outside the
+                // f16 path summed its chunk tiles into uninitialised slots on the first growth)
+                if (scratch_.get() != before && wl->n_heavy)
                     BFH_HIP(hipMemsetAsync(scratch_.get(), 0, static_cast<size_t>(wl->n_heavy) * als_slot_floats(vdim_) * sizeof(float), stream));
+                if (wl->n_def > 0) wsplit = false;
             }
             if (wsplit) {   // the scale of the split pass, decided on the device (als_gram_kernel's rule), together with the block-interleaved copy of
                 // the other factor the producers gather from; both are kept while that factor does not change (the chunks of one half-epoch share them)

@@ -1019,6 +1019,7 @@ class BprHandle : public SgdHandle {
         q.nq = nq;
         for (int i = 0; i < 16; ++i) q.xcd_queue[i] = im_xcd_queue_[i];
         q.p_nt = im_p_nt_;
+        q.study = im_study_;
         q.hot_user = im_hot_user_.get();
         q.rep_P = p_any ? repP_.get() : nullptr;
         q.rep_pstride = static_cast<int64_t>(P_rows_) * vdim_;

@@ -57,6 +57,7 @@ struct ImQueues {
                                // a wave works on its XCD's copy (small shards: see launch_item_major)
     int64_t rep_pstride;
     int p_nt;                  // P rows are read / written with the non-temporal hint (they are streamed once per triple; study knob)
+    int study;                 // measurement knob: bit 0 = the chip-wide atomics of the negatives' rows are NOT issued (wrong results: timing only)
     int strict;                // test hook: wait for every memory operation of a triple before the next one starts
     int32_t* trace;            // test hook (single-wave runs): sigmoid-table index of every triple in processing order, or null
 };
@@ -742,10 +743,10 @@ __global__ __launch_bounds__(256, 5) void bpr_item_major_dual_kernel(SgdParams p
                 if (at_u) hrow_atomic_add(dpu, Pu, nk);
                 else hrow_store(pu, Pu, nk);
                 if (c.update_j && !same) {
-                    if (at_j) hrow_atomic_add(dj, Qj, nk);
+                    if (at_j) { if (!(q.study & 1)) hrow_atomic_add(dj, Qj, nk); }
                     else hrow_store(qj, Qj, nk);
                     if (c.use_bias && l32 == 0) {
-                        if (at_j) atomic_add_f32(Bj, dbj);
+                        if (at_j) { if (!(q.study & 1)) atomic_add_f32(Bj, dbj); }
                         else *Bj = bj;
                     }
                 }

@@ -27,6 +27,7 @@ struct Rccl {
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGetVersion) GetVersion = nullptr;
 };
 
 Rccl& rccl() {
@@ -52,6 +53,7 @@ Rccl& rccl() {
         x.GroupStart = reinterpret_cast<decltype(x.GroupStart)>(sym("ncclGroupStart"));
         x.GroupEnd = reinterpret_cast<decltype(x.GroupEnd)>(sym("ncclGroupEnd"));
         x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(sym("ncclGetErrorString"));
+        x.GetVersion = reinterpret_cast<decltype(x.GetVersion)>(sym("ncclGetVersion"));
         return x;
     }();
     return r;
@@ -113,6 +115,20 @@ Comm::Comm(int n_ranks, int rank, const char* id128, int dev) {
     BFH_REQUIRE(count == n_ranks, "comm_create: RCCL reports " + std::to_string(count) + " ranks, expected " + std::to_string(n_ranks));
 }
 
+// what the communicator that exists reports NOW: ncclCommCount of the live RCCL communicator (not the number it was asked for)
+int Comm::live_size() const {
+    if (!comm_) return size_;
+    int count = 0;
+    check(rccl().CommCount(static_cast<ncclComm_t>(comm_), &count), "ncclCommCount");
+    return count;
+}
+std::string Comm::transport() const {
+    if (shm_) return "shm-test";
+    int v = 0;
+    check(rccl().GetVersion(&v), "ncclGetVersion");
+    return "rccl " + std::to_string(v / 10000) + "." + std::to_string((v / 100) % 100) + "." + std::to_string(v % 100);
+}
+
 Comm::~Comm() {
     delete shm_;
     if (comm_) (void)rccl().CommDestroy(static_cast<ncclComm_t>(comm_));
@@ -170,7 +186,20 @@ void* bfh_comm_create(int n_ranks, int rank, const char* unique_id, int device) 
 
 void bfh_comm_destroy(void* c) { delete static_cast<Comm*>(c); }
 int bfh_comm_rank(void* c) { return c ? static_cast<Comm*>(c)->rank() : BFH_ERR_INVALID; }
-int bfh_comm_size(void* c) { return c ? static_cast<Comm*>(c)->size() : BFH_ERR_INVALID; }
+int bfh_comm_size(void* c) {
+    if (!c) return BFH_ERR_INVALID;
+    int n = BFH_ERR_HIP;
+    (void)guarded(c, [&] { n = static_cast<Comm*>(c)->live_size(); return BFH_OK; });
+    return n;
+}
+int bfh_comm_transport(void* c, char* out, size_t bytes) {
+    return guarded(c, [&] {
+        BFH_REQUIRE(out && bytes > 0, "comm_transport: bad arguments");
+        const std::string t = static_cast<Comm*>(c)->transport();
+        std::snprintf(out, bytes, "%s", t.c_str());
+        return BFH_OK;
+    });
+}
 
 // every rank contributes rank + 1 per element; all must read n (n + 1) / 2 back
 int bfh_comm_self_test(void* c) {

@@ -22,6 +22,8 @@ class Comm : public HandleBase {
     ~Comm() override;
     int rank() const { return rank_; }
     int size() const { return size_; }
+    int live_size() const;                                    // ranks the LIVE communicator reports (ncclCommCount; the test transport: as attached)
+    std::string transport() const;                            // "rccl <version>" | "shm-test"
     // sum all-reduce; `send == recv` is in place
     void all_reduce_f32(const float* send, float* recv, size_t count, hipStream_t s);
     void all_reduce_i32(const int* send, int* recv, size_t count, hipStream_t s);

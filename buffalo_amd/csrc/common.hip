@@ -59,7 +59,14 @@ void HostStager::d2h(void* dst, const void* src_dev, size_t bytes, hipStream_t s
         }
     };
     std::vector<std::thread> th;
-    for (int t = 0; t < workers; ++t) th.emplace_back(work, t);
+    th.reserve(static_cast<size_t>(workers));
+    try {
+        for (int t = 0; t < workers; ++t) th.emplace_back(work, t);
+    } catch (...) {   // a thread could not be started: the ones that run are told to stop and JOINED (a joinable std::thread's destructor terminates)
+        failed.store(1);
+        for (auto& x : th) x.join();
+        throw Error(BFH_ERR_HIP, "device -> host staging copy: could not start a drain thread");
+    }
     hipError_t err = hipSuccess;
     for (int64_t k = 0; k < n_chunks && err == hipSuccess && !failed.load(); ++k) {
         const int slot = static_cast<int>(k % kSlots);

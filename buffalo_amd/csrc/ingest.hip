@@ -323,6 +323,17 @@ struct TextTriples {
     int64_t reparsed = 0;
 };
 
+// re-parsed lines back to their places: line idx[j] takes (hr, hc, hv)[j]
+__global__ __launch_bounds__(256) void text_scatter_kernel(const int64_t* __restrict__ idx, const int32_t* __restrict__ hr, const int32_t* __restrict__ hc,
+                                                           const float* __restrict__ hv, int64_t m, int64_t total_lines, int32_t* __restrict__ r,
+                                                           int32_t* __restrict__ c, float* __restrict__ v) {
+    const int64_t j = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (j >= m) return;
+    const int64_t k = idx[j];
+    if (k < 0 || k >= total_lines) return;
+    r[k] = hr[j]; c[k] = hc[j]; v[k] = hv[j];
+}
+
 static void parse_text_on_device(const char* text, int64_t bytes, int64_t total_lines, TextTriples& T, hipStream_t stream) {
     BFH_REQUIRE(text && bytes > 0 && total_lines > 0, "text parse: empty input");
     T.text.resize(static_cast<size_t>(bytes) + 16);
@@ -383,18 +394,22 @@ static void parse_text_on_device(const char* text, int64_t bytes, int64_t total_
         sscanf(line.c_str(), "%d %d %f", &rr, &cc, &vv);
         hr[j] = rr; hc[j] = cc; hv[j] = vv;
     }
-    // scatter back (few lines: one small copy each would do, but a flagged FILE can be all of them)
-    if (T.reparsed == total_lines) {
-        BFH_HIP(hipMemcpy(T.r.get(), hr.data(), hr.size() * 4, hipMemcpyHostToDevice));
-        BFH_HIP(hipMemcpy(T.c.get(), hc.data(), hc.size() * 4, hipMemcpyHostToDevice));
-        BFH_HIP(hipMemcpy(T.v.get(), hv.data(), hv.size() * 4, hipMemcpyHostToDevice));
-    } else {
-        for (size_t j = 0; j < idx.size(); ++j) {
-            BFH_HIP(hipMemcpy(T.r.get() + idx[j], &hr[j], 4, hipMemcpyHostToDevice));
-            BFH_HIP(hipMemcpy(T.c.get() + idx[j], &hc[j], 4, hipMemcpyHostToDevice));
-            BFH_HIP(hipMemcpy(T.v.get() + idx[j], &hv[j], 4, hipMemcpyHostToDevice));
-        }
-    }
+    // scatter back: the list and the re-parsed values go up ONCE and a small kernel puts every line where it belongs.  (Round 5 copied 3 x 4
+    // bytes per line synchronously -- millions of blocking copies for a file of 17-digit values -- and, when EVERY line was flagged but the list
+    // still held them, wrote the values in the list's order, which is the order of the flagging atomics, not of the file.)
+    const size_t m = idx.size();
+    DevBuf<int64_t> d_idx;
+    DevBuf<int32_t> d_r, d_c;
+    DevBuf<float> d_v;
+    d_idx.resize(m); d_r.resize(m); d_c.resize(m); d_v.resize(m);
+    BFH_HIP(hipMemcpyAsync(d_idx.get(), idx.data(), m * 8, hipMemcpyHostToDevice, stream));
+    BFH_HIP(hipMemcpyAsync(d_r.get(), hr.data(), m * 4, hipMemcpyHostToDevice, stream));
+    BFH_HIP(hipMemcpyAsync(d_c.get(), hc.data(), m * 4, hipMemcpyHostToDevice, stream));
+    BFH_HIP(hipMemcpyAsync(d_v.get(), hv.data(), m * 4, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(text_scatter_kernel, dim3(static_cast<unsigned>((m + 255) / 256)), dim3(256), 0, stream, d_idx.get(), d_r.get(), d_c.get(), d_v.get(),
+                       static_cast<int64_t>(m), total_lines, T.r.get(), T.c.get(), T.v.get());
+    BFH_HIP(hipGetLastError());
+    BFH_HIP(hipStreamSynchronize(stream));   // the staging vectors and buffers die with this frame
 }
 
 static void parse_triples(const char* text, int64_t bytes, int64_t total_lines, int32_t* rows, int32_t* cols, float* vals, bfh_stats* stats) {

@@ -258,7 +258,8 @@ int bfh_comm_unique_id(char* out, size_t bytes);
 void* bfh_comm_create(int n_ranks, int rank, const char* unique_id, int device);
 void bfh_comm_destroy(void* comm);
 int bfh_comm_rank(void* comm);
-int bfh_comm_size(void* comm);
+int bfh_comm_size(void* comm);        /* ranks of the LIVE communicator: ncclCommCount, not the number bfh_comm_create was asked for */
+int bfh_comm_transport(void* comm, char* out, size_t bytes);   /* "rccl <major.minor.patch>" (libbuffalo_hip_test.so over shared memory: "shm-test") */
 int bfh_comm_self_test(void* comm);
 int bfh_comm_all_reduce_f64(void* comm, double* values, int n);
 int bfh_bpr_set_comm(void* h, void* comm);

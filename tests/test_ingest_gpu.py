@@ -122,6 +122,23 @@ def test_plain_rating_file_needs_no_host_help(oracle):
     np.testing.assert_array_equal(v.view(np.uint32), vo.view(np.uint32))
 
 
+def test_a_file_of_nothing_but_handed_back_lines_keeps_its_order(oracle):
+    """Every value carries more than 19 significant digits, so EVERY line is handed back to sscanf while the list of flagged lines still holds them
+    all: the list is in the order of the flagging atomics, not of the file, and the re-parsed values have to land on their own lines (round 5
+    copied them back in list order: ADVICE r05).  Ids distinct per line so that a permutation cannot hide."""
+    from buffalo_amd.ingest import parse_triples
+    rng = np.random.default_rng(21)
+    n = 30000                                   # > one block of the parse kernel, < the list's capacity
+    rows, cols = np.arange(1, n + 1), rng.integers(1, 7000, n)
+    text = ("\n".join("%d %d %.25f" % (r_, c_, x) for r_, c_, x in zip(rows, cols, rng.random(n) * 5)) + "\n").encode()
+    (r, c, v), st = parse_triples(text, n, with_stats=True)
+    ro, co, vo = oracle.parse_triples(text, n)
+    assert st["merges"] == n
+    np.testing.assert_array_equal(r, ro)
+    np.testing.assert_array_equal(c, co)
+    np.testing.assert_array_equal(v.view(np.uint32), vo.view(np.uint32))
+
+
 @pytest.mark.parametrize("sort_key", [1, 2])
 def test_text_to_csr_matches_the_reference_builder(oracle, sort_key, tmp_path):
     """bfh_text_to_csr = fileio.hpp:263-420 end to end (parse -> stable sort -> END offsets -> 0-based minors): against the reference's own
