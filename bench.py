@@ -754,6 +754,7 @@ def measured_stream_bandwidth(n_bytes=1 << 30, reps=20):
 # `cpu_baseline` as FLAT scalars.  Everything else (per-epoch lists, byte models, per-kernel tables, the long descriptions) goes to
 # `bench_extra.json` (repo root and gpurun_out/) and to an EARLIER stdout line prefixed "BENCH_EXTRA ".
 LINE_LIMIT = 4096
+REFBENCH_QB_REFERENCE = 183.0   # |Qb| of the reference path (threaded oracle) after lr 0.05 -> 0.0001 over 10 epochs on load_matrix("ml20m", 7), init seed 7
 HEAD_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
 # flat roofline keys the line can do without, first to go first (the contract's own keys are never dropped)
 ROOFLINE_OPTIONAL = ("warp_c5_traffic_source", "traffic_source", "warp_c5_sort_and_gather_ms", "warp_c5_trial_kernel_ms", "warp_c5_epochs_run",
@@ -1152,7 +1153,10 @@ def run_extras(args, csr, out):
     b = extra.get("bpr_lr005") or {}
     if "kernel_ms_per_launch" in b:
         rf.update({"bpr_lr005_kernel_ms": b["kernel_ms_per_launch"], "bpr_lr005_frac": b["frac"], "bpr_lr005_kernel_ms_max": b["kernel_ms_per_launch_max"],
-                   "bpr_lr005_updates_per_s": b["updates_per_s_after_first"]})
+                   "bpr_lr005_updates_per_s": b["updates_per_s_after_first"],
+                   # |Qb| after the schedule against the reference path's: 183.0 at 8 / 64 / 128 / 256 workers alike (profiles/r06_bpr_lr005_width_and_knobs.txt);
+                   # the bias norm does not depend on the schedule's width, so it is the one norm of this case a constant can stand for (seed 7, this matrix)
+                   "bpr_lr005_norm_gap_Qb": b["norm_Qb"] / REFBENCH_QB_REFERENCE - 1.0})
     a = extra.get("als_ml20m_d128") or {}
     if "epoch_ms" in a:
         rf.update({"als_epoch_ms": a["epoch_ms"], "als_kernel_ms": a["kernel_ms_per_epoch"], "als_hbm_frac": a["hbm"]["frac"],

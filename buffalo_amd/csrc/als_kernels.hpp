@@ -2547,6 +2547,7 @@ __global__ __launch_bounds__(256) void als_solve_kernel(AlsParams p, const AlsHe
 
 }  // namespace bfh
 #include "als_pc.hpp"
+#include "als_ts.hpp"
 namespace bfh {
 
 // ------------------------------------------------------------------------------------------------
@@ -2875,9 +2876,21 @@ class AlsHandle : public HandleBase {
         if (big) { if (lk) BFH_PC(TT, true, true); else BFH_PC(TT, true, false); }     \
         else { if (lk) BFH_PC(TT, false, true); else BFH_PC(TT, false, false); }       \
     } while (0)
-                if (T == 2) BFH_PC_T(2);
+#define BFH_TS(BG, LS)                                                                                                              \
+    do {                                                                                                                            \
+        BFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(als_ts_kernel<4, BG, LS>), hipFuncAttributeMaxDynamicSharedMemorySize, AlsTs<4>::LDS_B)); \
+        hipLaunchKernelGGL((als_ts_kernel<4, BG, LS>), dim3(pblocks), dim3(512), AlsTs<4>::LDS_B, stream, p, wl->work.get(), items, scratch_.get(), \
+                           qi_.get(), wl->defer.get(), pc_err_.get());                                                              \
+    } while (0)
+                // "als_ts" (vdim 128): the tiles of a row split over the two waves of a SIMD, both waves prepare and consume (als_ts.hpp)
+                if (T == 4 && ts_) {
+                    if (big) { if (lk) BFH_TS(true, true); else BFH_TS(true, false); }
+                    else { if (lk) BFH_TS(false, true); else BFH_TS(false, false); }
+                }
+                else if (T == 2) BFH_PC_T(2);
                 else if (T == 3) BFH_PC_T(3);
                 else BFH_PC_T(4);
+#undef BFH_TS
 #undef BFH_PC_T
 #undef BFH_PC
                 BFH_HIP(hipGetLastError());
@@ -3243,6 +3256,7 @@ class AlsHandle : public HandleBase {
         else if (name == "als_debug") debug_ = static_cast<int>(v);
         else if (name == "als_split_wcut") split_wcut_ = static_cast<float>(v);   // weights above this take the fp32 side path (default 2^15; tests lower it)
         else if (name == "als_split_f16") split_f16_ = v != 0;             // 0: the in-place iALS++ rows keep the fp32 matrix instruction
+        else if (name == "als_ts") ts_ = static_cast<int>(v);   // 1: als_ts_kernel instead of the pairs at vdim 128 (als_ts.hpp)
         else if (name == "als_pc") {
             BFH_REQUIRE(v >= 0 && v <= 2, "als_pc must be 0, 1 or 2");
             pc_ = static_cast<int>(v);
@@ -3305,6 +3319,7 @@ class AlsHandle : public HandleBase {
     bool no_inreg_ = false;
     bool split_f16_ = true;
     int pc_ = 1;
+    int ts_ = 0;
     float split_wcut_ = 32768.0f;
     uint64_t fver_[2] = {1, 1};     // bumped whenever P (0) / Q (1) may have changed on the device
     uint64_t vals_ver_ = 1;         // bumped whenever confidence values were uploaded

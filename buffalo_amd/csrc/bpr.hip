@@ -976,19 +976,29 @@ class BprHandle : public SgdHandle {
         // ... nor with "xcd_merge_mean": the mean already scales the sum by 1 / n, and a saturation weight (between 1 / n and 1) on top of it
         // would damp the rows twice.  The weight of n replicas assumes the merge sums exactly those: nq <= kXcdReplicas
         BFH_REQUIRE(nq <= kXcdReplicas, "hogwild_atomic=3: more queues than per-XCD replicas");
+        // The stiffness constants model a row that contracts towards a local equilibrium by exp(-lr k) per step with k = the curvature of the
+        // sigmoid (<= 1/4).  They were calibrated at the reference's default lr (0.002).  A row whose steps are large -- a higher lr -- sits in
+        // the flat part of the sigmoid for most of them (the reference path's own biases at lr 0.05: logits of a few per cent), its curvature is a
+        // fraction of 1/4, and the constant over-damps: measured on the reference benchmark's schedule (lr 0.05 -> 0.0001, 10 epochs) the merged
+        // negative steps of the biases were scaled by ~0.36 in the middle epochs and |Qb| ended at 147.7 against 183.0 for the reference path at
+        // EVERY pool width and for this library's own all-atomic kernel (profiles/r06_bpr_lr005_width_and_knobs.txt, r06_bpr_lr005_bias_rows.txt).
+        // Above the calibration lr the constants therefore shrink like lr_ref / lr: the argument x = lr k m of the saturation weight stays what it
+        // is at lr_ref.  ("xcd_stiff_lr_ref" = 0: the constants at every lr, the form up to round 5.)
+        const double lr_ref = xcd_stiff_lr_ref_micro_ * 1e-6;
+        const double stiff_scale = (lr_ref > 0.0 && static_cast<double>(c.lr) > lr_ref) ? lr_ref / static_cast<double>(c.lr) : 1.0;
         const bool w_items = (xcd_stiff_q_milli_ > 0 || xcd_stiff_b_milli_ > 0) && !im_single_wave_ && !xcd_merge_mean_;
         const bool w_users = xcd_stiff_p_milli_ > 0 && spread_mode != 0 && !im_single_wave_ && !xcd_merge_mean_;
         if (w_items) {
             xcd_wq_.resize(static_cast<size_t>(Q_rows_));
             xcd_wb_.resize(static_cast<size_t>(Q_rows_));
             hipLaunchKernelGGL(xcd_item_weight_kernel, dim3((Q_rows_ + 255) / 256), dim3(256), 0, stream, uniform_ ? nullptr : p.cum_table, cum_total_, Q_rows_,
-                               triples / static_cast<double>(segments), uniform_ ? 1.0 / Q_rows_ : 0.0, static_cast<double>(c.lr), xcd_stiff_q_milli_ * 1e-3,
-                               xcd_stiff_b_milli_ * 1e-3, nq, xcd_wq_.get(), xcd_wb_.get());
+                               triples / static_cast<double>(segments), uniform_ ? 1.0 / Q_rows_ : 0.0, static_cast<double>(c.lr), xcd_stiff_q_milli_ * 1e-3 * stiff_scale,
+                               xcd_stiff_b_milli_ * 1e-3 * stiff_scale, nq, xcd_wq_.get(), xcd_wb_.get());
         }
         if (w_users) {
             xcd_wp_.resize(static_cast<size_t>(P_rows_));
             hipLaunchKernelGGL(xcd_user_weight_kernel, dim3((next_x - start_x + 255) / 256), dim3(256), 0, stream, p.indptr, start_x, next_x - start_x,
-                               static_cast<double>(num_neg_) / static_cast<double>(segments), static_cast<double>(c.lr), xcd_stiff_p_milli_ * 1e-3, nq, spread_mode,
+                               static_cast<double>(num_neg_) / static_cast<double>(segments), static_cast<double>(c.lr), xcd_stiff_p_milli_ * 1e-3 * stiff_scale, nq, spread_mode,
                                heavy_deg, xcd_wp_.get());
         }
         BFH_HIP(hipGetLastError());

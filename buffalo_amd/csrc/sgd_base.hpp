@@ -144,6 +144,12 @@ class SgdHandle : public HandleBase {
     // (a weight on Q moves |Q| AWAY from the oracles, one on the replicated P rows changes nothing), and at lr 0.05 the drift rule has the item
     // rows chip-wide, so no weight reaches them.
     int xcd_stiff_q_milli_ = 0, xcd_stiff_b_milli_ = 250, xcd_stiff_p_milli_ = 0;
+    // the learning rate (in units of 1e-6) the stiffness constants were calibrated at: above it they shrink like lr_ref / lr, i.e. the saturation
+    // argument x = lr k m stops growing with the learning rate (0: the constants apply at every lr -- the form up to round 5, which damped the
+    // negatives' bias steps to 0.36 of their sum at lr 0.035 and left |Qb| 19 % low on the reference benchmark's schedule: profiles/r06_bpr_lr005_*)
+    // Measured (profiles/r06_bpr_lr005_stiffness_rule.txt): refbench |Qb| 147.7 (off) / 159.6 (5000) / 171.6 (2000) / 176.1 (1000) / 180.8 (no weight at all) against 183.0;
+    // the bench case (lr 0.002) 91.93 / 91.93 / 91.93 / 92.34 / 93.04 against oracle pairs 90.2 .. 92.8 on four boxes -- 1000 sits inside every pair's band.
+    int xcd_stiff_lr_ref_micro_ = 1000;
     // learning rate (permille) up to which users get per-XCD replicas.  Above it (study at lr 0.05): plain sums end at |Qb| 109 against the oracles'
     // 91.6; with xcd_stiff_p = 50 |P| 424 / |Qb| 95.5 against 428.7 / 94.8 for the owner form (oracle 430.6 / 91.6) for 6 % of the walk -- not taken.
     int im_user_lr_max_milli_ = 10;
