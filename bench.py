@@ -414,20 +414,88 @@ def _warp_cpu_baseline(indptr, keys, I, d, seed, start_entries=200000, seconds=6
                       % (m1, m1 / nnz, cores, d1)}
 
 
-def _warp_epochs(g, U, indptr, nnz, d, I, epochs, until_T=None, max_epochs=None):
+def _warp_epochs(g, U, indptr, nnz, d, I, epochs, until_T=None, max_epochs=None, after_first_jobs=None):
     """`epochs` epochs; with `until_T`, further ones (at most `max_epochs` in all) until the trial loop scores that many negatives
-    per positive -- the regime training lives in, not the first epochs' T = 1 where every first draw violates the margin."""
+    per positive -- the regime training lives in, not the first epochs' T = 1 where every first draw violates the margin.
+    `after_first_jobs`: called once between the first epoch's add_jobs and its update_parameters (the results check reads the accumulated
+    gradient rows there; the copy sits in epoch 1's time, which is never the quoted one)."""
     eps = []
     e = 0
     while e < epochs or (until_T is not None and e < (max_epochs or epochs) and eps[-1]["mean_scored_negatives_T"] < until_T):
         g.reset_stats()
         t0 = time.perf_counter()
         g.add_jobs(0, U, indptr, None)
+        if e == 0 and after_first_jobs is not None:
+            after_first_jobs()
         g.update_parameters()
         dt = time.perf_counter() - t0
         eps.append(warp_epoch_row(g.stats(), nnz, d, U, I, dt))
         e += 1
     return eps
+
+
+def warp_results_check(indptr, keys, P0, Q0, Qb0, grad_device_full, n_users, total_nnz, opt):
+    """Results at the size the device ran (/root/reference/lib/algo_impl/warp/warp.cc:128-158).  P and Q are frozen inside a WARP epoch
+    (warp.cc:157-159 accumulates gradients, the optimizer step comes with update_parameters), so the gradient row a user has accumulated at the end of the
+    FIRST epoch's add_jobs depends on its own positives alone: the oracle (counter sampler -- the device's draw function --, csr order, one inline worker:
+    deterministic) run on the first `n_users` users from the same initial state reproduces what the full-size device epoch did to them.  Compared:
+      * the accumulated gradient rows of those users, full-size device run vs oracle (max |diff| / max |row|, bound 1e-4);
+      * against a second, small device run on the same users: the number of scored negatives (trials) and of accepted positives -- IDENTICAL -- and its
+        gradient rows (1e-4);
+      * the users' rows after the optimizer step, reported as the share of coordinates further than 1e-4 apart: adagrad's first step is lr * sign(g), so a
+        coordinate whose 100 contributions cancel to rounding noise may step the other way (bound 1e-5 of the coordinates; the gradients are the sharp part)."""
+    from buffalo_amd.backend import CyWARP
+    from oracle import oracle as orc
+    orc.build()
+    n = int(n_users)
+    m = int(indptr[n - 1])
+    ip, k = np.ascontiguousarray(indptr[:n]), np.ascontiguousarray(keys[:m])
+    I, d = Q0.shape
+    Po = np.ascontiguousarray(P0[:n]).copy()
+    o = orc.OracleWARP()
+    path = _opt_file(dict(opt, accelerator=False, num_workers=1))
+    assert o.init(path)
+    os.unlink(path)
+    o.initialize_model(Po, Q0.copy(), Qb0.copy(), total_nnz)
+    o.set_cumulative_table(np.zeros(I, np.int64), I)
+    o.set_modes(sampler="counter", pos_order="csr", inline=True)
+    o.launch_workers()
+    t0 = time.perf_counter()
+    o.add_jobs(0, n, ip, k)
+    g_or = o.state("gradP").reshape(-1, d)[:n].copy()
+    so = o.stats()
+    cpu_s = time.perf_counter() - t0
+    o.update_parameters()
+    o.join()
+    # the same users through a small device run: the counters of the full-size run are totals over ALL users
+    Ps = np.ascontiguousarray(P0[:n]).copy()
+    sub = CyWARP()
+    path = _opt_file(dict(opt))
+    assert sub.init(path)
+    os.unlink(path)
+    sub.initialize_model(Ps, Q0.copy(), Qb0.copy(), total_nnz, True)
+    sub.set_cumulative_table(np.zeros(I, np.int64), I)
+    sub.set_resident_csr(ip, k)
+    sub.add_jobs(0, n, ip, None)
+    g_sub = sub.device_tensor("gradP", (n, d)).cpu().numpy().copy()
+    ss = sub.stats()
+    sub.update_parameters()
+    sub.synchronize(True)
+    del sub
+    gden = float(np.abs(g_or).max()) or 1.0
+    e_full = float(np.abs(grad_device_full - g_or).max() / gden)
+    e_sub = float(np.abs(g_sub - g_or).max() / gden)
+    pden = float(np.abs(Po).max()) or 1.0
+    far = float((np.abs(Ps - Po) > 1e-4 * pden).mean())
+    counts_o = (int(so["scored_negatives"]), int(so["updates"]))
+    counts_d = (int(ss["scored_negatives"]), int(ss["accepted"]))
+    return {"users": n, "positives": m, "oracle_seconds": cpu_s,
+            "scored_negatives_oracle": counts_o[0], "accepted_oracle": counts_o[1], "scored_negatives_device": counts_d[0], "accepted_device": counts_d[1],
+            "grad_rows_full_run_vs_oracle": e_full, "grad_rows_sample_run_vs_oracle": e_sub, "grad_rows_max_abs": gden,
+            "rows_after_step_share_of_coordinates_apart": far,
+            "agrees_with_device": bool(counts_o == counts_d and e_full < 1e-4 and e_sub < 1e-4 and gden > 1e-3 and far < 1e-5),
+            "what": "first epoch, first %d users: oracle (counter sampler, one inline worker) vs the full-size device epoch's accumulated gradient rows of those users "
+                    "(max |diff| / max |g|, bound 1e-4) and vs a device run on those users alone (trial and accept counts, identical)" % n}
 
 
 def _warp_summary(eps, out):
@@ -472,14 +540,14 @@ def extra_warp(csr, seed, epochs=3, cpu=True):
     return out
 
 
-def warp_c5_inputs(skew=True, u0=0, u1=None, users=10_000_000):
+def warp_c5_inputs(skew=True, u0=0, u1=None, users=10_000_000, items=1_000_000):
     """BASELINE configs[4]'s shape for ONE GPU: 10 M users x 1 M items, 1 B interactions, d=256.  Every user has 100 items, one in
     each 10,000-wide band of the catalogue (sorted keys, no duplicates).  `skew`: the item inside a band is floor(10^4 x^3) for a
     hashed x in [0, 1) -- a popularity law (the head item of a band is chosen by 4.6 % of the users), so that there is something to
     rank and the trial loop leaves the T = 1 regime as it does on real data; without it (round 2's generator) every epoch accepts
     the first draw.  Factors signed N(0, 1/d^2) (Q-18), P tiled from 65,536 distinct rows to keep host generation to seconds.
     41.9 GB resident (P, Q, gradients, adagrad state, keys, row ids)."""
-    I5, deg, d = 1_000_000, 100, WARP_D
+    I5, deg, d = items, 100, WARP_D
     u1 = users if u1 is None else u1
     U5 = u1 - u0                                   # this rank's users [u0, u1) of `users` (N > 1: --workload warp_c5)
     step = I5 // deg
@@ -527,7 +595,14 @@ def extra_warp_c5(seed, epochs=6, cpu=True):
     g.initialize_model(P, Q, Qb, nnz, True)
     g.set_resident_csr(indptr, keys)
     up_s = time.perf_counter() - t0
-    eps = _warp_epochs(g, U, indptr, nnz, d, I, epochs, until_T=3.0, max_epochs=12)
+    chk = {}
+    n_chk = int(os.environ.get("BFH_WARP_CHECK_USERS", "20000"))
+
+    def grab():   # the accumulated gradient rows of the first users after epoch 1's add_jobs, straight from HBM
+        chk["G"] = g.device_tensor("gradP", (U, d))[:n_chk].cpu().numpy().copy()
+    P0 = np.ascontiguousarray(P[:n_chk]).copy() if cpu else None
+    Q0 = Q.copy() if cpu else None
+    eps = _warp_epochs(g, U, indptr, nnz, d, I, epochs, until_T=3.0, max_epochs=12, after_first_jobs=grab if cpu else None)
     out = _warp_summary(eps, {
         "config": "WARP adagrad, dot score, max_trials 500, configs[4]-shaped synthetic (%d x %d, %d nnz), d=%d, f32, ONE GPU, everything "
                   "resident in HBM" % (U, I, nnz, d),
@@ -541,6 +616,12 @@ def extra_warp_c5(seed, epochs=6, cpu=True):
         n100 = U // 100
         out["cpu_baseline"] = _warp_cpu_baseline(indptr[:n100], keys[:int(indptr[n100 - 1])], I, d, seed, seconds=4.0)
         out["cpu_baseline"]["sample"] += "; the first 1/100 of the users against the full item table, to be scaled linearly (SURVEY 8(d))"
+        try:
+            out["results_check"] = warp_results_check(indptr, keys, P0, Q0, np.zeros((I, 1), np.float32), chk["G"], n_chk, nnz, WARP_OPT)
+            out["agrees_with_device"] = out["results_check"]["agrees_with_device"]
+        except Exception as e:  # noqa: BLE001 -- reported, never silently dropped
+            out["results_check"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            out["agrees_with_device"] = False
     return out
 
 
@@ -1178,6 +1259,8 @@ def run_extras(args, csr, out):
         rf.update({"warp_c5_epoch_ms": c5["epoch_ms"], "warp_c5_T": c5["mean_scored_negatives_T"], "warp_c5_accepted_frac": last["accepted_frac"],
                    "warp_c5_epochs_run": len(c5["epochs"]), "warp_c5_implemented_model_frac": c5["implemented_model_frac"],
                    "warp_c5_sort_and_gather_ms": last["sort_and_gather_ms"], "warp_c5_trial_kernel_ms": last["trial_kernel_ms"]})
+        if "agrees_with_device" in c5:   # the results check at configs[4] size (warp_results_check: oracle on the first users vs the device's rows and counts)
+            rf["warp_c5_agrees_with_device"] = c5["agrees_with_device"]
         tr = c5.get("counter_traffic") or {}
         if isinstance(tr, dict) and tr.get("hbm_bytes_per_epoch"):
             dev_ms = last["trial_kernel_ms"] + last["sort_and_gather_ms"] + last["optimizer_ms"]
@@ -1218,9 +1301,18 @@ def run_warp_c5(args, ctx):
         comm = ctx.make_comm()
         g.set_comm(comm)
     n_local = u1 - u0
+    # results check at the size that runs (one GPU, rank 0): the accumulated gradient rows of the first users after the FIRST add_jobs of this object, read
+    # from HBM (a 20 MB copy once, in the first step -- a warm-up step unless --warmup 0), against the oracle afterwards (warp_results_check)
+    n_chk = min(n_local, int(os.environ.get("BFH_WARP_CHECK_USERS", "20000")))
+    chk = {}
+    want_check = world == 1 and not args.no_cpu_baseline
+    P0 = np.ascontiguousarray(P[:n_chk]).copy() if want_check else None
+    Q0 = Q.copy() if want_check else None
 
     def step():
         g.add_jobs(0, n_local, indptr, None)
+        if want_check and "G" not in chk:
+            chk["G"] = g.device_tensor("gradP", (n_local, d))[:n_chk].cpu().numpy().copy()
         g.update_parameters()
 
     elapsed = timed_steps(ctx, step, args.steps, args.warmup, before_timing=g.reset_stats)
@@ -1269,6 +1361,13 @@ def run_warp_c5(args, ctx):
         n100 = max(1, (u1 - u0) // 100)
         out["cpu_baseline"] = _warp_cpu_baseline(indptr[:n100], keys[:int(indptr[n100 - 1])], I5, d, args.seed, seconds=10.0)
         out["cpu_baseline"]["sample"] += "; the first 1/100 of the users against the full item table"
+        try:
+            rc = warp_results_check(indptr, keys, P0, Q0, np.zeros((I5, 1), np.float32), chk["G"], n_chk, total_nnz, dict(WARP_OPT, num_iters=args.steps + args.warmup))
+            out["results_check"] = rc
+            out["roofline"]["agrees_with_device"] = rc["agrees_with_device"]
+        except Exception as e:  # noqa: BLE001 -- reported, never silently dropped
+            out["results_check"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            out["roofline"]["agrees_with_device"] = False
     return out
 
 

@@ -2857,8 +2857,8 @@ class AlsHandle : public HandleBase {
                 p.batch = 16;   // rows per ticket at most (fewer where the rows are long)
             }
             if (use_pc) {
-                if (pc_err_.size() < 2) pc_err_.resize(2);
-                BFH_HIP(hipMemsetAsync(pc_err_.get(), 0, 2 * sizeof(int), stream));
+                if (pc_err_.size() < 8) pc_err_.resize(8);   // [0] error bits, [1] placement statistic, [2..5] the clock probe of workgroup 0 (als_debug bit 1024)
+                BFH_HIP(hipMemsetAsync(pc_err_.get(), 0, 8 * sizeof(int), stream));
                 const int nslots = wl->n_heavy + wl->n_def_rows;
                 if (wl->n_def_rows)   // (the heavy rows' slots were zeroed above)
                     BFH_HIP(hipMemsetAsync(scratch_.get() + static_cast<size_t>(wl->n_heavy) * per_row, 0, static_cast<size_t>(wl->n_def_rows) * per_row * sizeof(float), stream));
@@ -3064,8 +3064,8 @@ class AlsHandle : public HandleBase {
         t_main_.end(slot, stream);
         double l[2] = {0, 0};
         if (compute_loss_) BFH_HIP(hipMemcpyAsync(l, loss_.get(), 2 * sizeof(double), hipMemcpyDeviceToHost, stream));
-        int pe[2] = {0, 0};
-        if (pc_launched) BFH_HIP(hipMemcpyAsync(pe, pc_err_.get(), 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
+        int pe[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (pc_launched) BFH_HIP(hipMemcpyAsync(pe, pc_err_.get(), 8 * sizeof(int), hipMemcpyDeviceToHost, stream));
         if (writeback_) {  // als.cu:403: updated rows go back to the caller's array
             float* hostF = axis == 0 ? hostP_ : hostQ_;
             const size_t off = static_cast<size_t>(start_x) * vdim_, cnt = static_cast<size_t>(nrows) * vdim_;
@@ -3078,6 +3078,12 @@ class AlsHandle : public HandleBase {
         stats.samples += n;
         if (pc_launched) {
             pc_same_simd_ = pe[1];
+            {   // als_debug bit 1024: shader clock of workgroup 0 over the kernel = s_memtime ticks per 100 MHz s_memrealtime tick
+                unsigned long long core = 0, real = 0;
+                std::memcpy(&core, pe + 2, 8);
+                std::memcpy(&real, pe + 4, 8);
+                pc_clock_mhz_ = real ? static_cast<int>(100.0 * static_cast<double>(core) / static_cast<double>(real)) : 0;
+            }
             if (pe[0] & 1) throw Error(BFH_ERR_HIP, "als_pc_kernel: a producer / consumer hand-off timed out (results of this call are invalid)");
             if (pe[0] & 2) throw Error(BFH_ERR_HIP, "als_pc_kernel: a weight outside the f16 path reached the kernel (stale weight scan)");
         }
@@ -3268,6 +3274,7 @@ class AlsHandle : public HandleBase {
 
     void device_buffer(const std::string& name, void** p, size_t* bytes) {
         ++fver_[0]; ++fver_[1];   // whoever holds a raw pointer may write through it: cached views of the factors are dropped
+        if (name == "als_pc_clock_mhz") { *p = nullptr; *bytes = static_cast<size_t>(pc_clock_mhz_); return; }   // als_debug bit 1024: shader clock during the last pair / tile-split launch
         if (name == "als_pc_same_simd") { *p = nullptr; *bytes = static_cast<size_t>(pc_same_simd_); return; }   // placement statistic of the last als_pc_kernel launch
         if (name == "P") { *p = P_.get(); *bytes = P_.bytes(); }
         else if (name == "Q") { *p = Q_.get(); *bytes = Q_.bytes(); }
@@ -3329,6 +3336,7 @@ class AlsHandle : public HandleBase {
     float qi_wcut_ = -1.f;
     DevBuf<int> pc_err_;
     int pc_same_simd_ = 0;
+    int pc_clock_mhz_ = 0;
     DevBuf<float> split_part_;
     DevBuf<float> split_out_;
     DevBuf<float> rowff_;

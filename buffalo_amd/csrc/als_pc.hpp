@@ -575,6 +575,9 @@ __device__ __forceinline__ void als_pc_consumer(const AlsParams& p, float* __res
                         const u32x4 Y = pr == 1 ? L[b] : H[b];
                         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, X), __builtin_bit_cast(f16x8_t, Y), acc[t], 0, 0, 0);
                     }
+                // (probe, als_debug bit 2048: the matrix instructions of a group spread out instead of back to back -- does the clock the power
+                //  management grants depend on how bursty the matrix pipe is driven?  profiles/r06_als_clock_probe.txt)
+                if (p.debug & 2048) __builtin_amdgcn_s_sleep(2);
             }
         };
         bool ok = true;
@@ -674,6 +677,10 @@ __global__ __launch_bounds__(512, 2) void als_pc_kernel(AlsParams p, const AlsWo
     extern __shared__ __attribute__((aligned(16))) char pc_lds[];
     using C = AlsPc<T>;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // (als_debug bit 1024: the shader clock this workgroup sees over the kernel -- s_memtime counts core cycles, s_memrealtime the constant 100 MHz)
+    const bool clk_probe = (p.debug & 1024) && blockIdx.x == 0 && tid == 0;
+    unsigned long long clk_c0 = 0, clk_r0 = 0;
+    if (clk_probe) { clk_c0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
     float* ff_acc = reinterpret_cast<float*>(pc_lds);
     int* role_tab = reinterpret_cast<int*>(pc_lds + C::FF_B + 4 * C::PAIR_B);   // [0..7] pair * 2 + role, [8..15] SIMD id of wave w
     {
@@ -723,6 +730,11 @@ __global__ __launch_bounds__(512, 2) void als_pc_kernel(AlsParams p, const AlsWo
     }
     if (rl & 1) als_pc_producer<T, BIG, LOSS>(p, work, n_items, Qi, defer, pl, err, lane);
     else als_pc_consumer<T, BIG, LOSS>(p, scratch, ff_acc, pl, err, lane);
+    if (clk_probe) {   // wave 0 of workgroup 0 at the end of ITS stream (the kernel's tail may run a little longer on other waves)
+        const unsigned long long dc = __builtin_amdgcn_s_memtime() - clk_c0, dr = __builtin_amdgcn_s_memrealtime() - clk_r0;
+        err[2] = static_cast<int>(dc & 0xffffffffull); err[3] = static_cast<int>(dc >> 32);
+        err[4] = static_cast<int>(dr & 0xffffffffull); err[5] = static_cast<int>(dr >> 32);
+    }
 }
 
 }  // namespace bfh

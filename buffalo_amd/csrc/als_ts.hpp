@@ -386,16 +386,16 @@ __device__ __forceinline__ void als_ts_wave(const AlsParams& p, const AlsWork* _
             __hip_atomic_store(flg + TS_PUB + ME, nown, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         if (!(dbg & 16)) {
-#pragma unroll
-            for (int pr = 0; pr < 3; ++pr) {   // small terms first: l h, h l, h h -- per tile the order of the pair kernel
-#pragma unroll
-                for (int t = 0; t < NTW; ++t) {
-                    const int a = als_tile_row<T>(NTW * ME + t), b = als_tile_col<T>(NTW * ME + t);
-                    const u32x4 X = pr == 0 ? L[a] : H[a];
-                    const u32x4 Y = pr == 1 ? L[b] : H[b];
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, X), __builtin_bit_cast(f16x8_t, Y), acc[t], 0, 0, 0);
-                }
-            }
+            // small terms first: l h, h l, h h -- per tile the order of the pair kernel.  (Compile-time tile indices: with run-time ones the
+            // operand arrays go to scratch and every matrix instruction waits for two scratch loads -- first contact, 10.2 ms per epoch.)
+            als_static_for<3 * NTW>([&](auto Ic) {
+                constexpr int i = decltype(Ic)::value;
+                constexpr int pr = i / NTW, t = i % NTW;
+                constexpr int a = als_tile_row<T>(NTW * ME + t), b = als_tile_col<T>(NTW * ME + t);
+                const u32x4 X = pr == 0 ? L[a] : H[a];
+                const u32x4 Y = pr == 1 ? L[b] : H[b];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, X), __builtin_bit_cast(f16x8_t, Y), acc[t], 0, 0, 0);
+            });
         }
         ++gcons;
         ++ncons_w[owner];
@@ -405,12 +405,12 @@ __device__ __forceinline__ void als_ts_wave(const AlsParams& p, const AlsWork* _
             float* S = scratch + static_cast<size_t>(Cc.slot) * als_slot_floats(VD);
             float* Sl = S + half * 4 * VD + col;
             const float osc = p.out_scale * sI2;
-#pragma unroll
-            for (int t = 0; t < NTW; ++t) {
-                const int a = als_tile_row<T>(NTW * ME + t), b = als_tile_col<T>(NTW * ME + t);
+            als_static_for<NTW>([&](auto Tc) {
+                constexpr int t = decltype(Tc)::value;
+                constexpr int a = als_tile_row<T>(NTW * ME + t), b = als_tile_col<T>(NTW * ME + t);
 #pragma unroll
                 for (int e = 0; e < 16; ++e) atomic_add_f32(Sl + (a * 32 + (e & 3) + 8 * (e >> 2)) * VD + b * 32, acc[t][e] * osc);
-            }
+            });
             return;
         }
         const int par = Cc.rseq & 1;
@@ -560,6 +560,10 @@ __global__ __launch_bounds__(512, 2) void als_ts_kernel(AlsParams p, const AlsWo
     extern __shared__ __attribute__((aligned(16))) char ts_lds[];
     using C = AlsTs<T>;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // (als_debug bit 1024: the shader clock this workgroup sees over the kernel -- s_memtime counts core cycles, s_memrealtime the constant 100 MHz)
+    const bool clk_probe = (p.debug & 1024) && blockIdx.x == 0 && tid == 0;
+    unsigned long long clk_c0 = 0, clk_r0 = 0;
+    if (clk_probe) { clk_c0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
     float* ff_acc = reinterpret_cast<float*>(ts_lds);
     int* role_tab = reinterpret_cast<int*>(ts_lds + C::FF_B + 4 * C::PAIR_B);   // [0..7] pair * 2 + wave-in-pair, [8..15] SIMD id of wave w
     {
@@ -604,6 +608,11 @@ __global__ __launch_bounds__(512, 2) void als_ts_kernel(AlsParams p, const AlsWo
     char* pl = ts_lds + C::FF_B + (rl >> 1) * C::PAIR_B;
     if (rl & 1) als_ts_wave<T, 1, BIG, LOSS>(p, work, n_items, scratch, Qi, defer, ff_acc, pl, err, lane);
     else als_ts_wave<T, 0, BIG, LOSS>(p, work, n_items, scratch, Qi, defer, ff_acc, pl, err, lane);
+    if (clk_probe) {   // wave 0 of workgroup 0 at the end of ITS stream (the kernel's tail may run a little longer on other waves)
+        const unsigned long long dc = __builtin_amdgcn_s_memtime() - clk_c0, dr = __builtin_amdgcn_s_memrealtime() - clk_r0;
+        err[2] = static_cast<int>(dc & 0xffffffffull); err[3] = static_cast<int>(dc >> 32);
+        err[4] = static_cast<int>(dr & 0xffffffffull); err[5] = static_cast<int>(dr >> 32);
+    }
 }
 
 }  // namespace bfh

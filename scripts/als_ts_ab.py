@@ -49,8 +49,10 @@ def timing(modes, epochs=4):
             ms, _ = half(g, axis)
             if ep:
                 per[axis].append(ms)
-    print("%-44s user half-epoch %.3f ms  item half-epoch %.3f ms  sum %.3f  (one pair per SIMD in %d of 256 workgroups)"
-          % (modes, np.mean(per[0]), np.mean(per[1]), np.mean(per[0]) + np.mean(per[1]), g.device_buffer("als_pc_same_simd")[1]), flush=True)
+    clk = g.device_buffer("als_pc_clock_mhz")[1] if modes.get("als_debug", 0) & 1024 else 0
+    print("%-44s user half-epoch %.3f ms  item half-epoch %.3f ms  sum %.3f  (one pair per SIMD in %d of 256 workgroups%s)"
+          % (modes, np.mean(per[0]), np.mean(per[1]), np.mean(per[0]) + np.mean(per[1]), g.device_buffer("als_pc_same_simd")[1],
+             "; shader clock of workgroup 0 over the last launch %d MHz" % clk if clk else ""), flush=True)
     del g
 
 
@@ -64,6 +66,10 @@ if "--ablate" in sys.argv:   # results are wrong with these, timings only
     for bits, what in ((1, "no block solve"), (16, "no matrix instructions"), (17, "neither"), (17 + 32, "neither, no preparation arithmetic"), (32, "no preparation arithmetic")):
         for ts in (0, 1):
             print("als_debug %d (%s):" % (bits, what), end=" ")
+            timing({"als_ts": ts, "als_debug": bits}, epochs=3)
+if "--clock" in sys.argv:   # als_debug bit 1024: the shader clock the kernel sees, with and without its matrix instructions
+    for ts in (0, 1):
+        for bits in (1024, 1024 + 16, 1024 + 17, 1024 + 49):
             timing({"als_ts": ts, "als_debug": bits}, epochs=3)
 if "--timing-only" in sys.argv:
     sys.exit(0)

@@ -134,3 +134,38 @@ def test_trial_counts_and_gradients_at_ml20m_scale(oracle):
     assert not np.array_equal(Po, P0[users])
     assert e_sub < 1e-4, e_sub
     assert e_full < 1e-4, e_full
+
+
+def test_results_at_a_tenth_of_configs4_size(oracle):
+    """a results check at the configs[4] SHAPE (bench.py's generator: 100 positives per user, one per band of the catalogue, popularity-skewed;
+    d = 256, adagrad, the benchmark's WARP options) at 1 M users x 100 K items / 100 M interactions -- a tenth of configs[4] on each axis, what the driver's suite
+    can hold.  The full-size device epoch against the oracle (counter sampler, one inline worker: /root/reference/lib/algo_impl/warp/warp.cc:128-158 statement by
+    statement) on the first 100 K users from the same initial state: identical trial and accept counts (against a device run on those users alone -- the full run's
+    counters are totals) and the users' accumulated gradient rows to 1e-4 (the rows after adagrad's first step -- lr * sign(g) -- are reported as a share of
+    coordinates: a coordinate whose hundred contributions cancel to rounding noise may step the other way).  bench.py's warp_c5 extra / --workload warp_c5 run the same check (warp_results_check)
+    at the full 10 M x 1 M size on 20 K users."""
+    import bench
+    from buffalo_amd.backend import CyWARP
+    U, I, d = 1_000_000, 100_000, bench.WARP_D
+    indptr, keys, P, Q, Qb = bench.warp_c5_inputs(users=U, items=I)
+    nnz = int(keys.shape[0])
+    assert nnz == 100 * U and int(keys.max()) < I
+    n_chk = 100_000
+    P0, Q0 = np.ascontiguousarray(P[:n_chk]).copy(), Q.copy()
+    g = CyWARP()
+    assert g.init(H.write_opt(bench.WARP_OPT))
+    g.sync_every_epoch = False
+    g.initialize_model(P, Q, Qb, nnz, True)
+    g.set_resident_csr(indptr, keys)
+    g.add_jobs(0, U, indptr, None)
+    grads = g.device_tensor("gradP", (U, d))[:n_chk].cpu().numpy().copy()      # the accumulated gradient rows, before the optimizer step
+    g.update_parameters()
+    st = g.stats()
+    del g
+    rc = bench.warp_results_check(indptr, keys, P0, Q0, np.zeros((I, 1), np.float32), grads, n_chk, nnz, bench.WARP_OPT)
+    print("\nWARP at 1 M x 100 K / 100 M nnz, d = 256: full epoch T %.2f accepted %.3f; check %s" % (st["scored_negatives"] / nnz, st["accepted"] / nnz, rc))
+    assert (rc["scored_negatives_device"], rc["accepted_device"]) == (rc["scored_negatives_oracle"], rc["accepted_oracle"]), rc
+    assert rc["grad_rows_max_abs"] > 1e-3, rc
+    assert rc["grad_rows_full_run_vs_oracle"] < 1e-4 and rc["grad_rows_sample_run_vs_oracle"] < 1e-4, rc
+    assert rc["rows_after_step_share_of_coordinates_apart"] < 1e-5, rc
+    assert rc["agrees_with_device"]
