@@ -2064,69 +2064,136 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
                     constexpr int QB0 = HWAVE ? 0 : R0, NQ = T - QB0, PO = R0 - QB0;   // blocks read from the slot, index of block R0 among them
                     const float* const src = ringf + (jg & 1) * SLOTF + (8 * half) * VD + QB0 * 32 + col;
                     const float* const ssw = ringf + (jg & 1) * SLOTF + 16 * VD + 8 * half;
-                    float qv[8][NQ], sw[8];
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        sw[r] = ssw[r];
-#pragma unroll
-                        for (int b = 0; b < NQ; ++b) qv[r][b] = src[r * VD + b * 32];
-                    }
-                    if constexpr (HWAVE) {   // the residual q.p0 - 1 of every entry, h and (loss) g_1 -- NQ == T here; the eight chains side by side
-                        float wgt[8], y[8];
-#pragma unroll
+                    u32x4 H[NB], Lo[NB];
+                    if constexpr (T <= 6) {
+                        float qv[8][NQ], sw[8];
+    #pragma unroll
                         for (int r = 0; r < 8; ++r) {
-                            wgt[r] = ssw[16 + r];
-                            y[r] = qv[r][0] * p0r[0];
-#pragma unroll
-                            for (int b = 1; b < T; ++b) y[r] = __builtin_fmaf(qv[r][b], p0r[b], y[r]);
+                            sw[r] = ssw[r];
+    #pragma unroll
+                            for (int b = 0; b < NQ; ++b) qv[r][b] = src[r * VD + b * 32];
                         }
-#pragma unroll
-                        for (int r = 0; r < 8; ++r) y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), 0x128, 0xf, 0xf, false));
-#pragma unroll
-                        for (int r = 0; r < 8; ++r) y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), 0x124, 0xf, 0xf, false));
-#pragma unroll
-                        for (int r = 0; r < 8; ++r) y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), 0x122, 0xf, 0xf, false));
-#pragma unroll
-                        for (int r = 0; r < 8; ++r) y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), 0x121, 0xf, 0xf, false));
-#pragma unroll
-                        for (int r = 0; r < 8; ++r) {
-                            const float yo = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, y[r]), 0x401F));
-                            const float cial = __builtin_fmaf(wgt[r], y[r] + yo, -wgt[r]);   // alpha v (q.p0 - 1)
-#pragma unroll
-                            for (int b = 0; b < T; ++b) hb[b] = __builtin_fmaf(cial, qv[r][b], hb[b]);
+                        if constexpr (HWAVE) {   // the residual q.p0 - 1 of every entry, h and (loss) g_1 -- NQ == T here; the eight chains side by side
+                            float wgt[8], y[8];
+    #pragma unroll
+                            for (int r = 0; r < 8; ++r) {
+                                wgt[r] = ssw[16 + r];
+                                y[r] = qv[r][0] * p0r[0];
+    #pragma unroll
+                                for (int b = 1; b < T; ++b) y[r] = __builtin_fmaf(qv[r][b], p0r[b], y[r]);
+                            }
+    #pragma unroll
+                            for (int r = 0; r < 8; ++r) y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), 0x128, 0xf, 0xf, false));
+    #pragma unroll
+                            for (int r = 0; r < 8; ++r) y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), 0x124, 0xf, 0xf, false));
+    #pragma unroll
+                            for (int r = 0; r < 8; ++r) y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), 0x122, 0xf, 0xf, false));
+    #pragma unroll
+                            for (int r = 0; r < 8; ++r) y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), 0x121, 0xf, 0xf, false));
+    #pragma unroll
+                            for (int r = 0; r < 8; ++r) {
+                                const float yo = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, y[r]), 0x401F));
+                                const float cial = __builtin_fmaf(wgt[r], y[r] + yo, -wgt[r]);   // alpha v (q.p0 - 1)
+    #pragma unroll
+                                for (int b = 0; b < T; ++b) hb[b] = __builtin_fmaf(cial, qv[r][b], hb[b]);
+                            }
+                            if (lossk) {   // g_1 = sum q over the real entries (wave-uniform branch)
+    #pragma unroll
+                                for (int r = 0; r < 8; ++r) {
+                                    const float one = (jg * 16 + 8 * half + r < n32) ? 1.0f : 0.f;
+    #pragma unroll
+                                    for (int b = 0; b < T; ++b) g1all[b] = __builtin_fmaf(one, qv[r][b], g1all[b]);
+                                }
+                            }
                         }
-                        if (lossk) {   // g_1 = sum q over the real entries (wave-uniform branch)
+    #pragma unroll
+                        for (int b = 0; b < NB; ++b)
+    #pragma unroll
+                            for (int j2 = 0; j2 < 4; ++j2) {
+                                unsigned h_, l_;
+                                als_split_pair_mix(qv[2 * j2][PO + b], sw[2 * j2], qv[2 * j2 + 1][PO + b], sw[2 * j2 + 1], h_, l_);
+                                H[b][j2] = h_;
+                                Lo[b][j2] = l_;
+                            }
+
+                    } else {
+                        // T = 7, 8 (128 / 144 accumulators): the blocks of the slot are taken ONE AT A TIME -- eight registers of rows in flight instead of
+                        // 8 x NQ (64 at T = 8), without which the allocator spills 600 registers.  The wave that forms the residuals walks the slot twice:
+                        // first the dots q.p0 block by block, then -- with the eight coefficients alpha v (q.p0 - 1) in hand -- h, g_1 and the cut.
+                        float sw[8], cial[8];
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) { sw[r] = ssw[r]; cial[r] = 0.f; }
+                        if constexpr (HWAVE) {   // (QB0 == 0: `src` starts at block 0)
+                            float wgt[8], y[8];
 #pragma unroll
                             for (int r = 0; r < 8; ++r) {
-                                const float one = (jg * 16 + 8 * half + r < n32) ? 1.0f : 0.f;
+                                wgt[r] = ssw[16 + r];
+                                y[r] = src[r * VD] * p0r[0];
+                            }
 #pragma unroll
-                                for (int b = 0; b < T; ++b) g1all[b] = __builtin_fmaf(one, qv[r][b], g1all[b]);
+                            for (int b = 1; b < T; ++b)
+#pragma unroll
+                                for (int r = 0; r < 8; ++r) y[r] = __builtin_fmaf(src[r * VD + b * 32], p0r[b], y[r]);
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), 0x128, 0xf, 0xf, false));
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), 0x124, 0xf, 0xf, false));
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), 0x122, 0xf, 0xf, false));
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) y[r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y[r]), 0x121, 0xf, 0xf, false));
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) {
+                                const float yo = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, y[r]), 0x401F));
+                                cial[r] = __builtin_fmaf(wgt[r], y[r] + yo, -wgt[r]);   // alpha v (q.p0 - 1)
+                            }
+                        }
+#pragma unroll
+                        for (int b = 0; b < NQ; ++b) {
+                            float qb[8];
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) qb[r] = src[r * VD + b * 32];
+                            if constexpr (HWAVE) {   // entry by entry, like the all-at-once form above: the same sums in the same order
+#pragma unroll
+                                for (int r = 0; r < 8; ++r) hb[b] = __builtin_fmaf(cial[r], qb[r], hb[b]);
+                                if (lossk) {
+#pragma unroll
+                                    for (int r = 0; r < 8; ++r) {
+                                        const float one = (jg * 16 + 8 * half + r < n32) ? 1.0f : 0.f;
+                                        g1all[b] = __builtin_fmaf(one, qb[r], g1all[b]);
+                                    }
+                                }
+                            }
+                            if (b >= PO) {
+#pragma unroll
+                                for (int j2 = 0; j2 < 4; ++j2) {
+                                    unsigned h_, l_;
+                                    als_split_pair_mix(qb[2 * j2], sw[2 * j2], qb[2 * j2 + 1], sw[2 * j2 + 1], h_, l_);
+                                    H[b - PO][j2] = h_;
+                                    Lo[b - PO][j2] = l_;
+                                }
                             }
                         }
                     }
-                    u32x4 H[NB], Lo[NB];
+                    // T >= 6: the fourth product l l as well (2^-22 of a term: what the three-product form drops).  With it the products are exact to
+                    // 2^-33 like the fp32 instruction's, and the one ill-conditioned tiny case that kept d = 192 on the fp32 form in round 5 (5.9x the
+                    // oracle's distance from float64 against 3.4x for the fp32 instruction, bound 4x) lands where the fp32 instruction does; a third more
+                    // matrix instructions, still a fraction of the fp32 form's (1/16 of the f16 rate)
+                    constexpr int NPROD = T >= 6 ? 4 : 3;
 #pragma unroll
-                    for (int b = 0; b < NB; ++b)
-#pragma unroll
-                        for (int j2 = 0; j2 < 4; ++j2) {
-                            unsigned h_, l_;
-                            als_split_pair_mix(qv[2 * j2][PO + b], sw[2 * j2], qv[2 * j2 + 1][PO + b], sw[2 * j2 + 1], h_, l_);
-                            H[b][j2] = h_;
-                            Lo[b][j2] = l_;
-                        }
-#pragma unroll
-                    for (int pr = 0; pr < 3; ++pr) {   // small terms first: l h, h l, h h
+                    for (int pr0 = 0; pr0 < NPROD; ++pr0) {   // small terms first: (l l,) l h, h l, h h
+                        const int pr = NPROD == 4 ? pr0 - 1 : pr0;   // -1: l l
 #pragma unroll
                         for (int sidx = 0; sidx < C::N0; ++sidx) {
-                            const u32x4 X = pr == 0 ? Lo[0] : H[0];
-                            const u32x4 Y = pr == 1 ? Lo[sidx] : H[sidx];
+                            const u32x4 X = pr <= 0 ? Lo[0] : H[0];
+                            const u32x4 Y = (pr == 1 || pr == -1) ? Lo[sidx] : H[sidx];
                             acc[sidx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, X), __builtin_bit_cast(f16x8_t, Y), acc[sidx], 0, 0, 0);
                         }
                         if constexpr (TWO) {
 #pragma unroll
                             for (int sidx = 0; sidx < C::N1; ++sidx) {
-                                const u32x4 X = pr == 0 ? Lo[R1 - R0] : H[R1 - R0];
-                                const u32x4 Y = pr == 1 ? Lo[R1 - R0 + sidx] : H[R1 - R0 + sidx];
+                                const u32x4 X = pr <= 0 ? Lo[R1 - R0] : H[R1 - R0];
+                                const u32x4 Y = (pr == 1 || pr == -1) ? Lo[R1 - R0 + sidx] : H[R1 - R0 + sidx];
                                 acc[C::N0 + sidx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, X), __builtin_bit_cast(f16x8_t, Y), acc[C::N0 + sidx], 0, 0, 0);
                             }
                         }
@@ -2391,8 +2458,12 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
     __syncthreads();
 }
 
+// workgroups of als_wide_kernel a CU holds: the fp32 form two (W waves of <= 144 accumulators); the split form three at T = 5 (96 accumulators: 168
+// registers), two at T = 6 (112) and one above (128 / 144 accumulators + the pieces of up to eight blocks want all 256 registers)
+__host__ __device__ constexpr int als_wide_blocks_per_cu(int T, bool split) { return split ? (T <= 5 ? 3 : (T == 6 ? 2 : 1)) : 2; }
+
 template <int T, bool BIG, bool SPLIT = false>
-__global__ __launch_bounds__((64 * ((T + 1) / 2 + (SPLIT ? 1 : 0))), (SPLIT ? 3 : 2)) void als_wide_kernel(AlsParams p, const AlsWork* __restrict__ work, int n_items,
+__global__ __launch_bounds__((64 * ((T + 1) / 2 + (SPLIT ? 1 : 0))), als_wide_blocks_per_cu(T, SPLIT)) void als_wide_kernel(AlsParams p, const AlsWork* __restrict__ work, int n_items,
                                                                                             float* __restrict__ scratch, int finalize) {
     constexpr int W = (T + 1) / 2, VD = 32 * T;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -2547,7 +2618,6 @@ __global__ __launch_bounds__(256) void als_solve_kernel(AlsParams p, const AlsHe
 
 }  // namespace bfh
 #include "als_pc.hpp"
-#include "als_ts.hpp"
 namespace bfh {
 
 // ------------------------------------------------------------------------------------------------
@@ -2876,21 +2946,9 @@ class AlsHandle : public HandleBase {
         if (big) { if (lk) BFH_PC(TT, true, true); else BFH_PC(TT, true, false); }     \
         else { if (lk) BFH_PC(TT, false, true); else BFH_PC(TT, false, false); }       \
     } while (0)
-#define BFH_TS(BG, LS)                                                                                                              \
-    do {                                                                                                                            \
-        BFH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(als_ts_kernel<4, BG, LS>), hipFuncAttributeMaxDynamicSharedMemorySize, AlsTs<4>::LDS_B)); \
-        hipLaunchKernelGGL((als_ts_kernel<4, BG, LS>), dim3(pblocks), dim3(512), AlsTs<4>::LDS_B, stream, p, wl->work.get(), items, scratch_.get(), \
-                           qi_.get(), wl->defer.get(), pc_err_.get());                                                              \
-    } while (0)
-                // "als_ts" (vdim 128): the tiles of a row split over the two waves of a SIMD, both waves prepare and consume (als_ts.hpp)
-                if (T == 4 && ts_) {
-                    if (big) { if (lk) BFH_TS(true, true); else BFH_TS(true, false); }
-                    else { if (lk) BFH_TS(false, true); else BFH_TS(false, false); }
-                }
-                else if (T == 2) BFH_PC_T(2);
+                if (T == 2) BFH_PC_T(2);
                 else if (T == 3) BFH_PC_T(3);
                 else BFH_PC_T(4);
-#undef BFH_TS
 #undef BFH_PC_T
 #undef BFH_PC
                 BFH_HIP(hipGetLastError());
@@ -2965,11 +3023,11 @@ class AlsHandle : public HandleBase {
             const int T = vdim_ / 32;
             const size_t lds = als_wide_lds_bytes(vdim_);
             int blocks = std::min(wl->n_work, num_cus_ * 2);
-            // "als_wide_split" (default on, T = 5 i.e. vdim 160 -- the top of the reference's own D sweep): the Gramian through the f16 matrix cores at fp32
-            // accuracy, rows gathered once per block by a producer wave (als_wide_item<SPLIT>).  T = 6 compiles and runs (2.3x faster) but one
-            // ill-conditioned tiny case lands at 5.9x the oracle's distance from float64 against 3.4x for the fp32 instruction and the 4x bound: left off
-            // for calls whose weights all fit the f16 path; als_defer_scan_kernel says so (cached per chunk while the values do not change)
-            bool wsplit = wide_split_ && split_f16_ && T == 5 && wl->n_work > 0;
+            // "als_wide_split" (default on; vdim 160 .. 224, "als_wide_split_max_t"): the Gramian through the f16 matrix cores at fp32 accuracy, rows gathered once
+            // per block by a producer wave (als_wide_item<SPLIT>); from T = 6 up with the fourth product l l (round 5 kept d = 192 on the fp32 form because
+            // the three-product form put one ill-conditioned tiny case at 5.9x the oracle's distance from float64: with l l it lands at 3.8x, bound 4x).
+            // For calls whose weights all fit the f16 path; als_defer_scan_kernel says so (cached per chunk while the values do not change)
+            bool wsplit = wide_split_ && split_f16_ && T >= 5 && T <= wide_split_max_t_ && wl->n_work > 0;
             if (wsplit) {
                 float* const before = scratch_.get();
                 scan_deferred(*wl, p, wl->n_work);
@@ -2987,7 +3045,10 @@ class AlsHandle : public HandleBase {
                 const size_t nq = static_cast<size_t>(p.op_rows) * vdim_;
                 if (qi_.size() < nq) { qi_.resize(nq); qi_side_ = -1; }
                 if (qi_side_ != oside || qi_ver_ != fver_[oside] || qi_wcut_ != split_wcut_) {
-                    hipLaunchKernelGGL(als_interleave_stats_kernel<5>, dim3(ALS_STAT_BLOCKS), dim3(256), 0, stream, p.Q, static_cast<size_t>(p.op_rows), qi_.get(), split_part_.get());
+                    if (T == 5) hipLaunchKernelGGL(als_interleave_stats_kernel<5>, dim3(ALS_STAT_BLOCKS), dim3(256), 0, stream, p.Q, static_cast<size_t>(p.op_rows), qi_.get(), split_part_.get());
+                    else if (T == 6) hipLaunchKernelGGL(als_interleave_stats_kernel<6>, dim3(ALS_STAT_BLOCKS), dim3(256), 0, stream, p.Q, static_cast<size_t>(p.op_rows), qi_.get(), split_part_.get());
+                    else if (T == 7) hipLaunchKernelGGL(als_interleave_stats_kernel<7>, dim3(ALS_STAT_BLOCKS), dim3(256), 0, stream, p.Q, static_cast<size_t>(p.op_rows), qi_.get(), split_part_.get());
+                    else hipLaunchKernelGGL(als_interleave_stats_kernel<8>, dim3(ALS_STAT_BLOCKS), dim3(256), 0, stream, p.Q, static_cast<size_t>(p.op_rows), qi_.get(), split_part_.get());
                     hipLaunchKernelGGL(als_split_scale_kernel, dim3(1), dim3(64), 0, stream, split_part_.get(), ALS_STAT_BLOCKS, split_wcut_, split_out_.get());
                     BFH_HIP(hipGetLastError());
                     qi_side_ = oside; qi_ver_ = fver_[oside]; qi_wcut_ = split_wcut_;
@@ -2996,7 +3057,7 @@ class AlsHandle : public HandleBase {
                 p.Qi = qi_.get();
             }
 #define BFH_WIDE_L(TT, BG, SP, ITEMS, N, FIN)                                                                                    \
-    hipLaunchKernelGGL((als_wide_kernel<TT, BG, SP>), dim3(std::max(1, std::min(N, num_cus_ * (SP ? 3 : 2)))), dim3(64 * ((TT + 1) / 2 + (SP ? 1 : 0))), als_wide_lds_bytes(vdim_, SP), stream, p, ITEMS, N, scratch_.get(), FIN)
+    hipLaunchKernelGGL((als_wide_kernel<TT, BG, SP>), dim3(std::max(1, std::min(N, num_cus_ * als_wide_blocks_per_cu(TT, SP)))), dim3(64 * ((TT + 1) / 2 + (SP ? 1 : 0))), als_wide_lds_bytes(vdim_, SP), stream, p, ITEMS, N, scratch_.get(), FIN)
 #define BFH_WIDE(TT, ITEMS, N, FIN)                                                                                              \
     do {                                                                                                                         \
         if (big) BFH_WIDE_L(TT, true, false, ITEMS, N, FIN);                                                                     \
@@ -3010,9 +3071,9 @@ class AlsHandle : public HandleBase {
 #define BFH_WIDE_T(ITEMS, N, FIN)                  \
     do {                                           \
         if (T == 5) { if (wsplit) BFH_WIDE_S(5, ITEMS, N, FIN); else BFH_WIDE(5, ITEMS, N, FIN); }    \
-        else if (T == 6) BFH_WIDE(6, ITEMS, N, FIN); \
-        else if (T == 7) BFH_WIDE(7, ITEMS, N, FIN); \
-        else BFH_WIDE(8, ITEMS, N, FIN);           \
+        else if (T == 6) { if (wsplit) BFH_WIDE_S(6, ITEMS, N, FIN); else BFH_WIDE(6, ITEMS, N, FIN); } \
+        else if (T == 7) { if (wsplit) BFH_WIDE_S(7, ITEMS, N, FIN); else BFH_WIDE(7, ITEMS, N, FIN); } \
+        else { if (wsplit) BFH_WIDE_S(8, ITEMS, N, FIN); else BFH_WIDE(8, ITEMS, N, FIN); }           \
     } while (0)
             (void)blocks;
             {   // FF p0 for every row of the call (the residual-first gradient starts from it, als_wide_item)
@@ -3262,7 +3323,7 @@ class AlsHandle : public HandleBase {
         else if (name == "als_debug") debug_ = static_cast<int>(v);
         else if (name == "als_split_wcut") split_wcut_ = static_cast<float>(v);   // weights above this take the fp32 side path (default 2^15; tests lower it)
         else if (name == "als_split_f16") split_f16_ = v != 0;             // 0: the in-place iALS++ rows keep the fp32 matrix instruction
-        else if (name == "als_ts") ts_ = static_cast<int>(v);   // 1: als_ts_kernel instead of the pairs at vdim 128 (als_ts.hpp)
+        else if (name == "als_wide_split_max_t") wide_split_max_t_ = static_cast<int>(v);   // the split-f16 wide kernel up to vdim 32 * this (5 .. 8)
         else if (name == "als_pc") {
             BFH_REQUIRE(v >= 0 && v <= 2, "als_pc must be 0, 1 or 2");
             pc_ = static_cast<int>(v);
@@ -3274,7 +3335,7 @@ class AlsHandle : public HandleBase {
 
     void device_buffer(const std::string& name, void** p, size_t* bytes) {
         ++fver_[0]; ++fver_[1];   // whoever holds a raw pointer may write through it: cached views of the factors are dropped
-        if (name == "als_pc_clock_mhz") { *p = nullptr; *bytes = static_cast<size_t>(pc_clock_mhz_); return; }   // als_debug bit 1024: shader clock during the last pair / tile-split launch
+        if (name == "als_pc_clock_mhz") { *p = nullptr; *bytes = static_cast<size_t>(pc_clock_mhz_); return; }   // als_debug bit 1024: shader clock during the last als_pc_kernel launch
         if (name == "als_pc_same_simd") { *p = nullptr; *bytes = static_cast<size_t>(pc_same_simd_); return; }   // placement statistic of the last als_pc_kernel launch
         if (name == "P") { *p = P_.get(); *bytes = P_.bytes(); }
         else if (name == "Q") { *p = Q_.get(); *bytes = Q_.bytes(); }
@@ -3326,7 +3387,10 @@ class AlsHandle : public HandleBase {
     bool no_inreg_ = false;
     bool split_f16_ = true;
     int pc_ = 1;
-    int ts_ = 0;
+    // the split-f16 wide kernel up to vdim 32 * this.  Measured (profiles/r06_als_wide_split_192_256.txt, ML-20M, ms per epoch of row kernels, split | fp32):
+    // d = 192 11.8 | 23.1, d = 224 23.3 | 26.0, d = 256 37.0 | 30.6 -- above T = 6 a CU holds ONE workgroup (128 / 144 accumulators want 256 registers) and
+    // the producer's three row sets spill (110 registers at T = 7, 600 at T = 8): T = 8 stays on the fp32 instruction
+    int wide_split_max_t_ = 7;
     float split_wcut_ = 32768.0f;
     uint64_t fver_[2] = {1, 1};     // bumped whenever P (0) / Q (1) may have changed on the device
     uint64_t vals_ver_ = 1;         // bumped whenever confidence values were uploaded

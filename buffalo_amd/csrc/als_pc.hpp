@@ -575,9 +575,6 @@ __device__ __forceinline__ void als_pc_consumer(const AlsParams& p, float* __res
                         const u32x4 Y = pr == 1 ? L[b] : H[b];
                         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, X), __builtin_bit_cast(f16x8_t, Y), acc[t], 0, 0, 0);
                     }
-                // (probe, als_debug bit 2048: the matrix instructions of a group spread out instead of back to back -- does the clock the power
-                //  management grants depend on how bursty the matrix pipe is driven?  profiles/r06_als_clock_probe.txt)
-                if (p.debug & 2048) __builtin_amdgcn_s_sleep(2);
             }
         };
         bool ok = true;

@@ -113,7 +113,7 @@ CASES = [
                           # rows' slots were zeroed, and the call falls back to the fp32 instantiation, which sums its chunk tiles into those slots
                           (160, dict(optimizer="ialspp"), "heavy_outliers"),
                           (192, dict(optimizer="ialspp"), "ml100k"), (192, dict(optimizer="ialspp"), "heavy")])
-@pytest.mark.parametrize("design", ["inreg", "scratch", "fp32", "wave", "ts"])
+@pytest.mark.parametrize("design", ["inreg", "scratch", "fp32", "wave"])
 def test_half_epochs_match_oracle(oracle, d, kw, shape, design):
     """Every half-epoch starts from bit-identical factors (the GPU model is re-synchronised to the
     oracle's after each comparison), so differences are the kernels' own.  Truncated fp32 CG is
@@ -127,14 +127,12 @@ def test_half_epochs_match_oracle(oracle, d, kw, shape, design):
     from buffalo_amd import synth
     if design == "scratch" and not (d == 128 and kw.get("block_size", 32) == 32):
         pytest.skip("identical to 'inreg' unless the in-register iALS++ solve applies")
-    wsplit = d == 160 and kw.get("block_size", 32) == 32 and kw.get("optimizer") in ("ialspp", "manual_cg")
+    wsplit = d in (160, 192, 224) and kw.get("block_size", 32) == 32 and kw.get("optimizer") in ("ialspp", "manual_cg")   # als_wide_kernel<SPLIT>: T = 5, 6, 7
     if design == "fp32" and not ((d == 128 and kw.get("block_size", 32) == 32) or wsplit):
-        pytest.skip("'fp32' = the in-register solve with the fp32 matrix instruction instead of the split-f16 pass: d = 128 cases (d = 160 / 192: als_wide_split 0)")
+        pytest.skip("'fp32' = the in-register solve with the fp32 matrix instruction instead of the split-f16 pass: d = 128 cases (d = 160 / 192 / 224: als_wide_split 0)")
     if design == "wave" and not (d in (64, 96, 128) and kw.get("block_size", 32) == 32 and kw.get("optimizer") == "ialspp"):
         pytest.skip("'wave' = round 3's wave-per-row split-f16 kernel instead of the producer / consumer pairs: in-place iALS++ cases")
-    if design == "ts" and not (d == 128 and kw.get("block_size", 32) == 32 and kw.get("optimizer") == "ialspp"):
-        pytest.skip("'ts' = the tile split over the two waves of a SIMD (als_ts_kernel) instead of the producer / consumer pairs: vdim 128 in-place iALS++ cases")
-    if shape == "heavy_outliers" and design not in ("inreg", "ts"):
+    if shape == "heavy_outliers" and design != "inreg":
         pytest.skip("the heavy + deferred rows case is about the default path's scratch slots")
     if shape == "outliers":
         base = tiny_csr(U=320, I=280, density=0.2, seed=31, counts=True)
@@ -167,7 +165,6 @@ def test_half_epochs_match_oracle(oracle, d, kw, shape, design):
     obj.set_mode("als_split_f16", int(design != "fp32" or wsplit))
     if wsplit:
         obj.set_mode("als_wide_split", int(design != "fp32"))
-    obj.set_mode("als_ts", int(design == "ts"))
     obj.set_mode("als_pc", 0 if design == "wave" else 2)   # 2: the pairs at d = 64 too (the default leaves T = 2 to the wave-per-row kernel, which is faster there)
     if shape in ("outliers", "heavy_outliers"):
         obj.set_mode("als_split_wcut", 500)   # alpha v = 4 * 2 * 100 and more: past the cut
