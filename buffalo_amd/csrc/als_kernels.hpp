@@ -121,7 +121,7 @@ __device__ __forceinline__ int next_row(int* ticket, int lane) {
 // (cublasSgemm in the reference, lib/cuda/als/als.cu:315-317, is deterministic too; fp32 atomics were
 // not, and iALS++ amplifies a 1e-7 wobble of FF through the cancellation in its gradient).
 // ------------------------------------------------------------------------------------------------
-template <int NT>
+template <int NT, int UPG = 8>
 __global__ __launch_bounds__(64) void als_gramian_kernel(const float* __restrict__ F, int rows, int vdim, int rows_per_slice,
                                                           double* __restrict__ FF) {
     const int lane = threadIdx.x;
@@ -136,12 +136,12 @@ __global__ __launch_bounds__(64) void als_gramian_kernel(const float* __restrict
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
     const int half = lane >> 5, col = lane & 31;
-    // Four row pairs per trip, all their loads issued before the first matrix instruction (round 5): with one pair per trip every trip
-    // paid a full memory round trip (2.8 us for four 64-cycle instructions; 384 us for ML-20M's user side against 77 for the items).
+    // UPG row pairs per trip, all their loads issued before the first matrix instruction (round 5: with one pair per trip every trip paid a full
+    // memory round trip), and -- round 6 -- the loads of the NEXT trip issued before this trip's matrix instructions (two register sets): with two
+    // waves per SIMD a trip's 2.5 us round trip was still most of its time (0.09 / 0.13 ms for ML-20M's items / users where the matrix
+    // instructions need 6 / 30 us; more slices do not help -- their fp64 atomics cost more than they hide: profiles/r06_als_gramian.txt).
     // The accumulation order per accumulator -- pair by pair -- is unchanged, so FF keeps its bits.
-    constexpr int UPG = 4;
-    for (int r = r0; r < r1; r += 2 * UPG) {
-        float a[UPG], b[UPG][NT];
+    auto load_trip = [&](int r, float (&a)[UPG], float (&b)[UPG][NT]) {
 #pragma unroll
         for (int u = 0; u < UPG; ++u) {
             const int row = r + 2 * u + half;
@@ -151,10 +151,21 @@ __global__ __launch_bounds__(64) void als_gramian_kernel(const float* __restrict
 #pragma unroll
             for (int g = 0; g < NT; ++g) b[u][g] = (ok && bj0 + g < T) ? fr[(bj0 + g) * 32 + col] : 0.f;
         }
+    };
+    auto mfma_trip = [&](const float (&a)[UPG], const float (&b)[UPG][NT]) {
 #pragma unroll
         for (int u = 0; u < UPG; ++u)
 #pragma unroll
             for (int g = 0; g < NT; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][g], acc[g], 0, 0, 0);
+    };
+    float a0[UPG], b0[UPG][NT], a1[UPG], b1[UPG][NT];
+    load_trip(r0, a0, b0);
+    for (int r = r0; r < r1; r += 4 * UPG) {
+        load_trip(r + 2 * UPG, a1, b1);     // (past the slice's end: zeros, no loads)
+        mfma_trip(a0, b0);
+        if (r + 2 * UPG >= r1) break;
+        load_trip(r + 4 * UPG, a0, b0);
+        mfma_trip(a1, b1);
     }
     // C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
@@ -1004,6 +1015,27 @@ __device__ __forceinline__ float half_sum(float v, int /*half*/) {
     return v + __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));               // and 0x1f, or 0, xor 0x10
 }
 
+// sum_col a[col] b[col] over the 32 lanes of half 0 for vectors BOTH halves hold alike (the block solve's: lane (half, col) carries element col), handed
+// to every lane: the bits of wave_sum(half == 0 ? a * b : 0) -- (r0 + r1) + (0 + 0) -- without the select, two of the four readlanes and two adds
+// (28 such sums per row: the block solve is issue-bound).  The product is rounded BEFORE the first addition, as the select made it:
+// left to -ffp-contract=fast it fuses into the first butterfly step, and that one rounding moved two ill-conditioned parity cases (d = 96 tiny,
+// outliers) from 1-2x to 4-10x of the oracle's distance from float64 (GPU call 11) -- three CG steps on blocks conditioned ~1e4 amplify it.
+__device__ __forceinline__ float als_dot32_uniform(float a, float b) {
+    float v;
+    {
+#pragma clang fp contract(off)
+        v = a * b;
+    }
+    asm volatile("" : "+v"(v));   // (and the rounded product stays a value of its own)
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));  // row_ror:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));  // row_ror:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));  // row_ror:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));  // row_ror:1
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    return r0 + r1;
+}
+
 // (A x)[32 blk + col] for the symmetric matrix whose upper-triangle tiles are `acc` and an LDS vector x (32 T floats);
 // `out`: 32 LDS floats of exchange space
 template <int T>
@@ -1078,8 +1110,10 @@ __device__ __forceinline__ void als_ialspp_inreg(const f32x16 (&acc)[T * (T + 1)
         md = ms * (md + __shfl_xor(md, 32, 64));
         const float bi = f0[blk] + h[blk] + md + p.reg * pblk;   // als.cc:286-297: gradient of the block at the current row
         float xr = 0.f, rr = bi, pvr = bi;
-        double rsold = static_cast<double>(wave_sum(half == 0 ? rr * rr : 0.f));
-        if (rsold > static_cast<double>(p.cg_tol)) {   // als.cc:313-345: 3 CG steps on M[blk,blk] + reg I
+        // (the reference keeps rsold / rsnew in double; they only ever hold float values, and every use -- the comparisons with the float cg_tol, the
+        //  quotients -- gives the same result on the floats themselves: round 6 dropped the conversions and the double compares from the chain)
+        float rsold = als_dot32_uniform(rr, rr);
+        if (rsold > p.cg_tol) {   // als.cc:313-345: 3 CG steps on M[blk,blk] + reg I
             for (int step = 0; step < 3; ++step) {
                 wave_lds_sync();
                 if (half == 0) pvs[col] = pvr;
@@ -1087,15 +1121,15 @@ __device__ __forceinline__ void als_ialspp_inreg(const f32x16 (&acc)[T * (T + 1)
                 float ap = als_tile_colpart(acc[als_tri<T>(blk, blk)], pvs, half);
                 ap = ms * (ap + __shfl_xor(ap, 32, 64));
                 ap += p.reg * pvr;
-                const float pap = wave_sum(half == 0 ? pvr * ap : 0.f);
+                const float pap = als_dot32_uniform(pvr, ap);
                 // als.cc:328: double / float rounded to float.  Both operands hold float values, and a quotient of two floats taken in
                 // double and rounded to float IS the correctly rounded float quotient (53 >= 2*24 + 2): one fp32 division, same bits
-                const float step_size = static_cast<float>(rsold) / pap;
+                const float step_size = rsold / pap;
                 xr += step_size * pvr;
                 rr -= step_size * ap;
-                const double rsnew = static_cast<double>(wave_sum(half == 0 ? rr * rr : 0.f));
-                if (rsnew < static_cast<double>(p.cg_tol)) break;
-                pvr = rr + (static_cast<float>(rsnew) / static_cast<float>(rsold)) * pvr;
+                const float rsnew = als_dot32_uniform(rr, rr);
+                if (rsnew < p.cg_tol) break;
+                pvr = rr + (rsnew / rsold) * pvr;
                 rsold = rsnew;
             }
         }
@@ -1951,7 +1985,9 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
                 fetch(1, myc_n, myw_n, mys_n);
                 // three sets of rows: while group pg is prepared from one, the rows of pg + 1 and pg + 2 are landing in the others and those of
                 // pg + 3 leave into the one just consumed
-                float qA[8][T], qB[8][T], qC[8][T];
+                // (two sets at T >= 7 were tried in round 6: the spill counts of T = 7 / 8 did not move -- the producer's rows are not what spills)
+                constexpr int NSET = 3;
+                float qA[8][T], qB[8][T], qC[NSET == 3 ? 8 : 1][NSET == 3 ? T : 1];
                 // the row ids of a group's entries, lane (col, half) <- entries 16 g + 8 half + r: all eight exchanges issued back to back (left to the
                 // compiler each exchange was followed by its wait and its load -- 24 serialised LDS round trips per group, 1.7 us of the 2.2 a group took)
                 auto group_ids = [&](int (&cid)[8], int src_c, int g) {
@@ -1980,7 +2016,7 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
                     group_ids(c2, myc, 2);
                     load_group(qA, c0);
                     load_group(qB, c1);
-                    load_group(qC, c2);
+                    if constexpr (NSET == 3) load_group(qC, c2);
                 }
                 // group pg: residual + h + g_1 from the rows, the pieces of all T blocks into `slot`, then the rows of group pg + 2 into the set
                 // keys of chunk 2, in flight since before the first preparation (see the commit in `prepare`)
@@ -2006,8 +2042,8 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
                         pend_v = pend_in ? p.vals[wk.kbeg + kk] : 0.f;
                     }
                     float wgt[8], sw[8];
-                    int cid[8];   // the rows of group pg + 3 (the keys of a chunk's groups 1, 2, 3 + 3 sit in the next chunk)
-                    group_ids(cid, g < 1 ? myc : myc_n, (g + 3) & 3);
+                    int cid[8];   // the rows of group pg + NSET (the keys of a chunk's last NSET groups + NSET sit in the next chunk)
+                    group_ids(cid, g < 4 - NSET ? myc : myc_n, (g + NSET) & 3);
 #pragma unroll
                     for (int r = 0; r < 8; ++r) wgt[r] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bsel + 64 * g + 4 * r, __builtin_bit_cast(int, myw)));
 #pragma unroll
@@ -2027,7 +2063,7 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
                             ringf[slot * SLOTF + 16 * VD + 16 + 8 * half + r] = wgt[r];   // alpha v: the residual's weight (last consumer)
                         }
                     }
-                    // the rows of group pg + 3 leave into the set just consumed
+                    // the rows of group pg + NSET leave into the set just consumed
                     load_group(q, cid);
                     {   // commit the keys fetched at the top of this preparation when it ends a chunk
                         const bool adv = g == 3;   // the next group opens a new 64-entry chunk
@@ -2048,9 +2084,11 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
                     prepare(qB, jg + 1, (jg + 1) & 1);
                     __syncthreads();
                     if (++jg >= ngroups) break;
-                    prepare(qC, jg + 1, (jg + 1) & 1);
-                    __syncthreads();
-                    if (++jg >= ngroups) break;
+                    if constexpr (NSET == 3) {
+                        prepare(qC, jg + 1, (jg + 1) & 1);
+                        __syncthreads();
+                        if (++jg >= ngroups) break;
+                    }
                     prepare(qA, jg + 1, (jg + 1) & 1);
                     __syncthreads();
                     ++jg;
@@ -2750,14 +2788,15 @@ class AlsHandle : public HandleBase {
         const int T = vdim_ / 32;
         constexpr int NT = 4;
         const int TG = (T + NT - 1) / NT;
-        int slices = (num_cus_ * 8) / (T * TG);
+        int slices = (num_cus_ * gram_waves_per_cu_) / (T * TG);
         if (slices < 1) slices = 1;
         int rps = (rows + slices - 1) / slices;
         rps = (rps + 1) & ~1;  // even: row pairs never straddle slices
         if (rps < 2) rps = 2;
         slices = (rows + rps - 1) / rps;
         const int slot = t_aux_.begin(stream);
-        hipLaunchKernelGGL(als_gramian_kernel<NT>, dim3(slices, T, TG), dim3(64), 0, stream, F, rows, vdim_, rps, FF64_.get());
+        if (gram_upg_ == 4) hipLaunchKernelGGL((als_gramian_kernel<NT, 4>), dim3(slices, T, TG), dim3(64), 0, stream, F, rows, vdim_, rps, FF64_.get());
+        else hipLaunchKernelGGL((als_gramian_kernel<NT, 8>), dim3(slices, T, TG), dim3(64), 0, stream, F, rows, vdim_, rps, FF64_.get());
         BFH_HIP(hipGetLastError());
         const int nff = vdim_ * vdim_;
         hipLaunchKernelGGL(als_gramian_round_kernel, dim3((nff + 255) / 256), dim3(256), 0, stream, FF64_.get(), FF_.get(), nff);
@@ -3323,6 +3362,8 @@ class AlsHandle : public HandleBase {
         else if (name == "als_debug") debug_ = static_cast<int>(v);
         else if (name == "als_split_wcut") split_wcut_ = static_cast<float>(v);   // weights above this take the fp32 side path (default 2^15; tests lower it)
         else if (name == "als_split_f16") split_f16_ = v != 0;             // 0: the in-place iALS++ rows keep the fp32 matrix instruction
+        else if (name == "als_gram_waves") gram_waves_per_cu_ = static_cast<int>(v);   // als_gramian_kernel: waves per CU (slices of the rows x tile rows)
+        else if (name == "als_gram_upg") gram_upg_ = static_cast<int>(v);             // ... row pairs per trip (4 | 8)
         else if (name == "als_wide_split_max_t") wide_split_max_t_ = static_cast<int>(v);   // the split-f16 wide kernel up to vdim 32 * this (5 .. 8)
         else if (name == "als_pc") {
             BFH_REQUIRE(v >= 0 && v <= 2, "als_pc must be 0, 1 or 2");
@@ -3391,6 +3432,9 @@ class AlsHandle : public HandleBase {
     // d = 192 11.8 | 23.1, d = 224 23.3 | 26.0, d = 256 37.0 | 30.6 -- above T = 6 a CU holds ONE workgroup (128 / 144 accumulators want 256 registers) and
     // the producer's three row sets spill (110 registers at T = 7, 600 at T = 8): T = 8 stays on the fp32 instruction
     int wide_split_max_t_ = 7;
+    // als_gramian_kernel: measured on ML-20M at d = 128 (profiles/r06_als_gramian.txt, ms for the items / the users): 4 waves per CU 0.048 / 0.109, 8: 0.086 / 0.143,
+    // 12: 0.118 / 0.163 -- every slice ends in 64 fp64 atomics per lane on the same 16 K addresses, so FEWER, longer slices win once a wave keeps its next trip in flight
+    int gram_waves_per_cu_ = 4, gram_upg_ = 8;
     float split_wcut_ = 32768.0f;
     uint64_t fver_[2] = {1, 1};     // bumped whenever P (0) / Q (1) may have changed on the device
     uint64_t vals_ver_ = 1;         // bumped whenever confidence values were uploaded

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 passes of the bench command (kernel stats of the very run that prints the bench line; PMC passes separately, as the
-# MI355X guide prescribes) -> gpurun_out/r5prof; summaries are then copied under profiles/ by hand (committed).
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r5prof
+# MI355X guide prescribes) -> gpurun_out/$PROF_DIR (default r6prof); summaries are then copied under profiles/ by hand (committed).
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${PROF_DIR:-r6prof}
 rm -rf $O; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 CMD="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline"

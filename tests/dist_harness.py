@@ -91,7 +91,7 @@ class PipelinedDeltaExchange:
 
 class DataParallelSGD:
     """Drives one accelerator object (CyBPR / CyWARP surface) on this rank's user shard, exchanging through
-    torch.distributed (the CPU tests with the oracle as the engine; `bench.py` with BFH_COMM=torch).  The product path
+    torch.distributed (the CPU tests with the oracle as the engine; `bench.py` has had no such path since round 6: without the library's communicator it fails).  The product path
     on GPUs is the library's own communicator: `obj.set_comm(Comm(...))` and plain `add_jobs` / `update_parameters`.
 
     `engine` must offer add_jobs / update_parameters plus `replicated_tensors(kind)` returning the
