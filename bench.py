@@ -611,7 +611,38 @@ def extra_warp_c5(seed, epochs=6, cpu=True):
     tr = _warp_counter_traffic("c5")
     if tr:
         out["counter_traffic"] = tr
-    del g
+    # ---- the SEARCHING regime at this size: with the option default margin (1.0, rows inside the unit ball) every positive of this
+    # synthetic shape finds a violator within two counted trials (T plateaus at 1.8, accepted_frac 1.0): the easy regime.  The trained model is taken
+    # back, the margin set to the 30 % quantile of x_ui - x_uj over 200,000 sampled triples (about 3 of 10 draws violate: T ~ 1 / 0.3 counted trials, the
+    # construction of tests/test_warp_scale_gpu.py), and three more epochs run from there with a fresh handle: trial kernel at T >= 3 on 10^9 positives.
+    try:
+        g.synchronize(True)                      # P, Q, Qb <- the device's model (through the pinned ring)
+        del g
+        rs = np.random.default_rng(1)
+        su = rs.integers(0, U, 200000)
+        si = keys[su.astype(np.int64) * 100 + rs.integers(0, 100, 200000)]
+        sj = rs.integers(0, I, 200000)
+        diff = np.einsum("ij,ij->i", P[su], Q[si] - Q[sj])
+        thr = float(np.quantile(diff, 0.30))
+        g2 = CyWARP()
+        # (lr 1e-6: a fresh adagrad state takes lr * sign(g) as its first step -- at the option's 0.05 that would throw the trained rows away; the work per
+        #  epoch does not depend on the step size)
+        path = _opt_file(dict(WARP_OPT, threshold=thr, lr=1e-6, min_lr=1e-6))
+        assert g2.init(path)
+        os.unlink(path)
+        g2.sync_every_epoch = False
+        g2.initialize_model(P, Q, Qb, nnz, True)
+        g2.set_resident_csr(indptr, keys)
+        eps2 = _warp_epochs(g2, U, indptr, nnz, d, I, 3)
+        del g2
+        last2 = eps2[-1]
+        out["searching_regime"] = {"threshold": thr, "what": "margin = the 30 % quantile of x_ui - x_uj over 200,000 sampled triples of the trained model; three epochs "
+                                                              "from that model, the last one quoted", "epochs": eps2, "epoch_ms": last2["epoch_ms"],
+                                   "mean_scored_negatives_T": last2["mean_scored_negatives_T"], "accepted_frac": last2["accepted_frac"],
+                                   "trial_kernel_ms": last2["trial_kernel_ms"], "sort_and_gather_ms": last2["sort_and_gather_ms"],
+                                   "implemented_model_frac": last2["implemented_model_frac"]}
+    except Exception as e:  # noqa: BLE001
+        out["searching_regime"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if cpu:
         n100 = U // 100
         out["cpu_baseline"] = _warp_cpu_baseline(indptr[:n100], keys[:int(indptr[n100 - 1])], I, d, seed, seconds=4.0)
@@ -1259,6 +1290,9 @@ def run_extras(args, csr, out):
         rf.update({"warp_c5_epoch_ms": c5["epoch_ms"], "warp_c5_T": c5["mean_scored_negatives_T"], "warp_c5_accepted_frac": last["accepted_frac"],
                    "warp_c5_epochs_run": len(c5["epochs"]), "warp_c5_implemented_model_frac": c5["implemented_model_frac"],
                    "warp_c5_sort_and_gather_ms": last["sort_and_gather_ms"], "warp_c5_trial_kernel_ms": last["trial_kernel_ms"]})
+        sr = c5.get("searching_regime") or {}
+        if "epoch_ms" in sr:            # the same size with the margin lowered until the trial loop has to search (T >= 3)
+            rf.update({"warp_c5_search_epoch_ms": sr["epoch_ms"], "warp_c5_search_T": sr["mean_scored_negatives_T"], "warp_c5_search_accepted_frac": sr["accepted_frac"]})
         if "agrees_with_device" in c5:   # the results check at configs[4] size (warp_results_check: oracle on the first users vs the device's rows and counts)
             rf["warp_c5_agrees_with_device"] = c5["agrees_with_device"]
         tr = c5.get("counter_traffic") or {}

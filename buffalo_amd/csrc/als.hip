@@ -79,7 +79,7 @@ int bfh_als_publish_rows(void* h, int axis, const int* bounds, int n_bounds) {
     return guarded(h, [&] { static_cast<AlsHandle*>(h)->publish_rows(axis, bounds, n_bounds); return BFH_OK; });
 }
 int bfh_als_get_stats(void* h, bfh_stats* out) {
-    return guarded(h, [&] { *out = static_cast<AlsHandle*>(h)->stats; return BFH_OK; });
+    return guarded(h, [&] { static_cast<AlsHandle*>(h)->flush_timers(); *out = static_cast<AlsHandle*>(h)->stats; return BFH_OK; });
 }
 int bfh_als_reset_stats(void* h) {
     return guarded(h, [&] { static_cast<AlsHandle*>(h)->stats = bfh_stats{}; return BFH_OK; });
@@ -142,7 +142,7 @@ int bfh_cfr_partial_update_context(void* h, int start_x, int next_x, const int64
     });
 }
 int bfh_cfr_get_stats(void* h, bfh_stats* out) {
-    return guarded(h, [&] { *out = static_cast<CfrHandle*>(h)->stats; return BFH_OK; });
+    return guarded(h, [&] { static_cast<CfrHandle*>(h)->flush_timers(); *out = static_cast<CfrHandle*>(h)->stats; return BFH_OK; });
 }
 int bfh_cfr_reset_stats(void* h) {
     return guarded(h, [&] { static_cast<CfrHandle*>(h)->stats = bfh_stats{}; return BFH_OK; });
@@ -197,7 +197,7 @@ int bfh_eals_estimate_loss(void* h, int nnz, const int64_t* indptr, const int32_
     });
 }
 int bfh_eals_get_stats(void* h, bfh_stats* out) {
-    return guarded(h, [&] { *out = static_cast<EalsHandle*>(h)->stats; return BFH_OK; });
+    return guarded(h, [&] { static_cast<EalsHandle*>(h)->flush_timers(); *out = static_cast<EalsHandle*>(h)->stats; return BFH_OK; });
 }
 int bfh_eals_reset_stats(void* h) {
     return guarded(h, [&] { static_cast<EalsHandle*>(h)->stats = bfh_stats{}; return BFH_OK; });

@@ -2802,8 +2802,15 @@ class AlsHandle : public HandleBase {
         hipLaunchKernelGGL(als_gramian_round_kernel, dim3((nff + 255) / 256), dim3(256), 0, stream, FF64_.get(), FF_.get(), nff);
         BFH_HIP(hipGetLastError());
         t_aux_.end(slot, stream);
-        BFH_HIP(hipStreamSynchronize(stream));
-        stats.aux_ms += t_aux_.drain();
+        // (no synchronisation here since round 6: nothing of the Gramian is read by the host, the next call on the stream waits for it anyway, and a
+        //  blocking call per precompute was ~30 us of the epoch; the timer is drained where the stream is idle next -- partial_update, get_stats)
+    }
+    // stream idle: account what the aux timer holds
+    void drain_aux() { stats.aux_ms += t_aux_.drain(); }
+    // bfh_*_get_stats: everything queued so far is part of the numbers
+    void flush_timers() {
+        if (stream) BFH_HIP(hipStreamSynchronize(stream));
+        drain_aux();
     }
 
     void partial_update(int start_x, int next_x, const int64_t* indptr, const int32_t* keys, const float* vals, int axis,
@@ -3173,6 +3180,7 @@ class AlsHandle : public HandleBase {
         }
         BFH_HIP(hipStreamSynchronize(stream));
         ++fver_[axis];   // the side just solved changed
+        drain_aux();
         stats.kernel_ms += t_main_.drain();
         stats.launches += 1;
         stats.samples += n;
@@ -3378,6 +3386,9 @@ class AlsHandle : public HandleBase {
         ++fver_[0]; ++fver_[1];   // whoever holds a raw pointer may write through it: cached views of the factors are dropped
         if (name == "als_pc_clock_mhz") { *p = nullptr; *bytes = static_cast<size_t>(pc_clock_mhz_); return; }   // als_debug bit 1024: shader clock during the last als_pc_kernel launch
         if (name == "als_pc_same_simd") { *p = nullptr; *bytes = static_cast<size_t>(pc_same_simd_); return; }   // placement statistic of the last als_pc_kernel launch
+        // whoever takes a raw pointer reads it on ANOTHER stream (torch's): everything this handle has queued is finished first
+        // (precompute no longer blocks: round 6)
+        if (stream) BFH_HIP(hipStreamSynchronize(stream));
         if (name == "P") { *p = P_.get(); *bytes = P_.bytes(); }
         else if (name == "Q") { *p = Q_.get(); *bytes = Q_.bytes(); }
         else if (name == "FF") { *p = FF_.get(); *bytes = FF_.bytes(); }
@@ -3433,8 +3444,11 @@ class AlsHandle : public HandleBase {
     // the producer's three row sets spill (110 registers at T = 7, 600 at T = 8): T = 8 stays on the fp32 instruction
     int wide_split_max_t_ = 7;
     // als_gramian_kernel: measured on ML-20M at d = 128 (profiles/r06_als_gramian.txt, ms for the items / the users): 4 waves per CU 0.048 / 0.109, 8: 0.086 / 0.143,
-    // 12: 0.118 / 0.163 -- every slice ends in 64 fp64 atomics per lane on the same 16 K addresses, so FEWER, longer slices win once a wave keeps its next trip in flight
-    int gram_waves_per_cu_ = 4, gram_upg_ = 8;
+    // 12: 0.118 / 0.163 -- every slice ends in 64 fp64 atomics per lane on the same 16 K addresses, so fewer, longer slices are faster.  The default STAYS at 8:
+    // the slice boundaries decide FF's last bits, and with 4 the one matrix-free tiny case at d = 160 / block_size 64 -- three CG steps on systems conditioned
+    // beyond fp32 -- lands at 20x the oracle's distance from float64 instead of 0.2x (deterministically; every other case unchanged: GPU call 14).  A re-roll of
+    // the rounding, not an error of either FF (both 7e-8 from float64) -- but the parity suite is held as it is.
+    int gram_waves_per_cu_ = 8, gram_upg_ = 8;
     float split_wcut_ = 32768.0f;
     uint64_t fver_[2] = {1, 1};     // bumped whenever P (0) / Q (1) may have changed on the device
     uint64_t vals_ver_ = 1;         // bumped whenever confidence values were uploaded
