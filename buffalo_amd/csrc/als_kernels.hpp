@@ -2102,7 +2102,7 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
                     constexpr int QB0 = HWAVE ? 0 : R0, NQ = T - QB0, PO = R0 - QB0;   // blocks read from the slot, index of block R0 among them
                     const float* const src = ringf + (jg & 1) * SLOTF + (8 * half) * VD + QB0 * 32 + col;
                     const float* const ssw = ringf + (jg & 1) * SLOTF + 16 * VD + 8 * half;
-                    u32x4 H[NB], Lo[NB];
+                    u32x4 H[T <= 6 ? NB : 2], Lo[T <= 6 ? NB : 2];   // T = 7, 8: the pieces of the tile rows' own blocks R0, R1 only
                     if constexpr (T <= 6) {
                         float qv[8][NQ], sw[8];
     #pragma unroll
@@ -2203,12 +2203,29 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
                                 }
                             }
                             if (b >= PO) {
+                                // ... and its products are issued at once: only the pieces of the two tile rows' OWN blocks (the X operands) stay, a
+                                // block's pieces (the Y operand) live for its eight matrix instructions -- 24 registers of pieces instead of 16 per block
+                                // (128 at T = 8, which with 144 accumulators spilled 600 registers into the group loop).  Per accumulator the order is
+                                // l l, l h, h l, h h as in the all-at-once form; the two tile rows' instructions alternate (no back-to-back dependence).
+                                const int bb = b - PO;   // block R0 + bb
+                                u32x4 Yh, Yl;
 #pragma unroll
                                 for (int j2 = 0; j2 < 4; ++j2) {
                                     unsigned h_, l_;
                                     als_split_pair_mix(qb[2 * j2], sw[2 * j2], qb[2 * j2 + 1], sw[2 * j2 + 1], h_, l_);
-                                    H[b - PO][j2] = h_;
-                                    Lo[b - PO][j2] = l_;
+                                    Yh[j2] = h_;
+                                    Yl[j2] = l_;
+                                }
+                                if (bb == 0) { H[0] = Yh; Lo[0] = Yl; }
+                                if (TWO && bb == R1 - R0) { H[1] = Yh; Lo[1] = Yl; }
+                                const bool second = TWO && bb >= R1 - R0;
+#pragma unroll
+                                for (int pr = -1; pr < 3; ++pr) {
+                                    const u32x4 Y = (pr == 1 || pr == -1) ? Yl : Yh;
+                                    acc[bb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, pr <= 0 ? Lo[0] : H[0]), __builtin_bit_cast(f16x8_t, Y), acc[bb], 0, 0, 0);
+                                    if (second)
+                                        acc[C::N0 + bb - (R1 - R0)] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, pr <= 0 ? Lo[1] : H[1]), __builtin_bit_cast(f16x8_t, Y),
+                                                                                                             acc[C::N0 + bb - (R1 - R0)], 0, 0, 0);
                                 }
                             }
                         }
@@ -2218,6 +2235,7 @@ __device__ __forceinline__ void als_wide_item(const AlsParams& p, const AlsWork&
                     // oracle's distance from float64 against 3.4x for the fp32 instruction, bound 4x) lands where the fp32 instruction does; a third more
                     // matrix instructions, still a fraction of the fp32 form's (1/16 of the f16 rate)
                     constexpr int NPROD = T >= 6 ? 4 : 3;
+                    if constexpr (T <= 6)   // (T = 7, 8: issued block by block above)
 #pragma unroll
                     for (int pr0 = 0; pr0 < NPROD; ++pr0) {   // small terms first: (l l,) l h, h l, h h
                         const int pr = NPROD == 4 ? pr0 - 1 : pr0;   // -1: l l

@@ -12,7 +12,8 @@ csr = bench.load_matrix("ml20m", 7)
 U, I, nnz = csr.num_users, csr.num_items, csr.nnz
 vals = (1 + np.random.default_rng(7).poisson(1.0, size=nnz)).astype(np.float32)
 col = ingest.coo_to_csr(csr.keys, csr.rows(), vals, I, U)
-CASES = (("split", {}), ("split, no pass", {"als_debug": 16}), ("fp32", {"als_wide_split": 0}))
+MAXT = {"als_wide_split_max_t": int(os.environ["ALS_WIDE_MAX_T"])} if "ALS_WIDE_MAX_T" in os.environ else {}   # e.g. 8: the split form at d = 256 too
+CASES = (("split", dict(MAXT)), ("split, no pass", dict(MAXT, als_debug=16)), ("fp32", {"als_wide_split": 0}))
 if "--split-only" in sys.argv:   # one line: the library in place (a variant build copied over it)
     CASES = (("split", {}),)
 if "--grid" in sys.argv:         # "als_debug" 1024 (an experiment's host-side switch, not in the tree: profiles/r05_als_wide_d160.txt): two blocks per CU with the three-block binary
