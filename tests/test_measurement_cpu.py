@@ -113,6 +113,15 @@ def test_bench_last_line_is_compact_and_keeps_the_contract():
     assert len(s2) <= bench.LINE_LIMIT
     l2 = json.loads(s2)
     assert "frac" in l2["roofline"] and "value" in l2["cpu_baseline"] and l2["value"] == line["value"]
+    # N > 1 (round 6): what the LIVE communicator reports travels as top-level scalars of the line; the round-6 keys of the N = 1 line are flat scalars too
+    multi = json.loads(json.dumps(full))
+    multi.update({"n_gpus": 8, "rccl_ranks": 8, "transport": "rccl 2.26.6"})
+    multi["roofline"].update({"bpr_lr005_norm_gap_Qb": -0.0375, "warp_c5_agrees_with_device": True, "warp_c5_search_T": 23.7, "warp_c5_search_epoch_ms": 4257.7,
+                              "warp_c5_search_accepted_frac": 0.9967})
+    l3 = json.loads(bench.compact_line(multi))
+    assert l3["rccl_ranks"] == 8 and l3["transport"] == "rccl 2.26.6" and l3["n_gpus"] == 8
+    assert l3["roofline"]["warp_c5_agrees_with_device"] is True and l3["roofline"]["bpr_lr005_norm_gap_Qb"] == -0.0375
+    assert "rccl_ranks" not in line and "transport" not in line          # ... and are absent at N = 1
 
 
 def test_bench_counter_traffic_is_refused_from_other_sources(tmp_path, monkeypatch):
