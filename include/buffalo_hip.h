@@ -174,7 +174,9 @@ int bfh_als_synchronize(void* h, int device_to_host);
  *                      biases (default 250 = the logistic loss's 1/4, the multi-GPU exchange's constant), the item factor rows and the
  *                      replicated user rows (default 0 = plain sum): a row whose replicas each took m steps between two merges is merged
  *                      with w = (1 - exp(-n x)) / (n (1 - exp(-x))), x = lr k (m - 1/n) (sum for cold rows -- exactly, up to one step per row -- mean for
- *                      saturated ones);
+ *                      saturated ones);  "xcd_stiff_lr_ref" (3, units of 1e-6, default 1000 = lr 0.001): the learning rate the curvatures were
+ *                      calibrated at -- above it they shrink like lr_ref / lr (at a high lr a row sits in the flat part of the sigmoid for most of
+ *                      its steps; the constant at every lr, 0, left the biases 19 % low on the reference benchmark's lr 0.05 -> 0.0001 schedule);
  *   "im_user_lr_max"   (3, permille, default 10) learning rate up to which "im_user_replicas" / "im_user_hybrid" apply;
  *   "im_max_stale"     (3) updates of one item row in flight unseen by the other waves, stated at lr 0.05 (scales 1/lr; default 16);
  *   "im_p_nt", "im_neg_limit"  (3) study knobs (non-temporal hint on the P rows; uniform negatives folded into the first rows
@@ -199,8 +201,11 @@ int bfh_als_synchronize(void* h, int device_to_host);
  *                      0 = v_mfma_f32_32x32x2_f32;  "als_split_wcut": rows holding a weight alpha*v above this (default 32768) or a
  *                      negative one go through the fp32 instruction + the dense-solve kernel (a scan of the weights, cached per
  *                      chunk, finds them);  "als_pc" (default 1) producer / consumer wave pairs for those rows where they win (d = 96, 128;
- *                      csrc/als_pc.hpp), 2 = also at d = 64, 0 = round 3's wave-per-row kernel everywhere (3 = the experimental one-wave-per-row DMA kernel of
- *                      csrc/als_solo.hpp at d = 128, only in a build with -DBFH_WITH_ALS_SOLO; the default build rejects it);  "als_inreg" 0 = every row through the scratch slot + als_solve_kernel. */
+ *                      csrc/als_pc.hpp), 2 = also at d = 64, 0 = round 3's wave-per-row kernel everywhere;  "als_inreg" 0 = every row through the scratch slot + als_solve_kernel;
+ *                      "als_wide_split" (default 1) / "als_wide_split_max_t" (default 7): 128 < vdim <= 32 * max_t on the split-f16 form of als_wide_kernel
+ *                      (from vdim 192 up with the fourth product l l), 0 = the fp32 instruction;  "als_gram_waves" / "als_gram_upg": waves per CU and row pairs
+ *                      per trip of als_gramian_kernel (8 / 8; the slice boundaries decide FF's last bits);  "als_debug": timing probes, results are wrong
+ *                      with any bit but 1024 (the shader clock of the last als_pc_kernel launch, read back as device buffer "als_pc_clock_mhz"). */
 int bfh_bpr_set_mode(void* h, const char* name, int64_t value);
 int bfh_warp_set_mode(void* h, const char* name, int64_t value);
 int bfh_als_set_mode(void* h, const char* name, int64_t value);
