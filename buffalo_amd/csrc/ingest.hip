@@ -13,6 +13,7 @@
 // back into minor ids and fill indptr from the positions where the major id changes.  All HBM-bound integer
 // work: 2 x (8 + 4) B per record and radix pass.
 #include <cstring>
+#include <thread>
 
 #include <cstdio>
 
@@ -384,15 +385,41 @@ static void parse_text_on_device(const char* text, int64_t bytes, int64_t total_
     }
     std::vector<int32_t> hr(idx.size()), hc(idx.size());
     std::vector<float> hv(idx.size());
-    std::string line;
-    for (size_t j = 0; j < idx.size(); ++j) {
-        const int64_t k = idx[j];
-        const int64_t beg = k == 0 ? 0 : nlh[k - 1] + 1, end = k < cap ? nlh[k] : bytes;
-        line.assign(text + beg, text + end);
-        int rr = 0, cc = 0;
-        float vv = 0.f;
-        sscanf(line.c_str(), "%d %d %f", &rr, &cc, &vv);
-        hr[j] = rr; hc[j] = cc; hv[j] = vv;
+    // every line is independent: above a few thousand of them the host's share is cut over up to 8 threads (a file of 17-digit reprs hands MOST of its
+    // lines back; one thread's sscanf is ~5 M lines per second)
+    auto reparse = [&](size_t j0, size_t j1) {
+        std::string line;
+        for (size_t j = j0; j < j1; ++j) {
+            const int64_t k = idx[j];
+            const int64_t beg = k == 0 ? 0 : nlh[k - 1] + 1, end = k < cap ? nlh[k] : bytes;
+            line.assign(text + beg, text + end);
+            int rr = 0, cc = 0;
+            float vv = 0.f;
+            sscanf(line.c_str(), "%d %d %f", &rr, &cc, &vv);
+            hr[j] = rr; hc[j] = cc; hv[j] = vv;
+        }
+    };
+    {
+        const size_t m0 = idx.size();
+        unsigned hw = std::thread::hardware_concurrency();
+        const size_t parts = std::max<size_t>(1, std::min<size_t>({8, hw ? hw : 1, m0 / 4096}));
+        if (parts == 1) {
+            reparse(0, m0);
+        } else {
+            std::vector<std::thread> th;
+            th.reserve(parts);
+            size_t started_to = 0;
+            try {
+                for (size_t t = 0; t < parts; ++t) {
+                    const size_t a = m0 * t / parts, b = m0 * (t + 1) / parts;
+                    th.emplace_back(reparse, a, b);
+                    started_to = b;
+                }
+            } catch (...) {   // a thread could not be started: the calling thread takes what is left
+            }
+            if (started_to < m0) reparse(started_to, m0);
+            for (auto& x : th) x.join();
+        }
     }
     // scatter back: the list and the re-parsed values go up ONCE and a small kernel puts every line where it belongs.  (Round 5 copied 3 x 4
     // bytes per line synchronously -- millions of blocking copies for a file of 17-digit values -- and, when EVERY line was flagged but the list
