@@ -1,0 +1,40 @@
+"""How much does the headline kernel's time move from handle to handle inside ONE process (same data, same code)?  Four handles one after the other,
+40 epochs each; prints kernel ms per launch, the device pointers of P / Q (placement) and the shader clock state is left to the box."""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+from buffalo_amd import synth
+from buffalo_amd.backend import CyBPR
+csr = bench.load_matrix("ml20m", 7)
+U, I, nnz = csr.num_users, csr.num_items, csr.nnz
+keep = []
+if os.environ.get("PREWARM", "0") != "0":   # allocate and free a large block first: does the FIRST handle then behave like the later ones?
+    import torch
+    gb = float(os.environ["PREWARM"])
+    t = torch.empty(int(gb * (1 << 30)), dtype=torch.uint8, device="cuda")
+    t.zero_()
+    torch.cuda.synchronize()
+    del t
+    torch.cuda.empty_cache()
+for rep in range(int(os.environ.get("REPS", "4"))):
+    P, Q, Qb = synth.init_factors(U, I, bench.D, seed=7)
+    g = CyBPR()
+    assert g.init(bench.write_opt(bench.bpr_options(45)))
+    g.sync_every_epoch = False
+    g.initialize_model(P, Q, Qb, nnz, True)
+    g.set_cumulative_table(np.zeros(I, np.int64), I)
+    g.set_resident_csr(csr.indptr, csr.keys)
+    for _ in range(5):
+        g.add_jobs(0, U, csr.indptr, None); g.update_parameters()
+    g.reset_stats()
+    for _ in range(40):
+        g.add_jobs(0, U, csr.indptr, None); g.update_parameters()
+    st = g.stats()
+    ptrs = {n: hex(g.device_buffer(n)[0]) for n in ("P", "Q")}
+    print("handle %d: kernel %.3f ms per launch, aux %.3f ms per epoch, %s" % (rep, st["kernel_ms"] / st["launches"], st["aux_ms"] / 40, ptrs), flush=True)
+    if os.environ.get("KEEP", "0") == "1":
+        keep.append(g)       # keep the allocations: the next handle lands elsewhere
+    else:
+        del g
