@@ -800,13 +800,22 @@ class BprHandle : public SgdHandle {
     // On small shards it loses (per-rank epoch at 4 shards 2.42 -> 2.54 ms, at 8 shards 1.31 -> 1.37: twice the rows held per queue
     // on few users turns more of them hot), so by default it is used from 6144 users per queue up (1 and 2 GPUs on ML-20M).
     bool im_dual() const { return im_dual_call_; }
+    // whole 32-element groups per row: the instantiation without per-lane guards ("im_dual_generic" = 1 keeps the guarded one: A/B)
+    int im_dual_nk() const { return (vdim_ % 32 == 0 && vdim_ <= 128 && !im_dual_generic_) ? vdim_ / 32 : 0; }
     void im_choose_dual(int64_t users_here, int nq) {
         im_dual_call_ = im_dual_ != 0 && vdim_ <= 128 && !im_prefetch() && !im_single_wave_ && !im_drain_only_ &&
                         (im_dual_ > 0 || users_here >= static_cast<int64_t>(nq) * 6144);
     }
     void im_launch(const SgdParams& p, const BprConsts& c, const ImQueues& q, int64_t waves, bool drain) {
         if (!drain && im_dual()) {
-            hipLaunchKernelGGL(bpr_item_major_dual_kernel, dim3(static_cast<unsigned>((waves + 3) / 4)), dim3(256), 0, stream, p, c, q);
+            const dim3 grid(static_cast<unsigned>((waves + 3) / 4)), block(256);
+            switch (im_dual_nk()) {
+                case 1: hipLaunchKernelGGL(bpr_item_major_dual_kernel<1>, grid, block, 0, stream, p, c, q); break;
+                case 2: hipLaunchKernelGGL(bpr_item_major_dual_kernel<2>, grid, block, 0, stream, p, c, q); break;
+                case 3: hipLaunchKernelGGL(bpr_item_major_dual_kernel<3>, grid, block, 0, stream, p, c, q); break;
+                case 4: hipLaunchKernelGGL(bpr_item_major_dual_kernel<4>, grid, block, 0, stream, p, c, q); break;
+                default: hipLaunchKernelGGL(bpr_item_major_dual_kernel<0>, grid, block, 0, stream, p, c, q); break;
+            }
             BFH_HIP(hipGetLastError());
             return;
         }
@@ -819,8 +828,15 @@ class BprHandle : public SgdHandle {
         if (waves_per_cu_ > 0) return static_cast<int64_t>(num_cus_) * waves_per_cu_;
         const int KV = (vdim_ + 255) / 256;
         const void* fn = nullptr;
-        if (im_dual())
-            fn = reinterpret_cast<const void*>(bpr_item_major_dual_kernel);
+        if (im_dual()) {
+            switch (im_dual_nk()) {
+                case 1: fn = reinterpret_cast<const void*>(bpr_item_major_dual_kernel<1>); break;
+                case 2: fn = reinterpret_cast<const void*>(bpr_item_major_dual_kernel<2>); break;
+                case 3: fn = reinterpret_cast<const void*>(bpr_item_major_dual_kernel<3>); break;
+                case 4: fn = reinterpret_cast<const void*>(bpr_item_major_dual_kernel<4>); break;
+                default: fn = reinterpret_cast<const void*>(bpr_item_major_dual_kernel<0>); break;
+            }
+        }
         else if (im_prefetch())
             fn = KV <= 1 ? reinterpret_cast<const void*>(bpr_item_major_kernel<4, true, false>)
                          : (KV <= 2 ? reinterpret_cast<const void*>(bpr_item_major_kernel<8, true, false>)

@@ -553,11 +553,11 @@ __device__ __forceinline__ float half_sum(float v, int half) {   // sum over the
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));  // row_ror:4
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));  // row_ror:2
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));  // row_ror:1
-    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
-    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
-    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
-    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
-    return half ? (r2 + r3) : (r0 + r1);
+    // every lane holds its 16-lane row's sum; the half's total = own row + the other row of the half (lane ^ 16: ds_swizzle, bit mode,
+    // xor mask 0x10 -- no memory access).  r0 + r1 in row 0, r1 + r0 in row 1: the same number (round 5 used four readlanes and a select)
+    const float o = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));
+    (void)half;
+    return v + o;
 }
 __device__ __forceinline__ void hrow_load(HRow& r, const float* rp, int nk) {   // rp = row + lane32; past the L1 (sc1)
 #pragma unroll
@@ -574,11 +574,18 @@ __device__ __forceinline__ void hrow_atomic_add(const HRow& r, float* rp, int nk
         if (k < nk) atomic_add_f32(rp + k * 32, r.v[k]);
 }
 
+// NK > 0: vdim == 32 * NK -- every lane holds NK elements of a row and no load / store / atomic needs a per-lane guard (the guards cost an
+// exec-mask branch per memory instruction: round 6's instruction diet); NK == 0: any vdim <= 128.
+template <int NK>
 __global__ __launch_bounds__(256, 5) void bpr_item_major_dual_kernel(SgdParams p, BprConsts c, ImQueues q) {
     const int lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31;
     const int vdim = p.vdim;
     // elements this lane holds: k * 32 + l32 < vdim
-    const int nk = l32 < vdim ? (vdim - l32 + 31) / 32 : 0;
+    const int nk = NK > 0 ? NK : (l32 < vdim ? (vdim - l32 + 31) / 32 : 0);
+    // the sigmoid table (bpr.cc:119-131) in LDS: its lookup sits in every triple's dependent chain
+    __shared__ float s_exp[1000];
+    for (int t = threadIdx.x; t < 1000; t += 256) s_exp[t] = c.exp_table[t];
+    __syncthreads();
     const int qq = q.xcd_queue[xcc_id_raw()];
     if (qq < 0) return;   // a workgroup on an XCD the probe did not see: the drain launch covers whatever is left
     float* const Qrep = c.rep_Q + static_cast<size_t>(qq) * c.rep_stride;
@@ -670,12 +677,19 @@ __global__ __launch_bounds__(256, 5) void bpr_item_major_dual_kernel(SgdParams p
 
         for (int j = 0; j < n_max; ++j) {
             // half-uniform metadata of this step (readlanes for both halves, one select)
-            const int item = half ? __builtin_amdgcn_readlane(it_[1], j) : __builtin_amdgcn_readlane(it_[0], j);
-            const int u = half ? __builtin_amdgcn_readlane(u_[1], j) : __builtin_amdgcn_readlane(u_[0], j);
-            const int neg = half ? __builtin_amdgcn_readlane(ng_[1], j) : __builtin_amdgcn_readlane(ng_[0], j);
-            const int pol = half ? __builtin_amdgcn_readlane(pl_[1], j) : __builtin_amdgcn_readlane(pl_[0], j);
+            // (both halves' values are read into scalar registers first: written as `half ? readlane(b) : readlane(a)` the compiler
+            // turns every field into a divergent if / else around the two readlanes -- 15 instructions and two branches per field)
             const int jn = j + 1 < 64 ? j + 1 : 63;
-            const int item_next = half ? __builtin_amdgcn_readlane(it_[1], jn) : __builtin_amdgcn_readlane(it_[0], jn);
+            const int it0 = __builtin_amdgcn_readlane(it_[0], j), it1 = __builtin_amdgcn_readlane(it_[1], j);
+            const int us0 = __builtin_amdgcn_readlane(u_[0], j), us1 = __builtin_amdgcn_readlane(u_[1], j);
+            const int ng0 = __builtin_amdgcn_readlane(ng_[0], j), ng1 = __builtin_amdgcn_readlane(ng_[1], j);
+            const int pl0 = __builtin_amdgcn_readlane(pl_[0], j), pl1 = __builtin_amdgcn_readlane(pl_[1], j);
+            const int in0 = __builtin_amdgcn_readlane(it_[0], jn), in1 = __builtin_amdgcn_readlane(it_[1], jn);
+            const int item = half ? it1 : it0;
+            const int u = half ? us1 : us0;
+            const int neg = half ? ng1 : ng0;
+            const int pol = half ? pl1 : pl0;
+            const int item_next = half ? in1 : in0;
             const bool act = j < n_mine;
             const bool at_u = (pol & 1) != 0, at_j = (pol & 2) != 0;
             const bool same = item == neg;
@@ -708,7 +722,7 @@ __global__ __launch_bounds__(256, 5) void bpr_item_major_dual_kernel(SgdParams p
             if (act) {
                 if (6.0f < x) logit = 0.0f;
                 else if (x < -6.0f) logit = 1.0f;
-                else logit = c.exp_table[static_cast<int>((x + 6.0f) * 83.0f)];
+                else logit = s_exp[static_cast<int>((x + 6.0f) * 83.0f)];
                 if (c.compute_loss) loss += static_cast<double>(log1pf(__expf(-fminf(fmaxf(x, -6.f), 6.f))));
             }
             bool want_flush = false;

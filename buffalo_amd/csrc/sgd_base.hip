@@ -971,6 +971,7 @@ void SgdHandle::set_mode(const std::string& name, int64_t v) {
     else if (name == "im_force_queues") { BFH_REQUIRE(v >= 0 && v <= 8, "im_force_queues must be in [0,8]"); im_force_queues_ = static_cast<int>(v); }
     else if (name == "im_p_nt") im_p_nt_ = v != 0;
     else if (name == "im_study") im_study_ = static_cast<int>(v);
+    else if (name == "im_dual_generic") im_dual_generic_ = v != 0;
     else if (name == "xcd_stiff_lr_ref") xcd_stiff_lr_ref_micro_ = static_cast<int>(v);
     else if (name == "im_dual") { BFH_REQUIRE(v >= -1 && v <= 1, "im_dual must be -1 (by the call's size), 0 or 1"); im_dual_ = static_cast<int>(v); }
     else if (name == "im_neg_limit") { BFH_REQUIRE(v >= 0, "im_neg_limit must be >= 0"); im_neg_limit_ = static_cast<int>(v); }

@@ -23,6 +23,8 @@ for rep in range(int(os.environ.get("REPS", "4"))):
     g = CyBPR()
     assert g.init(bench.write_opt(bench.bpr_options(45)))
     g.sync_every_epoch = False
+    for k, v in __import__("json").loads(os.environ.get("MODES", "{}")).items():
+        g.set_mode(k, v)
     g.initialize_model(P, Q, Qb, nnz, True)
     g.set_cumulative_table(np.zeros(I, np.int64), I)
     g.set_resident_csr(csr.indptr, csr.keys)
