@@ -164,6 +164,8 @@ def test_triples_parallel_disjoint_rows(oracle):
     (128, dict(num_negative_samples=2, use_bias=False), dict(im_dual=1, im_max_stale=1, xcd_hot_tau=1)),   # flush every triple, atomic rows
     (40, dict(update_j=False), dict(im_dual=1, im_presample=0, im_user_replicas=1)),
     (32, dict(update_i=False), dict(im_dual=1, n_chunks=3)),
+    (64, dict(num_negative_samples=2), dict(im_dual=1)),                  # round 6: the whole-group instantiation NK = 2 (128 / 96 / 32 above: NK = 4 / 3 / 1)
+    (128, {}, dict(im_dual=1, im_dual_generic=1)),       # ... and the guarded instantiation at a vdim the whole-group one normally takes
     # lr <= 0.01: the heavy users alone get per-XCD replicas of P (im_user_hybrid, the whole-matrix default).  Every user of this
     # matrix has one entry, so with the collision threshold at 0.5 all of them count as heavy at the owner's share and none at the
     # spread share: every row goes through a replica and the delta-rule merge; with the knob off through its owner XCD
