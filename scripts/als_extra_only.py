@@ -1,5 +1,5 @@
 import json, sys
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 csr = bench.load_matrix("ml20m", 7)
 out = bench.extra_als(csr, 7, epochs=3, cpu=False)
