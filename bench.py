@@ -1184,8 +1184,8 @@ def run_bpr(args, ctx):
     alg_bytes = bytes_per_update * (st["samples"] / max(st["launches"], 1))
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
     traffic, traffic_source = counter_traffic()
-    # the library's own rule for the two-triples-per-wave walk (bfh_bpr_set_mode "im_dual"): vdim <= 128 and >= 6144 users per queue
-    dual_walk = hog == "3" and knobs.get("im_dual", "-1") != "0" and (knobs.get("im_dual", "-1") == "1" or n_local_users >= 8 * 6144)
+    # the library's own rule for the two-triples-per-wave walk (bfh_bpr_set_mode "im_dual"): vdim <= 128 and >= 1024 users per queue
+    dual_walk = hog == "3" and knobs.get("im_dual", "-1") != "0" and (knobs.get("im_dual", "-1") == "1" or n_local_users >= 8 * 1024)
     strict_b = 16 * D + 20 + 8 * D / (nnz / U)
     out = {
         "metric": "BPRMF training throughput (interactions/s), ML-20M-shaped synthetic, d=128",

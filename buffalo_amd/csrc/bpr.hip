@@ -797,14 +797,15 @@ class BprHandle : public SgdHandle {
     // Measured (profiles/r02_dual_triples_per_wave.txt, same box): 4.95 -> 4.56 ms per launch (4.20 without the hot-user atomics, whose
     // share grows because twice as many rows are held per queue); 16, 20 and 24 waves per CU give the same time -- the walk is at the
     // fabric's ceiling there, so the kernel is built for 5 waves per SIMD (81 VGPRs, no scratch).  "im_dual" = 0 keeps the one-triple walk.
-    // On small shards it loses (per-rank epoch at 4 shards 2.42 -> 2.54 ms, at 8 shards 1.31 -> 1.37: twice the rows held per queue
-    // on few users turns more of them hot), so by default it is used from 6144 users per queue up (1 and 2 GPUs on ML-20M).
+    // Rounds 2-5: on small shards it lost (per-rank epoch at 4 shards 2.42 -> 2.54 ms, at 8 shards 1.31 -> 1.37: twice the rows held per queue
+    // on few users turns more of them hot) and was used from 6144 users per queue up.  After round 6's diet of the kernel it wins there too
+    // (profiles/r06_walk_variance.txt, call 32: 4 shards 2.29 -> 1.94 ms, 8 shards 1.42 -> 1.29), so the default is now 1024 users per queue.
     bool im_dual() const { return im_dual_call_; }
     // whole 32-element groups per row: the instantiation without per-lane guards ("im_dual_generic" = 1 keeps the guarded one: A/B)
     int im_dual_nk() const { return (vdim_ % 32 == 0 && vdim_ <= 128 && !im_dual_generic_) ? vdim_ / 32 : 0; }
     void im_choose_dual(int64_t users_here, int nq) {
         im_dual_call_ = im_dual_ != 0 && vdim_ <= 128 && !im_prefetch() && !im_single_wave_ && !im_drain_only_ &&
-                        (im_dual_ > 0 || users_here >= static_cast<int64_t>(nq) * 6144);
+                        (im_dual_ > 0 || users_here >= static_cast<int64_t>(nq) * 1024);
     }
     void im_launch(const SgdParams& p, const BprConsts& c, const ImQueues& q, int64_t waves, bool drain) {
         if (!drain && im_dual()) {

@@ -162,7 +162,7 @@ class SgdHandle : public HandleBase {
     int im_presample_ahead_ = 1;   // ... and the next epoch's on a side stream while this epoch's walk runs
     int im_blocks_ = 0;            // policy 3: runs an item's entries are cut into inside a queue (0 = from the learning rate)
     bool im_dual_call_ = false;    // decided per call (im_choose_dual)
-    int im_dual_ = -1;             // policy 3: two triples per wave at vdim <= 128 (bpr_item_major_dual_kernel); -1: from 6144 users per queue up, 1: always, 0: never
+    int im_dual_ = -1;             // policy 3: two triples per wave at vdim <= 128 (bpr_item_major_dual_kernel); -1: from 1024 users per queue up (6144 until round 6), 1: always, 0: never
     int im_neg_limit_ = 0;         // policy 3 study knob: fold the uniform negatives into the first rows of Q
     bool im_dual_generic_ = false; // "im_dual_generic": the two-triples walk with per-lane guards at every vdim (A/B against the whole-group instantiations)
     int im_study_ = 0;             // policy 3 measurement knob (never set by a front): bit 0 drops the chip-wide atomics of the negatives' rows (profiles/r06_bpr_lr005_*)

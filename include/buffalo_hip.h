@@ -182,7 +182,7 @@ int bfh_als_synchronize(void* h, int device_to_host);
  *   "im_p_nt", "im_neg_limit"  (3) study knobs (non-temporal hint on the P rows; uniform negatives folded into the first rows
  *                      of Q): DESIGN.md 4.1 "what bounds it" -- not for training;
  *   "im_dual"          (3) two triples per wave at vdim <= 128 (the half-waves walk two slices side by side): -1 (default) = for calls
- *                      with 6144 users per queue or more, 1 = always, 0 = never;
+ *                      with 1024 users per queue or more (6144 until round 6), 1 = always, 0 = never;
  *   "im_user_replicas" (3) 1 = per-XCD replicas of P (entries spread over the queues by position, delta rule at the merges)
  *                      instead of one owner XCD per user; -1 (default) = when a call has fewer than 3072 users per queue
  *                      (the shards of an 8-GPU ML-20M run) and lr <= 0.01, 0 = never;
