@@ -165,7 +165,10 @@ CASES = {
     # the lr it was calibrated at (profiles/r06_bpr_lr005_bias_rows.txt: every bias lifted by +0.12 .. +0.33 once the rows leave the chip-wide atomics); with the
     # lr-aware constant ("xcd_stiff_lr_ref", bpr.hip) it is 176.1 (-3.8 %), the loss 0.19411 against 0.19244 (+0.9 %): bounds 27 % -> 8 %, 5 % -> 3 %.
     # precision@10 and the overlap keep wide slack: the oracle pairs' own ranking scatter from run to run is as large as their distance to the walk.
-    "refbench": (dict(lr=0.05, min_lr=0.0001), 10, (128, 256), {"loss": (0.03, 3.0), "P": (0.08, 1.0), "Q": (0.08, 1.0), "Qb": (0.08, 3.0),
+    # Later in round 6: the reference path's OWN factor norms at 128 / 256 workers move from box to box with the host (|P| 8.47 / 7.56 on the box of the width
+    # study, 7.57 / 7.43 on the box of the round's last full run, where the walk's 8.32 -- 8.24 .. 8.32 on every box -- was 10.9 % above the pair's mean and the
+    # 8 % bound failed): the factor-norm bounds are 15 %, still inside what the reference does to itself across pool widths (7.4 .. 10.5).
+    "refbench": (dict(lr=0.05, min_lr=0.0001), 10, (128, 256), {"loss": (0.03, 3.0), "P": (0.15, 1.0), "Q": (0.15, 1.0), "Qb": (0.08, 3.0),
                                                                  "prec10": (0.12, 3.0)}, 0.40),
 }
 
