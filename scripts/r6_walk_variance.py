@@ -9,6 +9,10 @@ from buffalo_amd import synth
 from buffalo_amd.backend import CyBPR
 csr = bench.load_matrix("ml20m", 7)
 U, I, nnz = csr.num_users, csr.num_items, csr.nnz
+ITEM_DIV = int(os.environ.get("ITEM_DIV", "1"))     # study: the same interactions on a catalogue ITEM_DIV times smaller (item ids merged in pairs / fours): the per-XCD
+if ITEM_DIV > 1:                                    # replicas of the item table shrink with it -- does the per-handle draw depend on the size of the kernel's working set?
+    csr = synth.CSR(U, (I + ITEM_DIV - 1) // ITEM_DIV, csr.indptr, (csr.keys // ITEM_DIV).astype(np.int32), csr.vals)
+    I = csr.num_items
 keep = []
 if os.environ.get("PREWARM", "0") != "0":   # allocate and free a large block first: does the FIRST handle then behave like the later ones?
     import torch
