@@ -2806,7 +2806,9 @@ class AlsHandle : public HandleBase {
         const int T = vdim_ / 32;
         constexpr int NT = 4;
         const int TG = (T + NT - 1) / NT;
-        int slices = (num_cus_ * gram_waves_per_cu_) / (T * TG);
+        // waves per CU: 4 at vdim 128 (configs[2]: 0.157 instead of 0.229 ms per epoch, every d = 128 parity case unchanged), 8 elsewhere (see gram_waves_per_cu_)
+        const int wpc = gram_waves_per_cu_ > 0 ? gram_waves_per_cu_ : (vdim_ == 128 ? 4 : 8);
+        int slices = (num_cus_ * wpc) / (T * TG);
         if (slices < 1) slices = 1;
         int rps = (rows + slices - 1) / slices;
         rps = (rps + 1) & ~1;  // even: row pairs never straddle slices
@@ -3462,11 +3464,11 @@ class AlsHandle : public HandleBase {
     // the producer's three row sets spill (110 registers at T = 7, 600 at T = 8): T = 8 stays on the fp32 instruction
     int wide_split_max_t_ = 7;
     // als_gramian_kernel: measured on ML-20M at d = 128 (profiles/r06_als_gramian.txt, ms for the items / the users): 4 waves per CU 0.048 / 0.109, 8: 0.086 / 0.143,
-    // 12: 0.118 / 0.163 -- every slice ends in 64 fp64 atomics per lane on the same 16 K addresses, so fewer, longer slices are faster.  The default STAYS at 8:
+    // 12: 0.118 / 0.163 -- every slice ends in 64 fp64 atomics per lane on the same 16 K addresses, so fewer, longer slices are faster.  Outside vdim 128 the default STAYS at 8:
     // the slice boundaries decide FF's last bits, and with 4 the one matrix-free tiny case at d = 160 / block_size 64 -- three CG steps on systems conditioned
     // beyond fp32 -- lands at 20x the oracle's distance from float64 instead of 0.2x (deterministically; every other case unchanged: GPU call 14).  A re-roll of
-    // the rounding, not an error of either FF (both 7e-8 from float64) -- but the parity suite is held as it is.
-    int gram_waves_per_cu_ = 8, gram_upg_ = 8;
+    // the rounding, not an error of either FF (both 7e-8 from float64) -- but the parity suite is held as it is: 0 = 4 waves per CU at vdim 128 only, 8 elsewhere.
+    int gram_waves_per_cu_ = 0, gram_upg_ = 8;
     float split_wcut_ = 32768.0f;
     uint64_t fver_[2] = {1, 1};     // bumped whenever P (0) / Q (1) may have changed on the device
     uint64_t vals_ver_ = 1;         // bumped whenever confidence values were uploaded

@@ -204,7 +204,7 @@ int bfh_als_synchronize(void* h, int device_to_host);
  *                      csrc/als_pc.hpp), 2 = also at d = 64, 0 = round 3's wave-per-row kernel everywhere;  "als_inreg" 0 = every row through the scratch slot + als_solve_kernel;
  *                      "als_wide_split" (default 1) / "als_wide_split_max_t" (default 7): 128 < vdim <= 32 * max_t on the split-f16 form of als_wide_kernel
  *                      (from vdim 192 up with the fourth product l l), 0 = the fp32 instruction;  "als_gram_waves" / "als_gram_upg": waves per CU and row pairs
- *                      per trip of als_gramian_kernel (8 / 8; the slice boundaries decide FF's last bits);  "als_debug": timing probes, results are wrong
+ *                      per trip of als_gramian_kernel (0 = 4 waves at vdim 128 and 8 elsewhere / 8; the slice boundaries decide FF's last bits);  "als_debug": timing probes, results are wrong
  *                      with any bit but 1024 (the shader clock of the last als_pc_kernel launch, read back as device buffer "als_pc_clock_mhz"). */
 int bfh_bpr_set_mode(void* h, const char* name, int64_t value);
 int bfh_warp_set_mode(void* h, const char* name, int64_t value);
