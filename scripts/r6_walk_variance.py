@@ -22,6 +22,14 @@ if os.environ.get("PREWARM", "0") != "0":   # allocate and free a large block fi
     torch.cuda.synchronize()
     del t
     torch.cuda.empty_cache()
+_dummy = []
+if int(os.environ.get("DUMMY_STREAMS", "0")) > 0:    # study: HIP streams created (and kept) before the first handle shift which hardware queue the handle's streams land on
+    import torch
+    _dummy = [torch.cuda.Stream() for _ in range(int(os.environ["DUMMY_STREAMS"]))]
+    for st in _dummy:
+        with torch.cuda.stream(st):
+            torch.zeros(8, device="cuda").add_(1)
+    torch.cuda.synchronize()
 for rep in range(int(os.environ.get("REPS", "4"))):
     P, Q, Qb = synth.init_factors(U, I, bench.D, seed=7)
     g = CyBPR()
