@@ -22,6 +22,23 @@ if os.environ.get("PREWARM", "0") != "0":   # allocate and free a large block fi
     torch.cuda.synchronize()
     del t
     torch.cuda.empty_cache()
+if os.environ.get("WARM_TINY", "0") != "0":    # study: a small throw-away handle first -- device code loaded, sort storage sized, streams created before the measured handle allocates
+    rng = np.random.default_rng(3)
+    tu, ti, per = 12000, 3000, 40
+    tkeys = np.sort(rng.integers(0, ti, size=(tu, per)), axis=1).astype(np.int32).reshape(-1)
+    tcsr = synth.CSR(tu, ti, np.arange(1, tu + 1, dtype=np.int64) * per, tkeys, np.ones(tu * per, np.float32))
+    tP, tQ, tQb = synth.init_factors(tu, ti, bench.D, seed=3)
+    t = CyBPR()
+    assert t.init(bench.write_opt(bench.bpr_options(4)))
+    t.sync_every_epoch = False
+    t.initialize_model(tP, tQ, tQb, tcsr.nnz, True)
+    t.set_cumulative_table(np.zeros(ti, np.int64), ti)
+    t.set_resident_csr(tcsr.indptr, tcsr.keys)
+    for _ in range(3):
+        t.add_jobs(0, tu, tcsr.indptr, None); t.update_parameters()
+    print("tiny handle: %s" % {k: v for k, v in t.stats().items() if k in ("launches", "samples")}, flush=True)
+    if os.environ["WARM_TINY"] == "1":
+        del t            # "2": keep it alive
 _dummy = []
 if int(os.environ.get("DUMMY_STREAMS", "0")) > 0:    # study: HIP streams created (and kept) before the first handle shift which hardware queue the handle's streams land on
     import torch
